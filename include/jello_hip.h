@@ -1,0 +1,138 @@
+/* jello_hip.h -- C ABI of libjello_hip.so, the MI355X (gfx950) replacement for Jello's
+ * engine/wgpu_engine.  These are exactly the entry points a Go `engine/hip_engine` package binds
+ * with cgo to replay a renderer.Recording (see INTEGRATION.md for the cgo stub).
+ *
+ * Mapping to the reference interface each call replaces:
+ *   jh_create / jh_destroy        wgpu_engine.New                      engine/wgpu_engine/wgpu.go:157-178
+ *   jh_upload                     Upload / UploadUniform commands      wgpu.go:353-370 (queue.WriteBuffer)
+ *   jh_image_upload               UploadImage command                  wgpu.go:372-418
+ *   jh_clear                      Clear command                        wgpu.go:565-585
+ *   jh_dispatch                   Dispatch command                     wgpu.go:454-497
+ *   jh_dispatch_indirect          DispatchIndirect command             wgpu.go:499-552
+ *   jh_download                   Download command + map               wgpu.go:554-563, 645-657
+ *   jh_free / jh_image_free       FreeBuffer / FreeImage (pool return) wgpu.go:587-616, 772-808
+ *   jh_image_import/buffer_import ExternalResource{ExternalImage,..}   wgpu.go:81-93, lib.go:257-262
+ *   jh_profile_*                  ProfilerGroup.Compute timestamps     engine/wgpu_engine/profiler.go:160-177
+ *   jh_stage                      renderer.FullShaders field order     renderer/render.go:17-43
+ * Binding order for every stage is the WGSL @binding order = renderer/render.go dispatch order.
+ *
+ * Conventions: plain pointers and sizes only; every call returns 0 on success or a negative
+ * jh_status (never aborts -- the reference panics, wgpu.go:77,213,282,544,558,594,955);
+ * one jh_ctx = one device + one stream, not thread-safe; several contexts (one per GPU) may be
+ * used concurrently from different threads/processes.  Work is enqueued asynchronously; only
+ * jh_download, jh_image_download, jh_sync and jh_profile_collect wait for the device.
+ */
+#ifndef JELLO_HIP_H
+#define JELLO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jh_ctx jh_ctx;
+
+typedef enum jh_status {
+    JH_OK = 0,
+    JH_ERR_INVALID = -1,     /* bad argument / unknown id / wrong binding count */
+    JH_ERR_DEVICE = -2,      /* HIP runtime error (jh_last_error has the text) */
+    JH_ERR_NO_DEVICE = -3,   /* no usable GPU */
+    JH_ERR_UNSUPPORTED = -4, /* stage not implemented by this build */
+    JH_ERR_OOM = -5
+} jh_status;
+
+/* renderer.FullShaders field order (renderer/render.go:17-43) */
+typedef enum jh_stage {
+    JH_PATHTAG_REDUCE = 0,
+    JH_PATHTAG_REDUCE2 = 1,
+    JH_PATHTAG_SCAN1 = 2,
+    JH_PATHTAG_SCAN_SMALL = 3,
+    JH_PATHTAG_SCAN_LARGE = 4,
+    JH_BBOX_CLEAR = 5,
+    JH_FLATTEN = 6,
+    JH_DRAW_REDUCE = 7,
+    JH_DRAW_LEAF = 8,
+    JH_CLIP_REDUCE = 9,
+    JH_CLIP_LEAF = 10,
+    JH_BINNING = 11,
+    JH_TILE_ALLOC = 12,
+    JH_BACKDROP_DYN = 13,
+    JH_PATH_COUNT_SETUP = 14,
+    JH_PATH_COUNT = 15,
+    JH_COARSE = 16,
+    JH_PATH_TILING_SETUP = 17,
+    JH_PATH_TILING = 18,
+    JH_FINE_AREA = 19,
+    JH_FINE_MSAA8 = 20,
+    JH_FINE_MSAA16 = 21,
+    JH_STAGE_COUNT = 22
+} jh_stage;
+
+/* renderer.ResourceProxy (renderer/recording.go:23-36) */
+typedef enum jh_binding_kind { JH_BIND_BUFFER = 1, JH_BIND_IMAGE = 2, JH_BIND_IMAGE_ARRAY = 3 } jh_binding_kind;
+typedef struct jh_binding {
+    uint32_t kind;       /* jh_binding_kind */
+    uint32_t count;      /* JH_BIND_IMAGE_ARRAY: number of ids */
+    uint64_t id;         /* buffer / image ResourceID */
+    const uint64_t* ids; /* JH_BIND_IMAGE_ARRAY */
+} jh_binding;
+
+typedef struct jh_profile_record {
+    int32_t stage; /* jh_stage */
+    uint32_t pad;
+    float ms; /* device time of the whole stage (all of its kernels), hipEvent pair */
+} jh_profile_record;
+
+/* ---- context ---- */
+int jh_create(jh_ctx** out, int device);
+void jh_destroy(jh_ctx* ctx);
+const char* jh_last_error(jh_ctx* ctx);
+const char* jh_stage_name(int stage);
+/* Run on a caller-owned HIP stream (e.g. torch's current stream); NULL = the context's own. */
+int jh_set_stream(jh_ctx* ctx, void* hip_stream);
+int jh_sync(jh_ctx* ctx);
+
+/* ---- buffers (ids are the recording's ResourceIDs; sizes in bytes) ---- */
+int jh_buffer_create(jh_ctx* ctx, uint64_t id, uint64_t size);
+int jh_buffer_import(jh_ctx* ctx, uint64_t id, void* device_ptr, uint64_t size); /* caller keeps ownership */
+int jh_upload(jh_ctx* ctx, uint64_t id, const void* data, uint64_t size);        /* creates the buffer if needed */
+int jh_clear(jh_ctx* ctx, uint64_t id, uint64_t offset, int64_t size);           /* size < 0: to the end */
+int jh_download(jh_ctx* ctx, uint64_t id, void* dst, uint64_t offset, uint64_t size);
+int jh_free(jh_ctx* ctx, uint64_t id); /* returns the allocation to the pool */
+void* jh_buffer_device_ptr(jh_ctx* ctx, uint64_t id);
+uint64_t jh_buffer_size(jh_ctx* ctx, uint64_t id);
+
+/* ---- images: linear device memory, row-major, format = renderer.ImageFormat ---- */
+int jh_image_create(jh_ctx* ctx, uint64_t id, uint32_t width, uint32_t height, int format);
+int jh_image_import(jh_ctx* ctx, uint64_t id, void* device_ptr, uint32_t width, uint32_t height, int format);
+int jh_image_upload(jh_ctx* ctx, uint64_t id, uint32_t width, uint32_t height, int format, const void* data, uint64_t size);
+int jh_image_download(jh_ctx* ctx, uint64_t id, void* dst, uint64_t size);
+int jh_image_free(jh_ctx* ctx, uint64_t id);
+void* jh_image_device_ptr(jh_ctx* ctx, uint64_t id);
+
+/* ---- dispatch ---- */
+int jh_dispatch(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uint32_t gz, const jh_binding* bindings, int n_bindings);
+int jh_dispatch_indirect(jh_ctx* ctx, int stage, uint64_t indirect_buffer_id, uint64_t offset, const jh_binding* bindings,
+                         int n_bindings);
+
+/* ---- profiling ---- */
+int jh_profile_enable(jh_ctx* ctx, int on);
+/* Waits for the device, writes up to max records (one per dispatch since the last collect), returns the count. */
+int jh_profile_collect(jh_ctx* ctx, jh_profile_record* out, int max);
+
+/* ---- diagnostics (not used by the render path) ----
+ * Evaluates one of the kernels' scalar math routines on n host floats: op 0 sin, 1 cos, 2 atan2(a,b),
+ * 3 acos, 4 asin, 5 |a|^(2/3), 6 a/b, 7 sqrt, 8 round-to-even, 9 u32(a), 10 i32(a), 11 f32->f16 bits,
+ * 12 a*b+a (uncontracted), 13 floor(a*b+0.5). */
+int jh_selftest_math(jh_ctx* ctx, int op, const float* a, const float* b, float* out, uint32_t n);
+
+/* ---- introspection ---- */
+int jh_device_info(jh_ctx* ctx, char* name, int name_len, int* compute_units, uint64_t* total_mem);
+uint64_t jh_pool_bytes(jh_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JELLO_HIP_H */

@@ -1,0 +1,226 @@
+// dmath.h -- device arithmetic rules shared by every jello_amd kernel (gfx950).
+//
+// The kernels restate the reference WGSL (engine/wgpu_engine/shaders/original/*.wgsl).  WGSL
+// leaves the precision of transcendentals implementation-defined; to make results reproducible
+// bit-for-bit (run to run, and against the CPU checker) every kernel uses:
+//   * IEEE binary32 + - * / sqrt with no contraction (build flag -ffp-contract=off, correctly
+//     rounded divide/sqrt are hipcc's default);
+//   * WGSL-spec min/max/clamp/sign/mix/fract; round() = ties-to-even; saturating u32()/i32();
+//   * sin/cos/atan2/acos/asin/|x|^(2/3) evaluated in binary64 by the fixed operation sequences
+//     below (Cody-Waite + Taylor, table-split atan, Halley cbrt) and rounded once to binary32 --
+//     the same policy as the reference's Go twin, which rounds float64 libm (jmath/jmath.go:48-87).
+//     FP64 vector rate on MI355X is ample; flatten is not the bandwidth-bound stage.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define JD __device__ __forceinline__
+
+namespace jd {
+
+JD uint32_t f2u(float f) { return __float_as_uint(f); }
+JD float u2f(uint32_t u) { return __uint_as_float(u); }
+
+JD float fmin_(float a, float b) { return (b < a) ? b : a; }
+JD float fmax_(float a, float b) { return (a < b) ? b : a; }
+JD float clamp_(float x, float lo, float hi) { return fmin_(fmax_(x, lo), hi); }
+JD int32_t imin_(int32_t a, int32_t b) { return (b < a) ? b : a; }
+JD int32_t imax_(int32_t a, int32_t b) { return (a < b) ? b : a; }
+JD int32_t iclamp_(int32_t x, int32_t lo, int32_t hi) { return imin_(imax_(x, lo), hi); }
+JD uint32_t umin_(uint32_t a, uint32_t b) { return (b < a) ? b : a; }
+JD uint32_t umax_(uint32_t a, uint32_t b) { return (a < b) ? b : a; }
+JD float sign_(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+JD float abs_(float x) { return u2f(f2u(x) & 0x7fffffffu); }
+JD float floor_(float x) { return floorf(x); }
+JD float ceil_(float x) { return ceilf(x); }
+JD float round_(float x) { return rintf(x); }
+JD float sqrt_(float x) { return sqrtf(x); }
+JD float fract_(float x) { return x - floorf(x); }
+JD float mix_(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
+JD uint32_t to_u32(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+JD int32_t to_i32(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (int32_t)0x80000000;
+    return (int32_t)f;
+}
+
+// ---- binary64 kernels ----
+JD double reduce_pio2(double x, int* q) {
+    const double TWO_OVER_PI = 0.6366197723675814;
+    const double PIO2_1 = 1.57079632673412561417e+00;
+    const double PIO2_1T = 6.07710050650619224932e-11;
+    double k = rint(x * TWO_OVER_PI);
+    double r = (x - k * PIO2_1) - k * PIO2_1T;
+    *q = (int)((long long)k & 3);
+    return r;
+}
+JD double sin_poly(double r) {
+    double z = r * r;
+    double p = -1.0 / 1307674368000.0;
+    p = 1.0 / 6227020800.0 + z * p;
+    p = -1.0 / 39916800.0 + z * p;
+    p = 1.0 / 362880.0 + z * p;
+    p = -1.0 / 5040.0 + z * p;
+    p = 1.0 / 120.0 + z * p;
+    p = -1.0 / 6.0 + z * p;
+    return r + r * (z * p);
+}
+JD double cos_poly(double r) {
+    double z = r * r;
+    double p = 1.0 / 20922789888000.0;
+    p = -1.0 / 87178291200.0 + z * p;
+    p = 1.0 / 479001600.0 + z * p;
+    p = -1.0 / 3628800.0 + z * p;
+    p = 1.0 / 40320.0 + z * p;
+    p = -1.0 / 720.0 + z * p;
+    p = 1.0 / 24.0 + z * p;
+    p = -0.5 + z * p;
+    return 1.0 + z * p;
+}
+JD double dsin(double x) {
+    int q;
+    double r = reduce_pio2(x, &q);
+    double s = (q & 1) ? cos_poly(r) : sin_poly(r);
+    return (q & 2) ? -s : s;
+}
+JD double dcos(double x) {
+    int q;
+    double r = reduce_pio2(x, &q);
+    double c = (q & 1) ? sin_poly(r) : cos_poly(r);
+    return ((q + 1) & 2) ? -c : c;
+}
+JD double atan_tab(int k) {
+    // atan(k/8), k = 0..8; a switch keeps the table in SGPR/inline constants instead of scratch.
+    switch (k) {
+        case 0: return 0.0;
+        case 1: return 0.12435499454676144;
+        case 2: return 0.24497866312686414;
+        case 3: return 0.35877067027057225;
+        case 4: return 0.4636476090008061;
+        case 5: return 0.5585993153435624;
+        case 6: return 0.6435011087932844;
+        case 7: return 0.7188299996216245;
+        default: return 0.7853981633974483;
+    }
+}
+JD double datan01(double a) {
+    if (!(a >= 0.0 && a <= 1.0)) return a;
+    double kf = rint(a * 8.0);
+    int k = (int)kf;
+    double c = kf * 0.125;
+    double t = (a - c) / (1.0 + a * c);
+    double z = t * t;
+    double p = 1.0 / 13.0;
+    p = -1.0 / 11.0 + z * p;
+    p = 1.0 / 9.0 + z * p;
+    p = -1.0 / 7.0 + z * p;
+    p = 1.0 / 5.0 + z * p;
+    p = -1.0 / 3.0 + z * p;
+    return atan_tab(k) + (t + t * (z * p));
+}
+JD bool dsignbit(double x) { return (__double_as_longlong(x) >> 63) != 0; }
+JD double datan2(double y, double x) {
+    const double PI = 3.141592653589793;
+    const double PIO2 = 1.5707963267948966;
+    double ax = fabs(x), ay = fabs(y);
+    double r;
+    if (ax == 0.0 && ay == 0.0) {
+        r = 0.0;
+    } else if (ay <= ax) {
+        r = datan01(ay / ax);
+    } else {
+        r = PIO2 - datan01(ax / ay);
+    }
+    if (dsignbit(x)) r = PI - r;
+    return dsignbit(y) ? -r : r;
+}
+JD double dacos(double x) { return datan2(sqrt((1.0 - x) * (1.0 + x)), x); }
+JD double dasin(double x) { return datan2(x, sqrt((1.0 - x) * (1.0 + x))); }
+JD double dcbrt_pos(double x) {
+    uint64_t hx = (uint64_t)__double_as_longlong(x) >> 32;
+    double t = __longlong_as_double((long long)((uint64_t)(hx / 3u + 715094163u) << 32));
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double t3 = t * t * t;
+        t = t * ((t3 + (x + x)) / ((t3 + t3) + x));
+    }
+    return t;
+}
+JD double dpow23(double ax) {
+    if (ax == 0.0) return 0.0;
+    double c = dcbrt_pos(ax);
+    return c * c;
+}
+
+JD float sin_(float x) { return (float)dsin((double)x); }
+JD float cos_(float x) { return (float)dcos((double)x); }
+JD float atan2_(float y, float x) { return (float)datan2((double)y, (double)x); }
+JD float acos_(float x) { return (float)dacos((double)x); }
+JD float asin_(float x) { return (float)dasin((double)x); }
+JD float pow23_abs_(float x) { return (float)dpow23((double)abs_(x)); }
+
+// binary16 <-> binary32 (hardware v_cvt, RTNE)
+JD float f16_to_f32(uint16_t h) {
+    union { uint16_t u; _Float16 f; } c;
+    c.u = h;
+    return (float)c.f;
+}
+JD uint16_t f32_to_f16(float f) {
+    union { uint16_t u; _Float16 h; } c;
+    c.h = (_Float16)f;
+    return c.u;
+}
+
+struct V2 {
+    float x, y;
+};
+JD V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
+JD V2 operator+(V2 a, V2 b) { return v2(a.x + b.x, a.y + b.y); }
+JD V2 operator-(V2 a, V2 b) { return v2(a.x - b.x, a.y - b.y); }
+JD V2 operator*(V2 a, float s) { return v2(a.x * s, a.y * s); }
+JD V2 operator*(float s, V2 a) { return v2(s * a.x, s * a.y); }
+JD V2 operator-(V2 a) { return v2(-a.x, -a.y); }
+JD float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+JD float length(V2 a) { return sqrt_(a.x * a.x + a.y * a.y); }
+JD V2 normalize(V2 a) { float l = length(a); return v2(a.x / l, a.y / l); }
+JD V2 vmix(V2 a, V2 b, float t) { return v2(mix_(a.x, b.x, t), mix_(a.y, b.y, t)); }
+JD bool veq(V2 a, V2 b) { return a.x == b.x && a.y == b.y; }
+
+struct Xf {  // shared/transform.wgsl Transform
+    float m0, m1, m2, m3, t0, t1;
+};
+JD V2 xf_apply(const Xf& t, V2 p) { return v2(t.m0 * p.x + t.m2 * p.y + t.t0, t.m1 * p.x + t.m3 * p.y + t.t1); }
+JD Xf xf_identity() { Xf r; r.m0 = 1.0f; r.m1 = 0.0f; r.m2 = 0.0f; r.m3 = 1.0f; r.t0 = 0.0f; r.t1 = 0.0f; return r; }
+JD Xf xf_inverse(const Xf& t) {
+    float inv_det = 1.0f / (t.m0 * t.m3 - t.m1 * t.m2);
+    Xf r;
+    r.m0 = inv_det * t.m3; r.m1 = inv_det * -t.m1; r.m2 = inv_det * -t.m2; r.m3 = inv_det * t.m0;
+    float ntx = -t.t0, nty = -t.t1;
+    r.t0 = r.m0 * ntx + r.m2 * nty;
+    r.t1 = r.m1 * ntx + r.m3 * nty;
+    return r;
+}
+JD Xf xf_mul(const Xf& a, const Xf& b) {
+    Xf r;
+    r.m0 = a.m0 * b.m0 + a.m2 * b.m1;
+    r.m1 = a.m1 * b.m0 + a.m3 * b.m1;
+    r.m2 = a.m0 * b.m2 + a.m2 * b.m3;
+    r.m3 = a.m1 * b.m2 + a.m3 * b.m3;
+    r.t0 = a.m0 * b.t0 + a.m2 * b.t1 + a.t0;
+    r.t1 = a.m1 * b.t0 + a.m3 * b.t1 + a.t1;
+    return r;
+}
+JD Xf xf_read(const uint32_t* scene, uint32_t transform_base, uint32_t ix) {
+    const uint32_t* p = scene + transform_base + ix * 6u;
+    Xf r;
+    r.m0 = u2f(p[0]); r.m1 = u2f(p[1]); r.m2 = u2f(p[2]); r.m3 = u2f(p[3]); r.t0 = u2f(p[4]); r.t1 = u2f(p[5]);
+    return r;
+}
+
+}  // namespace jd

@@ -1,0 +1,222 @@
+// kcommon.h -- shared device helpers: bounds-checked buffer views (the WGSL robust-access rule:
+// out-of-range reads give zero, writes are dropped -- also what keeps a malformed scene from
+// faulting the GPU), wave64/LDS block scans, and the launcher declarations used by jello_hip.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/jello_formats.h"
+#include "dmath.h"
+
+#define JL_WG 256
+
+namespace jk {
+
+template <typename T>
+struct Buf {
+    T* p;
+    uint32_t n;  // element count
+    JD T rd(uint32_t i) const {
+        if (i < n) return p[i];
+        T z;
+        __builtin_memset(&z, 0, sizeof(T));
+        return z;
+    }
+    JD void wr(uint32_t i, const T& v) const {
+        if (i < n) p[i] = v;
+    }
+    JD bool ok(uint32_t i) const { return i < n; }
+};
+
+template <typename T>
+static inline Buf<T> mkbuf(void* p, uint64_t bytes) {
+    Buf<T> b;
+    b.p = (T*)p;
+    uint64_t n = bytes / sizeof(T);
+    b.n = n > 0xffffffffull ? 0xffffffffu : (uint32_t)n;
+    return b;
+}
+
+// ---- wave64 primitives ----
+JD uint32_t lane_id() { return threadIdx.x & 63u; }
+JD uint32_t wave_incl_scan_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if (lane_id() >= (uint32_t)o) v += t;
+    }
+    return v;
+}
+JD uint32_t wave_reduce_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Exclusive scan of one u32 per thread across a 256-thread block.  `sh` needs 5 words.
+// Returns the exclusive prefix; *total receives the block sum.
+JD uint32_t block_excl_scan_u32(uint32_t v, uint32_t* sh, uint32_t* total) {
+    uint32_t incl = wave_incl_scan_u32(v);
+    uint32_t w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane_id() == 63u) sh[w] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+        uint32_t s = sh[i];
+        if (i < w) base += s;
+    }
+    *total = sh[0] + sh[1] + sh[2] + sh[3];
+    return base + incl - v;
+}
+
+// K-word monoid (component-wise u32 add): exclusive block scan.  sh needs 4*K words.
+template <int K>
+struct MonoidK {
+    uint32_t v[K];
+};
+template <int K>
+JD MonoidK<K> monoid_add(const MonoidK<K>& a, const MonoidK<K>& b) {
+    MonoidK<K> c;
+#pragma unroll
+    for (int i = 0; i < K; i++) c.v[i] = a.v[i] + b.v[i];
+    return c;
+}
+template <int K>
+JD MonoidK<K> block_excl_scan_monoid(const MonoidK<K>& in, uint32_t* sh, MonoidK<K>* total) {
+    MonoidK<K> incl = in;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            uint32_t t = __shfl_up(incl.v[i], o, 64);
+            if (lane_id() >= (uint32_t)o) incl.v[i] += t;
+        }
+    }
+    uint32_t w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane_id() == 63u) {
+#pragma unroll
+        for (int i = 0; i < K; i++) sh[w * K + i] = incl.v[i];
+    }
+    __syncthreads();
+    MonoidK<K> out, tot;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        uint32_t base = 0, t = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            uint32_t s = sh[j * K + i];
+            if (j < w) base += s;
+            t += s;
+        }
+        out.v[i] = base + incl.v[i] - in.v[i];
+        tot.v[i] = t;
+    }
+    *total = tot;
+    return out;
+}
+template <int K>
+JD MonoidK<K> block_reduce_monoid(const MonoidK<K>& in, uint32_t* sh) {
+    MonoidK<K> r = in;
+#pragma unroll
+    for (int i = 0; i < K; i++) r.v[i] = wave_reduce_u32(r.v[i]);
+    uint32_t w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane_id() == 0u) {
+#pragma unroll
+        for (int i = 0; i < K; i++) sh[w * K + i] = r.v[i];
+    }
+    __syncthreads();
+    MonoidK<K> t;
+#pragma unroll
+    for (int i = 0; i < K; i++) t.v[i] = sh[i] + sh[K + i] + sh[2 * K + i] + sh[3 * K + i];
+    return t;
+}
+
+// shared/pathtag.wgsl:58-71
+JD MonoidK<5> reduce_tag(uint32_t tag_word) {
+    MonoidK<5> c;
+    uint32_t point_count = tag_word & 0x3030303u;
+    c.v[1] = __popc((point_count * 7u) & 0x4040404u);          // pathseg_ix
+    c.v[0] = __popc(tag_word & (0x20u * 0x1010101u));           // trans_ix
+    uint32_t n_points = point_count + ((tag_word >> 2) & 0x1010101u);
+    uint32_t a = n_points + (n_points & (((tag_word >> 3) & 0x1010101u) * 15u));
+    a += a >> 8;
+    a += a >> 16;
+    c.v[2] = a & 0xffu;                                          // pathseg_offset
+    c.v[4] = __popc(tag_word & (0x10u * 0x1010101u));            // path_ix
+    c.v[3] = __popc(tag_word & (0x40u * 0x1010101u)) * 2u;       // style_ix
+    return c;
+}
+// shared/drawtag.wgsl:46-53
+JD MonoidK<4> map_draw_tag(uint32_t t) {
+    MonoidK<4> c;
+    c.v[0] = (t != 0u) ? 1u : 0u;
+    c.v[1] = t & 1u;
+    c.v[2] = (t >> 2) & 7u;
+    c.v[3] = (t >> 6) & 0xfu;
+    return c;
+}
+
+}  // namespace jk
+
+// ------------------------------------------------------------------------------------------------
+// Host-side launcher interface (implemented in the kernels_*.hip files, called by jello_hip.cpp)
+// ------------------------------------------------------------------------------------------------
+struct JhBound {
+    void* ptr;
+    uint64_t size;  // bytes
+    uint32_t width, height;
+    int format;
+};
+
+struct JhScratch;  // per-context scratch allocator, defined in jello_hip.cpp
+void* jh_scratch_get(JhScratch* s, int slot, uint64_t bytes);  // grows on demand, returns device pointer (nullptr on OOM)
+
+struct JhLaunch {
+    hipStream_t stream;
+    JhScratch* scratch;
+    uint32_t gx, gy, gz;
+    const JhBound* b;
+    int nb;
+    const JhBound* images;  // JH_BIND_IMAGE_ARRAY contents for fine
+    int n_images;
+    const uint32_t* indirect;  // device pointer to IndirectCount (indirect dispatch) or nullptr
+    int num_cus;
+};
+
+enum {  // scratch slots
+    JH_SCR_SCAN_TMP = 0,
+    JH_SCR_A = 1,
+    JH_SCR_B = 2,
+    JH_SCR_C = 3,
+    JH_SCR_D = 4,
+    JH_SCR_E = 5,
+    JH_SCR_F = 6,
+    JH_SCR_COUNT = 8
+};
+
+// Generic device-side exclusive scan of u32 (stride in words between consecutive inputs).
+// n is read from *n_dev when n_dev != nullptr (clamped to n_max), else n_max.  Writes out[0..n) and
+// *total_dev (if non-null).  Three launches, no inter-workgroup spinning.
+int jh_scan_u32(const JhLaunch& L, const uint32_t* in, uint32_t in_stride, uint32_t* out, uint32_t n_max, const uint32_t* n_dev,
+                uint32_t* total_dev);
+
+int jh_launch_pathtag(const JhLaunch& L, int stage);
+int jh_launch_bbox_clear(const JhLaunch& L);
+int jh_launch_flatten(const JhLaunch& L);
+int jh_launch_draw_reduce(const JhLaunch& L);
+int jh_launch_draw_leaf(const JhLaunch& L);
+int jh_launch_clip_reduce(const JhLaunch& L);
+int jh_launch_clip_leaf(const JhLaunch& L);
+int jh_launch_binning(const JhLaunch& L);
+int jh_launch_tile_alloc(const JhLaunch& L);
+int jh_launch_path_count_setup(const JhLaunch& L);
+int jh_launch_path_count(const JhLaunch& L);
+int jh_launch_backdrop_dyn(const JhLaunch& L);
+int jh_launch_coarse(const JhLaunch& L);
+int jh_launch_path_tiling_setup(const JhLaunch& L);
+int jh_launch_path_tiling(const JhLaunch& L);
+int jh_launch_fine_area(const JhLaunch& L);

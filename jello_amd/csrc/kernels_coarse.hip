@@ -1,0 +1,383 @@
+// kernels_coarse.hip -- K16 coarse (orig/coarse.wgsl:153-462): per 256x256-px bin, merge the binned
+// draw objects in draw order, decide per 16x16 tile which of them touch it, and emit the per-tile
+// command list (PTCL, shared/ptcl.wgsl) that fine interprets.
+//
+// MI355X design: the WGSL hands out segment slices, 256-word PTCL chunks and blend-spill space with
+// atomicAdd, so seg_data / JUMP targets / blend_ix differ from run to run.  Here coarse runs twice
+// over the same templated body:
+//   k_coarse<false>  walks every tile's command stream WITHOUT writing it and records, per tile,
+//                    the segments, PTCL chunk words and blend-spill pixels it will need;
+//   3 exclusive scans in (bin, tile-in-bin) order -- the order of the reference's sequential twin
+//                    (shaders/cpu/cpu.go:1096-1270) -- give every tile its bases, totals land in
+//                    bump.{segments,ptcl,blend};
+//   k_coarse<true>   walks again and writes PTCL + ~seg_ix with those bases.
+// => bit-identical PTCL on every run.  One 256-thread workgroup per bin, one thread per tile, bin
+// bitmaps (8 x 256 u32) and per-draw tile rectangles staged in 16 KiB of LDS, as in the WGSL.
+// Algorithmic bytes: 4 B per (draw,bin) bin_data + 32 B Path + 8 B Tile per (draw,tile) + PTCL out.
+#include "kcommon.h"
+
+using namespace jk;
+using namespace jd;
+
+namespace {
+
+struct Cmd {
+    const JlConfig* cfg;
+    JlBump* bump;
+    Buf<uint32_t> ptcl;
+    uint32_t cmd_offset, cmd_limit;
+    uint32_t chunk_base;   // word offset (relative to ptcl_dyn_start) of this tile's first chunk
+    uint32_t chunk_words;  // PTCL words of dynamic chunks taken so far
+    uint32_t seg_base, seg_used;
+};
+
+template <bool WRITE>
+JD void alloc_cmd(Cmd& c, uint32_t size) {  // coarse.wgsl:70-88
+    if (c.cmd_offset + size >= c.cmd_limit) {
+        uint32_t ptcl_dyn_start = c.cfg->width_in_tiles * c.cfg->height_in_tiles * JL_PTCL_INITIAL_ALLOC;
+        uint32_t new_cmd = ptcl_dyn_start + c.chunk_base + c.chunk_words;
+        c.chunk_words += JL_PTCL_INCREMENT;
+        if (WRITE) {
+            if (new_cmd + JL_PTCL_INCREMENT > c.cfg->ptcl_size) {
+                new_cmd = 0u;
+                atomicOr(&c.bump->failed, (uint32_t)JL_STAGE_COARSE);
+            }
+            c.ptcl.wr(c.cmd_offset, JL_CMD_JUMP);
+            c.ptcl.wr(c.cmd_offset + 1u, new_cmd);
+        }
+        c.cmd_offset = new_cmd;
+        c.cmd_limit = c.cmd_offset + (JL_PTCL_INCREMENT - JL_PTCL_HEADROOM);
+    }
+}
+
+template <bool WRITE>
+JD void write_path(Cmd& c, const Buf<JlTile>& tiles, JlTile tile, uint32_t tile_ix, uint32_t draw_flags) {  // coarse.wgsl:90-112
+    uint32_t n_segs = tile.segment_count_or_ix;
+    if (n_segs != 0u) {
+        uint32_t seg_ix = c.seg_base + c.seg_used;
+        c.seg_used += n_segs;
+        alloc_cmd<WRITE>(c, 4u);
+        if (WRITE) {
+            if (tiles.ok(tile_ix)) tiles.p[tile_ix].segment_count_or_ix = ~seg_ix;
+            bool even_odd = (draw_flags & 1u) != 0u;
+            c.ptcl.wr(c.cmd_offset, JL_CMD_FILL);
+            c.ptcl.wr(c.cmd_offset + 1u, (n_segs << 1) | (even_odd ? 1u : 0u));
+            c.ptcl.wr(c.cmd_offset + 2u, seg_ix);
+            c.ptcl.wr(c.cmd_offset + 3u, (uint32_t)tile.backdrop);
+        }
+        c.cmd_offset += 4u;
+    } else {
+        alloc_cmd<WRITE>(c, 1u);
+        if (WRITE) c.ptcl.wr(c.cmd_offset, JL_CMD_SOLID);
+        c.cmd_offset += 1u;
+    }
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlDrawMonoid> draw_monoids,
+                                                  Buf<JlBinHeader> bin_headers, Buf<uint32_t> info_bin_data, Buf<JlPath> paths, Buf<JlTile> tiles,
+                                                  JlBump* __restrict__ bump, Buf<uint32_t> ptcl, uint32_t* __restrict__ cnt_seg,
+                                                  uint32_t* __restrict__ cnt_chunk, uint32_t* __restrict__ cnt_blend,
+                                                  const uint32_t* __restrict__ base_seg, const uint32_t* __restrict__ base_chunk,
+                                                  const uint32_t* __restrict__ base_blend) {
+    __shared__ uint32_t sh_bitmaps[8][JL_N_TILE];
+    __shared__ uint32_t sh_part_count[JL_WG];
+    __shared__ uint32_t sh_part_offsets[JL_WG];
+    __shared__ uint32_t sh_drawobj_ix[JL_WG];
+    __shared__ uint32_t sh_tile_stride[JL_WG];
+    __shared__ uint32_t sh_tile_width[JL_WG];
+    __shared__ uint32_t sh_tile_x0y0[JL_WG];
+    __shared__ uint32_t sh_tile_count[JL_WG];
+    __shared__ uint32_t sh_tile_base[JL_WG];
+    __shared__ uint32_t sh_scan[8];
+
+    const uint32_t lid = threadIdx.x;
+    const uint32_t width_in_bins = (cfg->width_in_tiles + JL_N_TILE_X - 1u) / JL_N_TILE_X;
+    const uint32_t bin_ix = width_in_bins * blockIdx.y + blockIdx.x;
+    const uint32_t slot = bin_ix * JL_N_TILE + lid;  // position in the canonical (bin, tile) order
+
+    {  // coarse.wgsl:161-176
+        uint32_t failed = bump->failed & (JL_STAGE_BINNING | JL_STAGE_TILE_ALLOC | JL_STAGE_FLATTEN);
+        if (bump->seg_counts > cfg->seg_counts_size) failed |= JL_STAGE_PATH_COUNT;
+        if (failed != 0u) {
+            if (WRITE) {
+                if (blockIdx.x == 0u && blockIdx.y == 0u && lid == 0u) atomicOr(&bump->failed, failed);
+            } else {
+                cnt_seg[slot] = 0u; cnt_chunk[slot] = 0u; cnt_blend[slot] = 0u;
+            }
+            return;
+        }
+    }
+    const uint32_t n_partitions = (cfg->layout.n_drawobj + JL_N_TILE - 1u) / JL_N_TILE;
+    const uint32_t bin_tile_x = JL_N_TILE_X * blockIdx.x;
+    const uint32_t bin_tile_y = JL_N_TILE_Y * blockIdx.y;
+    const uint32_t tile_x = lid % JL_N_TILE_X;
+    const uint32_t tile_y = lid / JL_N_TILE_X;
+    const uint32_t this_tile_ix = (bin_tile_y + tile_y) * cfg->width_in_tiles + bin_tile_x + tile_x;
+    const uint32_t BLEND_CLIP = (128u << 8) | 0u;  // MIX_CLIP << 8 | COMPOSE_SRC_OVER (Jello numbering, blend.wgsl:199-202)
+
+    Cmd c;
+    c.cfg = cfg; c.bump = bump; c.ptcl = ptcl;
+    c.cmd_offset = this_tile_ix * JL_PTCL_INITIAL_ALLOC;
+    c.cmd_limit = c.cmd_offset + (JL_PTCL_INITIAL_ALLOC - JL_PTCL_HEADROOM);
+    c.chunk_base = WRITE ? base_chunk[slot] : 0u;
+    c.chunk_words = 0u;
+    c.seg_base = WRITE ? base_seg[slot] : 0u;
+    c.seg_used = 0u;
+
+    uint32_t clip_zero_depth = 0u, clip_depth = 0u;
+    uint32_t partition_ix = 0u, rd_ix = 0u, wr_ix = 0u, part_start_ix = 0u, ready_ix = 0u;
+    uint32_t render_blend_depth = 0u, max_blend_depth = 0u;
+    const uint32_t blend_offset = c.cmd_offset;
+    c.cmd_offset += 1u;
+
+    for (;;) {
+        for (uint32_t i = 0; i < 8u; i++) sh_bitmaps[i][lid] = 0u;
+        for (;;) {
+            if (ready_ix == wr_ix && partition_ix < n_partitions) {
+                part_start_ix = ready_ix;
+                uint32_t count = 0u;
+                if (partition_ix + lid < n_partitions) {
+                    uint32_t in_ix = (partition_ix + lid) * JL_N_TILE + bin_ix;
+                    JlBinHeader bh = bin_headers.rd(in_ix);
+                    count = bh.element_count;
+                    sh_part_offsets[lid] = bh.chunk_offset;
+                }
+                uint32_t tot;
+                uint32_t excl = block_excl_scan_u32(count, sh_scan, &tot);
+                sh_part_count[lid] = part_start_ix + excl + count;
+                __syncthreads();
+                ready_ix = sh_part_count[JL_WG - 1u];
+                partition_ix += JL_WG;
+            }
+            uint32_t ix = rd_ix + lid;
+            if (ix >= wr_ix && ix < ready_ix) {
+                uint32_t part_ix = 0u;
+                for (uint32_t i = 0; i < 8u; i++) {
+                    uint32_t probe = part_ix + (128u >> i);
+                    if (ix >= sh_part_count[probe - 1u]) part_ix = probe;
+                }
+                ix -= (part_ix > 0u) ? sh_part_count[part_ix - 1u] : part_start_ix;
+                uint32_t offset = cfg->layout.bin_data_start + sh_part_offsets[part_ix];
+                sh_drawobj_ix[lid] = info_bin_data.rd(offset + ix);
+            }
+            wr_ix = umin_(rd_ix + JL_N_TILE, ready_ix);
+            if (wr_ix - rd_ix >= JL_N_TILE || (wr_ix >= ready_ix && partition_ix >= n_partitions)) break;
+            __syncthreads();
+        }
+        // sh_drawobj_ix[0 .. wr_ix - rd_ix) holds the merged binning results of this batch.
+        uint32_t tag = JL_DRAWTAG_NOP;
+        uint32_t drawobj_ix = 0u;
+        if (lid + rd_ix < wr_ix) {
+            drawobj_ix = sh_drawobj_ix[lid];
+            tag = scene.rd(cfg->layout.drawtag_base + drawobj_ix);
+        }
+        uint32_t tile_count = 0u;
+        if (tag != JL_DRAWTAG_NOP) {
+            uint32_t path_ix = draw_monoids.rd(drawobj_ix).path_ix;
+            JlPath path = paths.rd(path_ix);
+            uint32_t stride = path.bbox[2] - path.bbox[0];
+            sh_tile_stride[lid] = stride;
+            int32_t dx = (int32_t)path.bbox[0] - (int32_t)bin_tile_x;
+            int32_t dy = (int32_t)path.bbox[1] - (int32_t)bin_tile_y;
+            int32_t x0 = iclamp_(dx, 0, JL_N_TILE_X);
+            int32_t y0 = iclamp_(dy, 0, JL_N_TILE_Y);
+            int32_t x1 = iclamp_((int32_t)path.bbox[2] - (int32_t)bin_tile_x, 0, JL_N_TILE_X);
+            int32_t y1 = iclamp_((int32_t)path.bbox[3] - (int32_t)bin_tile_y, 0, JL_N_TILE_Y);
+            sh_tile_width[lid] = (uint32_t)(x1 - x0);
+            sh_tile_x0y0[lid] = (uint32_t)x0 | ((uint32_t)y0 << 16);
+            tile_count = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
+            sh_tile_base[lid] = path.tiles - (uint32_t)(dy * (int32_t)stride + dx);
+        }
+        uint32_t total_tile_count;
+        uint32_t excl_tc = block_excl_scan_u32(tile_count, sh_scan, &total_tile_count);
+        sh_tile_count[lid] = excl_tc + tile_count;
+        __syncthreads();
+        for (uint32_t ix = lid; ix < total_tile_count; ix += JL_N_TILE) {
+            uint32_t el_ix = 0u;
+            for (uint32_t i = 0; i < 8u; i++) {
+                uint32_t probe = el_ix + (128u >> i);
+                if (ix >= sh_tile_count[probe - 1u]) el_ix = probe;
+            }
+            uint32_t d_ix = sh_drawobj_ix[el_ix];
+            uint32_t d_tag = scene.rd(cfg->layout.drawtag_base + d_ix);
+            uint32_t seq_ix = ix - (el_ix > 0u ? sh_tile_count[el_ix - 1u] : 0u);
+            uint32_t width = sh_tile_width[el_ix];
+            uint32_t x0y0 = sh_tile_x0y0[el_ix];
+            uint32_t x = (x0y0 & 0xffffu) + seq_ix % width;
+            uint32_t y = (x0y0 >> 16) + seq_ix / width;
+            uint32_t tile_ix = sh_tile_base[el_ix] + sh_tile_stride[el_ix] * y + x;
+            JlTile tile = tiles.rd(tile_ix);
+            bool is_clip = (d_tag & 1u) != 0u;
+            bool is_blend = false;
+            JlDrawMonoid dm = draw_monoids.rd(d_ix);
+            if (is_clip) {
+                uint32_t blend = scene.rd(cfg->layout.drawdata_base + dm.scene_offset);
+                is_blend = blend != BLEND_CLIP;
+            }
+            uint32_t draw_flags = info_bin_data.rd(dm.info_offset);
+            bool even_odd = (draw_flags & 1u) != 0u;
+            uint32_t n_segs = tile.segment_count_or_ix;
+            int32_t bd = tile.backdrop;
+            int32_t absbd = bd < 0 ? (int32_t)(0u - (uint32_t)bd) : bd;
+            bool backdrop_clear = (even_odd ? (absbd & 1) : bd) == 0;
+            bool include_tile = n_segs != 0u || (backdrop_clear == is_clip) || is_blend;
+            if (include_tile) {
+                uint32_t el_slice = el_ix / 32u;
+                uint32_t el_mask = 1u << (el_ix & 31u);
+                atomicOr(&sh_bitmaps[el_slice][y * JL_N_TILE_X + x], el_mask);
+            }
+        }
+        __syncthreads();
+        // Write the per-tile command list for this tile (coarse.wgsl:344-444)
+        uint32_t slice_ix = 0u;
+        uint32_t bitmap = sh_bitmaps[0][lid];
+        for (;;) {
+            if (bitmap == 0u) {
+                slice_ix += 1u;
+                if (slice_ix == 8u) break;
+                bitmap = sh_bitmaps[slice_ix][lid];
+                if (bitmap == 0u) continue;
+            }
+            uint32_t el_ix = slice_ix * 32u + (uint32_t)__builtin_ctz(bitmap);
+            uint32_t d_ix = sh_drawobj_ix[el_ix];
+            bitmap &= bitmap - 1u;
+            uint32_t drawtag = scene.rd(cfg->layout.drawtag_base + d_ix);
+            JlDrawMonoid dm = draw_monoids.rd(d_ix);
+            uint32_t dd = cfg->layout.drawdata_base + dm.scene_offset;
+            uint32_t di = dm.info_offset;
+            uint32_t draw_flags = info_bin_data.rd(di);
+            if (clip_zero_depth == 0u) {
+                uint32_t tile_ix = sh_tile_base[el_ix] + sh_tile_stride[el_ix] * tile_y + tile_x;
+                JlTile tile = tiles.rd(tile_ix);
+                switch (drawtag) {
+                    case JL_DRAWTAG_FILL_COLOR: {
+                        write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);
+                        alloc_cmd<WRITE>(c, 5u);
+                        if (WRITE) {
+                            c.ptcl.wr(c.cmd_offset, JL_CMD_COLOR);
+                            c.ptcl.wr(c.cmd_offset + 1u, scene.rd(dd));
+                            c.ptcl.wr(c.cmd_offset + 2u, scene.rd(dd + 1u));
+                            c.ptcl.wr(c.cmd_offset + 3u, scene.rd(dd + 2u));
+                            c.ptcl.wr(c.cmd_offset + 4u, scene.rd(dd + 3u));
+                        }
+                        c.cmd_offset += 5u;
+                        break;
+                    }
+                    case JL_DRAWTAG_FILL_LIN_GRADIENT:
+                    case JL_DRAWTAG_FILL_RAD_GRADIENT:
+                    case JL_DRAWTAG_FILL_SWEEP_GRADIENT: {
+                        write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);
+                        alloc_cmd<WRITE>(c, 3u);
+                        if (WRITE) {
+                            uint32_t ty = drawtag == JL_DRAWTAG_FILL_LIN_GRADIENT ? JL_CMD_LIN_GRAD
+                                          : (drawtag == JL_DRAWTAG_FILL_RAD_GRADIENT ? JL_CMD_RAD_GRAD : JL_CMD_SWEEP_GRAD);
+                            c.ptcl.wr(c.cmd_offset, ty);
+                            c.ptcl.wr(c.cmd_offset + 1u, scene.rd(dd));
+                            c.ptcl.wr(c.cmd_offset + 2u, di + 1u);
+                        }
+                        c.cmd_offset += 3u;
+                        break;
+                    }
+                    case JL_DRAWTAG_FILL_IMAGE: {
+                        write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);
+                        alloc_cmd<WRITE>(c, 2u);
+                        if (WRITE) {
+                            c.ptcl.wr(c.cmd_offset, JL_CMD_IMAGE);
+                            c.ptcl.wr(c.cmd_offset + 1u, di + 1u);
+                        }
+                        c.cmd_offset += 2u;
+                        break;
+                    }
+                    case JL_DRAWTAG_BEGIN_CLIP: {
+                        if (tile.segment_count_or_ix == 0u && tile.backdrop == 0) {
+                            clip_zero_depth = clip_depth + 1u;
+                        } else {
+                            alloc_cmd<WRITE>(c, 1u);
+                            if (WRITE) c.ptcl.wr(c.cmd_offset, JL_CMD_BEGIN_CLIP);
+                            c.cmd_offset += 1u;
+                            render_blend_depth += 1u;
+                            max_blend_depth = umax_(max_blend_depth, render_blend_depth);
+                        }
+                        clip_depth += 1u;
+                        break;
+                    }
+                    case JL_DRAWTAG_END_CLIP: {
+                        clip_depth -= 1u;
+                        write_path<WRITE>(c, tiles, tile, tile_ix, 0u);
+                        alloc_cmd<WRITE>(c, 3u);
+                        if (WRITE) {
+                            c.ptcl.wr(c.cmd_offset, JL_CMD_END_CLIP);
+                            c.ptcl.wr(c.cmd_offset + 1u, scene.rd(dd));
+                            c.ptcl.wr(c.cmd_offset + 2u, scene.rd(dd + 1u));
+                        }
+                        c.cmd_offset += 3u;
+                        render_blend_depth -= 1u;
+                        break;
+                    }
+                    default: break;
+                }
+            } else {
+                if (drawtag == JL_DRAWTAG_BEGIN_CLIP) {
+                    clip_depth += 1u;
+                } else if (drawtag == JL_DRAWTAG_END_CLIP) {
+                    if (clip_depth == clip_zero_depth) clip_zero_depth = 0u;
+                    clip_depth -= 1u;
+                }
+            }
+        }
+        rd_ix += JL_N_TILE;
+        if (rd_ix >= ready_ix && partition_ix >= n_partitions) break;
+        __syncthreads();
+    }
+    uint32_t scratch_size = 0u;
+    bool in_target = bin_tile_x + tile_x < cfg->width_in_tiles && bin_tile_y + tile_y < cfg->height_in_tiles;
+    if (in_target && max_blend_depth > JL_BLEND_STACK_SPLIT) scratch_size = (max_blend_depth - JL_BLEND_STACK_SPLIT) * JL_TILE_WIDTH * JL_TILE_HEIGHT;
+    if (WRITE) {
+        if (in_target) {
+            c.ptcl.wr(c.cmd_offset, JL_CMD_END);
+            uint32_t blend_ix = 0u;
+            if (scratch_size != 0u) {
+                blend_ix = base_blend[slot];
+                if (blend_ix + scratch_size > cfg->blend_size) atomicOr(&bump->failed, (uint32_t)JL_STAGE_COARSE);
+            }
+            c.ptcl.wr(blend_offset, blend_ix);
+        }
+    } else {
+        cnt_seg[slot] = c.seg_used;
+        cnt_chunk[slot] = c.chunk_words;
+        cnt_blend[slot] = scratch_size;
+    }
+}
+
+}  // namespace
+
+// [config, scene, draw_monoids, bin_headers, info_bin_data, paths, tiles, bump, ptcl]
+int jh_launch_coarse(const JhLaunch& L) {
+    if (L.nb < 9) return -1;
+    if (L.gx == 0 || L.gy == 0) return 0;
+    uint32_t n = L.gx * L.gy * JL_N_TILE;
+    uint32_t* scr = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)n * 4 * 6);
+    if (!scr) return -5;
+    uint32_t *cnt_seg = scr, *cnt_chunk = scr + n, *cnt_blend = scr + 2 * (size_t)n;
+    uint32_t *base_seg = scr + 3 * (size_t)n, *base_chunk = scr + 4 * (size_t)n, *base_blend = scr + 5 * (size_t)n;
+    auto cfg = (const JlConfig*)L.b[0].ptr;
+    auto scene = mkbuf<uint32_t>(L.b[1].ptr, L.b[1].size);
+    auto dm = mkbuf<JlDrawMonoid>(L.b[2].ptr, L.b[2].size);
+    auto bh = mkbuf<JlBinHeader>(L.b[3].ptr, L.b[3].size);
+    auto ibd = mkbuf<uint32_t>(L.b[4].ptr, L.b[4].size);
+    auto paths = mkbuf<JlPath>(L.b[5].ptr, L.b[5].size);
+    auto tiles = mkbuf<JlTile>(L.b[6].ptr, L.b[6].size);
+    JlBump* bump = (JlBump*)L.b[7].ptr;
+    auto ptcl = mkbuf<uint32_t>(L.b[8].ptr, L.b[8].size);
+    dim3 grid(L.gx, L.gy), blk(JL_WG);
+    hipLaunchKernelGGL(k_coarse<false>, grid, blk, 0, L.stream, cfg, scene, dm, bh, ibd, paths, tiles, bump, ptcl, cnt_seg, cnt_chunk, cnt_blend,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    int rc = jh_scan_u32(L, cnt_seg, 1, base_seg, n, nullptr, &bump->segments);
+    if (!rc) rc = jh_scan_u32(L, cnt_chunk, 1, base_chunk, n, nullptr, &bump->ptcl);
+    if (!rc) rc = jh_scan_u32(L, cnt_blend, 1, base_blend, n, nullptr, &bump->blend);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_coarse<true>, grid, blk, 0, L.stream, cfg, scene, dm, bh, ibd, paths, tiles, bump, ptcl, (uint32_t*)nullptr,
+                       (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend);
+    return 0;
+}

@@ -1,0 +1,657 @@
+// kernels_flatten.hip -- K6 flatten (orig/flatten.wgsl:46-901): one thread per path-tag byte;
+// Euler-spiral subdivision of fills, GPU stroke expansion (offset curves, caps, joins, arcs).
+//
+// MI355X design: the WGSL allocates every output line with atomicAdd(bump.lines), which makes the
+// LineSoup order run-dependent.  Here the stage is count -> exclusive scan -> emit:
+//   pass 1  k_flatten<false>  each thread runs the subdivision logic and only COUNTS its lines
+//                              (no per-line point evaluation, no stores except one u32);
+//   scan    jh_scan_u32        line base per tag byte; the total lands in bump.lines;
+//   pass 2  k_flatten<true>   same arithmetic, lines stored at base+k, path bbox via atomicMin/Max
+//                              (commutative, so deterministic).
+// Result: lines are ordered by (tag byte, emission order) -- the reference's own sequential order
+// (shaders/cpu/flatten.go:664-823).  Algorithmic traffic: scene bytes + 20 B / tag word in,
+// 24 B / line out.  The stage is ALU/latency-bound (f64 transcendentals, divergent trip counts).
+#include "kcommon.h"
+
+using namespace jk;
+using namespace jd;
+
+namespace {
+
+struct CubicParams { float th0, th1, chord_len, err; };
+struct EulerParams { float th0, th1, k0, k1, ch; };
+struct CubicPoints { V2 p0, p1, p2, p3; };
+struct PointDeriv { V2 point, deriv; };
+struct PathTagData { uint32_t tag_byte; MonoidK<5> monoid; };
+
+#define DERIV_THRESH 1e-6f
+#define DERIV_THRESH_SQUARED (DERIV_THRESH * DERIV_THRESH)
+#define DERIV_EPS 1e-6f
+#define SUBDIV_LIMIT (1.0f / 65536.0f)
+#define K1_THRESH 1e-3f
+#define DIST_THRESH 1e-3f
+#define TANGENT_THRESH 1e-6f
+
+template <bool EMIT>
+struct Out {
+    const JlConfig* cfg;
+    Buf<JlLineSoup> lines;
+    uint32_t cursor;  // EMIT: next line index; !EMIT: running count
+    float bx0, by0, bx1, by1;
+
+    JD uint32_t alloc(uint32_t n) {
+        uint32_t ix = cursor;
+        cursor += n;
+        return ix;
+    }
+    JD void write_line(uint32_t line_ix, uint32_t path_ix, V2 p0, V2 p1) {  // flatten.wgsl:749-756
+        if (EMIT) {
+            bx0 = fmin_(bx0, fmin_(p0.x, p1.x));
+            by0 = fmin_(by0, fmin_(p0.y, p1.y));
+            bx1 = fmax_(bx1, fmax_(p0.x, p1.x));
+            by1 = fmax_(by1, fmax_(p0.y, p1.y));
+            if (line_ix < cfg->lines_size && lines.ok(line_ix)) {
+                JlLineSoup l;
+                l.path_ix = path_ix; l.pad = 0; l.p0[0] = p0.x; l.p0[1] = p0.y; l.p1[0] = p1.x; l.p1[1] = p1.y;
+                lines.p[line_ix] = l;
+            }
+        }
+    }
+    JD void write_line_t(uint32_t line_ix, uint32_t path_ix, V2 p0, V2 p1, const Xf& t) {
+        if (EMIT) write_line(line_ix, path_ix, xf_apply(t, p0), xf_apply(t, p1));
+    }
+    JD void output_line_t(uint32_t path_ix, V2 p0, V2 p1, const Xf& t) {
+        uint32_t ix = alloc(1);
+        write_line_t(ix, path_ix, p0, p1, t);
+    }
+};
+
+JD CubicParams cubic_from_points_derivs(V2 p0, V2 p1, V2 q0, V2 q1, float dt) {  // flatten.wgsl:94-133
+    V2 chord = p1 - p0;
+    float chord_squared = dot(chord, chord);
+    float chord_len = sqrt_(chord_squared);
+    CubicParams r;
+    if (chord_squared < DERIV_THRESH_SQUARED) {
+        float chord_err = sqrt_((float)(9.0 / 32.0) * (dot(q0, q0) + dot(q1, q1))) * dt;
+        r.th0 = 0.0f; r.th1 = 0.0f; r.chord_len = DERIV_THRESH; r.err = chord_err;
+        return r;
+    }
+    float scale = dt / chord_squared;
+    V2 h0 = v2(q0.x * chord.x + q0.y * chord.y, q0.y * chord.x - q0.x * chord.y);
+    float th0 = atan2_(h0.y, h0.x);
+    float d0 = length(h0) * scale;
+    V2 h1 = v2(q1.x * chord.x + q1.y * chord.y, q1.x * chord.y - q1.y * chord.x);
+    float th1 = atan2_(h1.y, h1.x);
+    float d1 = length(h1) * scale;
+    float cth0 = cos_(th0);
+    float cth1 = cos_(th1);
+    float err = 2.0f;
+    if (cth0 * cth1 >= 0.0f) {
+        const float TWO_THIRDS = (float)(2.0 / 3.0);
+        float e0 = TWO_THIRDS / fmax_(1.0f + cth0, 1e-9f);
+        float e1 = TWO_THIRDS / fmax_(1.0f + cth1, 1e-9f);
+        float s0 = sin_(th0);
+        float s1 = sin_(th1);
+        float s01 = cth0 * s1 + cth1 * s0;
+        float amin = 0.15f * (2.0f * e0 * s0 + 2.0f * e1 * s1 - e0 * e1 * s01);
+        float a = 0.15f * (2.0f * d0 * s0 + 2.0f * d1 * s1 - d0 * d1 * s01);
+        float aerr = abs_(a - amin);
+        float symm = abs_(th0 + th1);
+        float asymm = abs_(th0 - th1);
+        float dist = length(v2(d0 - e0, d1 - e1));
+        float symm2 = symm * symm;
+        float ctr = (4.625e-6f * symm * symm2 + 7.5e-3f * asymm) * symm2;
+        float halo = (5e-3f * symm + 7e-2f * asymm) * dist;
+        err = ctr + 1.55f * aerr + halo;
+    }
+    err *= chord_len;
+    r.th0 = th0; r.th1 = th1; r.chord_len = chord_len; r.err = err;
+    return r;
+}
+
+JD EulerParams es_params_from_angles(float th0, float th1) {  // flatten.wgsl:135-158
+    float k0 = th0 + th1;
+    float dth = th1 - th0;
+    float d2 = dth * dth;
+    float k2 = k0 * k0;
+    float a = 6.0f;
+    a -= d2 * (float)(1.0 / 70.0);
+    a -= (d2 * d2) * (float)(1.0 / 10780.0);
+    a += (d2 * d2 * d2) * 2.769178184818219e-07f;
+    float b = -0.1f + d2 * (float)(1.0 / 4200.0) + d2 * d2 * 1.6959677820260655e-05f;
+    float c = (float)(-1.0 / 1400.0) + d2 * 6.84915970574303e-05f - k2 * 7.936475029053326e-06f;
+    a += (b + c * k2) * k2;
+    float k1 = dth * a;
+    float ch = 1.0f;
+    ch -= d2 * (float)(1.0 / 40.0);
+    ch += (d2 * d2) * 0.00034226190482569864f;
+    ch -= (d2 * d2 * d2) * 1.9349474568904524e-06f;
+    float b_ = (float)(-1.0 / 24.0) + d2 * 0.0024702380951963226f - d2 * d2 * 3.7297408997537985e-05f;
+    float c_ = (float)(1.0 / 1920.0) - d2 * 4.87350869747975e-05f - k2 * 3.1001936068463107e-06f;
+    ch += (b_ + c_ * k2) * k2;
+    EulerParams r;
+    r.th0 = th0; r.th1 = th1; r.k0 = k0; r.k1 = k1; r.ch = ch;
+    return r;
+}
+JD float es_params_eval_th(const EulerParams& p, float t) { return (p.k0 + 0.5f * p.k1 * (t - 1.0f)) * t - p.th0; }
+
+JD V2 integ_euler_10(float k0, float k1) {  // flatten.wgsl:165-195
+    float t1_1 = k0;
+    float t1_2 = 0.5f * k1;
+    float t2_2 = t1_1 * t1_1;
+    float t2_3 = 2.0f * (t1_1 * t1_2);
+    float t2_4 = t1_2 * t1_2;
+    float t3_4 = t2_2 * t1_2 + t2_3 * t1_1;
+    float t3_6 = t2_4 * t1_2;
+    float t4_4 = t2_2 * t2_2;
+    float t4_5 = 2.0f * (t2_2 * t2_3);
+    float t4_6 = 2.0f * (t2_2 * t2_4) + t2_3 * t2_3;
+    float t4_7 = 2.0f * (t2_3 * t2_4);
+    float t4_8 = t2_4 * t2_4;
+    float t5_6 = t4_4 * t1_2 + t4_5 * t1_1;
+    float t5_8 = t4_6 * t1_2 + t4_7 * t1_1;
+    float t6_6 = t4_4 * t2_2;
+    float t6_7 = t4_4 * t2_3 + t4_5 * t2_2;
+    float t6_8 = t4_4 * t2_4 + t4_5 * t2_3 + t4_6 * t2_2;
+    float t7_8 = t6_6 * t1_2 + t6_7 * t1_1;
+    float t8_8 = t6_6 * t2_2;
+    float u = 1.0f;
+    u -= (float)(1.0 / 24.0) * t2_2 + (float)(1.0 / 160.0) * t2_4;
+    u += (float)(1.0 / 1920.0) * t4_4 + (float)(1.0 / 10752.0) * t4_6 + (float)(1.0 / 55296.0) * t4_8;
+    u -= (float)(1.0 / 322560.0) * t6_6 + (float)(1.0 / 1658880.0) * t6_8;
+    u += (float)(1.0 / 92897280.0) * t8_8;
+    float v = (float)(1.0 / 12.0) * t1_2;
+    v -= (float)(1.0 / 480.0) * t3_4 + (float)(1.0 / 2688.0) * t3_6;
+    v += (float)(1.0 / 53760.0) * t5_6 + (float)(1.0 / 276480.0) * t5_8;
+    v -= (float)(1.0 / 11612160.0) * t7_8;
+    return v2(u, v);
+}
+JD V2 es_params_eval(const EulerParams& p, float t) {  // :197-209
+    float thm = es_params_eval_th(p, t * 0.5f);
+    float k0 = p.k0, k1 = p.k1;
+    V2 uv = integ_euler_10((k0 + k1 * (0.5f * t - 0.5f)) * t, k1 * t * t);
+    float scale = t / p.ch;
+    float s = scale * sin_(thm);
+    float c = scale * cos_(thm);
+    float x = uv.x * c - uv.y * s;
+    float y = -uv.y * c - uv.x * s;
+    return v2(x, y);
+}
+JD V2 es_params_eval_with_offset(const EulerParams& p, float t, float offset) {  // :211-215
+    float th = es_params_eval_th(p, t);
+    V2 v = offset * v2(sin_(th), cos_(th));
+    return es_params_eval(p, t) + v;
+}
+JD V2 es_seg_eval_with_offset(V2 es_p0, V2 es_p1, const EulerParams& p, float t, float normalized_offset) {  // :222-226
+    V2 chord = es_p1 - es_p0;
+    V2 xy = es_params_eval_with_offset(p, t, normalized_offset);
+    return es_p0 + v2(chord.x * xy.x - chord.y * xy.y, chord.x * xy.y + chord.y * xy.x);
+}
+JD float pow_1_5_signed(float x) { return x * sqrt_(abs_(x)); }
+
+#define BREAK1 0.8f
+#define BREAK2 1.25f
+#define BREAK3 2.1f
+#define SIN_SCALE 1.0976991822760038f
+#define QUAD_A1 0.6406f
+#define QUAD_B1 -0.81f
+#define QUAD_C1 0.9148117935952064f
+#define QUAD_A2 0.5f
+#define QUAD_B2 -0.156f
+#define QUAD_C2 0.16145779359520596f
+#define FRAC_PI_4 0.7853981633974483f
+#define CBRT_9_8 1.040041911525952f
+
+JD float espc_int_approx(float x) {  // :250-262
+    float y = abs_(x);
+    float a;
+    if (y < BREAK1) {
+        a = sin_(SIN_SCALE * y) * (1.0f / SIN_SCALE);
+    } else if (y < BREAK2) {
+        a = (float)(2.8284271247461903 / 3.0) * pow_1_5_signed(y - 1.0f) + FRAC_PI_4;
+    } else {
+        bool lt = y < BREAK3;
+        float qa = lt ? QUAD_A1 : QUAD_A2, qb = lt ? QUAD_B1 : QUAD_B2, qc = lt ? QUAD_C1 : QUAD_C2;
+        a = (qa * y + qb) * y + qc;
+    }
+    return a * sign_(x);
+}
+JD float espc_int_inv_approx(float x) {  // :264-278
+    // const QUAD_W/V/U are f32 const-expressions in the WGSL (flatten.wgsl:241-246)
+    const float QUAD_W1 = 0.5f * QUAD_B1 / QUAD_A1;
+    const float QUAD_V1 = 1.0f / QUAD_A1;
+    const float QUAD_U1 = QUAD_W1 * QUAD_W1 - QUAD_C1 / QUAD_A1;
+    const float QUAD_W2 = 0.5f * QUAD_B2 / QUAD_A2;
+    const float QUAD_V2 = 1.0f / QUAD_A2;
+    const float QUAD_U2 = QUAD_W2 * QUAD_W2 - QUAD_C2 / QUAD_A2;
+    float y = abs_(x);
+    float a;
+    if (y < 0.7010707591262915f) {
+        a = asin_(y * SIN_SCALE) * (1.0f / SIN_SCALE);
+    } else if (y < 0.903249293595206f) {
+        float b = y - FRAC_PI_4;
+        float u = pow23_abs_(b) * sign_(b);
+        a = u * CBRT_9_8 + 1.0f;
+    } else {
+        bool lt = y < 2.038857793595206f;
+        float qu = lt ? QUAD_U1 : QUAD_U2, qv = lt ? QUAD_V1 : QUAD_V2, qw = lt ? QUAD_W1 : QUAD_W2;
+        a = sqrt_(qu + qv * y) - qw;
+    }
+    return a * sign_(x);
+}
+JD PointDeriv eval_cubic_and_deriv(V2 p0, V2 p1, V2 p2, V2 p3, float t) {  // :285-293
+    float m = 1.0f - t;
+    float mm = m * m;
+    float mt = m * t;
+    float tt = t * t;
+    PointDeriv r;
+    r.point = p0 * (mm * m) + (p1 * (3.0f * mm) + p2 * (3.0f * mt) + p3 * tt) * t;
+    r.deriv = (p1 - p0) * mm + (p2 - p1) * (2.0f * mt) + (p3 - p2) * tt;
+    return r;
+}
+JD V2 cubic_start_tangent(V2 p0, V2 p1, V2 p2, V2 p3) {  // :295-301
+    const float EPS = 1e-12f;
+    V2 d01 = p1 - p0, d02 = p2 - p0, d03 = p3 - p0;
+    V2 inner = (dot(d02, d02) > EPS) ? d02 : d03;
+    return (dot(d01, d01) > EPS) ? d01 : inner;
+}
+JD V2 cubic_end_tangent(V2 p0, V2 p1, V2 p2, V2 p3) {  // :303-309
+    const float EPS = 1e-12f;
+    V2 d23 = p3 - p2, d13 = p3 - p1, d03 = p3 - p0;
+    V2 inner = (dot(d13, d13) > EPS) ? d13 : d03;
+    return (dot(d23, d23) > EPS) ? d23 : inner;
+}
+
+// flatten.wgsl:328-477
+template <bool EMIT>
+JD void flatten_euler(Out<EMIT>& o, const CubicPoints& cubic, uint32_t path_ix, const Xf& local_to_device, float offset, V2 start_p,
+                      V2 end_p) {
+    V2 p0, p1, p2, p3;
+    float scale;
+    Xf transform;
+    V2 t_start = start_p, t_end = end_p;
+    if (offset == 0.0f) {
+        p0 = xf_apply(local_to_device, cubic.p0);
+        p1 = xf_apply(local_to_device, cubic.p1);
+        p2 = xf_apply(local_to_device, cubic.p2);
+        p3 = xf_apply(local_to_device, cubic.p3);
+        scale = 1.0f;
+        transform = xf_identity();
+        t_start = p0;
+        t_end = p3;
+    } else {
+        p0 = cubic.p0; p1 = cubic.p1; p2 = cubic.p2; p3 = cubic.p3;
+        transform = local_to_device;
+        scale = 0.5f * length(v2(transform.m0 + transform.m3, transform.m1 - transform.m2)) +
+                length(v2(transform.m0 - transform.m3, transform.m1 + transform.m2));
+    }
+    if (veq(p0, p1) && veq(p0, p2) && veq(p0, p3)) return;
+
+    const float tol = 0.25f;
+    uint32_t t0_u = 0u;
+    float dt = 1.0f;
+    V2 last_p = p0;
+    V2 last_q = p1 - p0;
+    if (dot(last_q, last_q) < DERIV_THRESH_SQUARED) last_q = eval_cubic_and_deriv(p0, p1, p2, p3, DERIV_EPS).deriv;
+    float last_t = 0.0f;
+    V2 lp0 = t_start;
+    for (;;) {
+        float t0 = (float)t0_u * dt;
+        if (t0 == 1.0f) break;
+        float t1 = t0 + dt;
+        V2 this_p0 = last_p;
+        V2 this_q0 = last_q;
+        PointDeriv this_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1);
+        if (dot(this_pq1.deriv, this_pq1.deriv) < DERIV_THRESH_SQUARED) {
+            PointDeriv new_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1 - DERIV_EPS);
+            this_pq1.deriv = new_pq1.deriv;
+            if (t1 < 1.0f) {
+                this_pq1.point = new_pq1.point;
+                t1 = t1 - DERIV_EPS;
+            }
+        }
+        float actual_dt = t1 - last_t;
+        CubicParams cp = cubic_from_points_derivs(this_p0, this_pq1.point, this_q0, this_pq1.deriv, actual_dt);
+        if (cp.err * scale <= tol || dt <= SUBDIV_LIMIT) {
+            EulerParams ep = es_params_from_angles(cp.th0, cp.th1);
+            float k0 = ep.k0 - 0.5f * ep.k1;
+            float k1 = ep.k1;
+            float normalized_offset = offset / cp.chord_len;
+            float dist_scaled = normalized_offset * ep.ch;
+            float scale_multiplier = sqrt_(0.125f * scale * cp.chord_len / (ep.ch * tol));
+            float a = 0.0f, b = 0.0f, integral = 0.0f, int0 = 0.0f, n_frac;
+            int robust = 0;
+            if (abs_(k1) < K1_THRESH) {
+                float k = ep.k0;
+                n_frac = sqrt_(abs_(k * (k * dist_scaled + 1.0f)));
+                robust = 1;
+            } else if (abs_(dist_scaled) < DIST_THRESH) {
+                a = k1;
+                b = k0;
+                int0 = pow_1_5_signed(b);
+                float int1 = pow_1_5_signed(a + b);
+                integral = int1 - int0;
+                n_frac = (float)(2.0 / 3.0) * integral / a;
+                robust = 2;
+            } else {
+                a = -2.0f * dist_scaled * k1;
+                b = -1.0f - 2.0f * dist_scaled * k0;
+                int0 = espc_int_approx(b);
+                float int1 = espc_int_approx(a + b);
+                integral = int1 - int0;
+                float k_peak = k0 - k1 * b / a;
+                float integrand_peak = sqrt_(abs_(k_peak * (k_peak * dist_scaled + 1.0f)));
+                n_frac = integral * integrand_peak / a;
+            }
+            float n = clamp_(ceil_(n_frac * scale_multiplier), 1.0f, 100.0f);
+            uint32_t n_u = to_u32(n);
+            if (EMIT) {
+                for (uint32_t i = 0; i < n_u; i++) {
+                    V2 lp1;
+                    if (i + 1u == n_u && t1 == 1.0f) {
+                        lp1 = t_end;
+                    } else {
+                        float t = (float)(i + 1u) / n;
+                        float s = t;
+                        if (robust != 1) {
+                            float u = integral * t + int0;
+                            float inv;
+                            if (robust == 2) inv = pow23_abs_(u) * sign_(u); else inv = espc_int_inv_approx(u);
+                            s = (inv - b) / a;
+                        }
+                        lp1 = es_seg_eval_with_offset(this_p0, this_pq1.point, ep, s, normalized_offset);
+                    }
+                    V2 l0 = (offset >= 0.0f) ? lp0 : lp1;
+                    V2 l1 = (offset >= 0.0f) ? lp1 : lp0;
+                    o.output_line_t(path_ix, l0, l1, transform);
+                    lp0 = lp1;
+                }
+            } else {
+                o.alloc(n_u);
+            }
+            last_p = this_pq1.point;
+            last_q = this_pq1.deriv;
+            last_t = t1;
+            t0_u += 1u;
+            uint32_t shift = (t0_u == 0u) ? 32u : (uint32_t)__builtin_ctz(t0_u);
+            t0_u = (shift >= 32u) ? 0u : (t0_u >> shift);
+            dt *= (float)(1u << (shift & 31u));
+        } else {
+            t0_u = t0_u * 2u;
+            dt *= 0.5f;
+        }
+    }
+}
+
+// flatten.wgsl:490-517
+template <bool EMIT>
+JD void flatten_arc(Out<EMIT>& o, uint32_t path_ix, V2 begin, V2 end, V2 center, float angle, const Xf& transform) {
+    V2 p0 = xf_apply(transform, begin);
+    V2 r = begin - center;
+    const float MIN_THETA = 0.0001f;
+    const float tol = 0.25f;
+    float radius = fmax_(tol, length(p0 - xf_apply(transform, center)));
+    float theta = fmax_(MIN_THETA, 2.0f * acos_(1.0f - tol / radius));
+    uint32_t n_lines = umax_(1u, to_u32(ceil_(angle / theta)));
+    uint32_t line_ix = o.alloc(n_lines);
+    if (EMIT) {
+        float cs = cos_(theta);
+        float sn = sin_(theta);
+        for (uint32_t i = 0; i < n_lines - 1u; i++) {
+            r = v2(cs * r.x + sn * r.y, -sn * r.x + cs * r.y);
+            V2 p1 = xf_apply(transform, center + r);
+            o.write_line(line_ix + i, path_ix, p0, p1);
+            p0 = p1;
+        }
+        V2 p1 = xf_apply(transform, end);
+        o.write_line(line_ix + n_lines - 1u, path_ix, p0, p1);
+    }
+}
+// flatten.wgsl:519-543
+template <bool EMIT>
+JD void draw_cap(Out<EMIT>& o, uint32_t path_ix, uint32_t cap_style, V2 point, V2 cap0, V2 cap1, V2 offset_tangent, const Xf& transform) {
+    if (cap_style == JL_STYLE_FLAGS_CAP_ROUND) {
+        flatten_arc<EMIT>(o, path_ix, cap0, cap1, point, 3.1415927f, transform);
+        return;
+    }
+    V2 start = cap0, end = cap1;
+    bool is_square = (cap_style == JL_STYLE_FLAGS_CAP_SQUARE);
+    uint32_t line_ix = o.alloc(is_square ? 3u : 1u);
+    if (is_square) {
+        V2 v = offset_tangent;
+        V2 p0 = start + v;
+        V2 p1 = end + v;
+        o.write_line_t(line_ix + 1u, path_ix, start, p0, transform);
+        o.write_line_t(line_ix + 2u, path_ix, p1, end, transform);
+        start = p0;
+        end = p1;
+    }
+    o.write_line_t(line_ix, path_ix, start, end, transform);
+}
+// flatten.wgsl:545-614
+template <bool EMIT>
+JD void draw_join(Out<EMIT>& o, uint32_t path_ix, uint32_t style_flags, V2 p0, V2 tan_prev, V2 tan_next, V2 n_prev, V2 n_next,
+                  const Xf& transform) {
+    V2 front0 = p0 + n_prev;
+    V2 front1 = p0 + n_next;
+    V2 back0 = p0 - n_next;
+    V2 back1 = p0 - n_prev;
+    float cr = tan_prev.x * tan_next.y - tan_prev.y * tan_next.x;
+    float d = dot(tan_prev, tan_next);
+    uint32_t join = style_flags & JL_STYLE_FLAGS_JOIN_MASK;
+    if (join == JL_STYLE_FLAGS_JOIN_BEVEL) {
+        uint32_t line_ix = o.alloc(2u);
+        o.write_line_t(line_ix, path_ix, front0, front1, transform);
+        o.write_line_t(line_ix + 1u, path_ix, back0, back1, transform);
+    } else if (join == JL_STYLE_FLAGS_JOIN_MITER) {
+        float hypot = length(v2(cr, d));
+        float miter_limit = f16_to_f32((uint16_t)(style_flags & JL_STYLE_MITER_LIMIT_MASK));
+        uint32_t line_ix;
+        if (2.0f * hypot < (hypot + d) * miter_limit * miter_limit && cr != 0.0f) {
+            bool is_backside = cr > 0.0f;
+            V2 fp_last = is_backside ? back1 : front0;
+            V2 fp_this = is_backside ? back0 : front1;
+            V2 p = is_backside ? back0 : front0;
+            V2 v = fp_this - fp_last;
+            float h = (tan_prev.x * v.y - tan_prev.y * v.x) / cr;
+            V2 miter_pt = fp_this - tan_next * h;
+            line_ix = o.alloc(3u);
+            o.write_line_t(line_ix, path_ix, p, miter_pt, transform);
+            line_ix += 1u;
+            if (is_backside) back0 = miter_pt; else front0 = miter_pt;
+        } else {
+            line_ix = o.alloc(2u);
+        }
+        o.write_line_t(line_ix, path_ix, front0, front1, transform);
+        o.write_line_t(line_ix + 1u, path_ix, back0, back1, transform);
+    } else if (join == JL_STYLE_FLAGS_JOIN_ROUND) {
+        V2 arc0, arc1, other0, other1;
+        if (cr > 0.0f) { arc0 = back0; arc1 = back1; other0 = front0; other1 = front1; }
+        else { arc0 = front0; arc1 = front1; other0 = back0; other1 = back1; }
+        flatten_arc<EMIT>(o, path_ix, arc0, arc1, p0, abs_(atan2_(cr, d)), transform);
+        o.output_line_t(path_ix, other0, other1, transform);
+    }
+}
+
+struct Scene {
+    const JlConfig* cfg;
+    Buf<uint32_t> scene;
+    Buf<JlTagMonoid> tag_monoids;
+};
+
+JD V2 read_f32_point(const Scene& s, uint32_t ix) {
+    uint32_t b = s.cfg->layout.pathdata_base + ix;
+    return v2(u2f(s.scene.rd(b)), u2f(s.scene.rd(b + 1u)));
+}
+JD V2 read_i16_point(const Scene& s, uint32_t ix) {
+    uint32_t raw = s.scene.rd(s.cfg->layout.pathdata_base + ix);
+    float x = (float)((int32_t)(raw << 16) >> 16);
+    float y = (float)((int32_t)raw >> 16);
+    return v2(x, y);
+}
+JD PathTagData compute_tag_monoid(const Scene& s, uint32_t ix) {  // flatten.wgsl:668-682
+    uint32_t tag_word = s.scene.rd(s.cfg->layout.pathtag_base + (ix >> 2));
+    uint32_t shift = (ix & 3u) * 8u;
+    MonoidK<5> tm = reduce_tag(tag_word & ((1u << shift) - 1u));
+    JlTagMonoid pm = s.tag_monoids.rd(ix >> 2);
+    tm.v[0] += pm.trans_ix; tm.v[1] += pm.pathseg_ix; tm.v[2] += pm.pathseg_offset; tm.v[3] += pm.style_ix; tm.v[4] += pm.path_ix;
+    PathTagData r;
+    r.tag_byte = (tag_word >> shift) & 0xffu;
+    tm.v[0] -= 1u;
+    tm.v[3] -= 2u;
+    r.monoid = tm;
+    return r;
+}
+JD CubicPoints read_path_segment(const Scene& s, const PathTagData& tag, bool is_stroke) {  // flatten.wgsl:691-747
+    V2 p0 = v2(0, 0), p1 = v2(0, 0), p2 = v2(0, 0), p3 = v2(0, 0);
+    uint32_t seg_type = tag.tag_byte & 3u;
+    uint32_t pathseg_offset = tag.monoid.v[2];
+    bool is_stroke_cap_marker = is_stroke && (tag.tag_byte & JL_PATH_TAG_SUBPATH_END) != 0u;
+    bool is_open = seg_type == JL_PATH_TAG_QUADTO;
+    if ((tag.tag_byte & JL_PATH_TAG_F32) != 0u) {
+        p0 = read_f32_point(s, pathseg_offset);
+        p1 = read_f32_point(s, pathseg_offset + 2u);
+        if (seg_type >= JL_PATH_TAG_QUADTO) {
+            p2 = read_f32_point(s, pathseg_offset + 4u);
+            if (seg_type == JL_PATH_TAG_CUBICTO) p3 = read_f32_point(s, pathseg_offset + 6u);
+        }
+    } else {
+        p0 = read_i16_point(s, pathseg_offset);
+        p1 = read_i16_point(s, pathseg_offset + 1u);
+        if (seg_type >= JL_PATH_TAG_QUADTO) {
+            p2 = read_i16_point(s, pathseg_offset + 2u);
+            if (seg_type == JL_PATH_TAG_CUBICTO) p3 = read_i16_point(s, pathseg_offset + 3u);
+        }
+    }
+    if (is_stroke_cap_marker && is_open) {
+        p0 = p1;
+        p1 = p2;
+        seg_type = JL_PATH_TAG_LINETO;
+    }
+    const float THIRD = (float)(1.0 / 3.0);
+    if (seg_type == JL_PATH_TAG_LINETO) {
+        p3 = p1;
+        p2 = vmix(p3, p0, THIRD);
+        p1 = vmix(p0, p3, THIRD);
+    } else if (seg_type == JL_PATH_TAG_QUADTO) {
+        p3 = p2;
+        p2 = vmix(p1, p2, THIRD);
+        p1 = vmix(p1, p0, THIRD);
+    }
+    CubicPoints r;
+    r.p0 = p0; r.p1 = p1; r.p2 = p2; r.p3 = p3;
+    return r;
+}
+
+// flatten.wgsl:809-901
+template <bool EMIT>
+__global__ __launch_bounds__(JL_WG) void k_flatten(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
+                                                   Buf<JlPathBbox> path_bboxes, Buf<JlLineSoup> lines, uint32_t* __restrict__ counts,
+                                                   const uint32_t* __restrict__ bases) {
+    uint32_t ix = blockIdx.x * JL_WG + threadIdx.x;
+    Scene s;
+    s.cfg = cfg; s.scene = scene; s.tag_monoids = tag_monoids;
+    Out<EMIT> o;
+    o.cfg = cfg; o.lines = lines;
+    o.cursor = EMIT ? bases[ix] : 0u;
+    o.bx0 = 1e31f; o.by0 = 1e31f; o.bx1 = -1e31f; o.by1 = -1e31f;
+
+    PathTagData tag = compute_tag_monoid(s, ix);
+    uint32_t path_ix = tag.monoid.v[4];
+    uint32_t style_ix = tag.monoid.v[3];
+    uint32_t trans_ix = tag.monoid.v[0];
+    uint32_t style_flags = scene.rd(cfg->layout.style_base + style_ix);
+    uint32_t draw_flags = ((style_flags & JL_STYLE_FLAGS_FILL) == 0u) ? 0u : 1u;
+    if (EMIT && (tag.tag_byte & JL_PATH_TAG_PATH) != 0u && path_bboxes.ok(path_ix)) {
+        path_bboxes.p[path_ix].draw_flags = draw_flags;
+        path_bboxes.p[path_ix].trans_ix = trans_ix;
+    }
+    uint32_t seg_type = tag.tag_byte & JL_PATH_TAG_SEG_TYPE;
+    if (seg_type != 0u) {
+        bool is_stroke = (style_flags & JL_STYLE_FLAGS_STYLE) != 0u;
+        Xf transform;
+        {
+            uint32_t base = cfg->layout.transform_base + trans_ix * 6u;
+            transform.m0 = u2f(scene.rd(base)); transform.m1 = u2f(scene.rd(base + 1u)); transform.m2 = u2f(scene.rd(base + 2u));
+            transform.m3 = u2f(scene.rd(base + 3u)); transform.t0 = u2f(scene.rd(base + 4u)); transform.t1 = u2f(scene.rd(base + 5u));
+        }
+        CubicPoints pts = read_path_segment(s, tag, is_stroke);
+        if (is_stroke) {
+            float linewidth = u2f(scene.rd(cfg->layout.style_base + style_ix + 1u));
+            float offset = 0.5f * linewidth;
+            bool is_open = (tag.tag_byte & JL_PATH_TAG_SEG_TYPE) != JL_PATH_TAG_LINETO;
+            bool is_stroke_cap_marker = (tag.tag_byte & JL_PATH_TAG_SUBPATH_END) != 0u;
+            if (is_stroke_cap_marker) {
+                if (is_open) {
+                    V2 tangent = cubic_start_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
+                    V2 offset_tangent = offset * normalize(tangent);
+                    V2 n = v2(offset_tangent.y * -1.0f, offset_tangent.x * 1.0f);
+                    draw_cap<EMIT>(o, path_ix, (style_flags & JL_STYLE_FLAGS_START_CAP_MASK) >> 2, pts.p0, pts.p0 - n, pts.p0 + n,
+                                   -offset_tangent, transform);
+                }
+            } else {
+                PathTagData ntag = compute_tag_monoid(s, ix + 1u);  // read_neighboring_segment, :790-800
+                CubicPoints npts = read_path_segment(s, ntag, true);
+                bool n_is_closed = (ntag.tag_byte & JL_PATH_TAG_SEG_TYPE) == JL_PATH_TAG_LINETO;
+                bool n_is_marker = (ntag.tag_byte & JL_PATH_TAG_SUBPATH_END) != 0u;
+                bool do_join = !n_is_marker || n_is_closed;
+                V2 neighbor_tangent = cubic_start_tangent(npts.p0, npts.p1, npts.p2, npts.p3);
+
+                const float TT = TANGENT_THRESH * TANGENT_THRESH;
+                V2 tan_start = cubic_start_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
+                if (dot(tan_start, tan_start) < TT) tan_start = v2(TANGENT_THRESH, 0.0f);
+                V2 tan_prev = cubic_end_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
+                if (dot(tan_prev, tan_prev) < TT) tan_prev = v2(TANGENT_THRESH, 0.0f);
+                V2 tan_next = neighbor_tangent;
+                if (dot(tan_next, tan_next) < TT) tan_next = v2(TANGENT_THRESH, 0.0f);
+                V2 n_start = offset * normalize(v2(-tan_start.y, tan_start.x));
+                V2 offset_tangent = offset * normalize(tan_prev);
+                V2 n_prev = v2(offset_tangent.y * -1.0f, offset_tangent.x * 1.0f);
+                V2 tnn = normalize(tan_next);
+                V2 n_next = v2((offset * tnn.y) * -1.0f, (offset * tnn.x) * 1.0f);
+                flatten_euler<EMIT>(o, pts, path_ix, transform, offset, pts.p0 + n_start, pts.p3 + n_prev);
+                flatten_euler<EMIT>(o, pts, path_ix, transform, -offset, pts.p0 - n_start, pts.p3 - n_prev);
+                if (do_join) {
+                    draw_join<EMIT>(o, path_ix, style_flags, pts.p3, tan_prev, tan_next, n_prev, n_next, transform);
+                } else {
+                    draw_cap<EMIT>(o, path_ix, (style_flags & JL_STYLE_FLAGS_END_CAP_MASK), pts.p3, pts.p3 + n_prev, pts.p3 - n_prev,
+                                   offset_tangent, transform);
+                }
+            }
+        } else {
+            flatten_euler<EMIT>(o, pts, path_ix, transform, 0.0f, pts.p0, pts.p3);
+        }
+        if (EMIT && (o.bx1 > o.bx0 || o.by1 > o.by0) && path_bboxes.ok(path_ix)) {
+            JlPathBbox* out = &path_bboxes.p[path_ix];
+            atomicMin(&out->x0, to_i32(floor_(o.bx0)));
+            atomicMin(&out->y0, to_i32(floor_(o.by0)));
+            atomicMax(&out->x1, to_i32(ceil_(o.bx1)));
+            atomicMax(&out->y1, to_i32(ceil_(o.by1)));
+        }
+    }
+    if (!EMIT) counts[ix] = o.cursor;
+}
+
+}  // namespace
+
+// [config, scene, tag_monoids, path_bboxes, bump, lines]
+int jh_launch_flatten(const JhLaunch& L) {
+    if (L.nb < 6) return -1;
+    if (L.gx == 0) return 0;
+    uint32_t n = L.gx * JL_WG;
+    uint32_t* counts = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)n * 4);
+    uint32_t* bases = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_B, (uint64_t)n * 4);
+    if (!counts || !bases) return -5;
+    auto cfg = (const JlConfig*)L.b[0].ptr;
+    auto scene = mkbuf<uint32_t>(L.b[1].ptr, L.b[1].size);
+    auto tm = mkbuf<JlTagMonoid>(L.b[2].ptr, L.b[2].size);
+    auto pb = mkbuf<JlPathBbox>(L.b[3].ptr, L.b[3].size);
+    JlBump* bump = (JlBump*)L.b[4].ptr;
+    auto lines = mkbuf<JlLineSoup>(L.b[5].ptr, L.b[5].size);
+    hipLaunchKernelGGL(k_flatten<false>, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, lines, counts, (const uint32_t*)nullptr);
+    int rc = jh_scan_u32(L, counts, 1, bases, n, nullptr, &bump->lines);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_flatten<true>, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, lines, (uint32_t*)nullptr,
+                       (const uint32_t*)bases);
+    return 0;
+}

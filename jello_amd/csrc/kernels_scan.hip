@@ -1,0 +1,405 @@
+// kernels_scan.hip -- monoid scans of the element pipeline on gfx950:
+//   K1-K4 pathtag_reduce / reduce2 / scan1 / scan_{small,large}  (orig/pathtag_*.wgsl)
+//   K5    bbox_clear                                              (orig/bbox_clear.wgsl:13-24)
+//   K7-K8 draw_reduce / draw_leaf                                 (orig/draw_reduce.wgsl, draw_leaf.wgsl)
+//   plus the generic u32 exclusive scan every deterministic allocator is built on.
+// All of these are HBM-bound integer work: 16 B / tag word in, 20 B out (K4); wave64 __shfl_up
+// prefix + a 4-entry LDS exchange per 256-thread block replaces the WGSL's 8-round LDS ladder.
+#include "kcommon.h"
+
+using namespace jk;
+using namespace jd;
+
+// ------------------------------------------------------------------------------------------------
+// generic exclusive scan (u32)
+// ------------------------------------------------------------------------------------------------
+#define SCAN_ITEMS 8
+#define SCAN_TILE (JL_WG * SCAN_ITEMS)
+
+__global__ __launch_bounds__(JL_WG) void k_scan_block_sums(const uint32_t* __restrict__ in, uint32_t stride, uint32_t n_max,
+                                                           const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t sh[8];
+    uint32_t n = n_dev ? umin_(*n_dev, n_max) : n_max;
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        uint32_t ix = base + i;
+        if (ix < n) s += in[(size_t)ix * stride];
+    }
+    MonoidK<1> m;
+    m.v[0] = s;
+    MonoidK<1> t = block_reduce_monoid<1>(m, sh);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = t.v[0];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_block_prefix(uint32_t* __restrict__ block_sums, uint32_t n_blocks, uint32_t* __restrict__ total_dev) {
+    __shared__ uint32_t sh[16];
+    __shared__ uint32_t carry_sh;
+    if (threadIdx.x == 0) carry_sh = 0;
+    __syncthreads();
+    for (uint32_t start = 0; start < n_blocks; start += 1024) {
+        uint32_t ix = start + threadIdx.x;
+        uint32_t v = ix < n_blocks ? block_sums[ix] : 0u;
+        uint32_t incl = wave_incl_scan_u32(v);
+        uint32_t w = threadIdx.x >> 6;
+        if (lane_id() == 63u) sh[w] = incl;
+        __syncthreads();
+        uint32_t base = 0, tot = 0;
+        for (uint32_t j = 0; j < 16; j++) {
+            uint32_t s = sh[j];
+            if (j < w) base += s;
+            tot += s;
+        }
+        uint32_t carry = carry_sh;
+        if (ix < n_blocks) block_sums[ix] = carry + base + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_sh = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_dev) *total_dev = carry_sh;
+}
+
+__global__ __launch_bounds__(JL_WG) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t stride, uint32_t* __restrict__ out, uint32_t n_max,
+                                                      const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t sh[8];
+    uint32_t n = n_dev ? umin_(*n_dev, n_max) : n_max;
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    if (blockIdx.x * SCAN_TILE >= n) return;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        uint32_t ix = base + i;
+        v[i] = ix < n ? in[(size_t)ix * stride] : 0u;
+        s += v[i];
+    }
+    uint32_t tot;
+    uint32_t excl = block_excl_scan_u32(s, sh, &tot) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        uint32_t ix = base + i;
+        if (ix < n) out[ix] = excl;
+        excl += v[i];
+    }
+}
+
+int jh_scan_u32(const JhLaunch& L, const uint32_t* in, uint32_t in_stride, uint32_t* out, uint32_t n_max, const uint32_t* n_dev,
+                uint32_t* total_dev) {
+    uint32_t n_blocks = (n_max + SCAN_TILE - 1) / SCAN_TILE;
+    if (n_blocks == 0) n_blocks = 1;
+    uint32_t* block_sums = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_SCAN_TMP, (uint64_t)n_blocks * 4);
+    if (!block_sums) return -5;
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(n_blocks), dim3(JL_WG), 0, L.stream, in, in_stride, n_max, n_dev, block_sums);
+    hipLaunchKernelGGL(k_scan_block_prefix, dim3(1), dim3(1024), 0, L.stream, block_sums, n_blocks, total_dev);
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_blocks), dim3(JL_WG), 0, L.stream, in, in_stride, out, n_max, n_dev, block_sums);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pathtag (K1-K4)
+// ------------------------------------------------------------------------------------------------
+JD void store_tm(JlTagMonoid* dst, const MonoidK<5>& m) {
+    dst->trans_ix = m.v[0]; dst->pathseg_ix = m.v[1]; dst->pathseg_offset = m.v[2]; dst->style_ix = m.v[3]; dst->path_ix = m.v[4];
+}
+JD MonoidK<5> load_tm(const Buf<JlTagMonoid>& b, uint32_t i) {
+    JlTagMonoid t = b.rd(i);
+    MonoidK<5> m;
+    m.v[0] = t.trans_ix; m.v[1] = t.pathseg_ix; m.v[2] = t.pathseg_offset; m.v[3] = t.style_ix; m.v[4] = t.path_ix;
+    return m;
+}
+
+// pathtag_reduce.wgsl:21-42
+__global__ __launch_bounds__(JL_WG) void k_pathtag_reduce(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> reduced) {
+    __shared__ uint32_t sh[20];
+    uint32_t ix = blockIdx.x * JL_WG + threadIdx.x;
+    MonoidK<5> agg = reduce_tag(scene.rd(cfg->layout.pathtag_base + ix));
+    MonoidK<5> t = block_reduce_monoid<5>(agg, sh);
+    if (threadIdx.x == 0 && reduced.ok(blockIdx.x)) store_tm(&reduced.p[blockIdx.x], t);
+}
+// pathtag_reduce2.wgsl:23-41
+__global__ __launch_bounds__(JL_WG) void k_pathtag_reduce2(Buf<JlTagMonoid> in, Buf<JlTagMonoid> out) {
+    __shared__ uint32_t sh[20];
+    uint32_t ix = blockIdx.x * JL_WG + threadIdx.x;
+    MonoidK<5> t = block_reduce_monoid<5>(load_tm(in, ix), sh);
+    if (threadIdx.x == 0 && out.ok(blockIdx.x)) store_tm(&out.p[blockIdx.x], t);
+}
+// Sum of parent[l] for l < wg (l < 256): the WGSL "reduce prefix of workgroups up to this one".
+JD MonoidK<5> parent_prefix(const Buf<JlTagMonoid>& parent, uint32_t wg, uint32_t* sh) {
+    MonoidK<5> agg;
+#pragma unroll
+    for (int i = 0; i < 5; i++) agg.v[i] = 0;
+    if (threadIdx.x < wg) agg = load_tm(parent, threadIdx.x);
+    return block_reduce_monoid<5>(agg, sh);
+}
+// pathtag_scan1.wgsl:26-67
+__global__ __launch_bounds__(JL_WG) void k_pathtag_scan1(Buf<JlTagMonoid> reduced, Buf<JlTagMonoid> reduced2, Buf<JlTagMonoid> out) {
+    __shared__ uint32_t sh[20];
+    MonoidK<5> prefix = parent_prefix(reduced2, blockIdx.x, sh);
+    uint32_t ix = blockIdx.x * JL_WG + threadIdx.x;
+    MonoidK<5> tot;
+    MonoidK<5> ex = block_excl_scan_monoid<5>(load_tm(reduced, ix), sh, &tot);
+    if (out.ok(ix)) store_tm(&out.p[ix], monoid_add(prefix, ex));
+}
+// pathtag_scan.wgsl:28-76
+template <bool SMALL>
+__global__ __launch_bounds__(JL_WG) void k_pathtag_scan(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> reduced,
+                                                        Buf<JlTagMonoid> out) {
+    __shared__ uint32_t sh[20];
+    MonoidK<5> prefix;
+    if (SMALL) prefix = parent_prefix(reduced, blockIdx.x, sh); else prefix = load_tm(reduced, blockIdx.x);
+    uint32_t ix = blockIdx.x * JL_WG + threadIdx.x;
+    MonoidK<5> tot;
+    MonoidK<5> ex = block_excl_scan_monoid<5>(reduce_tag(scene.rd(cfg->layout.pathtag_base + ix)), sh, &tot);
+    if (out.ok(ix)) store_tm(&out.p[ix], monoid_add(prefix, ex));
+}
+
+int jh_launch_pathtag(const JhLaunch& L, int stage) {
+    if (L.gx == 0) return 0;
+    dim3 g(L.gx), blk(JL_WG);
+    switch (stage) {
+        case 0:
+            if (L.nb < 3) return -1;
+            hipLaunchKernelGGL(k_pathtag_reduce, g, blk, 0, L.stream, (const JlConfig*)L.b[0].ptr, mkbuf<uint32_t>(L.b[1].ptr, L.b[1].size),
+                               mkbuf<JlTagMonoid>(L.b[2].ptr, L.b[2].size));
+            break;
+        case 1:
+            if (L.nb < 2) return -1;
+            hipLaunchKernelGGL(k_pathtag_reduce2, g, blk, 0, L.stream, mkbuf<JlTagMonoid>(L.b[0].ptr, L.b[0].size),
+                               mkbuf<JlTagMonoid>(L.b[1].ptr, L.b[1].size));
+            break;
+        case 2:
+            if (L.nb < 3) return -1;
+            hipLaunchKernelGGL(k_pathtag_scan1, g, blk, 0, L.stream, mkbuf<JlTagMonoid>(L.b[0].ptr, L.b[0].size),
+                               mkbuf<JlTagMonoid>(L.b[1].ptr, L.b[1].size), mkbuf<JlTagMonoid>(L.b[2].ptr, L.b[2].size));
+            break;
+        case 3:
+        case 4: {
+            if (L.nb < 4) return -1;
+            auto cfg = (const JlConfig*)L.b[0].ptr;
+            auto scene = mkbuf<uint32_t>(L.b[1].ptr, L.b[1].size);
+            auto red = mkbuf<JlTagMonoid>(L.b[2].ptr, L.b[2].size);
+            auto out = mkbuf<JlTagMonoid>(L.b[3].ptr, L.b[3].size);
+            if (stage == 3) hipLaunchKernelGGL(k_pathtag_scan<true>, g, blk, 0, L.stream, cfg, scene, red, out);
+            else hipLaunchKernelGGL(k_pathtag_scan<false>, g, blk, 0, L.stream, cfg, scene, red, out);
+            break;
+        }
+        default: return -1;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bbox_clear (K5)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(JL_WG) void k_bbox_clear(const JlConfig* __restrict__ cfg, Buf<JlPathBbox> bb) {
+    uint32_t ix = blockIdx.x * JL_WG + threadIdx.x;
+    if (ix < cfg->layout.n_path && bb.ok(ix)) {
+        bb.p[ix].x0 = 0x7fffffff;
+        bb.p[ix].y0 = 0x7fffffff;
+        bb.p[ix].x1 = (int32_t)0x80000000;
+        bb.p[ix].y1 = (int32_t)0x80000000;
+    }
+}
+int jh_launch_bbox_clear(const JhLaunch& L) {
+    if (L.nb < 2) return -1;
+    if (L.gx == 0) return 0;
+    hipLaunchKernelGGL(k_bbox_clear, dim3(L.gx), dim3(JL_WG), 0, L.stream, (const JlConfig*)L.b[0].ptr, mkbuf<JlPathBbox>(L.b[1].ptr, L.b[1].size));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// draw_reduce / draw_leaf (K7-K8)
+// ------------------------------------------------------------------------------------------------
+JD uint32_t read_draw_tag(const JlConfig* cfg, const Buf<uint32_t>& scene, uint32_t ix) {  // shared/util.wgsl:15-24
+    return ix < cfg->layout.n_drawobj ? scene.rd(cfg->layout.drawtag_base + ix) : 0u;
+}
+JD void store_dm(JlDrawMonoid* d, const MonoidK<4>& m) { d->path_ix = m.v[0]; d->clip_ix = m.v[1]; d->scene_offset = m.v[2]; d->info_offset = m.v[3]; }
+JD MonoidK<4> load_dm(const Buf<JlDrawMonoid>& b, uint32_t i) {
+    JlDrawMonoid t = b.rd(i);
+    MonoidK<4> m;
+    m.v[0] = t.path_ix; m.v[1] = t.clip_ix; m.v[2] = t.scene_offset; m.v[3] = t.info_offset;
+    return m;
+}
+
+// draw_reduce.wgsl:22-55
+__global__ __launch_bounds__(JL_WG) void k_draw_reduce(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlDrawMonoid> reduced) {
+    __shared__ uint32_t sh[16];
+    uint32_t num_blocks_total = (cfg->layout.n_drawobj + (JL_WG - 1u)) / JL_WG;
+    uint32_t n_blocks_base = num_blocks_total / JL_WG;
+    uint32_t remainder = num_blocks_total % JL_WG;
+    uint32_t first_block = n_blocks_base * blockIdx.x + umin_(blockIdx.x, remainder);
+    uint32_t n_blocks = n_blocks_base + (blockIdx.x < remainder ? 1u : 0u);
+    uint32_t block_index = first_block * JL_WG + threadIdx.x;
+    MonoidK<4> agg;
+#pragma unroll
+    for (int i = 0; i < 4; i++) agg.v[i] = 0;
+    for (uint32_t i = 0; i < n_blocks; i++) {
+        agg = monoid_add(agg, map_draw_tag(read_draw_tag(cfg, scene, block_index)));
+        block_index += JL_WG;
+    }
+    MonoidK<4> t = block_reduce_monoid<4>(agg, sh);
+    if (threadIdx.x == 0 && reduced.ok(blockIdx.x)) store_dm(&reduced.p[blockIdx.x], t);
+}
+
+JD Xf from_poly2(V2 p0, V2 p1) {  // draw_leaf.wgsl:279-284
+    Xf r;
+    r.m0 = p1.y - p0.y; r.m1 = p0.x - p1.x; r.m2 = p1.x - p0.x; r.m3 = p1.y - p0.y; r.t0 = p0.x; r.t1 = p0.y;
+    return r;
+}
+JD Xf two_point_to_unit_line(V2 p0, V2 p1) {  // draw_leaf.wgsl:272-277
+    Xf tmp1 = from_poly2(p0, p1);
+    Xf inv = xf_inverse(tmp1);
+    Xf tmp2 = from_poly2(v2(0.0f, 0.0f), v2(1.0f, 0.0f));
+    return xf_mul(tmp2, inv);
+}
+JD Xf xf_scale(float sx, float sy) { Xf r; r.m0 = sx; r.m1 = 0.0f; r.m2 = 0.0f; r.m3 = sy; r.t0 = 0.0f; r.t1 = 0.0f; return r; }
+JD Xf xf_read_guarded(const Buf<uint32_t>& scene, uint32_t transform_base, uint32_t ix) {
+    uint32_t base = transform_base + ix * 6u;
+    Xf r;
+    r.m0 = u2f(scene.rd(base)); r.m1 = u2f(scene.rd(base + 1u)); r.m2 = u2f(scene.rd(base + 2u)); r.m3 = u2f(scene.rd(base + 3u));
+    r.t0 = u2f(scene.rd(base + 4u)); r.t1 = u2f(scene.rd(base + 5u));
+    return r;
+}
+
+// draw_leaf.wgsl:52-270
+__global__ __launch_bounds__(JL_WG) void k_draw_leaf(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlDrawMonoid> reduced,
+                                                     Buf<JlPathBbox> path_bbox, Buf<JlDrawMonoid> draw_monoid, Buf<uint32_t> info,
+                                                     Buf<JlClipInp> clip_inp) {
+    __shared__ uint32_t sh[16];
+    MonoidK<4> agg;
+#pragma unroll
+    for (int i = 0; i < 4; i++) agg.v[i] = 0;
+    if (threadIdx.x < blockIdx.x) agg = load_dm(reduced, threadIdx.x);
+    MonoidK<4> prefix = block_reduce_monoid<4>(agg, sh);
+
+    uint32_t num_blocks_total = (cfg->layout.n_drawobj + JL_WG - 1u) / JL_WG;
+    uint32_t n_blocks_base = num_blocks_total / JL_WG;
+    uint32_t remainder = num_blocks_total % JL_WG;
+    uint32_t first_block = n_blocks_base * blockIdx.x + umin_(blockIdx.x, remainder);
+    uint32_t n_blocks = n_blocks_base + (blockIdx.x < remainder ? 1u : 0u);
+    uint32_t block_start = first_block * JL_WG;
+    for (uint32_t blk = 0; blk < n_blocks; blk++, block_start += JL_WG) {
+        uint32_t ix = block_start + threadIdx.x;
+        uint32_t tag_word = read_draw_tag(cfg, scene, ix);
+        MonoidK<4> tot;
+        MonoidK<4> m = monoid_add(prefix, block_excl_scan_monoid<4>(map_draw_tag(tag_word), sh, &tot));
+        if (ix < cfg->layout.n_drawobj && draw_monoid.ok(ix)) store_dm(&draw_monoid.p[ix], m);
+        uint32_t dd = cfg->layout.drawdata_base + m.v[2];
+        uint32_t di = m.v[3];
+        if (tag_word == 0x50u || tag_word == 0x114u || tag_word == 0x29cu || tag_word == 0x254u || tag_word == 0x248u || tag_word == 0x9u) {
+            JlPathBbox bbox = path_bbox.rd(m.v[0]);
+            uint32_t draw_flags = bbox.draw_flags;
+            Xf transform = xf_scale(0.0f, 0.0f);
+            if (tag_word == 0x114u || tag_word == 0x29cu || tag_word == 0x254u || tag_word == 0x248u)
+                transform = xf_read_guarded(scene, cfg->layout.transform_base, bbox.trans_ix);
+            if (tag_word == 0x50u) {
+                info.wr(di, draw_flags);
+            } else if (tag_word == 0x114u) {
+                info.wr(di, draw_flags);
+                V2 p0 = v2(u2f(scene.rd(dd + 1u)), u2f(scene.rd(dd + 2u)));
+                V2 p1 = v2(u2f(scene.rd(dd + 3u)), u2f(scene.rd(dd + 4u)));
+                p0 = xf_apply(transform, p0);
+                p1 = xf_apply(transform, p1);
+                V2 dxy = p1 - p0;
+                float scale = 1.0f / dot(dxy, dxy);
+                V2 line_xy = dxy * scale;
+                float line_c = -dot(p0, line_xy);
+                info.wr(di + 1u, f2u(line_xy.x));
+                info.wr(di + 2u, f2u(line_xy.y));
+                info.wr(di + 3u, f2u(line_c));
+            } else if (tag_word == 0x29cu) {
+                const float GRADIENT_EPSILON = 1.0f / (float)(1u << 12);
+                info.wr(di, draw_flags);
+                V2 p0 = v2(u2f(scene.rd(dd + 1u)), u2f(scene.rd(dd + 2u)));
+                V2 p1 = v2(u2f(scene.rd(dd + 3u)), u2f(scene.rd(dd + 4u)));
+                float r0 = u2f(scene.rd(dd + 5u));
+                float r1 = u2f(scene.rd(dd + 6u));
+                Xf user_to_gradient = xf_inverse(transform);
+                Xf xform = xf_scale(0.0f, 0.0f);
+                float focal_x = 0.0f, radius = 0.0f;
+                uint32_t kind = 0u, flags = 0u;
+                if (abs_(r0 - r1) <= GRADIENT_EPSILON) {
+                    kind = JL_RAD_GRAD_KIND_STRIP;
+                    float scaled = r0 / length(p0 - p1);
+                    xform = xf_mul(two_point_to_unit_line(p0, p1), user_to_gradient);
+                    radius = scaled * scaled;
+                } else {
+                    kind = JL_RAD_GRAD_KIND_CONE;
+                    if (veq(p0, p1)) {
+                        kind = JL_RAD_GRAD_KIND_CIRCULAR;
+                        p0 = v2(p0.x + GRADIENT_EPSILON, p0.y + GRADIENT_EPSILON);
+                    }
+                    if (r1 == 0.0f) {
+                        flags |= JL_RAD_GRAD_SWAPPED;
+                        V2 tmp_p = p0; p0 = p1; p1 = tmp_p;
+                        float tmp_r = r0; r0 = r1; r1 = tmp_r;
+                    }
+                    focal_x = r0 / (r0 - r1);
+                    V2 cf = (1.0f - focal_x) * p0 + focal_x * p1;
+                    radius = r1 / length(cf - p1);
+                    Xf user_to_unit_line = xf_mul(two_point_to_unit_line(cf, p1), user_to_gradient);
+                    if (abs_(radius - 1.0f) <= GRADIENT_EPSILON) {
+                        kind = JL_RAD_GRAD_KIND_FOCAL_ON_CIRCLE;
+                        float scale = 0.5f * abs_(1.0f - focal_x);
+                        xform = xf_mul(xf_scale(scale, scale), user_to_unit_line);
+                    } else {
+                        float a = radius * radius - 1.0f;
+                        float scale_ratio = abs_(1.0f - focal_x) / a;
+                        float scale_x = radius * scale_ratio;
+                        float scale_y = sqrt_(abs_(a)) * scale_ratio;
+                        xform = xf_mul(xf_scale(scale_x, scale_y), user_to_unit_line);
+                    }
+                }
+                info.wr(di + 1u, f2u(xform.m0)); info.wr(di + 2u, f2u(xform.m1)); info.wr(di + 3u, f2u(xform.m2)); info.wr(di + 4u, f2u(xform.m3));
+                info.wr(di + 5u, f2u(xform.t0)); info.wr(di + 6u, f2u(xform.t1));
+                info.wr(di + 7u, f2u(focal_x));
+                info.wr(di + 8u, f2u(radius));
+                info.wr(di + 9u, (flags << 3) | kind);
+            } else if (tag_word == 0x254u) {
+                info.wr(di, draw_flags);
+                V2 p0 = v2(u2f(scene.rd(dd + 1u)), u2f(scene.rd(dd + 2u)));
+                Xf tr = xf_identity();
+                tr.t0 = p0.x; tr.t1 = p0.y;
+                Xf inv = xf_inverse(xf_mul(transform, tr));
+                info.wr(di + 1u, f2u(inv.m0)); info.wr(di + 2u, f2u(inv.m1)); info.wr(di + 3u, f2u(inv.m2)); info.wr(di + 4u, f2u(inv.m3));
+                info.wr(di + 5u, f2u(inv.t0)); info.wr(di + 6u, f2u(inv.t1));
+                info.wr(di + 7u, scene.rd(dd + 3u));
+                info.wr(di + 8u, scene.rd(dd + 4u));
+            } else if (tag_word == 0x248u) {
+                info.wr(di, draw_flags);
+                Xf inv = xf_inverse(transform);
+                info.wr(di + 1u, f2u(inv.m0)); info.wr(di + 2u, f2u(inv.m1)); info.wr(di + 3u, f2u(inv.m2)); info.wr(di + 4u, f2u(inv.m3));
+                info.wr(di + 5u, f2u(inv.t0)); info.wr(di + 6u, f2u(inv.t1));
+                info.wr(di + 7u, scene.rd(dd));
+                info.wr(di + 8u, scene.rd(dd + 1u));
+            }
+        }
+        if (tag_word == 0x9u || tag_word == 0x21u) {
+            uint32_t path_ix = ~ix;
+            if (tag_word == 0x9u) path_ix = m.v[0];
+            JlClipInp ci;
+            ci.ix = ix;
+            ci.path_ix = (int32_t)path_ix;
+            clip_inp.wr(m.v[1], ci);
+        }
+        prefix = monoid_add(prefix, tot);
+    }
+}
+
+int jh_launch_draw_reduce(const JhLaunch& L) {
+    if (L.nb < 3) return -1;
+    if (L.gx == 0) return 0;
+    hipLaunchKernelGGL(k_draw_reduce, dim3(L.gx), dim3(JL_WG), 0, L.stream, (const JlConfig*)L.b[0].ptr, mkbuf<uint32_t>(L.b[1].ptr, L.b[1].size),
+                       mkbuf<JlDrawMonoid>(L.b[2].ptr, L.b[2].size));
+    return 0;
+}
+int jh_launch_draw_leaf(const JhLaunch& L) {
+    if (L.nb < 7) return -1;
+    if (L.gx == 0) return 0;
+    hipLaunchKernelGGL(k_draw_leaf, dim3(L.gx), dim3(JL_WG), 0, L.stream, (const JlConfig*)L.b[0].ptr, mkbuf<uint32_t>(L.b[1].ptr, L.b[1].size),
+                       mkbuf<JlDrawMonoid>(L.b[2].ptr, L.b[2].size), mkbuf<JlPathBbox>(L.b[3].ptr, L.b[3].size),
+                       mkbuf<JlDrawMonoid>(L.b[4].ptr, L.b[4].size), mkbuf<uint32_t>(L.b[5].ptr, L.b[5].size),
+                       mkbuf<JlClipInp>(L.b[6].ptr, L.b[6].size));
+    return 0;
+}

@@ -1,0 +1,686 @@
+// kernels_tile.hip -- binning, tile allocation, path_count / path_tiling ("path_coarse"), backdrop:
+//   K11 binning           orig/binning.wgsl:58-184
+//   K12 tile_alloc        orig/tile_alloc.wgsl:35-123
+//   K13 path_count_setup  orig/path_count_setup.wgsl:17-27
+//   K14 path_count        orig/path_count.wgsl:51-202
+//   K15 backdrop_dyn      orig/backdrop_dyn.wgsl:28-86
+//   K17 path_tiling_setup orig/path_tiling_setup.wgsl:20-32
+//   K18 path_tiling       orig/path_tiling.wgsl:39-173
+//
+// MI355X design: every bump `atomicAdd` of the WGSL becomes count -> exclusive scan -> write, in the
+// reference's sequential order, so all outputs are run-to-run identical:
+//   binning     per-(workgroup,bin) element counts -> scan (wg-major) -> chunk offsets;
+//   tile_alloc  per-draw-object tile counts -> scan -> Path.tiles;
+//   path_count  per-line crossing counts -> scan -> SegmentCount slots; per-tile counts by
+//               no-return atomics (a sum, order-free); the per-tile arrival rank
+//               `seg_within_slice` is computed afterwards as the rank of the crossing's global
+//               index inside its tile's list (k_pc_scatter/k_pc_rank) instead of the value an
+//               atomicAdd happened to return.
+// The WGSL indirect dispatches become grid-stride loops bounded by the IndirectCount the setup
+// kernels write, so no host readback is needed.  All of this is HBM/atomic-bound integer work.
+#include "kcommon.h"
+
+using namespace jk;
+using namespace jd;
+
+namespace {
+
+struct Bb4 { float v[4]; };
+
+JD void bbox_intersect(const float* a, const float* b, float* o) {  // shared/bbox.wgsl:21-23
+    float r0 = fmax_(a[0], b[0]), r1 = fmax_(a[1], b[1]), r2 = fmin_(a[2], b[2]), r3 = fmin_(a[3], b[3]);
+    o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3;
+}
+
+// ------------------------------------------------------------------------------------------------
+// binning.  PASS 0: counts (+ intersected bbox).  PASS 1: chunk offsets known -> headers + bin_data.
+// ------------------------------------------------------------------------------------------------
+template <int PASS>
+__global__ __launch_bounds__(JL_WG) void k_binning(const JlConfig* __restrict__ cfg, Buf<JlDrawMonoid> draw_monoids, Buf<JlPathBbox> path_bbox_buf,
+                                                   Buf<Bb4> clip_bbox_buf, Buf<Bb4> intersected_bbox, JlBump* __restrict__ bump,
+                                                   Buf<uint32_t> bin_data, Buf<JlBinHeader> bin_header, uint32_t* __restrict__ counts,
+                                                   const uint32_t* __restrict__ offsets) {
+    __shared__ uint32_t sh_bitmaps[8][JL_N_TILE];
+    __shared__ uint32_t sh_count[4][JL_N_TILE];
+    __shared__ uint32_t sh_chunk_offset[JL_N_TILE];
+    const float SX = 0.00390625f, SY = 0.00390625f;
+    uint32_t lid = threadIdx.x;
+    uint32_t gid = blockIdx.x * JL_WG + lid;
+    for (uint32_t i = 0; i < 8u; i++) sh_bitmaps[i][lid] = 0u;
+    if (bump->lines > cfg->lines_size) {  // binning.wgsl:67-78 (uniform: read of a value written by an earlier stage)
+        if (PASS == 1 && gid == 0u) atomicOr(&bump->failed, (uint32_t)JL_STAGE_FLATTEN);
+        if (PASS == 0) counts[gid] = 0u;
+        return;
+    }
+    __syncthreads();
+    uint32_t element_ix = gid;
+    int32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    if (element_ix < cfg->layout.n_drawobj) {
+        JlDrawMonoid dm = draw_monoids.rd(element_ix);
+        float clip_bbox[4] = {-1e9f, -1e9f, 1e9f, 1e9f};
+        if (dm.clip_ix > 0u) {
+            Bb4 cb = clip_bbox_buf.rd(umin_(dm.clip_ix - 1u, cfg->layout.n_clip - 1u));
+            clip_bbox[0] = cb.v[0]; clip_bbox[1] = cb.v[1]; clip_bbox[2] = cb.v[2]; clip_bbox[3] = cb.v[3];
+        }
+        JlPathBbox pb = path_bbox_buf.rd(dm.path_ix);
+        float pbf[4] = {(float)pb.x0, (float)pb.y0, (float)pb.x1, (float)pb.y1};
+        Bb4 bbox;
+        bbox_intersect(clip_bbox, pbf, bbox.v);
+        if (PASS == 0) intersected_bbox.wr(element_ix, bbox);
+        if (bbox.v[0] < bbox.v[2] && bbox.v[1] < bbox.v[3]) {
+            x0 = to_i32(floor_(bbox.v[0] * SX));
+            y0 = to_i32(floor_(bbox.v[1] * SY));
+            x1 = to_i32(ceil_(bbox.v[2] * SX));
+            y1 = to_i32(ceil_(bbox.v[3] * SY));
+        }
+    }
+    int32_t width_in_bins = (int32_t)((cfg->width_in_tiles + 15u) / 16u);
+    int32_t height_in_bins = (int32_t)((cfg->height_in_tiles + 15u) / 16u);
+    x0 = iclamp_(x0, 0, width_in_bins);
+    y0 = iclamp_(y0, 0, height_in_bins);
+    x1 = iclamp_(x1, 0, width_in_bins);
+    y1 = iclamp_(y1, 0, height_in_bins);
+    if (x0 == x1) y1 = y0;
+    int32_t x = x0, y = y0;
+    uint32_t my_slice = lid / 32u;
+    uint32_t my_mask = 1u << (lid & 31u);
+    while (y < y1) {
+        uint32_t bin = (uint32_t)(y * width_in_bins + x);
+        if (bin < JL_N_TILE) atomicOr(&sh_bitmaps[my_slice][bin], my_mask);
+        x += 1;
+        if (x == x1) { x = x0; y += 1; }
+    }
+    __syncthreads();
+    uint32_t element_count = 0u;
+    for (uint32_t i = 0; i < 4u; i++) {
+        element_count += __popc(sh_bitmaps[i * 2u][lid]);
+        uint32_t lo = element_count;
+        element_count += __popc(sh_bitmaps[i * 2u + 1u][lid]);
+        uint32_t hi = element_count;
+        sh_count[i][lid] = lo | (hi << 16);
+    }
+    if (PASS == 0) {
+        counts[gid] = element_count;
+        return;
+    }
+    uint32_t chunk_offset = offsets[gid];
+    if (chunk_offset + element_count > cfg->binning_size) {
+        chunk_offset = 0u;
+        atomicOr(&bump->failed, (uint32_t)JL_STAGE_BINNING);
+    }
+    sh_chunk_offset[lid] = chunk_offset;
+    JlBinHeader h;
+    h.element_count = element_count;
+    h.chunk_offset = chunk_offset;
+    bin_header.wr(gid, h);
+    __syncthreads();
+    x = x0; y = y0;
+    while (y < y1) {
+        uint32_t bin_ix = (uint32_t)(y * width_in_bins + x);
+        if (bin_ix < JL_N_TILE) {
+            uint32_t out_mask = sh_bitmaps[my_slice][bin_ix];
+            if ((out_mask & my_mask) != 0u) {
+                uint32_t idx = __popc(out_mask & (my_mask - 1u));
+                if (my_slice > 0u) {
+                    uint32_t count_ix = my_slice - 1u;
+                    uint32_t count_packed = sh_count[count_ix / 2u][bin_ix];
+                    idx += (count_packed >> (16u * (count_ix & 1u))) & 0xffffu;
+                }
+                uint32_t offset = cfg->layout.bin_data_start + sh_chunk_offset[bin_ix];
+                bin_data.wr(offset + idx, element_ix);
+            }
+        }
+        x += 1;
+        if (x == x1) { x = x0; y += 1; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile_alloc.  PASS 0: bbox + tile counts.  PASS 1: offsets known -> Path.tiles, zero the tiles.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(JL_WG) void k_tile_alloc_count(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<Bb4> draw_bboxes,
+                                                            const JlBump* __restrict__ bump, Buf<JlPath> paths, uint32_t* __restrict__ counts) {
+    uint32_t drawobj_ix = blockIdx.x * JL_WG + threadIdx.x;
+    if ((bump->failed & (JL_STAGE_BINNING | JL_STAGE_FLATTEN)) != 0u) {  // tile_alloc.wgsl:43-50
+        counts[drawobj_ix] = 0u;
+        return;
+    }
+    const float SX = 1.0f / 16.0f, SY = 1.0f / 16.0f;
+    uint32_t drawtag = 0u;
+    if (drawobj_ix < cfg->layout.n_drawobj) drawtag = scene.rd(cfg->layout.drawtag_base + drawobj_ix);
+    int32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    if (drawtag != JL_DRAWTAG_NOP && drawtag != JL_DRAWTAG_END_CLIP) {
+        Bb4 bbox = draw_bboxes.rd(drawobj_ix);
+        if (bbox.v[0] < bbox.v[2] && bbox.v[1] < bbox.v[3]) {
+            x0 = to_i32(floor_(bbox.v[0] * SX));
+            y0 = to_i32(floor_(bbox.v[1] * SY));
+            x1 = to_i32(ceil_(bbox.v[2] * SX));
+            y1 = to_i32(ceil_(bbox.v[3] * SY));
+        }
+    }
+    uint32_t ux0 = (uint32_t)iclamp_(x0, 0, (int32_t)cfg->width_in_tiles);
+    uint32_t uy0 = (uint32_t)iclamp_(y0, 0, (int32_t)cfg->height_in_tiles);
+    uint32_t ux1 = (uint32_t)iclamp_(x1, 0, (int32_t)cfg->width_in_tiles);
+    uint32_t uy1 = (uint32_t)iclamp_(y1, 0, (int32_t)cfg->height_in_tiles);
+    counts[drawobj_ix] = (ux1 - ux0) * (uy1 - uy0);
+    if (drawobj_ix < cfg->layout.n_drawobj && paths.ok(drawobj_ix)) {
+        JlPath p;
+        p.bbox[0] = ux0; p.bbox[1] = uy0; p.bbox[2] = ux1; p.bbox[3] = uy1;
+        p.tiles = 0u; p.pad[0] = 0u; p.pad[1] = 0u; p.pad[2] = 0u;
+        paths.p[drawobj_ix] = p;
+    }
+}
+__global__ __launch_bounds__(JL_WG) void k_tile_alloc_write(const JlConfig* __restrict__ cfg, JlBump* __restrict__ bump, Buf<JlPath> paths,
+                                                            Buf<JlTile> tiles, const uint32_t* __restrict__ counts,
+                                                            const uint32_t* __restrict__ offsets, uint32_t n_total) {
+    if ((bump->failed & (JL_STAGE_BINNING | JL_STAGE_FLATTEN)) != 0u) return;
+    uint32_t wg_first = blockIdx.x * JL_WG;
+    uint32_t drawobj_ix = wg_first + threadIdx.x;
+    uint32_t wg_off = offsets[wg_first];
+    uint32_t last = wg_first + JL_WG - 1u;
+    uint32_t wg_cnt = (last < n_total ? offsets[last] + counts[last] : 0u) - wg_off;
+    uint32_t my_sub = offsets[drawobj_ix] - wg_off;
+    uint32_t offset = wg_off;
+    if (offset + wg_cnt > cfg->tiles_size) {  // tile_alloc.wgsl:93-99
+        offset = 0u;
+        if (threadIdx.x == JL_WG - 1u) atomicOr(&bump->failed, (uint32_t)JL_STAGE_TILE_ALLOC);
+    }
+    if (drawobj_ix < cfg->layout.n_drawobj && paths.ok(drawobj_ix)) paths.p[drawobj_ix].tiles = offset + my_sub;
+    JlTile z;
+    z.backdrop = 0;
+    z.segment_count_or_ix = 0u;
+    for (uint32_t i = threadIdx.x; i < wg_cnt; i += JL_WG) tiles.wr(offset + i, z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// setup kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void k_path_count_setup(const JlBump* __restrict__ bump, JlIndirectCount* __restrict__ ind) {
+    if (bump->failed != 0u) ind->x = 0u; else ind->x = (bump->lines + (JL_WG - 1u)) / JL_WG;
+    ind->y = 1u;
+    ind->z = 1u;
+}
+__global__ void k_path_tiling_setup(const JlBump* __restrict__ bump, JlIndirectCount* __restrict__ ind, Buf<uint32_t> ptcl) {
+    if (bump->failed != 0u) {
+        ind->x = 0u;
+        ptcl.wr(0u, ~0u);
+    } else {
+        ind->x = (bump->seg_counts + (JL_WG - 1u)) / JL_WG;
+    }
+    ind->y = 1u;
+    ind->z = 1u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// path_count
+// ------------------------------------------------------------------------------------------------
+JD uint32_t span(float a, float b) { return to_u32(fmax_(ceil_(fmax_(a, b)) - floor_(fmin_(a, b)), 1.0f)); }
+#define ONE_MINUS_ULP 0.99999994f
+#define ROBUST_EPSILON 2e-7f
+#define TILE_SCALE 0.0625f
+
+struct LineSetup {
+    bool valid;
+    bool is_down, is_positive_slope;
+    float a, b, x0, y0, x_sign, s0y;
+    uint32_t imin, imax;
+    int32_t ymin, ymax, delta;
+    int32_t bbox[4];
+    int32_t stride;
+    uint32_t tiles;
+};
+
+// Everything of path_count.wgsl:61-166 that precedes the side effects.
+JD LineSetup line_setup(const JlLineSoup& line, const Buf<JlPath>& paths) {
+    LineSetup r;
+    r.valid = false;
+    V2 lp0 = v2(line.p0[0], line.p0[1]), lp1 = v2(line.p1[0], line.p1[1]);
+    bool is_down = lp1.y >= lp0.y;
+    V2 xy0 = is_down ? lp0 : lp1;
+    V2 xy1 = is_down ? lp1 : lp0;
+    V2 s0 = xy0 * TILE_SCALE;
+    V2 s1 = xy1 * TILE_SCALE;
+    uint32_t count_x = span(s0.x, s1.x) - 1u;
+    uint32_t count = count_x + span(s0.y, s1.y);
+    float dx = abs_(s1.x - s0.x);
+    float dy = s1.y - s0.y;
+    if (dx + dy == 0.0f) return r;
+    if (dy == 0.0f && floor_(s0.y) == s0.y) return r;
+    float idxdy = 1.0f / (dx + dy);
+    float a = dx * idxdy;
+    bool is_positive_slope = s1.x >= s0.x;
+    float x_sign = is_positive_slope ? 1.0f : -1.0f;
+    float xt0 = floor_(s0.x * x_sign);
+    float c = s0.x * x_sign - xt0;
+    float y0 = floor_(s0.y);
+    float ytop = (s0.y == s1.y) ? ceil_(s0.y) : (y0 + 1.0f);
+    float b = fmin_((dy * c + dx * (ytop - s0.y)) * idxdy, ONE_MINUS_ULP);
+    float robust_err = floor_(a * ((float)count - 1.0f) + b) - (float)count_x;
+    if (robust_err != 0.0f) a -= ROBUST_EPSILON * sign_(robust_err);
+    float x0 = xt0 * x_sign + (is_positive_slope ? 0.0f : -1.0f);
+
+    JlPath path = paths.rd(line.path_ix);
+    int32_t bbox[4] = {(int32_t)path.bbox[0], (int32_t)path.bbox[1], (int32_t)path.bbox[2], (int32_t)path.bbox[3]};
+    float xmin = fmin_(s0.x, s1.x);
+    int32_t stride = bbox[2] - bbox[0];
+    if (s0.y >= (float)bbox[3] || s1.y <= (float)bbox[1] || xmin >= (float)bbox[2] || stride == 0) return r;
+    uint32_t imin = 0u;
+    if (s0.y < (float)bbox[1]) {
+        float iminf = round_(((float)bbox[1] - y0 + b - a) / (1.0f - a)) - 1.0f;
+        if (y0 + iminf - floor_(a * iminf + b) < (float)bbox[1]) iminf += 1.0f;
+        imin = to_u32(iminf);
+    }
+    uint32_t imax = count;
+    if (s1.y > (float)bbox[3]) {
+        float imaxf = round_(((float)bbox[3] - y0 + b - a) / (1.0f - a)) - 1.0f;
+        if (y0 + imaxf - floor_(a * imaxf + b) < (float)bbox[3]) imaxf += 1.0f;
+        imax = to_u32(imaxf);
+    }
+    int32_t delta = is_down ? -1 : 1;
+    int32_t ymin = 0, ymax = 0;
+    if (fmax_(s0.x, s1.x) <= (float)bbox[0]) {
+        ymin = to_i32(ceil_(s0.y));
+        ymax = to_i32(ceil_(s1.y));
+        imax = imin;
+    } else {
+        float fudge = is_positive_slope ? 0.0f : 1.0f;
+        if (xmin < (float)bbox[0]) {
+            float f = round_((x_sign * ((float)bbox[0] - x0) - b + fudge) / a);
+            if ((x0 + x_sign * floor_(a * f + b) < (float)bbox[0]) == is_positive_slope) f += 1.0f;
+            int32_t ynext = to_i32(y0 + f - floor_(a * f + b) + 1.0f);
+            if (is_positive_slope) {
+                if (to_u32(f) > imin) {
+                    ymin = to_i32(y0 + ((y0 == s0.y) ? 0.0f : 1.0f));
+                    ymax = ynext;
+                    imin = to_u32(f);
+                }
+            } else {
+                if (to_u32(f) < imax) {
+                    ymin = ynext;
+                    ymax = to_i32(ceil_(s1.y));
+                    imax = to_u32(f);
+                }
+            }
+        }
+        if (fmax_(s0.x, s1.x) > (float)bbox[2]) {
+            float f = round_((x_sign * ((float)bbox[2] - x0) - b + fudge) / a);
+            if ((x0 + x_sign * floor_(a * f + b) < (float)bbox[2]) == is_positive_slope) f += 1.0f;
+            if (is_positive_slope) imax = umin_(imax, to_u32(f)); else imin = umax_(imin, to_u32(f));
+        }
+    }
+    imax = umax_(imin, imax);
+    ymin = imax_(ymin, bbox[1]);
+    ymax = imin_(ymax, bbox[3]);
+    r.valid = true;
+    r.is_down = is_down; r.is_positive_slope = is_positive_slope;
+    r.a = a; r.b = b; r.x0 = x0; r.y0 = y0; r.x_sign = x_sign; r.s0y = s0.y;
+    r.imin = imin; r.imax = imax; r.ymin = ymin; r.ymax = ymax; r.delta = delta;
+    r.bbox[0] = bbox[0]; r.bbox[1] = bbox[1]; r.bbox[2] = bbox[2]; r.bbox[3] = bbox[3];
+    r.stride = stride;
+    r.tiles = path.tiles;
+    return r;
+}
+
+// pass 1: crossings per line
+__global__ __launch_bounds__(JL_WG) void k_pc_count(const JlBump* __restrict__ bump, const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines,
+                                                    Buf<JlPath> paths, uint32_t* __restrict__ counts, uint32_t counts_n) {
+    uint32_t n_lines = umin_(bump->lines, counts_n);
+    uint32_t n_threads = umin_(ind->x * JL_WG, counts_n);
+    for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
+        uint32_t c = 0u;
+        if (gid < n_threads && lines.ok(gid)) {
+            LineSetup s = line_setup(lines.p[gid], paths);
+            if (s.valid) c = s.imax - s.imin;
+        }
+        counts[gid] = c;
+    }
+}
+// pass 2: backdrops, per-tile counts, SegmentCount records (slice rank filled by k_pc_rank)
+__global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump,
+                                                   const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines, Buf<JlPath> paths, Buf<JlTile> tile,
+                                                   Buf<JlSegmentCount> seg_counts, const uint32_t* __restrict__ seg_bases, uint32_t bases_n,
+                                                   uint32_t* __restrict__ tile_of, uint32_t tile_of_n) {
+    uint32_t n_lines = umin_(umin_(bump->lines, bases_n), ind->x * JL_WG);
+    for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
+        if (!lines.ok(gid)) continue;
+        LineSetup s = line_setup(lines.p[gid], paths);
+        if (!s.valid) continue;
+        for (int32_t y = s.ymin; y < s.ymax; y++) {
+            uint32_t base = (uint32_t)((int32_t)s.tiles + (y - s.bbox[1]) * s.stride);
+            if (tile.ok(base)) atomicAdd(&tile.p[base].backdrop, s.delta);
+        }
+        float last_z = floor_(s.a * ((float)s.imin - 1.0f) + s.b);
+        uint32_t seg_base = seg_bases[gid];
+        for (uint32_t i = s.imin; i < s.imax; i++) {
+            float zf = s.a * (float)i + s.b;
+            float z = floor_(zf);
+            int32_t y = to_i32(s.y0 + (float)i - z);
+            int32_t x = to_i32(s.x0 + s.x_sign * z);
+            int32_t base = (int32_t)s.tiles + (y - s.bbox[1]) * s.stride - s.bbox[0];
+            bool top_edge = (i == 0u) ? (s.y0 == s.s0y) : (last_z == z);
+            if (top_edge && x + 1 < s.bbox[2]) {
+                int32_t x_bump = imax_(x + 1, s.bbox[0]);
+                uint32_t t = (uint32_t)(base + x_bump);
+                if (tile.ok(t)) atomicAdd(&tile.p[t].backdrop, s.delta);
+            }
+            uint32_t t = (uint32_t)(base + x);
+            if (tile.ok(t)) atomicAdd(&tile.p[t].segment_count_or_ix, 1u);
+            uint32_t seg_ix = seg_base + i - s.imin;
+            if (seg_ix < cfg->seg_counts_size && seg_counts.ok(seg_ix)) {
+                JlSegmentCount sc;
+                sc.line_ix = gid;
+                sc.counts = i;  // low 16 bits; the slice rank is OR-ed in by k_pc_rank
+                seg_counts.p[seg_ix] = sc;
+                if (seg_ix < tile_of_n) tile_of[seg_ix] = t;
+            }
+            last_z = z;
+        }
+    }
+}
+// pass 3: scatter crossing indices into per-tile lists (order inside a list is irrelevant)
+__global__ __launch_bounds__(JL_WG) void k_pc_scatter(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
+                                                      const uint32_t* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
+                                                      uint32_t* __restrict__ cursor, uint32_t tiles_cap, uint32_t* __restrict__ list) {
+    uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
+    for (uint32_t k = blockIdx.x * JL_WG + threadIdx.x; k < n; k += gridDim.x * JL_WG) {
+        uint32_t t = tile_of[k];
+        if (t >= tiles_cap || !tile.ok(t)) continue;
+        uint32_t pos = list_base[t] + atomicAdd(&cursor[t], 1u);
+        if (pos < n_cap) list[pos] = k;
+    }
+}
+// pass 4: seg_within_slice = rank of k among the crossings of its tile
+__global__ __launch_bounds__(JL_WG) void k_pc_rank(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
+                                                   const uint32_t* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
+                                                   uint32_t tiles_cap, const uint32_t* __restrict__ list, Buf<JlSegmentCount> seg_counts) {
+    uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
+    for (uint32_t k = blockIdx.x * JL_WG + threadIdx.x; k < n; k += gridDim.x * JL_WG) {
+        uint32_t t = tile_of[k];
+        if (t >= tiles_cap || !tile.ok(t) || !seg_counts.ok(k)) continue;
+        uint32_t base = list_base[t];
+        uint32_t cnt = tile.p[t].segment_count_or_ix;
+        uint32_t rank = 0u;
+        for (uint32_t j = 0; j < cnt; j++) {
+            uint32_t pos = base + j;
+            if (pos < n_cap && list[pos] < k) rank++;
+        }
+        seg_counts.p[k].counts |= rank << 16;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backdrop_dyn.wgsl:28-86
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(JL_WG) void k_backdrop_dyn(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlPath> paths,
+                                                        Buf<JlTile> tiles) {
+    __shared__ uint32_t sh_row_width[JL_WG];
+    __shared__ uint32_t sh_row_count[JL_WG];
+    __shared__ uint32_t sh_offset[JL_WG];
+    __shared__ uint32_t sh_scan[8];
+    if (bump->failed != 0u) return;
+    uint32_t lid = threadIdx.x;
+    uint32_t drawobj_ix = blockIdx.x * JL_WG + lid;
+    uint32_t row_count = 0u;
+    if (drawobj_ix < cfg->layout.n_drawobj) {
+        JlPath path = paths.rd(drawobj_ix);
+        sh_row_width[lid] = path.bbox[2] - path.bbox[0];
+        row_count = path.bbox[3] - path.bbox[1];
+        sh_offset[lid] = path.tiles;
+    } else {
+        sh_row_width[lid] = 0u;
+        sh_offset[lid] = 0u;
+    }
+    uint32_t total_rows;
+    uint32_t excl = block_excl_scan_u32(row_count, sh_scan, &total_rows);
+    sh_row_count[lid] = excl + row_count;  // inclusive
+    __syncthreads();
+    for (uint32_t row = lid; row < total_rows; row += JL_WG) {
+        uint32_t el_ix = 0u;
+        for (uint32_t i = 0; i < 8u; i++) {
+            uint32_t probe = el_ix + (128u >> i);
+            if (row >= sh_row_count[probe - 1u]) el_ix = probe;
+        }
+        uint32_t width = sh_row_width[el_ix];
+        if (width > 0u) {
+            uint32_t seq_ix = row - (el_ix > 0u ? sh_row_count[el_ix - 1u] : 0u);
+            uint32_t tile_ix = sh_offset[el_ix] + seq_ix * width;
+            int32_t sum = tiles.rd(tile_ix).backdrop;
+            for (uint32_t x = 1u; x < width; x++) {
+                tile_ix += 1u;
+                if (!tiles.ok(tile_ix)) break;
+                sum += tiles.p[tile_ix].backdrop;
+                tiles.p[tile_ix].backdrop = sum;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// path_tiling.wgsl:39-173
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(JL_WG) void k_path_tiling(const JlBump* __restrict__ bump, const JlIndirectCount* __restrict__ ind,
+                                                       Buf<JlSegmentCount> seg_counts, Buf<JlLineSoup> lines, Buf<JlPath> paths, Buf<JlTile> tiles,
+                                                       Buf<JlSegment> segments) {
+    uint32_t n_segments = umin_(bump->seg_counts, ind->x * JL_WG);
+    for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_segments; gid += gridDim.x * JL_WG) {
+        JlSegmentCount sc = seg_counts.rd(gid);
+        JlLineSoup line = lines.rd(sc.line_ix);
+        uint32_t seg_within_slice = sc.counts >> 16;
+        uint32_t seg_within_line = sc.counts & 0xffffu;
+        V2 lp0 = v2(line.p0[0], line.p0[1]), lp1 = v2(line.p1[0], line.p1[1]);
+        bool is_down = lp1.y >= lp0.y;
+        V2 xy0 = is_down ? lp0 : lp1;
+        V2 xy1 = is_down ? lp1 : lp0;
+        V2 s0 = xy0 * TILE_SCALE;
+        V2 s1 = xy1 * TILE_SCALE;
+        uint32_t count_x = span(s0.x, s1.x) - 1u;
+        uint32_t count = count_x + span(s0.y, s1.y);
+        float dx = abs_(s1.x - s0.x);
+        float dy = s1.y - s0.y;
+        float idxdy = 1.0f / (dx + dy);
+        float a = dx * idxdy;
+        bool is_positive_slope = s1.x >= s0.x;
+        float x_sign = is_positive_slope ? 1.0f : -1.0f;
+        float xt0 = floor_(s0.x * x_sign);
+        float c = s0.x * x_sign - xt0;
+        float y0i = floor_(s0.y);
+        float ytop = (s0.y == s1.y) ? ceil_(s0.y) : (y0i + 1.0f);
+        float b = fmin_((dy * c + dx * (ytop - s0.y)) * idxdy, ONE_MINUS_ULP);
+        float robust_err = floor_(a * ((float)count - 1.0f) + b) - (float)count_x;
+        if (robust_err != 0.0f) a -= ROBUST_EPSILON * sign_(robust_err);
+        int32_t x0i = to_i32(xt0 * x_sign + 0.5f * (x_sign - 1.0f));
+        float z = floor_(a * (float)seg_within_line + b);
+        int32_t x = x0i + to_i32(x_sign * z);
+        int32_t y = to_i32(y0i + (float)seg_within_line - z);
+        JlPath path = paths.rd(line.path_ix);
+        int32_t bbox[4] = {(int32_t)path.bbox[0], (int32_t)path.bbox[1], (int32_t)path.bbox[2], (int32_t)path.bbox[3]};
+        int32_t stride = bbox[2] - bbox[0];
+        int32_t tile_ix = (int32_t)path.tiles + (y - bbox[1]) * stride + x - bbox[0];
+        JlTile tile = tiles.rd((uint32_t)tile_ix);
+        uint32_t seg_start = ~tile.segment_count_or_ix;
+        if ((int32_t)seg_start < 0) continue;
+        V2 tile_xy = v2((float)x * 16.0f, (float)y * 16.0f);
+        V2 tile_xy1 = tile_xy + v2(16.0f, 16.0f);
+        if (seg_within_line > 0u) {
+            float z_prev = floor_(a * ((float)seg_within_line - 1.0f) + b);
+            if (z == z_prev) {
+                float xt = xy0.x + (xy1.x - xy0.x) * (tile_xy.y - xy0.y) / (xy1.y - xy0.y);
+                xt = clamp_(xt, tile_xy.x + 1e-3f, tile_xy1.x);
+                xy0 = v2(xt, tile_xy.y);
+            } else {
+                float x_clip = is_positive_slope ? tile_xy.x : tile_xy1.x;
+                float yt = xy0.y + (xy1.y - xy0.y) * (x_clip - xy0.x) / (xy1.x - xy0.x);
+                yt = clamp_(yt, tile_xy.y + 1e-3f, tile_xy1.y);
+                xy0 = v2(x_clip, yt);
+            }
+        }
+        if (seg_within_line < count - 1u) {
+            float z_next = floor_(a * ((float)seg_within_line + 1.0f) + b);
+            if (z == z_next) {
+                float xt = xy0.x + (xy1.x - xy0.x) * (tile_xy1.y - xy0.y) / (xy1.y - xy0.y);
+                xt = clamp_(xt, tile_xy.x + 1e-3f, tile_xy1.x);
+                xy1 = v2(xt, tile_xy1.y);
+            } else {
+                float x_clip = is_positive_slope ? tile_xy1.x : tile_xy.x;
+                float yt = xy0.y + (xy1.y - xy0.y) * (x_clip - xy0.x) / (xy1.x - xy0.x);
+                yt = clamp_(yt, tile_xy.y + 1e-3f, tile_xy1.y);
+                xy1 = v2(x_clip, yt);
+            }
+        }
+        float y_edge = 1e9f;
+        V2 p0 = xy0 - tile_xy;
+        V2 p1 = xy1 - tile_xy;
+        const float EPSILON = 1e-6f;
+        if (p0.x == 0.0f) {
+            if (p1.x == 0.0f) {
+                p0.x = EPSILON;
+                if (p0.y == 0.0f) {
+                    p1.x = EPSILON;
+                    p1.y = 16.0f;
+                } else {
+                    p1.x = 2.0f * EPSILON;
+                    p1.y = p0.y;
+                }
+            } else if (p0.y == 0.0f) {
+                p0.x = EPSILON;
+            } else {
+                y_edge = p0.y;
+            }
+        } else if (p1.x == 0.0f) {
+            if (p1.y == 0.0f) p1.x = EPSILON; else y_edge = p1.y;
+        }
+        if (p0.x == floor_(p0.x) && p0.x != 0.0f) p0.x -= EPSILON;
+        if (p1.x == floor_(p1.x) && p1.x != 0.0f) p1.x -= EPSILON;
+        if (!is_down) { V2 tmp = p0; p0 = p1; p1 = tmp; }
+        JlSegment seg;
+        seg.p0[0] = p0.x; seg.p0[1] = p0.y; seg.p1[0] = p1.x; seg.p1[1] = p1.y; seg.y_edge = y_edge; seg.pad = 0u;
+        segments.wr(seg_start + seg_within_slice, seg);
+    }
+}
+
+
+
+}  // namespace
+
+static inline uint32_t stride_grid(const JhLaunch& L, uint64_t n_items) {
+    uint64_t blocks = (n_items + JL_WG - 1) / JL_WG;
+    uint64_t cap = (uint64_t)(L.num_cus > 0 ? L.num_cus : 256) * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return (uint32_t)blocks;
+}
+
+// [config, draw_monoids, path_bbox, clip_bbox, intersected_bbox, bump, bin_data, bin_header]
+int jh_launch_binning(const JhLaunch& L) {
+    if (L.nb < 8) return -1;
+    if (L.gx == 0) return 0;
+    uint32_t n = L.gx * JL_WG;
+    uint32_t* counts = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)n * 4);
+    uint32_t* offsets = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_B, (uint64_t)n * 4);
+    if (!counts || !offsets) return -5;
+    auto cfg = (const JlConfig*)L.b[0].ptr;
+    auto dm = mkbuf<JlDrawMonoid>(L.b[1].ptr, L.b[1].size);
+    auto pb = mkbuf<JlPathBbox>(L.b[2].ptr, L.b[2].size);
+    auto cb = mkbuf<Bb4>(L.b[3].ptr, L.b[3].size);
+    auto ib = mkbuf<Bb4>(L.b[4].ptr, L.b[4].size);
+    JlBump* bump = (JlBump*)L.b[5].ptr;
+    auto bd = mkbuf<uint32_t>(L.b[6].ptr, L.b[6].size);
+    auto bh = mkbuf<JlBinHeader>(L.b[7].ptr, L.b[7].size);
+    hipLaunchKernelGGL(k_binning<0>, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, dm, pb, cb, ib, bump, bd, bh, counts, (const uint32_t*)nullptr);
+    int rc = jh_scan_u32(L, counts, 1, offsets, n, nullptr, &bump->binning);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_binning<1>, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, dm, pb, cb, ib, bump, bd, bh, (uint32_t*)nullptr,
+                       (const uint32_t*)offsets);
+    return 0;
+}
+
+// [config, scene, draw_bboxes, bump, paths, tiles]
+int jh_launch_tile_alloc(const JhLaunch& L) {
+    if (L.nb < 6) return -1;
+    if (L.gx == 0) return 0;
+    uint32_t n = L.gx * JL_WG;
+    uint32_t* counts = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)n * 4);
+    uint32_t* offsets = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_B, (uint64_t)n * 4);
+    if (!counts || !offsets) return -5;
+    auto cfg = (const JlConfig*)L.b[0].ptr;
+    auto scene = mkbuf<uint32_t>(L.b[1].ptr, L.b[1].size);
+    auto db = mkbuf<Bb4>(L.b[2].ptr, L.b[2].size);
+    JlBump* bump = (JlBump*)L.b[3].ptr;
+    auto paths = mkbuf<JlPath>(L.b[4].ptr, L.b[4].size);
+    auto tiles = mkbuf<JlTile>(L.b[5].ptr, L.b[5].size);
+    hipLaunchKernelGGL(k_tile_alloc_count, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, scene, db, (const JlBump*)bump, paths, counts);
+    int rc = jh_scan_u32(L, counts, 1, offsets, n, nullptr, &bump->tile);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tile_alloc_write, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, bump, paths, tiles, (const uint32_t*)counts,
+                       (const uint32_t*)offsets, n);
+    return 0;
+}
+
+// [bump, indirect]
+int jh_launch_path_count_setup(const JhLaunch& L) {
+    if (L.nb < 2) return -1;
+    hipLaunchKernelGGL(k_path_count_setup, dim3(1), dim3(1), 0, L.stream, (const JlBump*)L.b[0].ptr, (JlIndirectCount*)L.b[1].ptr);
+    return 0;
+}
+// [bump, indirect, ptcl]
+int jh_launch_path_tiling_setup(const JhLaunch& L) {
+    if (L.nb < 3) return -1;
+    hipLaunchKernelGGL(k_path_tiling_setup, dim3(1), dim3(1), 0, L.stream, (const JlBump*)L.b[0].ptr, (JlIndirectCount*)L.b[1].ptr,
+                       mkbuf<uint32_t>(L.b[2].ptr, L.b[2].size));
+    return 0;
+}
+
+// indirect; [config, bump, lines, paths, tile, seg_counts]
+int jh_launch_path_count(const JhLaunch& L) {
+    if (L.nb < 6 || !L.indirect) return -1;
+    auto cfg = (const JlConfig*)L.b[0].ptr;
+    JlBump* bump = (JlBump*)L.b[1].ptr;
+    auto lines = mkbuf<JlLineSoup>(L.b[2].ptr, L.b[2].size);
+    auto paths = mkbuf<JlPath>(L.b[3].ptr, L.b[3].size);
+    auto tile = mkbuf<JlTile>(L.b[4].ptr, L.b[4].size);
+    auto segc = mkbuf<JlSegmentCount>(L.b[5].ptr, L.b[5].size);
+    auto ind = (const JlIndirectCount*)L.indirect;
+    uint32_t lines_cap = lines.n, seg_cap = segc.n, tiles_cap = tile.n;
+    uint32_t* counts = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)lines_cap * 4);
+    uint32_t* bases = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_B, (uint64_t)lines_cap * 4);
+    uint32_t* tile_of = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_C, (uint64_t)seg_cap * 4);
+    uint32_t* list = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)seg_cap * 4);
+    uint32_t* list_base = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_E, (uint64_t)tiles_cap * 4);
+    uint32_t* cursor = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_F, (uint64_t)tiles_cap * 4);
+    if (!counts || !bases || !tile_of || !list || !list_base || !cursor) return -5;
+    uint32_t gl = stride_grid(L, lines_cap), gs = stride_grid(L, seg_cap);
+    hipLaunchKernelGGL(k_pc_count, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, paths, counts, lines_cap);
+    int rc = jh_scan_u32(L, counts, 1, bases, lines_cap, &bump->lines, &bump->seg_counts);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pc_emit, dim3(gl), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, ind, lines, paths, tile, segc,
+                       (const uint32_t*)bases, lines_cap, tile_of, seg_cap);
+    // per-tile list bases: exclusive scan of Tile.segment_count_or_ix over the allocated tiles
+    rc = jh_scan_u32(L, ((const uint32_t*)tile.p) + 1, 2, list_base, tiles_cap, &bump->tile, nullptr);
+    if (rc) return rc;
+    (void)hipMemsetAsync(cursor, 0, (size_t)tiles_cap * 4, L.stream);
+    hipLaunchKernelGGL(k_pc_scatter, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint32_t*)tile_of, seg_cap,
+                       (const uint32_t*)list_base, cursor, tiles_cap, list);
+    hipLaunchKernelGGL(k_pc_rank, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint32_t*)tile_of, seg_cap,
+                       (const uint32_t*)list_base, tiles_cap, (const uint32_t*)list, segc);
+    return 0;
+}
+
+// [config, bump, paths, tiles]
+int jh_launch_backdrop_dyn(const JhLaunch& L) {
+    if (L.nb < 4) return -1;
+    if (L.gx == 0) return 0;
+    hipLaunchKernelGGL(k_backdrop_dyn, dim3(L.gx), dim3(JL_WG), 0, L.stream, (const JlConfig*)L.b[0].ptr, (const JlBump*)L.b[1].ptr,
+                       mkbuf<JlPath>(L.b[2].ptr, L.b[2].size), mkbuf<JlTile>(L.b[3].ptr, L.b[3].size));
+    return 0;
+}
+
+// indirect; [bump, seg_counts, lines, paths, tiles, segments]
+int jh_launch_path_tiling(const JhLaunch& L) {
+    if (L.nb < 6 || !L.indirect) return -1;
+    auto segc = mkbuf<JlSegmentCount>(L.b[1].ptr, L.b[1].size);
+    uint32_t g = stride_grid(L, segc.n);
+    hipLaunchKernelGGL(k_path_tiling, dim3(g), dim3(JL_WG), 0, L.stream, (const JlBump*)L.b[0].ptr, (const JlIndirectCount*)L.indirect, segc,
+                       mkbuf<JlLineSoup>(L.b[2].ptr, L.b[2].size), mkbuf<JlPath>(L.b[3].ptr, L.b[3].size),
+                       mkbuf<JlTile>(L.b[4].ptr, L.b[4].size), mkbuf<JlSegment>(L.b[5].ptr, L.b[5].size));
+    return 0;
+}

@@ -142,6 +142,35 @@ void jl_scene_counts(void* s, uint32_t out[4]) {
     out[0] = e.num_paths; out[1] = e.num_path_segments; out[2] = e.num_clips; out[3] = e.num_open_clips;
 }
 
+// Bulk helper for the synthetic benchmark scenes: for each i, Fill(NonZero, identity, solid fill_rgba[i])
+// of the closed cubic pts[i] and, if widths[i] > 0, Stroke(width, join, caps, solid stroke_rgba[i]) of the
+// open cubic.  Exactly equivalent to calling jl_scene_fill / jl_scene_stroke in a loop.
+int jl_scene_fill_stroke_cubics(void* s, int n, const double* pts, const double* fill_rgba, const double* stroke_rgba, const double* widths,
+                                int join, int start_cap, int end_cap) {
+    Scene* sc = (Scene*)s;
+    Affine id;
+    try {
+        for (int i = 0; i < n; i++) {
+            const double* p = pts + (size_t)i * 8;
+            BezPath path;
+            path.push_back(PathEl{PathElKind::MoveTo, {p[0], p[1]}, {0, 0}, {0, 0}});
+            path.push_back(PathEl{PathElKind::CubicTo, {p[2], p[3]}, {p[4], p[5]}, {p[6], p[7]}});
+            const double* fc = fill_rgba + (size_t)i * 4;
+            sc->fill(Fill::NonZero, id, Brush::solid(Color{fc[0], fc[1], fc[2], fc[3]}), id, path);
+            if (widths && widths[i] > 0) {
+                Stroke st;
+                st.width = widths[i]; st.join = (Join)join; st.start_cap = (Cap)start_cap; st.end_cap = (Cap)end_cap;
+                const double* scol = stroke_rgba + (size_t)i * 4;
+                sc->stroke(st, id, Brush::solid(Color{scol[0], scol[1], scol[2], scol[3]}), id, path);
+            }
+        }
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+    return 0;
+}
+
 // ---- Recording (record-only: needs no GPU) ----
 struct RecHandle {
     Renderer::Result result;

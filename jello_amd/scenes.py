@@ -1,0 +1,145 @@
+"""Seeded synthetic scenes for the BASELINE.json configs.
+
+C1  rect fill + stroked cubic, 512x512 (plumbing)
+C2  tiger substitute: ~300 seeded blobs, fills + strokes, 1024x1024 (the Ghostscript tiger's path
+    data is not in the reference tree; this is flagged as a substitute)
+C3  n random stroked+filled cubic Beziers (headline: n = 100k at 4096x4096)
+C4  nested clips + radial gradients + blends (30k paths at 2048x2048)
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from .scene import (Brush, Cap, Color, ColorStop, Compose, Extend, Fill, Join, Mix, Path, RenderParams, Scene, Stroke)
+
+SEED = 0x6A656C6C6F  # "jello"
+_M64 = (1 << 64) - 1
+
+
+class SplitMix64:
+    def __init__(self, seed=SEED):
+        self.s = seed & _M64
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & _M64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+        return z ^ (z >> 31)
+
+    def uniform(self, lo=0.0, hi=1.0):
+        return lo + (hi - lo) * ((self.next() >> 11) * (1.0 / (1 << 53)))
+
+
+def splitmix64_array(n, seed=SEED):
+    """Vectorised SplitMix64: the same stream as SplitMix64(seed).next() called n times -> uniform [0,1)."""
+    i = np.arange(1, n + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + i * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def scene_c1():
+    s = Scene()
+    s.fill(Fill.NonZero, None, Brush.solid((1, 0, 0, 1)), None, Path.rect(10, 10, 200, 150))
+    p = Path().move_to(50, 300).cubic_to(150, 100, 350, 500, 450, 300)
+    s.stroke(Stroke(8, Join.Miter, 4, Cap.Butt, Cap.Butt), None, Brush.solid((0, 0, 1, 1)), None, p)
+    return s, RenderParams(512, 512)
+
+
+def scene_c3(n_paths=100_000, size=4096, seed=SEED, spread=32.0, stroked=True):
+    """n random cubic Beziers, each filled (non-zero) and then stroked (round join, butt caps)."""
+    # 17 uniforms per path, drawn in this order: anchor xy, 3 x (dx, dy), fill rgba, width, stroke rgba
+    u = splitmix64_array(n_paths * 17, seed).reshape(n_paths, 17)
+    anchor = u[:, 0:2] * size
+    pts = np.empty((n_paths, 8), dtype=np.float64)
+    pts[:, 0:2] = anchor
+    for k in range(3):
+        pts[:, 2 + 2 * k:4 + 2 * k] = anchor + (u[:, 2 + 2 * k:4 + 2 * k] * 2.0 - 1.0) * spread
+    fill = np.ascontiguousarray(u[:, 8:12])
+    widths = np.ascontiguousarray(0.5 + u[:, 12] * 3.5) if stroked else None
+    stroke = np.ascontiguousarray(u[:, 13:17])
+    s = Scene()
+    dp = ctypes.POINTER(ctypes.c_double)
+    pts = np.ascontiguousarray(pts)
+    rc = s._L.jl_scene_fill_stroke_cubics(s._h, n_paths, pts.ctypes.data_as(dp), fill.ctypes.data_as(dp), stroke.ctypes.data_as(dp),
+                                          widths.ctypes.data_as(dp) if stroked else None, int(Join.Round), int(Cap.Butt), int(Cap.Butt))
+    if rc != 0:
+        raise RuntimeError(s._L.jl_last_error().decode())
+    return s, RenderParams(size, size)
+
+
+def scene_c2(n_blobs=300, size=1024, seed=SEED + 2):
+    """Tiger substitute: blobs of 3-6 cubic segments, filled (some even-odd) and some stroked with miter/round joins and caps."""
+    r = SplitMix64(seed)
+    s = Scene()
+    for i in range(n_blobs):
+        cx, cy = r.uniform(0, size), r.uniform(0, size)
+        rad = r.uniform(8, 120)
+        nseg = 3 + int(r.uniform(0, 4))
+        p = Path()
+        ang0 = r.uniform(0, 2 * math.pi)
+        pts = []
+        for k in range(nseg):
+            a = ang0 + 2 * math.pi * k / nseg
+            rr = rad * r.uniform(0.5, 1.2)
+            pts.append((cx + rr * math.cos(a), cy + rr * math.sin(a)))
+        p.move_to(*pts[0])
+        for k in range(nseg):
+            a, b = pts[k], pts[(k + 1) % nseg]
+            c1 = (a[0] + r.uniform(-rad, rad) * 0.5, a[1] + r.uniform(-rad, rad) * 0.5)
+            c2 = (b[0] + r.uniform(-rad, rad) * 0.5, b[1] + r.uniform(-rad, rad) * 0.5)
+            p.cubic_to(c1[0], c1[1], c2[0], c2[1], b[0], b[1])
+        p.close()
+        col = (r.uniform(), r.uniform(), r.uniform(), r.uniform(0.3, 1.0))
+        rule = Fill.EvenOdd if i % 5 == 0 else Fill.NonZero
+        s.fill(rule, None, Brush.solid(col), None, p)
+        if i % 3 == 0:
+            joins = [Join.Bevel, Join.Miter, Join.Round]
+            caps = [Cap.Butt, Cap.Square, Cap.Round]
+            st = Stroke(r.uniform(0.5, 6), joins[i % 3 if i % 9 else (i // 9) % 3], 4.0, caps[(i // 3) % 3], caps[(i // 6) % 3])
+            q = Path()
+            q.move_to(*pts[0])
+            for k in range(1, nseg):
+                q.line_to(*pts[k]) if k % 2 else q.quad_to(cx, cy, *pts[k])
+            s.stroke(st, None, Brush.solid((r.uniform(), r.uniform(), r.uniform(), 1.0)), None, q)
+    return s, RenderParams(size, size, base_color=(1, 1, 1, 1))
+
+
+def scene_c4(n_paths=30_000, size=2048, seed=SEED + 4, group=10, depth=3):
+    """Groups of `group` paths under PushLayer(blend (Mix i%16, SrcOver), alpha .8, clip = random circle) nested `depth` deep;
+    every 3rd brush a 3-stop radial gradient."""
+    r = SplitMix64(seed)
+    s = Scene()
+    i = 0
+    gi = 0
+    while i < n_paths:
+        layers = 0
+        for d in range(depth):
+            cx, cy = r.uniform(0, size), r.uniform(0, size)
+            mix = Mix(gi % 16) if d == 0 else Mix.Clip
+            s.push_layer(mix, Compose.SrcOver, 0.8 if d == 0 else 1.0, None, Path.circle(cx, cy, 128.0 + 64.0 * (depth - d)))
+            layers += 1
+            gi += 1
+        for _ in range(group):
+            if i >= n_paths:
+                break
+            ax, ay = r.uniform(0, size), r.uniform(0, size)
+            p = Path().move_to(ax, ay)
+            p.cubic_to(ax + r.uniform(-96, 96), ay + r.uniform(-96, 96), ax + r.uniform(-96, 96), ay + r.uniform(-96, 96),
+                       ax + r.uniform(-96, 96), ay + r.uniform(-96, 96))
+            if i % 3 == 2:
+                stops = [ColorStop(0.0, (r.uniform(), r.uniform(), r.uniform(), 1.0)), ColorStop(0.5, (r.uniform(), r.uniform(), r.uniform(), 0.8)),
+                         ColorStop(1.0, (r.uniform(), r.uniform(), r.uniform(), 0.6))]
+                b = Brush.radial((ax, ay), 4.0, (ax + 10, ay + 5), 80.0, stops, Extend.Pad)
+            else:
+                b = Brush.solid((r.uniform(), r.uniform(), r.uniform(), r.uniform(0.2, 1.0)))
+            s.fill(Fill.NonZero, None, b, None, p)
+            i += 1
+        for _ in range(layers):
+            s.pop_layer()
+    return s, RenderParams(size, size, base_color=(0, 0, 0, 1))

@@ -1,0 +1,89 @@
+"""-m gpu: the device scalar routines (jello_amd/csrc/dmath.h) must agree bit for bit with the
+oracle's (oracle/omath.h) -- this is what makes flatten's line counts reproducible -- and the
+build must not contract a*b+c into an FMA."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import oracle_engine
+
+pytestmark = pytest.mark.gpu
+FP = ctypes.POINTER(ctypes.c_float)
+
+
+def gpu_op(engine, op, a, b=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    out = np.empty_like(a)
+    bp = None
+    if b is not None:
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        bp = b.ctypes.data_as(FP)
+    engine.hip.jh_selftest_math.argtypes = [ctypes.c_void_p, ctypes.c_int, FP, FP, FP, ctypes.c_uint32]
+    rc = engine.hip.jh_selftest_math(engine.ctx, op, a.ctypes.data_as(FP), bp, out.ctypes.data_as(FP), a.size)
+    assert rc == 0
+    return out
+
+
+def cpu_vec(name, a, b=None):
+    L = oracle_engine.lib()
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    out = np.empty_like(a)
+    if b is None:
+        getattr(L, name)(a.ctypes.data_as(FP), out.ctypes.data_as(FP), ctypes.c_int(a.size))
+    else:
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        getattr(L, name)(a.ctypes.data_as(FP), b.ctypes.data_as(FP), out.ctypes.data_as(FP), ctypes.c_int(a.size))
+    return out
+
+
+def bits(x):
+    return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+
+
+N = 1 << 21
+
+
+@pytest.mark.parametrize("op,name,lo,hi", [(0, "oracle_vec_sin", -40, 40), (1, "oracle_vec_cos", -40, 40), (3, "oracle_vec_acos", -1, 1),
+                                           (4, "oracle_vec_asin", -1, 1), (5, "oracle_vec_pow23", -8, 8)])
+def test_unary_transcendentals_bit_exact(engine, op, name, lo, hi):
+    rng = np.random.default_rng(op + 1)
+    x = (rng.random(N) * (hi - lo) + lo).astype(np.float32)
+    x[:8] = [0.0, -0.0, 1.0, -1.0, 0.5, 1e-30, -1e-30, 0.78539816]
+    assert np.array_equal(bits(gpu_op(engine, op, x)), bits(cpu_vec(name, x)))
+
+
+def test_atan2_bit_exact(engine):
+    rng = np.random.default_rng(7)
+    y = (rng.standard_normal(N) * 10 ** rng.uniform(-6, 6, N)).astype(np.float32)
+    x = (rng.standard_normal(N) * 10 ** rng.uniform(-6, 6, N)).astype(np.float32)
+    y[:6] = [0.0, -0.0, 0.0, 1.0, -1.0, 0.0]
+    x[:6] = [0.0, -1.0, -1.0, 0.0, 0.0, 1.0]
+    assert np.array_equal(bits(gpu_op(engine, 2, y, x)), bits(cpu_vec("oracle_vec_atan2", y, x)))
+
+
+def test_ieee_div_sqrt_round_and_no_fma(engine):
+    rng = np.random.default_rng(11)
+    a = (rng.standard_normal(N) * 10 ** rng.uniform(-20, 20, N)).astype(np.float32)
+    b = (rng.standard_normal(N) * 10 ** rng.uniform(-20, 20, N)).astype(np.float32)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(bits(gpu_op(engine, 6, a, b)), bits(a / b)), "f32 division is not correctly rounded"
+        assert np.array_equal(bits(gpu_op(engine, 7, np.abs(a))), bits(np.sqrt(np.abs(a)))), "f32 sqrt is not correctly rounded"
+        c = (rng.random(N) * 4 - 2).astype(np.float32)
+        d = (rng.random(N) * 4 - 2).astype(np.float32)
+        assert np.array_equal(bits(gpu_op(engine, 12, c, d)), bits((c * d).astype(np.float32) + c)), "a*b+a was contracted to an FMA"
+    h = (np.arange(-2000, 2000, dtype=np.float32) * 0.5)
+    assert np.array_equal(gpu_op(engine, 8, h), np.rint(h)), "round() must be ties-to-even"
+    sat = np.array([-1.0, 0.0, 0.9, 1.0, 4.2949673e9, 5e9, np.nan, -np.inf, np.inf, 2.5], dtype=np.float32)
+    assert list(gpu_op(engine, 9, sat).view(np.uint32)) == [0, 0, 0, 1, 0xffffffff, 0xffffffff, 0, 0, 0xffffffff, 2]
+    assert list(gpu_op(engine, 10, sat).view(np.int32)) == [-1, 0, 0, 1, 2147483647, 2147483647, 0, -2147483648, 2147483647, 2]
+
+
+def test_f16_store_conversion(engine):
+    rng = np.random.default_rng(5)
+    x = np.concatenate([(rng.standard_normal(1 << 18) * 10 ** rng.uniform(-9, 5, 1 << 18)).astype(np.float32),
+                        np.array([0, 65504, 65519.99, 65520, 1e9, 5.96e-8, 2.98e-8, 2.9802322e-8, 6.1e-5], dtype=np.float32)])
+    got = gpu_op(engine, 11, x).view(np.uint32).astype(np.uint16)
+    with np.errstate(over="ignore"):
+        want = x.astype(np.float16).view(np.uint16)
+    assert np.array_equal(got, want)

@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of BASELINE.json: "Mpixels/sec fine-raster + paths/sec, 100k-path
+4096^2 scene, 1/2/4/8 MI355X".
+
+A step = one full pass of the hot path (pathtag scan -> flatten -> draw/clip scans -> binning ->
+tile_alloc -> path_count -> backdrop -> coarse -> path_tiling -> fine) over one synthetic scene that is
+already resident in HBM (scene bytes + config uploaded before the timed region).  At N > 1 every rank
+renders its own independent scene (weak scaling, no data-path collective) and the finished RGBA16F
+images are gathered to rank 0 over RCCL, overlapped with the next frame.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--paths", type=int, default=100_000)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import jello_amd
+    from jello_amd import BumpSizes, scenes
+    from jello_amd.engine import RUN_DISPATCHES, RUN_UPLOADS
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    W = H = args.size
+    # independent scene per rank (same generator, different seed)
+    scene, params = scenes.scene_c3(args.paths, args.size, seed=scenes.SEED + rank)
+    eng = jello_amd.Engine(dev.index)
+    host = jello_amd.Host()
+    stream = torch.cuda.current_stream(dev)
+    eng.set_stream(stream.cuda_stream)
+
+    # ---- size the bump buffers once (regrow loop), outside the timed region ----
+    params.bump = BumpSizes(lines=1 << 22, seg_counts=1 << 23, segments=1 << 23, tiles=1 << 22, ptcl=1 << 26, bin_data=1 << 21)
+    rec0, bump, attempts = eng.render(scene, params, robust=True)
+    if bump["failed"]:
+        raise RuntimeError("bump allocation still failing after regrow: %s" % bump)
+    cfg0 = rec0.config
+    margin = lambda x: int(x * 1.1) + 4096
+    params.bump = BumpSizes(lines=margin(bump["lines"]), seg_counts=margin(bump["seg_counts"]), segments=margin(bump["segments"]),
+                            tiles=margin(bump["tile"]), ptcl=margin(bump["ptcl"] + cfg0["width_in_tiles"] * cfg0["height_in_tiles"] * 64),
+                            bin_data=margin(bump["binning"] + cfg0["bin_data_start"]), blend_spill=max(4096, margin(bump["blend"])))
+    del rec0
+    rec = host.record(scene, params)
+    cfg = rec.config
+
+    # output images: torch owns the device memory (double-buffered for the overlapped gather)
+    outs = [torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(2)]
+    gathered = None
+    if world > 1 and rank == 0 and not args.no_gather:
+        gathered = [[torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(world)] for _ in range(2)]
+
+    eng.run(rec, RUN_UPLOADS | RUN_DISPATCHES, outs[0].data_ptr())  # uploads scene/config; allocates every buffer
+    torch.cuda.synchronize(dev)
+
+    pending = [None, None]
+
+    def step(i, profile=False):
+        k = i & 1
+        if pending[k] is not None:
+            pending[k].wait()
+            pending[k] = None
+        eng.run(rec, RUN_DISPATCHES, outs[k].data_ptr())
+        if world > 1 and not args.no_gather:
+            pending[k] = dist.gather(outs[k], gathered[k] if rank == 0 else None, dst=0, async_op=True)
+
+    for i in range(args.warmup):
+        step(i)
+    for p in pending:
+        if p is not None:
+            p.wait()
+    pending[:] = [None, None]
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    for p in pending:
+        if p is not None:
+            p.wait()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    prof = eng.profile_collect(1 << 16)
+    eng.profile(False)
+
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+
+    # ---- per-stage device times (hipEvent pairs recorded on the launch stream during the timed region) ----
+    stage_ms = {}
+    for name, ms in prof:
+        stage_ms[name] = stage_ms.get(name, 0.0) + ms
+    stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
+    fine_ms = stage_ms.get("fine_area", float("nan"))
+
+    result = None
+    if rank == 0:
+        # ---- algorithmic bytes of the fine stage, from the PTCL this run produced ----
+        ptcl_id, ptcl_size = rec.buffer("ptclBuf")
+        ptcl = eng.download(ptcl_id, dtype=np.uint32)
+        st = (ctypes.c_uint64 * 8)()
+        rc = eng._L.jl_ptcl_stats(ptcl.ctypes.data, ptcl.size, cfg["width_in_tiles"], cfg["height_in_tiles"], st)
+        if rc != 0:
+            raise RuntimeError("malformed PTCL")
+        words, segs, info_words, texels, spill_px = st[0], st[1], st[2], st[3], st[4]
+        b_fine = 4 * words + 24 * segs + 4 * info_words + 8 * texels + 32 * spill_px + 8 * W * H
+        achieved = b_fine / (fine_ms * 1e-3) / 1e9
+        bump_now = eng.download(rec.buffer("bumpBuf")[0], dtype=np.uint32)[:8]
+        roofline = {"kernel": "k_fine_area", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes": int(b_fine), "avg_ms": round(fine_ms, 4),
+                    "segment_pixel_evals": int(segs) * 256}
+        pm = os.path.join(ROOT, "profiles", "fine_traffic.json")
+        if os.path.exists(pm):
+            try:
+                roofline["traffic"] = json.load(open(pm)).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(host)
+        mpix = W * H * world / (elapsed / args.steps) / 1e6
+        result = {
+            "metric": "Mpixels/sec fine-raster + paths/sec, 100k-path 4096^2 scene", "value": round(mpix, 2), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: %d random stroked+filled cubic Beziers, %dx%d RGBA16F target, area AA, one independent scene per GPU"
+                                   % (args.paths, W, H),
+                       "paths": args.paths, "draw_objects": cfg["n_drawobj"], "width": W, "height": H,
+                       "parallelism": "scene-per-gpu x%d%s" % (world, "" if world == 1 or args.no_gather else " + RCCL image gather")},
+            "paths_per_s": round(args.paths * world / (elapsed / args.steps), 1),
+            "fine_mpixels_per_s": round(W * H / (fine_ms * 1e-3) / 1e6, 2),
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "bump": {k: int(v) for k, v in zip(["failed", "binning", "ptcl", "tile", "seg_counts", "segments", "blend", "lines"], bump_now)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "device": eng.device_info()["name"],
+        }
+    eng.release(rec)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def cpu_baseline(host):
+    """The CPU restatement of the Jello/Vello pipeline (oracle/, single thread) timed on a bounded
+    sample of the same workload: the C3 generator at 1/4 of the area with the same path density."""
+    from jello_amd import BumpSizes, scenes
+    from oracle.oracle_engine import OracleEngine
+    n, size = 25_000, 2048
+    scene, params = scenes.scene_c3(n, size)
+    params.bump = BumpSizes(lines=1 << 22, seg_counts=1 << 22, segments=1 << 22, tiles=1 << 22, ptcl=1 << 25, bin_data=1 << 20)
+    rec = host.record(scene, params)
+    orc = OracleEngine()
+    t0 = time.perf_counter()
+    orc.run(rec)
+    dt = time.perf_counter() - t0
+    bump = orc.get(rec, "bumpBuf", np.uint32)[:8]
+    if bump[0] != 0:
+        raise RuntimeError("oracle bump failure in cpu_baseline")
+    return {"value": round(size * size / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": "CPU restatement of the Jello/Vello pipeline (oracle/, 1 thread), C3 generator with %d paths at %dx%d "
+                      "(1/4 of the headline area, same density), all stages incl. fine" % (n, size, size),
+            "seconds": round(dt, 3), "paths_per_s": round(n / dt, 1),
+            "stage_seconds": {k: round(v, 4) for k, v in orc.stage_seconds.items()},
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -132,6 +132,7 @@ def _declare(L):
     L.jl_scene_stream.argtypes = [vp, ci, ctypes.POINTER(vp)]
     L.jl_scene_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
     L.jl_scene_fill_stroke_cubics.argtypes = [vp, ci, dp, dp, dp, dp, ci, ci, ci]
+    L.jl_ptcl_stats.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
     L.jl_host_new.restype = vp
     L.jl_host_free.argtypes = [vp]
     L.jl_record.restype = vp

@@ -271,6 +271,42 @@ void jl_recording_wg_counts(void* r, uint32_t* out, int n) {  // flattened Workg
     if (k < n) out[k] = w.use_large_path_scan ? 1u : 0u;
 }
 
+// ---- PTCL statistics (profiling aid: the algorithmic-bytes model of the fine stage) ----
+// out[0] words visited (incl. blend_ix, JUMP, END)  out[1] sum of n_segs over CMD_FILL  out[2] info words read
+// out[3] gradient/image texel fetches per pixel-command (x256 px)  out[4] blend-spill pixels written+read  out[5] tiles
+// out[6] FILL commands  out[7] COLOR commands  Returns 0, or -1 on a malformed stream.
+int jl_ptcl_stats(const uint32_t* ptcl, uint64_t n_words, uint32_t width_in_tiles, uint32_t height_in_tiles, uint64_t* out) {
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    uint64_t n_tiles = (uint64_t)width_in_tiles * height_in_tiles;
+    for (uint64_t t = 0; t < n_tiles; t++) {
+        uint64_t ix = t * 64;
+        if (ix >= n_words) return -1;
+        out[0] += 1;
+        ix += 1;
+        uint32_t depth = 0;
+        for (uint64_t guard = 0;; guard++) {
+            if (ix >= n_words || guard > (1u << 24)) return -1;
+            uint32_t tag = ptcl[ix];
+            if (tag == JL_CMD_END) { out[0] += 1; break; }
+            switch (tag) {
+                case JL_CMD_FILL: out[0] += 4; out[1] += ptcl[ix + 1] >> 1; out[6] += 1; ix += 4; break;
+                case JL_CMD_SOLID: out[0] += 1; ix += 1; break;
+                case JL_CMD_COLOR: out[0] += 5; out[7] += 1; ix += 5; break;
+                case JL_CMD_LIN_GRAD: out[0] += 3; out[2] += 3; out[3] += 256; ix += 3; break;
+                case JL_CMD_RAD_GRAD: out[0] += 3; out[2] += 9; out[3] += 256; ix += 3; break;
+                case JL_CMD_SWEEP_GRAD: out[0] += 3; out[2] += 8; out[3] += 256; ix += 3; break;
+                case JL_CMD_IMAGE: out[0] += 2; out[2] += 8; out[3] += 4 * 256; ix += 2; break;
+                case JL_CMD_BEGIN_CLIP: out[0] += 1; if (depth >= JL_BLEND_STACK_SPLIT) out[4] += 256; depth++; ix += 1; break;
+                case JL_CMD_END_CLIP: out[0] += 3; if (depth > 0) depth--; if (depth >= JL_BLEND_STACK_SPLIT) out[4] += 256; ix += 3; break;
+                case JL_CMD_JUMP: out[0] += 2; ix = ptcl[ix + 1]; break;
+                default: return -1;
+            }
+        }
+        out[5] += 1;
+    }
+    return 0;
+}
+
 // ---- Engine (needs the GPU) ----
 void* jl_engine_new(int device) {
     Engine* e = nullptr;

@@ -1,0 +1,44 @@
+"""Multi-GPU sharding of the render path.
+
+Two modes, neither needs a collective on the data path:
+  * scenes: independent scenes, one per rank (weak scaling) -- `scene_seed_for_rank`;
+  * bands:  disjoint bin-row bands of ONE target -- every rank runs the cheap element stages on the
+            whole scene (replicated, so allocation scans and hence PTCL addresses are identical on
+            every rank) and coarse+fine only for its band -- `band_for_rank`.
+The only exchange is the final image gather to rank 0 (`gather_images`): RCCL on GPUs ("nccl"
+backend), gloo in the CPU tests.
+"""
+from . import scenes
+
+
+def scene_seed_for_rank(rank, base=scenes.SEED):
+    return base + int(rank)
+
+
+def band_for_rank(height_in_bins, world, rank):
+    """Contiguous range [y0, y1) of 256-px bin rows owned by `rank`; earlier ranks take the remainder."""
+    base, rem = divmod(int(height_in_bins), int(world))
+    y0 = rank * base + min(rank, rem)
+    y1 = y0 + base + (1 if rank < rem else 0)
+    return y0, y1
+
+
+def gather_images(dist, local, rank, world, dst=0, async_op=False, out=None):
+    """Gather every rank's finished image tensor to `dst`.  Returns (list of tensors on dst | None, work)."""
+    import torch
+    if world == 1:
+        return [local], None
+    if rank == dst and out is None:
+        out = [torch.empty_like(local) for _ in range(world)]
+    work = dist.gather(local, out if rank == dst else None, dst=dst, async_op=async_op)
+    return (out if rank == dst else None), work
+
+
+def assemble_bands(images, height_in_bins, world):
+    """Stitch per-rank band images (each full-size, only its band valid) into one image (on dst)."""
+    import torch
+    out = torch.zeros_like(images[0])
+    for r, im in enumerate(images):
+        y0, y1 = band_for_rank(height_in_bins, world, r)
+        out[y0 * 256:y1 * 256] = im[y0 * 256:y1 * 256]
+    return out

@@ -187,12 +187,12 @@ def main():
 
 def cpu_baseline(host):
     """The CPU restatement of the Jello/Vello pipeline (oracle/, single thread) timed on a bounded
-    sample of the same workload: the C3 generator at 1/4 of the area with the same path density."""
+    sample of the same workload: one frame of the full headline scene (about 5-10 s of CPU work)."""
     from jello_amd import BumpSizes, scenes
     from oracle.oracle_engine import OracleEngine
-    n, size = 25_000, 2048
+    n, size = 100_000, 4096
     scene, params = scenes.scene_c3(n, size)
-    params.bump = BumpSizes(lines=1 << 22, seg_counts=1 << 22, segments=1 << 22, tiles=1 << 22, ptcl=1 << 25, bin_data=1 << 20)
+    params.bump = BumpSizes(lines=1 << 22, seg_counts=1 << 23, segments=1 << 23, tiles=1 << 21, ptcl=1 << 25, bin_data=1 << 20)
     rec = host.record(scene, params)
     orc = OracleEngine()
     t0 = time.perf_counter()
@@ -203,7 +203,7 @@ def cpu_baseline(host):
         raise RuntimeError("oracle bump failure in cpu_baseline")
     return {"value": round(size * size / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
             "sample": "CPU restatement of the Jello/Vello pipeline (oracle/, 1 thread), C3 generator with %d paths at %dx%d "
-                      "(1/4 of the headline area, same density), all stages incl. fine" % (n, size, size),
+                      "= the full headline workload, one frame, all stages incl. fine" % (n, size, size),
             "seconds": round(dt, 3), "paths_per_s": round(n / dt, 1),
             "stage_seconds": {k: round(v, 4) for k, v in orc.stage_seconds.items()},
             "host_cpus": os.cpu_count()}

@@ -195,6 +195,7 @@ enum {  // scratch slots
     JH_SCR_D = 4,
     JH_SCR_E = 5,
     JH_SCR_F = 6,
+    JH_SCR_G = 7,
     JH_SCR_COUNT = 8
 };
 

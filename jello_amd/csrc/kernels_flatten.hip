@@ -2,12 +2,14 @@
 // Euler-spiral subdivision of fills, GPU stroke expansion (offset curves, caps, joins, arcs).
 //
 // MI355X design: the WGSL allocates every output line with atomicAdd(bump.lines), which makes the
-// LineSoup order run-dependent.  Here the stage is count -> exclusive scan -> emit:
-//   pass 1  k_flatten<false>  each thread runs the subdivision logic and only COUNTS its lines
-//                              (no per-line point evaluation, no stores except one u32);
-//   scan    jh_scan_u32        line base per tag byte; the total lands in bump.lines;
-//   pass 2  k_flatten<true>   same arithmetic, lines stored at base+k, path bbox via atomicMin/Max
-//                              (commutative, so deterministic).
+// LineSoup order run-dependent.  Here the stage is classify -> count -> scan -> emit:
+//   k_flatten_classify      one thread per tag byte: splits it into up to 3 work items (see below) and
+//                           appends them to a heavy / light list; writes PathBbox.draw_flags/trans_ix;
+//   k_flatten_items<false>  one thread per item: runs the subdivision logic and only COUNTS its lines
+//                           (no per-line point evaluation) into counts[slot];
+//   jh_scan_u32             line base per slot; the total lands in bump.lines;
+//   k_flatten_items<true>   same arithmetic, lines stored at base+k, path bbox via atomicMin/Max
+//                           (commutative, so deterministic).
 // Result: lines are ordered by (tag byte, emission order) -- the reference's own sequential order
 // (shaders/cpu/flatten.go:664-823).  Algorithmic traffic: scene bytes + 20 B / tag word in,
 // 24 B / line out.  The stage is ALU/latency-bound (f64 transcendentals, divergent trip counts).
@@ -543,93 +545,150 @@ JD CubicPoints read_path_segment(const Scene& s, const PathTagData& tag, bool is
     return r;
 }
 
-// flatten.wgsl:809-901
-template <bool EMIT>
-__global__ __launch_bounds__(JL_WG) void k_flatten(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
-                                                   Buf<JlPathBbox> path_bboxes, Buf<JlLineSoup> lines, uint32_t* __restrict__ counts,
-                                                   const uint32_t* __restrict__ bases) {
+// ------------------------------------------------------------------------------------------------
+// Work decomposition.  The WGSL runs one invocation per tag byte (flatten.wgsl:809-901); in a wave of
+// 64 consecutive tag bytes only a few lanes hold a curve and a stroked cubic costs several times a
+// filled one, so SIMD utilisation is poor.  Here every tag byte is split into up to three independent
+// ITEMS -- slot = 3*tag_ix + sub:
+//     fill segment            sub 0: flatten_euler(offset 0)
+//     stroke segment          sub 0: flatten_euler(+offset)   sub 1: flatten_euler(-offset)   sub 2: join or end cap
+//     open-stroke cap marker  sub 0: start cap
+// Slots are in the reference's emission order, so "count per slot -> exclusive scan -> emit at base" still
+// yields the canonical LineSoup order.  Items are appended (wave-aggregated atomics; list order is
+// irrelevant) to a HEAVY list (quad/cubic Euler flattening) or a LIGHT list (lines, caps, joins), and the
+// count/emit kernels walk heavy-then-light so that waves are homogeneous.
+// ------------------------------------------------------------------------------------------------
+struct Seg {
+    PathTagData tag;
+    uint32_t style_flags;
+    bool is_stroke;
+};
+
+JD Seg load_seg(const Scene& s, uint32_t ix) {
+    Seg r;
+    r.tag = compute_tag_monoid(s, ix);
+    r.style_flags = s.scene.rd(s.cfg->layout.style_base + r.tag.monoid.v[3]);
+    r.is_stroke = (r.style_flags & JL_STYLE_FLAGS_STYLE) != 0u;
+    return r;
+}
+
+JD void append_item(uint32_t* __restrict__ list, uint32_t* __restrict__ counters, uint32_t cap, bool heavy, uint32_t slot) {
+    uint32_t pos = atomicAdd(&counters[heavy ? 0 : 1], 1u);  // hipcc aggregates this per wave
+    if (pos < cap) list[heavy ? pos : (cap - 1u - pos)] = slot;
+}
+
+__global__ __launch_bounds__(JL_WG) void k_flatten_classify(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
+                                                            Buf<JlPathBbox> path_bboxes, uint32_t* __restrict__ list,
+                                                            uint32_t* __restrict__ counters, uint32_t cap) {
     uint32_t ix = blockIdx.x * JL_WG + threadIdx.x;
     Scene s;
     s.cfg = cfg; s.scene = scene; s.tag_monoids = tag_monoids;
-    Out<EMIT> o;
-    o.cfg = cfg; o.lines = lines;
-    o.cursor = EMIT ? bases[ix] : 0u;
-    o.bx0 = 1e31f; o.by0 = 1e31f; o.bx1 = -1e31f; o.by1 = -1e31f;
-
-    PathTagData tag = compute_tag_monoid(s, ix);
-    uint32_t path_ix = tag.monoid.v[4];
-    uint32_t style_ix = tag.monoid.v[3];
-    uint32_t trans_ix = tag.monoid.v[0];
-    uint32_t style_flags = scene.rd(cfg->layout.style_base + style_ix);
-    uint32_t draw_flags = ((style_flags & JL_STYLE_FLAGS_FILL) == 0u) ? 0u : 1u;
-    if (EMIT && (tag.tag_byte & JL_PATH_TAG_PATH) != 0u && path_bboxes.ok(path_ix)) {
-        path_bboxes.p[path_ix].draw_flags = draw_flags;
-        path_bboxes.p[path_ix].trans_ix = trans_ix;
+    Seg g = load_seg(s, ix);
+    uint32_t path_ix = g.tag.monoid.v[4];
+    if ((g.tag.tag_byte & JL_PATH_TAG_PATH) != 0u && path_bboxes.ok(path_ix)) {  // flatten.wgsl:825-828
+        path_bboxes.p[path_ix].draw_flags = ((g.style_flags & JL_STYLE_FLAGS_FILL) == 0u) ? 0u : 1u;
+        path_bboxes.p[path_ix].trans_ix = g.tag.monoid.v[0];
     }
-    uint32_t seg_type = tag.tag_byte & JL_PATH_TAG_SEG_TYPE;
-    if (seg_type != 0u) {
-        bool is_stroke = (style_flags & JL_STYLE_FLAGS_STYLE) != 0u;
-        Xf transform;
-        {
-            uint32_t base = cfg->layout.transform_base + trans_ix * 6u;
-            transform.m0 = u2f(scene.rd(base)); transform.m1 = u2f(scene.rd(base + 1u)); transform.m2 = u2f(scene.rd(base + 2u));
-            transform.m3 = u2f(scene.rd(base + 3u)); transform.t0 = u2f(scene.rd(base + 4u)); transform.t1 = u2f(scene.rd(base + 5u));
-        }
-        CubicPoints pts = read_path_segment(s, tag, is_stroke);
-        if (is_stroke) {
-            float linewidth = u2f(scene.rd(cfg->layout.style_base + style_ix + 1u));
-            float offset = 0.5f * linewidth;
-            bool is_open = (tag.tag_byte & JL_PATH_TAG_SEG_TYPE) != JL_PATH_TAG_LINETO;
-            bool is_stroke_cap_marker = (tag.tag_byte & JL_PATH_TAG_SUBPATH_END) != 0u;
-            if (is_stroke_cap_marker) {
-                if (is_open) {
-                    V2 tangent = cubic_start_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
-                    V2 offset_tangent = offset * normalize(tangent);
-                    V2 n = v2(offset_tangent.y * -1.0f, offset_tangent.x * 1.0f);
-                    draw_cap<EMIT>(o, path_ix, (style_flags & JL_STYLE_FLAGS_START_CAP_MASK) >> 2, pts.p0, pts.p0 - n, pts.p0 + n,
-                                   -offset_tangent, transform);
-                }
+    uint32_t seg_type = g.tag.tag_byte & JL_PATH_TAG_SEG_TYPE;
+    if (seg_type == 0u) return;
+    bool curved = seg_type != JL_PATH_TAG_LINETO;
+    if (!g.is_stroke) {
+        append_item(list, counters, cap, curved, ix * 3u);
+    } else if ((g.tag.tag_byte & JL_PATH_TAG_SUBPATH_END) != 0u) {
+        if (curved) append_item(list, counters, cap, false, ix * 3u);  // open path: start cap (closed: nothing)
+    } else {
+        append_item(list, counters, cap, curved, ix * 3u);
+        append_item(list, counters, cap, curved, ix * 3u + 1u);
+        append_item(list, counters, cap, false, ix * 3u + 2u);
+    }
+}
+
+template <bool EMIT>
+JD void run_item(const JlConfig* cfg, const Scene& s, const Buf<JlPathBbox>& path_bboxes, Out<EMIT>& o, uint32_t slot) {
+    uint32_t ix = slot / 3u, sub = slot - ix * 3u;
+    Seg g = load_seg(s, ix);
+    uint32_t path_ix = g.tag.monoid.v[4];
+    uint32_t style_ix = g.tag.monoid.v[3];
+    uint32_t trans_ix = g.tag.monoid.v[0];
+    uint32_t style_flags = g.style_flags;
+    Xf transform;
+    {
+        uint32_t base = cfg->layout.transform_base + trans_ix * 6u;
+        transform.m0 = u2f(s.scene.rd(base)); transform.m1 = u2f(s.scene.rd(base + 1u)); transform.m2 = u2f(s.scene.rd(base + 2u));
+        transform.m3 = u2f(s.scene.rd(base + 3u)); transform.t0 = u2f(s.scene.rd(base + 4u)); transform.t1 = u2f(s.scene.rd(base + 5u));
+    }
+    CubicPoints pts = read_path_segment(s, g.tag, g.is_stroke);
+    if (g.is_stroke) {
+        float linewidth = u2f(s.scene.rd(cfg->layout.style_base + style_ix + 1u));
+        float offset = 0.5f * linewidth;
+        bool is_stroke_cap_marker = (g.tag.tag_byte & JL_PATH_TAG_SUBPATH_END) != 0u;
+        if (is_stroke_cap_marker) {
+            // open path start cap (flatten.wgsl:845-852)
+            V2 tangent = cubic_start_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
+            V2 offset_tangent = offset * normalize(tangent);
+            V2 n = v2(offset_tangent.y * -1.0f, offset_tangent.x * 1.0f);
+            draw_cap<EMIT>(o, path_ix, (style_flags & JL_STYLE_FLAGS_START_CAP_MASK) >> 2, pts.p0, pts.p0 - n, pts.p0 + n, -offset_tangent,
+                           transform);
+        } else {
+            const float TT = TANGENT_THRESH * TANGENT_THRESH;
+            V2 tan_prev = cubic_end_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
+            if (dot(tan_prev, tan_prev) < TT) tan_prev = v2(TANGENT_THRESH, 0.0f);
+            V2 offset_tangent = offset * normalize(tan_prev);
+            V2 n_prev = v2(offset_tangent.y * -1.0f, offset_tangent.x * 1.0f);
+            if (sub < 2u) {
+                V2 tan_start = cubic_start_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
+                if (dot(tan_start, tan_start) < TT) tan_start = v2(TANGENT_THRESH, 0.0f);
+                V2 n_start = offset * normalize(v2(-tan_start.y, tan_start.x));
+                if (sub == 0u) flatten_euler<EMIT>(o, pts, path_ix, transform, offset, pts.p0 + n_start, pts.p3 + n_prev);
+                else flatten_euler<EMIT>(o, pts, path_ix, transform, -offset, pts.p0 - n_start, pts.p3 - n_prev);
             } else {
                 PathTagData ntag = compute_tag_monoid(s, ix + 1u);  // read_neighboring_segment, :790-800
                 CubicPoints npts = read_path_segment(s, ntag, true);
                 bool n_is_closed = (ntag.tag_byte & JL_PATH_TAG_SEG_TYPE) == JL_PATH_TAG_LINETO;
                 bool n_is_marker = (ntag.tag_byte & JL_PATH_TAG_SUBPATH_END) != 0u;
                 bool do_join = !n_is_marker || n_is_closed;
-                V2 neighbor_tangent = cubic_start_tangent(npts.p0, npts.p1, npts.p2, npts.p3);
-
-                const float TT = TANGENT_THRESH * TANGENT_THRESH;
-                V2 tan_start = cubic_start_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
-                if (dot(tan_start, tan_start) < TT) tan_start = v2(TANGENT_THRESH, 0.0f);
-                V2 tan_prev = cubic_end_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
-                if (dot(tan_prev, tan_prev) < TT) tan_prev = v2(TANGENT_THRESH, 0.0f);
-                V2 tan_next = neighbor_tangent;
-                if (dot(tan_next, tan_next) < TT) tan_next = v2(TANGENT_THRESH, 0.0f);
-                V2 n_start = offset * normalize(v2(-tan_start.y, tan_start.x));
-                V2 offset_tangent = offset * normalize(tan_prev);
-                V2 n_prev = v2(offset_tangent.y * -1.0f, offset_tangent.x * 1.0f);
-                V2 tnn = normalize(tan_next);
-                V2 n_next = v2((offset * tnn.y) * -1.0f, (offset * tnn.x) * 1.0f);
-                flatten_euler<EMIT>(o, pts, path_ix, transform, offset, pts.p0 + n_start, pts.p3 + n_prev);
-                flatten_euler<EMIT>(o, pts, path_ix, transform, -offset, pts.p0 - n_start, pts.p3 - n_prev);
                 if (do_join) {
+                    V2 tan_next = cubic_start_tangent(npts.p0, npts.p1, npts.p2, npts.p3);
+                    if (dot(tan_next, tan_next) < TT) tan_next = v2(TANGENT_THRESH, 0.0f);
+                    V2 tnn = normalize(tan_next);
+                    V2 n_next = v2((offset * tnn.y) * -1.0f, (offset * tnn.x) * 1.0f);
                     draw_join<EMIT>(o, path_ix, style_flags, pts.p3, tan_prev, tan_next, n_prev, n_next, transform);
                 } else {
-                    draw_cap<EMIT>(o, path_ix, (style_flags & JL_STYLE_FLAGS_END_CAP_MASK), pts.p3, pts.p3 + n_prev, pts.p3 - n_prev,
-                                   offset_tangent, transform);
+                    draw_cap<EMIT>(o, path_ix, (style_flags & JL_STYLE_FLAGS_END_CAP_MASK), pts.p3, pts.p3 + n_prev, pts.p3 - n_prev, offset_tangent,
+                                   transform);
                 }
             }
-        } else {
-            flatten_euler<EMIT>(o, pts, path_ix, transform, 0.0f, pts.p0, pts.p3);
         }
-        if (EMIT && (o.bx1 > o.bx0 || o.by1 > o.by0) && path_bboxes.ok(path_ix)) {
-            JlPathBbox* out = &path_bboxes.p[path_ix];
-            atomicMin(&out->x0, to_i32(floor_(o.bx0)));
-            atomicMin(&out->y0, to_i32(floor_(o.by0)));
-            atomicMax(&out->x1, to_i32(ceil_(o.bx1)));
-            atomicMax(&out->y1, to_i32(ceil_(o.by1)));
-        }
+    } else {
+        flatten_euler<EMIT>(o, pts, path_ix, transform, 0.0f, pts.p0, pts.p3);
     }
-    if (!EMIT) counts[ix] = o.cursor;
+    if (EMIT && (o.bx1 > o.bx0 || o.by1 > o.by0) && path_bboxes.ok(path_ix)) {  // flatten.wgsl:893-899 (min/max are order-free)
+        JlPathBbox* out = &path_bboxes.p[path_ix];
+        atomicMin(&out->x0, to_i32(floor_(o.bx0)));
+        atomicMin(&out->y0, to_i32(floor_(o.by0)));
+        atomicMax(&out->x1, to_i32(ceil_(o.bx1)));
+        atomicMax(&out->y1, to_i32(ceil_(o.by1)));
+    }
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(JL_WG) void k_flatten_items(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
+                                                         Buf<JlPathBbox> path_bboxes, Buf<JlLineSoup> lines, const uint32_t* __restrict__ list,
+                                                         const uint32_t* __restrict__ counters, uint32_t cap, uint32_t* __restrict__ counts,
+                                                         const uint32_t* __restrict__ bases) {
+    Scene s;
+    s.cfg = cfg; s.scene = scene; s.tag_monoids = tag_monoids;
+    uint32_t n_heavy = umin_(counters[0], cap), n_light = umin_(counters[1], cap - n_heavy);
+    uint32_t n = n_heavy + n_light;
+    for (uint32_t t = blockIdx.x * JL_WG + threadIdx.x; t < n; t += gridDim.x * JL_WG) {
+        uint32_t slot = t < n_heavy ? list[t] : list[cap - 1u - (t - n_heavy)];
+        Out<EMIT> o;
+        o.cfg = cfg; o.lines = lines;
+        o.cursor = EMIT ? bases[slot] : 0u;
+        o.bx0 = 1e31f; o.by0 = 1e31f; o.bx1 = -1e31f; o.by1 = -1e31f;
+        run_item<EMIT>(cfg, s, path_bboxes, o, slot);
+        if (!EMIT) counts[slot] = o.cursor;
+    }
 }
 
 }  // namespace
@@ -638,20 +697,32 @@ __global__ __launch_bounds__(JL_WG) void k_flatten(const JlConfig* __restrict__ 
 int jh_launch_flatten(const JhLaunch& L) {
     if (L.nb < 6) return -1;
     if (L.gx == 0) return 0;
-    uint32_t n = L.gx * JL_WG;
-    uint32_t* counts = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)n * 4);
-    uint32_t* bases = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_B, (uint64_t)n * 4);
-    if (!counts || !bases) return -5;
+    uint32_t n_tags = L.gx * JL_WG;
+    uint64_t n_slots64 = (uint64_t)n_tags * 3;
+    if (n_slots64 > 0xfffffff0ull) return -1;
+    uint32_t n_slots = (uint32_t)n_slots64;
+    uint32_t* counts = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)n_slots * 4);
+    uint32_t* bases = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_B, (uint64_t)n_slots * 4);
+    uint32_t* list = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_C, (uint64_t)n_slots * 4);
+    uint32_t* counters = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, 256);
+    if (!counts || !bases || !list || !counters) return -5;
     auto cfg = (const JlConfig*)L.b[0].ptr;
     auto scene = mkbuf<uint32_t>(L.b[1].ptr, L.b[1].size);
     auto tm = mkbuf<JlTagMonoid>(L.b[2].ptr, L.b[2].size);
     auto pb = mkbuf<JlPathBbox>(L.b[3].ptr, L.b[3].size);
     JlBump* bump = (JlBump*)L.b[4].ptr;
     auto lines = mkbuf<JlLineSoup>(L.b[5].ptr, L.b[5].size);
-    hipLaunchKernelGGL(k_flatten<false>, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, lines, counts, (const uint32_t*)nullptr);
-    int rc = jh_scan_u32(L, counts, 1, bases, n, nullptr, &bump->lines);
+    (void)hipMemsetAsync(counters, 0, 8, L.stream);
+    (void)hipMemsetAsync(counts, 0, (size_t)n_slots * 4, L.stream);
+    hipLaunchKernelGGL(k_flatten_classify, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list, counters, n_slots);
+    uint32_t cap_blocks = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * 8u;
+    uint32_t g = (n_slots + JL_WG - 1) / JL_WG;
+    if (g > cap_blocks) g = cap_blocks;
+    hipLaunchKernelGGL(k_flatten_items<false>, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, lines, (const uint32_t*)list,
+                       (const uint32_t*)counters, n_slots, counts, (const uint32_t*)nullptr);
+    int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_flatten<true>, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, lines, (uint32_t*)nullptr,
-                       (const uint32_t*)bases);
+    hipLaunchKernelGGL(k_flatten_items<true>, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, lines, (const uint32_t*)list,
+                       (const uint32_t*)counters, n_slots, (uint32_t*)nullptr, (const uint32_t*)bases);
     return 0;
 }

@@ -28,6 +28,14 @@ def test_c3_random_cubics(engine, n, size):
     assert r["bump"]["lines"] > n
 
 
+def test_c3_headline_full_size(engine):
+    """BASELINE.json configs[2] at full size: 100k stroked+filled cubics, 4096x4096 -- every buffer bit-exact."""
+    s, p = scenes.scene_c3(100_000, 4096)
+    p.bump = BumpSizes(lines=1 << 22, seg_counts=1 << 23, segments=1 << 23, tiles=1 << 21, ptcl=1 << 25, bin_data=1 << 20)
+    r = compare(engine, s, p)
+    assert r["bump"]["lines"] > 3_000_000 and r["bump"]["failed"] == 0
+
+
 def test_c2_blobs_all_joins_caps_evenodd(engine):
     s, p = scenes.scene_c2(300, 1024)
     compare(engine, s, p)

@@ -4,11 +4,16 @@
 // un-premultiplied RGBA16F.
 //
 // MI355X design: one wave64 per tile (64 lanes x 4 horizontally adjacent pixels, exactly the
-// WGSL's (4,16) workgroup).  The PTCL stream and the segment records are the same for all 64 lanes,
-// so the command index is kept wave-uniform (readfirstlane) and PTCL/segment words come through the
-// scalar cache (s_load) instead of 64 redundant vector loads -- each datum is fetched once per tile,
-// which is what the algorithmic-bytes model of the roofline assumes.  Pixels leave as two 16-byte
-// stores per lane (4 px x RGBA16F = 32 B; 4 lanes cover one 128-B row segment).
+// WGSL's (4,16) workgroup).  The PTCL stream and the segment records are the same for all 64 lanes, so
+// each datum is fetched ONCE per tile with wide coalesced loads (the algorithmic-bytes model of the
+// roofline) and then broadcast on-chip:
+//   * PTCL: the 64-word head, then each 256-word chunk (one dwordx4 per lane = 1 KiB per wave
+//     instruction) is staged in a wave-private 1 KiB LDS window; the interpreter reads command words
+//     with uniform ds_reads, the command index stays in SGPRs (readfirstlane);
+//   * segments: coarse allocates a tile's segment slices back to back, so lane i keeps segment
+//     base+i of a 64-segment window in registers (plus a prefetched next window) and the per-segment
+//     loop broadcasts the 5 floats with v_readlane -- no dependent memory latency per segment.
+// Pixels leave as two 16-byte stores per lane (4 px x RGBA16F = 32 B; 4 lanes cover one 128-B row).
 // The 4-deep clip/blend stack lives in registers (statically indexed), deeper levels spill to
 // blend_spill exactly like the WGSL.
 #include "kcommon.h"
@@ -164,12 +169,30 @@ JD V4 over(V4 bg, V4 fg, float area) {
     return v4(bg.x * k + fg_i.x, bg.y * k + fg_i.y, bg.z * k + fg_i.z, bg.w * k + fg_i.w);
 }
 
+struct SegWin {  // lane i holds segment base+i
+    float p0x, p0y, p1x, p1y, ye;
+};
+JD SegWin load_segwin(const float* __restrict__ segments, uint32_t segments_n, uint32_t base) {
+    SegWin w;
+    uint32_t so = base + (threadIdx.x & 63u);
+    w.p0x = 0.0f; w.p0y = 0.0f; w.p1x = 0.0f; w.p1y = 0.0f; w.ye = 0.0f;
+    if (so < segments_n) {
+        const float2* sp = (const float2*)(segments + (size_t)so * 6);
+        float2 a = sp[0], b = sp[1], c = sp[2];
+        w.p0x = a.x; w.p0y = a.y; w.p1x = b.x; w.p1y = b.y; w.ye = c.x;
+    }
+    return w;
+}
+JD float bcast(float v, uint32_t lane) { return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(v), (int)lane)); }
+
 __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ cfg, const float* __restrict__ segments, uint32_t segments_n,
                                                   const uint32_t* __restrict__ ptcl, uint32_t ptcl_n, const uint32_t* __restrict__ info,
                                                   uint32_t info_n, Buf<V4> blend_spill, uint16_t* __restrict__ output, uint32_t out_w,
                                                   uint32_t out_h, const uint16_t* __restrict__ gradients, uint32_t grad_h, FineImages images) {
+    __shared__ uint32_t win[JL_PTCL_INCREMENT];  // wave-private PTCL window
     if (ptcl_n == 0u || ptcl[0] == ~0u) return;  // fine.wgsl:889-893
-    const uint32_t lx = threadIdx.x & 3u, ly = threadIdx.x >> 2;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t lx = lane & 3u, ly = lane >> 2;
     const uint32_t tile_ix = blockIdx.y * cfg->width_in_tiles + blockIdx.x;
     const uint32_t gx = blockIdx.x * 4u + lx, gy = blockIdx.y * 16u + ly;
     const float xyx = (float)(gx * 4u), xyy = (float)gy;
@@ -182,8 +205,15 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
     for (int i = 0; i < 4; i++) { bs0[i] = v4(0, 0, 0, 0); bs1[i] = bs0[i]; bs2[i] = bs0[i]; bs3[i] = bs0[i]; }
     uint32_t clip_depth = 0u;
     float area[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    uint32_t cmd_ix = tile_ix * JL_PTCL_INITIAL_ALLOC;
-    auto P = [&](uint32_t i) -> uint32_t { return i < ptcl_n ? ptcl[i] : 0u; };
+    // PTCL window: words [win_base, win_base + win_len) of the global stream live in `win`
+    uint32_t win_base = tile_ix * JL_PTCL_INITIAL_ALLOC;
+    {
+        uint32_t gi = win_base + lane;
+        win[lane] = gi < ptcl_n ? ptcl[gi] : 0u;
+    }
+    __syncthreads();
+    uint32_t cmd_ix = 0u;  // relative to win_base
+    auto P = [&](uint32_t rel) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)win[rel & (JL_PTCL_INCREMENT - 1u)]); };
     auto I = [&](uint32_t i) -> uint32_t { return i < info_n ? info[i] : 0u; };
     const uint32_t blend_offset = P(cmd_ix);
     cmd_ix += 1u;
@@ -194,14 +224,18 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
         return v4(f16_to_f32((uint16_t)(raw.x & 0xffffu)), f16_to_f32((uint16_t)(raw.x >> 16)), f16_to_f32((uint16_t)(raw.y & 0xffffu)),
                   f16_to_f32((uint16_t)(raw.y >> 16)));
     };
+    // segment windows
+    SegWin cur, nxt;
+    cur.p0x = cur.p0y = cur.p1x = cur.p1y = cur.ye = 0.0f;
+    nxt = cur;
+    uint32_t cur_base = 0xffffffffu, nxt_base = 0xffffffffu;  // "no window"
     for (uint32_t guard = 0; guard < (1u << 24); guard++) {
-        cmd_ix = uni(cmd_ix);
-        uint32_t tag = uni(P(cmd_ix));
+        uint32_t tag = P(cmd_ix);
         if (tag == JL_CMD_END) break;
         if (tag == JL_CMD_FILL) {  // fill_path, fine.wgsl:824-878
-            uint32_t size_and_rule = uni(P(cmd_ix + 1u));
-            uint32_t seg_data = uni(P(cmd_ix + 2u));
-            int32_t backdrop = (int32_t)uni(P(cmd_ix + 3u));
+            uint32_t size_and_rule = P(cmd_ix + 1u);
+            uint32_t seg_data = P(cmd_ix + 2u);
+            int32_t backdrop = (int32_t)P(cmd_ix + 3u);
             uint32_t n_segs = size_and_rule >> 1;
             bool even_odd = (size_and_rule & 1u) != 0u;
             float backdrop_f = (float)backdrop;
@@ -209,11 +243,21 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             for (int i = 0; i < 4; i++) area[i] = backdrop_f;
             for (uint32_t s = 0; s < n_segs; s++) {
                 uint32_t so = seg_data + s;
-                float p0x = 0.0f, p0y = 0.0f, p1x = 0.0f, p1y = 0.0f, y_edge_v = 0.0f;
-                if (so < segments_n) {
-                    const float* sp = segments + (size_t)so * 6;
-                    p0x = sp[0]; p0y = sp[1]; p1x = sp[2]; p1y = sp[3]; y_edge_v = sp[4];
+                uint32_t rel = so - cur_base;
+                if (cur_base == 0xffffffffu || rel >= 64u) {  // uniform: advance / reload the window
+                    if (nxt_base != 0xffffffffu && so - nxt_base < 64u) {
+                        cur = nxt;
+                        cur_base = nxt_base;
+                    } else {
+                        cur = load_segwin(segments, segments_n, so);
+                        cur_base = so;
+                    }
+                    nxt_base = cur_base + 64u;
+                    nxt = load_segwin(segments, segments_n, nxt_base);  // prefetch; consumed much later
+                    rel = so - cur_base;
                 }
+                float p0x = bcast(cur.p0x, rel), p0y = bcast(cur.p0y, rel), p1x = bcast(cur.p1x, rel), p1y = bcast(cur.p1y, rel);
+                float y_edge_v = bcast(cur.ye, rel);
                 float y = p0y - lxyy;
                 float dlx = p1x - p0x, dly = p1y - p0y;
                 float y0 = clamp_(y, 0.0f, 1.0f);
@@ -257,7 +301,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             for (int i = 0; i < 4; i++) area[i] = 1.0f;
             cmd_ix += 1u;
         } else if (tag == JL_CMD_COLOR) {
-            V4 fg = v4(u2f(uni(P(cmd_ix + 1u))), u2f(uni(P(cmd_ix + 2u))), u2f(uni(P(cmd_ix + 3u))), u2f(uni(P(cmd_ix + 4u))));
+            V4 fg = v4(u2f(P(cmd_ix + 1u)), u2f(P(cmd_ix + 2u)), u2f(P(cmd_ix + 3u)), u2f(P(cmd_ix + 4u)));
 #pragma unroll
             for (int i = 0; i < 4; i++) rgba[i] = over(rgba[i], fg, area[i]);
             cmd_ix += 5u;
@@ -286,8 +330,8 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             clip_depth += 1u;
             cmd_ix += 1u;
         } else if (tag == JL_CMD_END_CLIP) {
-            uint32_t blend = uni(P(cmd_ix + 1u));
-            float alpha = u2f(uni(P(cmd_ix + 2u)));
+            uint32_t blend = P(cmd_ix + 1u);
+            float alpha = u2f(P(cmd_ix + 2u));
             clip_depth -= 1u;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -310,11 +354,27 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             }
             cmd_ix += 3u;
         } else if (tag == JL_CMD_JUMP) {
-            cmd_ix = uni(P(cmd_ix + 1u));
+            win_base = P(cmd_ix + 1u);
+            cmd_ix = 0u;
+            __syncthreads();  // everyone is done reading the old window
+            {
+                uint32_t gi = win_base + lane * 4u;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (gi + 3u < ptcl_n && (win_base & 3u) == 0u) {
+                    v = *(const uint4*)(ptcl + gi);
+                } else {
+                    if (gi < ptcl_n) v.x = ptcl[gi];
+                    if (gi + 1u < ptcl_n) v.y = ptcl[gi + 1u];
+                    if (gi + 2u < ptcl_n) v.z = ptcl[gi + 2u];
+                    if (gi + 3u < ptcl_n) v.w = ptcl[gi + 3u];
+                }
+                *(uint4*)(&win[lane * 4u]) = v;
+            }
+            __syncthreads();
         } else if (tag == JL_CMD_LIN_GRAD) {
-            uint32_t index_mode = uni(P(cmd_ix + 1u));
+            uint32_t index_mode = P(cmd_ix + 1u);
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
-            uint32_t io = uni(P(cmd_ix + 2u));
+            uint32_t io = P(cmd_ix + 2u);
             float line_x = u2f(I(io)), line_y = u2f(I(io + 1u)), line_c = u2f(I(io + 2u));
             float d = line_x * xyx + line_y * xyy + line_c;
 #pragma unroll
@@ -325,9 +385,9 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             }
             cmd_ix += 3u;
         } else if (tag == JL_CMD_RAD_GRAD) {
-            uint32_t index_mode = uni(P(cmd_ix + 1u));
+            uint32_t index_mode = P(cmd_ix + 1u);
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
-            uint32_t io = uni(P(cmd_ix + 2u));
+            uint32_t io = P(cmd_ix + 2u);
             float m0 = u2f(I(io)), m1 = u2f(I(io + 1u)), m2 = u2f(I(io + 2u)), m3 = u2f(I(io + 3u));
             float xl0 = u2f(I(io + 4u)), xl1 = u2f(I(io + 5u));
             float focal_x = u2f(I(io + 6u));
@@ -371,9 +431,9 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             }
             cmd_ix += 3u;
         } else if (tag == JL_CMD_SWEEP_GRAD) {
-            uint32_t index_mode = uni(P(cmd_ix + 1u));
+            uint32_t index_mode = P(cmd_ix + 1u);
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
-            uint32_t io = uni(P(cmd_ix + 2u));
+            uint32_t io = P(cmd_ix + 2u);
             float m0 = u2f(I(io)), m1 = u2f(I(io + 1u)), m2 = u2f(I(io + 2u)), m3 = u2f(I(io + 3u));
             float xl0 = u2f(I(io + 4u)), xl1 = u2f(I(io + 5u));
             float t0 = u2f(I(io + 6u)), t1 = u2f(I(io + 7u));
@@ -399,7 +459,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             }
             cmd_ix += 3u;
         } else if (tag == JL_CMD_IMAGE) {
-            uint32_t io = uni(P(cmd_ix + 1u));
+            uint32_t io = P(cmd_ix + 1u);
             float m0 = u2f(I(io)), m1 = u2f(I(io + 1u)), m2 = u2f(I(io + 2u)), m3 = u2f(I(io + 3u));
             float xl0 = u2f(I(io + 4u)), xl1 = u2f(I(io + 5u));
             uint32_t index = I(io + 6u);

@@ -47,6 +47,7 @@ struct jh_ctx {
     uint64_t total_mem = 0;
     std::unordered_map<uint64_t, Alloc> buffers;
     std::unordered_map<uint64_t, Alloc> images;
+    std::unordered_map<uint64_t, JlConfig> config_shadow;  // host copies of uploaded ConfigUniforms (by buffer id)
     std::multimap<uint64_t, void*> pool;  // capacity -> free allocation
     uint64_t pool_bytes = 0;
     JhScratch scratch;
@@ -235,6 +236,7 @@ int jh_upload(jh_ctx* ctx, uint64_t id, const void* data, uint64_t size) {
     Alloc* a;
     int rc = buffer_get_or_create(ctx, id, size, &a);
     if (rc) return rc;
+    if (size == sizeof(JlConfig)) std::memcpy(&ctx->config_shadow[id], data, sizeof(JlConfig));
     if (size) HIP_TRY(ctx, hipMemcpyAsync(a->ptr, data, size, hipMemcpyHostToDevice, ctx->stream));
     // The host slice is only valid for the duration of the call (reference: queue.WriteBuffer copies).
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -271,6 +273,7 @@ int jh_free(jh_ctx* ctx, uint64_t id) {
     if (it == ctx->buffers.end()) return JH_OK;  // the reference ignores frees of unknown ids (wgpu.go:601-603)
     if (it->second.owned) ctx->pool.insert({it->second.capacity, it->second.ptr});
     ctx->buffers.erase(it);
+    ctx->config_shadow.erase(id);
     return JH_OK;
 }
 
@@ -416,6 +419,11 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
     L.n_images = (int)images.size();
     L.indirect = indirect;
     L.num_cus = ctx->num_cus;
+    L.cfg_host = nullptr;
+    if (n_bindings > 0 && bindings[0].kind == JH_BIND_BUFFER) {
+        auto sh = ctx->config_shadow.find(bindings[0].id);
+        if (sh != ctx->config_shadow.end()) L.cfg_host = &sh->second;
+    }
     ProfEntry pe;
     if (ctx->profiling) {
         auto get_event = [&](hipEvent_t* e) {

@@ -185,6 +185,7 @@ struct JhLaunch {
     int n_images;
     const uint32_t* indirect;  // device pointer to IndirectCount (indirect dispatch) or nullptr
     int num_cus;
+    const JlConfig* cfg_host;  // host shadow of the uploaded ConfigUniform bound at index 0, or nullptr
 };
 
 enum {  // scratch slots

@@ -185,6 +185,7 @@ JD SegWin load_segwin(const float* __restrict__ segments, uint32_t segments_n, u
 }
 JD float bcast(float v, uint32_t lane) { return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(v), (int)lane)); }
 
+template <bool CLIPS>
 __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ cfg, const float* __restrict__ segments, uint32_t segments_n,
                                                   const uint32_t* __restrict__ ptcl, uint32_t ptcl_n, const uint32_t* __restrict__ info,
                                                   uint32_t info_n, Buf<V4> blend_spill, uint16_t* __restrict__ output, uint32_t out_w,
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
 #pragma unroll
             for (int i = 0; i < 4; i++) rgba[i] = over(rgba[i], fg, area[i]);
             cmd_ix += 5u;
-        } else if (tag == JL_CMD_BEGIN_CLIP) {
+        } else if (CLIPS && tag == JL_CMD_BEGIN_CLIP) {
             if (clip_depth < JL_BLEND_STACK_SPLIT) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             }
             clip_depth += 1u;
             cmd_ix += 1u;
-        } else if (tag == JL_CMD_END_CLIP) {
+        } else if (CLIPS && tag == JL_CMD_END_CLIP) {
             uint32_t blend = P(cmd_ix + 1u);
             float alpha = u2f(P(cmd_ix + 2u));
             clip_depth -= 1u;
@@ -553,8 +554,16 @@ int jh_launch_fine_area(const JhLaunch& L) {
         imgs.n = i + 1;
     }
     uint32_t grad_h = (grad.ptr && grad.width == JL_GRADIENT_WIDTH) ? grad.height : 0u;
-    hipLaunchKernelGGL(k_fine_area, dim3(L.gx, L.gy), dim3(64), 0, L.stream, cfg, (const float*)L.b[1].ptr, segments_n, (const uint32_t*)L.b[2].ptr,
-                       ptcl_n, (const uint32_t*)L.b[3].ptr, info_n, spill, (uint16_t*)out.ptr, out.width, out.height,
-                       (const uint16_t*)grad.ptr, grad_h, imgs);
+    // Scenes without clip layers (ConfigUniform.n_clip == 0, read from the host shadow of the uploaded uniform)
+    // use the variant without the 64-register blend stack: higher occupancy.
+    bool clips = !(L.cfg_host && L.cfg_host->layout.n_clip == 0u);
+    if (clips)
+        hipLaunchKernelGGL(k_fine_area<true>, dim3(L.gx, L.gy), dim3(64), 0, L.stream, cfg, (const float*)L.b[1].ptr, segments_n,
+                           (const uint32_t*)L.b[2].ptr, ptcl_n, (const uint32_t*)L.b[3].ptr, info_n, spill, (uint16_t*)out.ptr, out.width,
+                           out.height, (const uint16_t*)grad.ptr, grad_h, imgs);
+    else
+        hipLaunchKernelGGL(k_fine_area<false>, dim3(L.gx, L.gy), dim3(64), 0, L.stream, cfg, (const float*)L.b[1].ptr, segments_n,
+                           (const uint32_t*)L.b[2].ptr, ptcl_n, (const uint32_t*)L.b[3].ptr, info_n, spill, (uint16_t*)out.ptr, out.width,
+                           out.height, (const uint16_t*)grad.ptr, grad_h, imgs);
     return 0;
 }

@@ -572,8 +572,8 @@ JD Seg load_seg(const Scene& s, uint32_t ix) {
     return r;
 }
 
-// One atomicAdd per wave and class: per-lane item counts are prefix-summed across the wave, the last
-// lane reserves the wave's range, every lane writes its own slots.  (A per-lane atomicAdd on two hot
+// One atomicAdd per workgroup and class: per-lane item counts are prefix-summed across the block, thread 0
+// reserves the block's range, every lane writes its own slots.  (A per-lane atomicAdd on two hot
 // words costs ~3.7 ms for 1.2 M items on MI355X; this costs ~10 us.)  List order is irrelevant for the
 // result but this keeps it nearly sorted by tag, i.e. coalesced scene reads and line writes later on.
 __global__ __launch_bounds__(JL_WG) void k_flatten_classify(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
@@ -601,15 +601,17 @@ __global__ __launch_bounds__(JL_WG) void k_flatten_classify(const JlConfig* __re
             if (curved) { nh = 2u; nl = 1u; } else { nl = 3u; }
         }
     }
-    uint32_t ih = wave_incl_scan_u32(nh), il = wave_incl_scan_u32(nl);
-    uint32_t base_h = 0u, base_l = 0u;
-    if (lane_id() == 63u) {
-        if (ih) base_h = atomicAdd(&counters[0], ih);
-        if (il) base_l = atomicAdd(&counters[1], il);
+    __shared__ uint32_t sh[12];
+    __shared__ uint32_t sh_base[2];
+    MonoidK<2> m, tot;
+    m.v[0] = nh; m.v[1] = nl;
+    MonoidK<2> ex = block_excl_scan_monoid<2>(m, sh, &tot);
+    if (threadIdx.x == 0) {  // one atomic pair per 256 tag bytes (a hot word sustains only ~88 atomics/us)
+        sh_base[0] = tot.v[0] ? atomicAdd(&counters[0], tot.v[0]) : 0u;
+        sh_base[1] = tot.v[1] ? atomicAdd(&counters[1], tot.v[1]) : 0u;
     }
-    base_h = __shfl(base_h, 63, 64);
-    base_l = __shfl(base_l, 63, 64);
-    uint32_t ph = base_h + ih - nh, pl = base_l + il - nl;
+    __syncthreads();
+    uint32_t ph = sh_base[0] + ex.v[0], pl = sh_base[1] + ex.v[1];
     uint32_t sub = 0u;
     for (uint32_t k = 0; k < nh; k++, sub++) {
         uint32_t pos = ph + k;

@@ -125,7 +125,7 @@ int jh_profile_collect(jh_ctx* ctx, jh_profile_record* out, int max);
 /* ---- diagnostics (not used by the render path) ----
  * Evaluates one of the kernels' scalar math routines on n host floats: op 0 sin, 1 cos, 2 atan2(a,b),
  * 3 acos, 4 asin, 5 |a|^(2/3), 6 a/b, 7 sqrt, 8 round-to-even, 9 u32(a), 10 i32(a), 11 f32->f16 bits,
- * 12 a*b+a (uncontracted), 13 floor(a*b+0.5). */
+ * 12 a*b+a (uncontracted), 13 floor(a*b+0.5), 14 min(a,b), 15 max(a,b), 16 clamp(a,0,1), 17 clamp(a*b,0,1). */
 int jh_selftest_math(jh_ctx* ctx, int op, const float* a, const float* b, float* out, uint32_t n);
 
 /* ---- introspection ---- */

@@ -5,7 +5,8 @@
 // bit-for-bit (run to run, and against the CPU checker) every kernel uses:
 //   * IEEE binary32 + - * / sqrt with no contraction (build flag -ffp-contract=off, correctly
 //     rounded divide/sqrt are hipcc's default);
-//   * WGSL-spec min/max/clamp/sign/mix/fract; round() = ties-to-even; saturating u32()/i32();
+//   * min/max = IEEE minNum/maxNum (v_min_f32/v_max_f32), clamp = min(max(x,lo),hi), WGSL-spec sign/mix/fract;
+//     round() = ties-to-even; saturating u32()/i32();
 //   * sin/cos/atan2/acos/asin/|x|^(2/3) evaluated in binary64 by the fixed operation sequences
 //     below (Cody-Waite + Taylor, table-split atan, Halley cbrt) and rounded once to binary32 --
 //     the same policy as the reference's Go twin, which rounds float64 libm (jmath/jmath.go:48-87).
@@ -21,8 +22,10 @@ namespace jd {
 JD uint32_t f2u(float f) { return __float_as_uint(f); }
 JD float u2f(uint32_t u) { return __uint_as_float(u); }
 
-JD float fmin_(float a, float b) { return (b < a) ? b : a; }
-JD float fmax_(float a, float b) { return (a < b) ? b : a; }
+// min/max = IEEE-754 minNum/maxNum as implemented by v_min_f32/v_max_f32: a NaN operand yields the other
+// operand, and -0 orders below +0.  (WGSL leaves NaN handling of min/max implementation-defined.)
+JD float fmin_(float a, float b) { return __builtin_fminf(a, b); }
+JD float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
 JD float clamp_(float x, float lo, float hi) { return fmin_(fmax_(x, lo), hi); }
 JD int32_t imin_(int32_t a, int32_t b) { return (b < a) ? b : a; }
 JD int32_t imax_(int32_t a, int32_t b) { return (a < b) ? b : a; }

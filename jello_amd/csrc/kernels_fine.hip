@@ -169,8 +169,9 @@ JD V4 over(V4 bg, V4 fg, float area) {
     return v4(bg.x * k + fg_i.x, bg.y * k + fg_i.y, bg.z * k + fg_i.z, bg.w * k + fg_i.w);
 }
 
-struct SegWin {  // lane i holds segment base+i
+struct SegWin {  // lane i holds segment base+i, plus the per-segment (pixel-independent) terms of fill_path
     float p0x, p0y, p1x, p1y, ye;
+    float recip, sgn;  // 1 / delta.y and sign(delta.x), computed once per segment instead of once per lane
 };
 JD SegWin load_segwin(const float* __restrict__ segments, uint32_t segments_n, uint32_t base) {
     SegWin w;
@@ -181,6 +182,8 @@ JD SegWin load_segwin(const float* __restrict__ segments, uint32_t segments_n, u
         float2 a = sp[0], b = sp[1], c = sp[2];
         w.p0x = a.x; w.p0y = a.y; w.p1x = b.x; w.p1y = b.y; w.ye = c.x;
     }
+    w.recip = 1.0f / (w.p1y - w.p0y);
+    w.sgn = sign_(w.p1x - w.p0x);
     return w;
 }
 JD float bcast(float v, uint32_t lane) { return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(v), (int)lane)); }
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
     };
     // segment windows
     SegWin cur, nxt;
-    cur.p0x = cur.p0y = cur.p1x = cur.p1y = cur.ye = 0.0f;
+    cur.p0x = cur.p0y = cur.p1x = cur.p1y = cur.ye = cur.recip = cur.sgn = 0.0f;
     nxt = cur;
     uint32_t cur_base = 0xffffffffu, nxt_base = 0xffffffffu;  // "no window"
     for (uint32_t guard = 0; guard < (1u << 24); guard++) {
@@ -259,13 +262,13 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                 }
                 float p0x = bcast(cur.p0x, rel), p0y = bcast(cur.p0y, rel), p1x = bcast(cur.p1x, rel), p1y = bcast(cur.p1y, rel);
                 float y_edge_v = bcast(cur.ye, rel);
+                float vec_y_recip = bcast(cur.recip, rel), sgn_dlx = bcast(cur.sgn, rel);
                 float y = p0y - lxyy;
                 float dlx = p1x - p0x, dly = p1y - p0y;
                 float y0 = clamp_(y, 0.0f, 1.0f);
                 float y1 = clamp_(y + dly, 0.0f, 1.0f);
                 float dy = y0 - y1;
                 if (dy != 0.0f) {
-                    float vec_y_recip = 1.0f / dly;
                     float t0 = (y0 - y) * vec_y_recip;
                     float t1 = (y1 - y) * vec_y_recip;
                     float startx = p0x - lxyx;
@@ -285,9 +288,13 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                         area[i] += a * dy;
                     }
                 }
-                float y_edge = sign_(dlx) * clamp_(lxyy - y_edge_v + 1.0f, 0.0f, 1.0f);
+                // y_edge >= 16 (path_tiling's "no edge" value is 1e9) clamps to 0 for every row of the tile: the term
+                // would add +-0, which cannot change a sum that started from +0 -- skip it (uniform branch).
+                if (y_edge_v < 16.0f) {
+                    float y_edge = sgn_dlx * clamp_(lxyy - y_edge_v + 1.0f, 0.0f, 1.0f);
 #pragma unroll
-                for (int i = 0; i < 4; i++) area[i] += y_edge;
+                    for (int i = 0; i < 4; i++) area[i] += y_edge;
+                }
             }
             if (even_odd) {
 #pragma unroll

@@ -24,6 +24,10 @@ __global__ void k_selftest_math(int op, const float* __restrict__ a, const float
         case 11: r = u2f((uint32_t)f32_to_f16(x)); break;
         case 12: r = x * y + x; break;      // must NOT be contracted to an FMA
         case 13: r = floor_(x * y + 0.5f); break;
+        case 14: r = fmin_(x, y); break;
+        case 15: r = fmax_(x, y); break;
+        case 16: r = clamp_(x, 0.0f, 1.0f); break;
+        case 17: r = clamp_(x * y, 0.0f, 1.0f); break;
         default: break;
     }
     out[i] = r;

@@ -6,7 +6,7 @@
 // no single bit pattern.  The oracle pins one:
 //
 //   * + - * / sqrt floor ceil are IEEE-754 binary32, no contraction (-ffp-contract=off);
-//   * min/max/clamp/sign/select/mix/fract follow the WGSL spec formulas literally;
+//   * min/max are IEEE minNum/maxNum (-0 < +0); clamp/sign/select/mix/fract follow the WGSL spec formulas;
 //   * round() is ties-to-even (WGSL), NOT Go's math.Round;
 //   * u32(f)/i32(f) saturate (WGSL), NaN -> 0;
 //   * sin cos atan2 acos asin pow(x,2/3) are evaluated in binary64 with the fixed
@@ -27,9 +27,20 @@ static inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f;
 static inline uint64_t d2u(double f) { uint64_t u; std::memcpy(&u, &f, 8); return u; }
 static inline double u2d(uint64_t u) { double f; std::memcpy(&f, &u, 8); return f; }
 
-// WGSL spec: min returns e2 if e2 < e1 else e1; max returns e2 if e1 < e2 else e1.
-static inline float fmin_(float a, float b) { return (b < a) ? b : a; }
-static inline float fmax_(float a, float b) { return (a < b) ? b : a; }
+// min/max: IEEE-754 minNum/maxNum with -0 < +0 (what gfx950's v_min_f32/v_max_f32 compute; WGSL leaves the
+// NaN behaviour of min/max implementation-defined): a NaN operand yields the other operand.
+static inline float fmin_(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return std::signbit(a) ? a : b;
+    return (b < a) ? b : a;
+}
+static inline float fmax_(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return std::signbit(a) ? b : a;
+    return (a < b) ? b : a;
+}
 static inline float clamp_(float x, float lo, float hi) { return fmin_(fmax_(x, lo), hi); }
 static inline int32_t imin_(int32_t a, int32_t b) { return (b < a) ? b : a; }
 static inline int32_t imax_(int32_t a, int32_t b) { return (a < b) ? b : a; }

@@ -2184,6 +2184,9 @@ float oracle_acos(float x) { return acos_(x); }
 float oracle_asin(float x) { return asin_(x); }
 float oracle_pow23(float x) { return pow23_abs_(x); }
 float oracle_round(float x) { return round_(x); }
+void oracle_vec_minmaxclamp(const float* a, const float* b, float* mn, float* mx, float* cl, int n) {
+    for (int i = 0; i < n; i++) { mn[i] = fmin_(a[i], b[i]); mx[i] = fmax_(a[i], b[i]); cl[i] = clamp_(a[i], 0.0f, 1.0f); }
+}
 uint32_t oracle_to_u32(float x) { return to_u32(x); }
 int32_t oracle_to_i32(float x) { return to_i32(x); }
 uint16_t oracle_f32_to_f16(float x) { return f32_to_f16_rtne(x); }

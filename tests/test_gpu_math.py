@@ -87,3 +87,28 @@ def test_f16_store_conversion(engine):
     with np.errstate(over="ignore"):
         want = x.astype(np.float16).view(np.uint16)
     assert np.array_equal(got, want)
+
+
+def test_min_max_clamp_semantics(engine):
+    """min/max are IEEE minNum/maxNum with -0 < +0 on both sides (oracle/omath.h <-> v_min_f32/v_max_f32)."""
+    rng = np.random.default_rng(13)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.nan, np.inf, -np.inf, 0.5, 1e-40, -1e-40, 2.0, -3.0], dtype=np.float32)
+    a, b = np.meshgrid(special, special)
+    a = np.concatenate([a.ravel(), rng.standard_normal(1 << 16).astype(np.float32)])
+    b = np.concatenate([b.ravel(), rng.standard_normal(1 << 16).astype(np.float32)])
+    L = oracle_engine.lib()
+    mn, mx, cl = np.empty_like(a), np.empty_like(a), np.empty_like(a)
+    L.oracle_vec_minmaxclamp(a.ctypes.data_as(FP), b.ctypes.data_as(FP), mn.ctypes.data_as(FP), mx.ctypes.data_as(FP), cl.ctypes.data_as(FP), ctypes.c_int(a.size))
+
+    def canon(x):
+        x = bits(x).copy()
+        x[(x & 0x7fffffff) > 0x7f800000] = 0x7fc00000
+        return x
+    assert np.array_equal(canon(gpu_op(engine, 14, a, b)), canon(mn))
+    assert np.array_equal(canon(gpu_op(engine, 15, a, b)), canon(mx))
+    assert np.array_equal(canon(gpu_op(engine, 16, a)), canon(cl))
+    with np.errstate(all="ignore"):
+        prod = (a * b).astype(np.float32)
+    cl2 = np.empty_like(a)
+    L.oracle_vec_minmaxclamp(prod.ctypes.data_as(FP), b.ctypes.data_as(FP), mn.ctypes.data_as(FP), mx.ctypes.data_as(FP), cl2.ctypes.data_as(FP), ctypes.c_int(a.size))
+    assert np.array_equal(canon(gpu_op(engine, 17, a, b)), canon(cl2))

@@ -2,17 +2,18 @@
 // Euler-spiral subdivision of fills, GPU stroke expansion (offset curves, caps, joins, arcs).
 //
 // MI355X design: the WGSL allocates every output line with atomicAdd(bump.lines), which makes the
-// LineSoup order run-dependent.  Here the stage is classify -> count -> scan -> emit:
-//   k_flatten_classify      one thread per tag byte: splits it into up to 3 work items (see below) and
-//                           appends them to a heavy / light list; writes PathBbox.draw_flags/trans_ix;
-//   k_flatten_items<false>  one thread per item: runs the subdivision logic and only COUNTS its lines
-//                           (no per-line point evaluation) into counts[slot];
-//   jh_scan_u32             line base per slot; the total lands in bump.lines;
-//   k_flatten_items<true>   same arithmetic, lines stored at base+k, path bbox via atomicMin/Max
-//                           (commutative, so deterministic).
+// LineSoup order run-dependent.  Here the stage is classify -> flatten-to-temp -> scan -> permute:
+//   k_flatten_classify   one thread per tag byte: splits it into up to 3 work items (see below) and appends them
+//                        to a heavy / light list; writes PathBbox.draw_flags/trans_ix;
+//   k_flatten_items      one thread per item: Euler-spiral subdivision / caps / joins; lines are written ONCE to a
+//                        temporary buffer in allocation order (LDS-chunked, order-free) with a key (item slot, k),
+//                        counts[slot] = lines of the item; path bbox via atomicMin/Max (commutative);
+//   jh_scan_u32          line base per slot; the total lands in bump.lines;
+//   k_flatten_permute    lines[bases[slot] + k] = temp line  (one coalesced read, one 24-byte scatter per line).
 // Result: lines are ordered by (tag byte, emission order) -- the reference's own sequential order
-// (shaders/cpu/flatten.go:664-823).  Algorithmic traffic: scene bytes + 20 B / tag word in,
-// 24 B / line out.  The stage is ALU/latency-bound (f64 transcendentals, divergent trip counts).
+// (shaders/cpu/flatten.go:664-823) -- with the subdivision arithmetic executed exactly once.
+// Algorithmic traffic: scene bytes + 20 B / tag word in, 24 B / line out (+ 56 B / line through the temp).
+// The stage is ALU/latency-bound (f64 transcendentals, divergent trip counts).
 #include "kcommon.h"
 
 using namespace jk;
@@ -34,17 +35,37 @@ struct PathTagData { uint32_t tag_byte; MonoidK<5> monoid; };
 #define DIST_THRESH 1e-3f
 #define TANGENT_THRESH 1e-6f
 
+#define FL_CHUNK 4096u          // temp line slots a workgroup reserves up front
+#define FL_INVALID 0xffffffffu
+
+// Line sink.  EMIT: lines go to a TEMPORARY buffer in allocation order (fast, order-free allocation:
+// LDS atomic on the workgroup's chunk, global atomic only when the chunk is exhausted) together with a
+// key (slot, k) = (work item, index of the line inside the item); k_flatten_permute then moves every
+// line to lines[bases[slot] + k], the canonical position.  !EMIT: only counts.
 template <bool EMIT>
 struct Out {
     const JlConfig* cfg;
-    Buf<JlLineSoup> lines;
-    uint32_t cursor;  // EMIT: next line index; !EMIT: running count
+    JlLineSoup* tlines;
+    uint2* tkeys;
+    uint32_t tcap;
+    uint32_t slot;
+    uint32_t cursor;           // lines emitted so far by this item (local index of the next line)
+    uint32_t a_first, a_tpos;  // current allocation: first local index and its temp position
+    uint32_t* lds_next;        // workgroup chunk cursor (LDS)
+    uint32_t lds_limit;
+    uint32_t* g_next;          // global temp cursor
     float bx0, by0, bx1, by1;
 
     JD uint32_t alloc(uint32_t n) {
-        uint32_t ix = cursor;
+        uint32_t first = cursor;
         cursor += n;
-        return ix;
+        if (EMIT) {
+            uint32_t p = atomicAdd(lds_next, n);
+            if (p + n > lds_limit) p = atomicAdd(g_next, n);
+            a_first = first;
+            a_tpos = p;
+        }
+        return first;
     }
     JD void write_line(uint32_t line_ix, uint32_t path_ix, V2 p0, V2 p1) {  // flatten.wgsl:749-756
         if (EMIT) {
@@ -52,10 +73,12 @@ struct Out {
             by0 = fmin_(by0, fmin_(p0.y, p1.y));
             bx1 = fmax_(bx1, fmax_(p0.x, p1.x));
             by1 = fmax_(by1, fmax_(p0.y, p1.y));
-            if (line_ix < cfg->lines_size && lines.ok(line_ix)) {
+            uint32_t t = a_tpos + (line_ix - a_first);
+            if (t < tcap) {
                 JlLineSoup l;
                 l.path_ix = path_ix; l.pad = 0; l.p0[0] = p0.x; l.p0[1] = p0.y; l.p1[0] = p1.x; l.p1[1] = p1.y;
-                lines.p[line_ix] = l;
+                tlines[t] = l;
+                tkeys[t] = make_uint2(slot, line_ix);
             }
         }
     }
@@ -348,6 +371,7 @@ JD void flatten_euler(Out<EMIT>& o, const CubicPoints& cubic, uint32_t path_ix, 
             float n = clamp_(ceil_(n_frac * scale_multiplier), 1.0f, 100.0f);
             uint32_t n_u = to_u32(n);
             if (EMIT) {
+                uint32_t first = o.alloc(n_u);
                 for (uint32_t i = 0; i < n_u; i++) {
                     V2 lp1;
                     if (i + 1u == n_u && t1 == 1.0f) {
@@ -365,7 +389,7 @@ JD void flatten_euler(Out<EMIT>& o, const CubicPoints& cubic, uint32_t path_ix, 
                     }
                     V2 l0 = (offset >= 0.0f) ? lp0 : lp1;
                     V2 l1 = (offset >= 0.0f) ? lp1 : lp0;
-                    o.output_line_t(path_ix, l0, l1, transform);
+                    o.write_line_t(first + i, path_ix, l0, l1, transform);
                     lp0 = lp1;
                 }
             } else {
@@ -691,23 +715,51 @@ JD void run_item(const JlConfig* cfg, const Scene& s, const Buf<JlPathBbox>& pat
     }
 }
 
-template <bool EMIT>
 __global__ __launch_bounds__(JL_WG) void k_flatten_items(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
-                                                         Buf<JlPathBbox> path_bboxes, Buf<JlLineSoup> lines, const uint32_t* __restrict__ list,
-                                                         const uint32_t* __restrict__ counters, uint32_t cap, uint32_t* __restrict__ counts,
-                                                         const uint32_t* __restrict__ bases) {
+                                                         Buf<JlPathBbox> path_bboxes, const uint32_t* __restrict__ list,
+                                                         uint32_t* __restrict__ counters, uint32_t cap, uint32_t* __restrict__ counts,
+                                                         JlLineSoup* __restrict__ tlines, uint2* __restrict__ tkeys, uint32_t tcap) {
+    __shared__ uint32_t sh_next;
+    __shared__ uint32_t sh_chunk;
     Scene s;
     s.cfg = cfg; s.scene = scene; s.tag_monoids = tag_monoids;
     uint32_t n_heavy = umin_(counters[0], cap), n_light = umin_(counters[1], cap - n_heavy);
     uint32_t n = n_heavy + n_light;
+    if (blockIdx.x * JL_WG >= n) return;  // uniform: this workgroup has no items
+    if (threadIdx.x == 0) {
+        uint32_t cb = atomicAdd(&counters[2], FL_CHUNK);
+        sh_chunk = cb;
+        sh_next = cb;
+    }
+    __syncthreads();
+    uint32_t chunk = sh_chunk;
+    for (uint32_t i = threadIdx.x; i < FL_CHUNK; i += JL_WG) {  // slots of the chunk that stay unused must read as invalid
+        uint32_t t = chunk + i;
+        if (t < tcap) tkeys[t] = make_uint2(FL_INVALID, 0u);
+    }
+    __syncthreads();
     for (uint32_t t = blockIdx.x * JL_WG + threadIdx.x; t < n; t += gridDim.x * JL_WG) {
         uint32_t slot = t < n_heavy ? list[t] : list[cap - 1u - (t - n_heavy)];
-        Out<EMIT> o;
-        o.cfg = cfg; o.lines = lines;
-        o.cursor = EMIT ? bases[slot] : 0u;
+        Out<true> o;
+        o.cfg = cfg; o.tlines = tlines; o.tkeys = tkeys; o.tcap = tcap; o.slot = slot;
+        o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
+        o.lds_next = &sh_next; o.lds_limit = chunk + FL_CHUNK; o.g_next = &counters[2];
         o.bx0 = 1e31f; o.by0 = 1e31f; o.bx1 = -1e31f; o.by1 = -1e31f;
-        run_item<EMIT>(cfg, s, path_bboxes, o, slot);
-        if (!EMIT) counts[slot] = o.cursor;
+        run_item<true>(cfg, s, path_bboxes, o, slot);
+        counts[slot] = o.cursor;
+    }
+}
+
+// lines[bases[slot] + k] = temp line: the canonical (tag byte, emission order) LineSoup order.
+__global__ __launch_bounds__(JL_WG) void k_flatten_permute(const JlConfig* __restrict__ cfg, const uint32_t* __restrict__ counters,
+                                                           const JlLineSoup* __restrict__ tlines, const uint2* __restrict__ tkeys, uint32_t tcap,
+                                                           const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines) {
+    uint32_t n = umin_(counters[2], tcap);
+    for (uint32_t x = blockIdx.x * JL_WG + threadIdx.x; x < n; x += gridDim.x * JL_WG) {
+        uint2 key = tkeys[x];
+        if (key.x >= n_slots) continue;
+        uint32_t dst = bases[key.x] + key.y;
+        if (dst < cfg->lines_size && lines.ok(dst)) lines.p[dst] = tlines[x];
     }
 }
 
@@ -721,28 +773,35 @@ int jh_launch_flatten(const JhLaunch& L) {
     uint64_t n_slots64 = (uint64_t)n_tags * 3;
     if (n_slots64 > 0xfffffff0ull) return -1;
     uint32_t n_slots = (uint32_t)n_slots64;
-    uint32_t* counts = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)n_slots * 4);
-    uint32_t* bases = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_B, (uint64_t)n_slots * 4);
-    uint32_t* list = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_C, (uint64_t)n_slots * 4);
-    uint32_t* counters = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, 256);
-    if (!counts || !bases || !list || !counters) return -5;
     auto cfg = (const JlConfig*)L.b[0].ptr;
     auto scene = mkbuf<uint32_t>(L.b[1].ptr, L.b[1].size);
     auto tm = mkbuf<JlTagMonoid>(L.b[2].ptr, L.b[2].size);
     auto pb = mkbuf<JlPathBbox>(L.b[3].ptr, L.b[3].size);
     JlBump* bump = (JlBump*)L.b[4].ptr;
     auto lines = mkbuf<JlLineSoup>(L.b[5].ptr, L.b[5].size);
-    (void)hipMemsetAsync(counters, 0, 8, L.stream);
-    (void)hipMemsetAsync(counts, 0, (size_t)n_slots * 4, L.stream);
-    hipLaunchKernelGGL(k_flatten_classify, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list, counters, n_slots);
     uint32_t cap_blocks = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * 8u;
     uint32_t g = (n_slots + JL_WG - 1) / JL_WG;
     if (g > cap_blocks) g = cap_blocks;
-    hipLaunchKernelGGL(k_flatten_items<false>, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, lines, (const uint32_t*)list,
-                       (const uint32_t*)counters, n_slots, counts, (const uint32_t*)nullptr);
+    uint64_t tcap64 = (uint64_t)lines.n + (uint64_t)g * FL_CHUNK;
+    if (tcap64 > 0xfffffff0ull) return -1;
+    uint32_t tcap = (uint32_t)tcap64;
+    uint32_t* counts = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)n_slots * 4);
+    uint32_t* bases = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_B, (uint64_t)n_slots * 4);
+    uint32_t* list = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_C, (uint64_t)n_slots * 4);
+    JlLineSoup* tlines = (JlLineSoup*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)tcap * sizeof(JlLineSoup));
+    uint2* tkeys = (uint2*)jh_scratch_get(L.scratch, JH_SCR_E, (uint64_t)tcap * sizeof(uint2));
+    uint32_t* counters = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, 256);
+    if (!counts || !bases || !list || !counters || !tlines || !tkeys) return -5;
+    (void)hipMemsetAsync(counters, 0, 16, L.stream);
+    (void)hipMemsetAsync(counts, 0, (size_t)n_slots * 4, L.stream);
+    hipLaunchKernelGGL(k_flatten_classify, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list, counters, n_slots);
+    hipLaunchKernelGGL(k_flatten_items, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, (const uint32_t*)list, counters, n_slots, counts,
+                       tlines, tkeys, tcap);
     int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_flatten_items<true>, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, lines, (const uint32_t*)list,
-                       (const uint32_t*)counters, n_slots, (uint32_t*)nullptr, (const uint32_t*)bases);
+    uint32_t gp = (tcap + JL_WG - 1) / JL_WG;
+    if (gp > cap_blocks) gp = cap_blocks;
+    hipLaunchKernelGGL(k_flatten_permute, dim3(gp), dim3(JL_WG), 0, L.stream, cfg, (const uint32_t*)counters, (const JlLineSoup*)tlines,
+                       (const uint2*)tkeys, tcap, (const uint32_t*)bases, n_slots, lines);
     return 0;
 }

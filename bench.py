@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     args = ap.parse_args()
 
     import torch
@@ -85,39 +86,59 @@ def main():
     torch.cuda.synchronize(dev)
 
     pending = [None, None]
+    # One frame is ~60 short launches (launch-bound on the host), so the dispatch-only replay of the
+    # recording is captured once into a hipGraph per output buffer and the timed steps replay it.
+    graphs = [None, None]
+    use_graph = not args.no_graph
+    if use_graph:
+        for k in range(2 if world > 1 and not args.no_gather else 1):
+            graphs[k] = eng.capture(rec, outs[k].data_ptr())
+        if graphs[1] is None:
+            graphs[1] = graphs[0]
+            outs[1] = outs[0]
 
-    def step(i, profile=False):
+    def step(i):
         k = i & 1
         if pending[k] is not None:
             pending[k].wait()
             pending[k] = None
-        eng.run(rec, RUN_DISPATCHES, outs[k].data_ptr())
+        if use_graph:
+            eng.replay(graphs[k])
+        else:
+            eng.run(rec, RUN_DISPATCHES, outs[k].data_ptr())
         if world > 1 and not args.no_gather:
             pending[k] = dist.gather(outs[k], gathered[k] if rank == 0 else None, dst=0, async_op=True)
 
+    def drain():
+        for j in range(2):
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
+
     for i in range(args.warmup):
         step(i)
-    for p in pending:
-        if p is not None:
-            p.wait()
-    pending[:] = [None, None]
+    drain()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
 
-    eng.profile(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    for p in pending:
-        if p is not None:
-            p.wait()
+    drain()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
+
+    # Per-stage device times: the same K steps once more, eagerly, with a hipEvent pair around every
+    # stage on the launch stream (events cannot be read back from inside a replayed graph).
+    eng.profile(True)
+    for i in range(args.steps):
+        eng.run(rec, RUN_DISPATCHES, outs[0].data_ptr())
+    torch.cuda.synchronize(dev)
     prof = eng.profile_collect(1 << 16)
     eng.profile(False)
 
@@ -171,12 +192,20 @@ def main():
                        "parallelism": "scene-per-gpu x%d%s" % (world, "" if world == 1 or args.no_gather else " + RCCL image gather")},
             "paths_per_s": round(args.paths * world / (elapsed / args.steps), 1),
             "fine_mpixels_per_s": round(W * H / (fine_ms * 1e-3) / 1e6, 2),
+            "launch": "hipGraph replay" if use_graph else "eager",
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "stage_ms_source": "eager replay of the same %d steps with a hipEvent pair per stage" % args.steps,
             "bump": {k: int(v) for k, v in zip(["failed", "binning", "ptcl", "tile", "seg_counts", "segments", "blend", "lines"], bump_now)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "device": eng.device_info()["name"],
         }
+    for g in set(id(x) for x in graphs if x is not None):
+        pass
+    if graphs[0] is not None:
+        eng.graph_destroy(graphs[0])
+        if graphs[1] is not graphs[0]:
+            eng.graph_destroy(graphs[1])
     eng.release(rec)
     if world > 1:
         dist.barrier()

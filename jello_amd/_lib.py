@@ -176,6 +176,10 @@ def _declare(L):
     hip.jh_set_stream.argtypes = [vp, vp]
     hip.jh_profile_enable.argtypes = [vp, ci]
     hip.jh_profile_collect.argtypes = [vp, vp, ci]
+    hip.jh_graph_begin.argtypes = [vp]
+    hip.jh_graph_end.argtypes = [vp, ctypes.POINTER(vp)]
+    hip.jh_graph_launch.argtypes = [vp, vp]
+    hip.jh_graph_destroy.argtypes = [vp, vp]
     hip.jh_free.argtypes = [vp, ctypes.c_uint64]
     hip.jh_clear.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64]
     hip.jh_pool_bytes.restype = ctypes.c_uint64

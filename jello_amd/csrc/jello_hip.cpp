@@ -481,6 +481,36 @@ int jh_dispatch_indirect(jh_ctx* ctx, int stage, uint64_t indirect_buffer_id, ui
     return dispatch_common(ctx, stage, 0, 1, 1, (const uint32_t*)((char*)it->second.ptr + offset), bindings, n_bindings);
 }
 
+// ---- hipGraph capture ----
+int jh_graph_begin(jh_ctx* ctx) {
+    if (!ctx) return JH_ERR_INVALID;
+    if (ctx->profiling) return fail(ctx, JH_ERR_INVALID, "jh_graph_begin: disable profiling first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    return JH_OK;
+}
+int jh_graph_end(jh_ctx* ctx, void** graph_exec) {
+    if (!ctx || !graph_exec) return JH_ERR_INVALID;
+    hipGraph_t graph = nullptr;
+    HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipGraphInstantiate");
+    *graph_exec = (void*)exec;
+    return JH_OK;
+}
+int jh_graph_launch(jh_ctx* ctx, void* graph_exec) {
+    if (!ctx || !graph_exec) return JH_ERR_INVALID;
+    HIP_TRY(ctx, hipGraphLaunch((hipGraphExec_t)graph_exec, ctx->stream));
+    return JH_OK;
+}
+int jh_graph_destroy(jh_ctx* ctx, void* graph_exec) {
+    if (!ctx) return JH_ERR_INVALID;
+    if (graph_exec) HIP_TRY(ctx, hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return JH_OK;
+}
+
 // ---- profiling ----
 int jh_profile_enable(jh_ctx* ctx, int on) {
     if (!ctx) return JH_ERR_INVALID;

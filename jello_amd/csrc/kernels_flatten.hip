@@ -35,7 +35,6 @@ struct PathTagData { uint32_t tag_byte; MonoidK<5> monoid; };
 #define DIST_THRESH 1e-3f
 #define TANGENT_THRESH 1e-6f
 
-#define FL_CHUNK 4096u          // temp line slots a workgroup reserves up front
 #define FL_INVALID 0xffffffffu
 
 // Line sink.  EMIT: lines go to a TEMPORARY buffer in allocation order (fast, order-free allocation:
@@ -718,7 +717,8 @@ JD void run_item(const JlConfig* cfg, const Scene& s, const Buf<JlPathBbox>& pat
 __global__ __launch_bounds__(JL_WG) void k_flatten_items(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
                                                          Buf<JlPathBbox> path_bboxes, const uint32_t* __restrict__ list,
                                                          uint32_t* __restrict__ counters, uint32_t cap, uint32_t* __restrict__ counts,
-                                                         JlLineSoup* __restrict__ tlines, uint2* __restrict__ tkeys, uint32_t tcap) {
+                                                         JlLineSoup* __restrict__ tlines, uint2* __restrict__ tkeys, uint32_t tcap,
+                                                         uint32_t FL_CHUNK) {
     __shared__ uint32_t sh_next;
     __shared__ uint32_t sh_chunk;
     Scene s;
@@ -779,9 +779,12 @@ int jh_launch_flatten(const JhLaunch& L) {
     auto pb = mkbuf<JlPathBbox>(L.b[3].ptr, L.b[3].size);
     JlBump* bump = (JlBump*)L.b[4].ptr;
     auto lines = mkbuf<JlLineSoup>(L.b[5].ptr, L.b[5].size);
-    uint32_t cap_blocks = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * 8u;
+    uint32_t cap_blocks = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * 4u;
     uint32_t g = (n_slots + JL_WG - 1) / JL_WG;
     if (g > cap_blocks) g = cap_blocks;
+    // temp line slots a workgroup reserves up front: its fair share of the line capacity + 25 %
+    uint32_t FL_CHUNK = (uint32_t)((((uint64_t)lines.n / g) * 5 / 4 + 255) & ~255ull);
+    if (FL_CHUNK < 256u) FL_CHUNK = 256u;
     uint64_t tcap64 = (uint64_t)lines.n + (uint64_t)g * FL_CHUNK;
     if (tcap64 > 0xfffffff0ull) return -1;
     uint32_t tcap = (uint32_t)tcap64;
@@ -796,11 +799,11 @@ int jh_launch_flatten(const JhLaunch& L) {
     (void)hipMemsetAsync(counts, 0, (size_t)n_slots * 4, L.stream);
     hipLaunchKernelGGL(k_flatten_classify, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list, counters, n_slots);
     hipLaunchKernelGGL(k_flatten_items, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, (const uint32_t*)list, counters, n_slots, counts,
-                       tlines, tkeys, tcap);
+                       tlines, tkeys, tcap, FL_CHUNK);
     int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);
     if (rc) return rc;
     uint32_t gp = (tcap + JL_WG - 1) / JL_WG;
-    if (gp > cap_blocks) gp = cap_blocks;
+    if (gp > cap_blocks * 2u) gp = cap_blocks * 2u;
     hipLaunchKernelGGL(k_flatten_permute, dim3(gp), dim3(JL_WG), 0, L.stream, cfg, (const uint32_t*)counters, (const JlLineSoup*)tlines,
                        (const uint2*)tkeys, tcap, (const uint32_t*)bases, n_slots, lines);
     return 0;

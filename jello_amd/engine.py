@@ -152,6 +152,24 @@ class Engine:
         names = ["failed", "binning", "ptcl", "tile", "seg_counts", "segments", "blend", "lines"]
         return Recording(self._L, h), dict(zip(names, bump)), attempts.value
 
+    def capture(self, recording, out_device_ptr=None):
+        """Capture one dispatch-only replay of `recording` into a hipGraph; returns an opaque handle for replay().
+        The recording must have been run once (buffers + scratch exist)."""
+        self._check(self.hip.jh_graph_begin(self.ctx), "graph_begin")
+        try:
+            self.run(recording, RUN_DISPATCHES, out_device_ptr)
+        finally:
+            g = ctypes.c_void_p()
+            rc = self.hip.jh_graph_end(self.ctx, ctypes.byref(g))
+        self._check(rc, "graph_end")
+        return g
+
+    def replay(self, graph):
+        self._check(self.hip.jh_graph_launch(self.ctx, graph), "graph_launch")
+
+    def graph_destroy(self, graph):
+        self.hip.jh_graph_destroy(self.ctx, graph)
+
     def sync(self):
         self._check(self.hip.jh_sync(self.ctx), "sync")
 

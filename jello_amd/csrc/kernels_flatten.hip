@@ -286,126 +286,252 @@ JD V2 cubic_end_tangent(V2 p0, V2 p1, V2 p2, V2 p3) {  // :303-309
     return (dot(d23, d23) > EPS) ? d23 : inner;
 }
 
-// flatten.wgsl:328-477
-template <bool EMIT>
-JD void flatten_euler(Out<EMIT>& o, const CubicPoints& cubic, uint32_t path_ix, const Xf& local_to_device, float offset, V2 start_p,
-                      V2 end_p) {
-    V2 p0, p1, p2, p3;
-    float scale;
-    Xf transform;
-    V2 t_start = start_p, t_end = end_p;
-    if (offset == 0.0f) {
-        p0 = xf_apply(local_to_device, cubic.p0);
-        p1 = xf_apply(local_to_device, cubic.p1);
-        p2 = xf_apply(local_to_device, cubic.p2);
-        p3 = xf_apply(local_to_device, cubic.p3);
-        scale = 1.0f;
-        transform = xf_identity();
-        t_start = p0;
-        t_end = p3;
-    } else {
-        p0 = cubic.p0; p1 = cubic.p1; p2 = cubic.p2; p3 = cubic.p3;
-        transform = local_to_device;
-        scale = 0.5f * length(v2(transform.m0 + transform.m3, transform.m1 - transform.m2)) +
-                length(v2(transform.m0 - transform.m3, transform.m1 + transform.m2));
-    }
-    if (veq(p0, p1) && veq(p0, p2) && veq(p0, p3)) return;
+struct Scene {
+    const JlConfig* cfg;
+    Buf<uint32_t> scene;
+    Buf<JlTagMonoid> tag_monoids;
+};
 
+// ------------------------------------------------------------------------------------------------
+// flatten_euler (flatten.wgsl:328-477), wave-cooperative.
+//
+// Every lane of the wave may own one Euler job (a cubic + offset).  The adaptive subdivision runs per
+// lane exactly as in the WGSL.  When lanes ACCEPT a piece in an iteration they publish its parameters in
+// LDS, the wave prefix-sums the pieces' line counts, and then ALL 64 lanes evaluate the lines of all
+// accepted pieces together (lane j takes line j: owner piece by binary search, end point by
+// es_seg_eval_with_offset, start point from lane j-1's end point / the piece's start).  This removes
+// the divergence of the per-lane `for i < n` loop, which otherwise dominates the stage.  Arithmetic per
+// point is the WGSL's, so results are bit-identical to the sequential formulation.
+// ------------------------------------------------------------------------------------------------
+enum {
+    F_INCL = 0, F_P0X, F_P0Y, F_P1X, F_P1Y, F_TH0, F_K0, F_K1, F_CH, F_A, F_B, F_INTEGRAL, F_INT0, F_NOFF, F_N, F_LP0X, F_LP0Y,
+    F_TENDX, F_TENDY, F_FLAGS, F_PATH, F_TPOS, F_FIRST, F_SLOT, F_TRANS, F_LPENDX, F_LPENDY, F_BX0, F_BY0, F_BX1, F_BY1, F_COUNT
+};
+typedef volatile uint32_t WaveLds[F_COUNT][64];
+
+JD void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// order-preserving float <-> uint key (for integer LDS atomic min/max on floats)
+JD uint32_t fkey(float f) { uint32_t b = f2u(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+JD float fkey_inv(uint32_t k) { return u2f((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+struct EulerJob {
+    bool valid;
+    CubicPoints cubic;
+    uint32_t path_ix, trans_ix;
+    Xf local_to_device;
+    float offset;
+    V2 start_p, end_p;
+};
+
+JD V2 piece_eval(WaveLds& W, uint32_t owner, uint32_t i_plus_1, uint32_t flags) {
+    float n = u2f(W[F_N][owner]);
+    float t = (float)i_plus_1 / n;
+    float s = t;
+    uint32_t robust = flags & 3u;
+    float a = u2f(W[F_A][owner]), b = u2f(W[F_B][owner]);
+    if (robust != 1u) {
+        float u = u2f(W[F_INTEGRAL][owner]) * t + u2f(W[F_INT0][owner]);
+        float inv;
+        if (robust == 2u) inv = pow23_abs_(u) * sign_(u); else inv = espc_int_inv_approx(u);
+        s = (inv - b) / a;
+    }
+    EulerParams ep;
+    ep.th0 = u2f(W[F_TH0][owner]); ep.th1 = 0.0f; ep.k0 = u2f(W[F_K0][owner]); ep.k1 = u2f(W[F_K1][owner]); ep.ch = u2f(W[F_CH][owner]);
+    V2 es_p0 = v2(u2f(W[F_P0X][owner]), u2f(W[F_P0Y][owner])), es_p1 = v2(u2f(W[F_P1X][owner]), u2f(W[F_P1Y][owner]));
+    return es_seg_eval_with_offset(es_p0, es_p1, ep, s, u2f(W[F_NOFF][owner]));
+}
+
+JD void flatten_euler_wave(Out<true>& o, const EulerJob& job, const Scene& sc, WaveLds& W) {
+    const uint32_t lane = lane_id();
+    V2 p0 = v2(0, 0), p1 = p0, p2 = p0, p3 = p0;
+    float scale = 1.0f;
+    V2 t_start = job.start_p, t_end = job.end_p;
+    bool done = !job.valid;
+    const float offset = job.offset;
+    if (job.valid) {
+        if (offset == 0.0f) {
+            p0 = xf_apply(job.local_to_device, job.cubic.p0);
+            p1 = xf_apply(job.local_to_device, job.cubic.p1);
+            p2 = xf_apply(job.local_to_device, job.cubic.p2);
+            p3 = xf_apply(job.local_to_device, job.cubic.p3);
+            scale = 1.0f;
+            t_start = p0;
+            t_end = p3;
+        } else {
+            p0 = job.cubic.p0; p1 = job.cubic.p1; p2 = job.cubic.p2; p3 = job.cubic.p3;
+            const Xf& tr = job.local_to_device;
+            scale = 0.5f * length(v2(tr.m0 + tr.m3, tr.m1 - tr.m2)) + length(v2(tr.m0 - tr.m3, tr.m1 + tr.m2));
+        }
+        if (veq(p0, p1) && veq(p0, p2) && veq(p0, p3)) done = true;
+    }
     const float tol = 0.25f;
     uint32_t t0_u = 0u;
     float dt = 1.0f;
     V2 last_p = p0;
     V2 last_q = p1 - p0;
-    if (dot(last_q, last_q) < DERIV_THRESH_SQUARED) last_q = eval_cubic_and_deriv(p0, p1, p2, p3, DERIV_EPS).deriv;
+    if (!done && dot(last_q, last_q) < DERIV_THRESH_SQUARED) last_q = eval_cubic_and_deriv(p0, p1, p2, p3, DERIV_EPS).deriv;
     float last_t = 0.0f;
     V2 lp0 = t_start;
+    W[F_BX0][lane] = fkey(1e31f); W[F_BY0][lane] = fkey(1e31f); W[F_BX1][lane] = fkey(-1e31f); W[F_BY1][lane] = fkey(-1e31f);
     for (;;) {
-        float t0 = (float)t0_u * dt;
-        if (t0 == 1.0f) break;
-        float t1 = t0 + dt;
-        V2 this_p0 = last_p;
-        V2 this_q0 = last_q;
-        PointDeriv this_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1);
-        if (dot(this_pq1.deriv, this_pq1.deriv) < DERIV_THRESH_SQUARED) {
-            PointDeriv new_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1 - DERIV_EPS);
-            this_pq1.deriv = new_pq1.deriv;
-            if (t1 < 1.0f) {
-                this_pq1.point = new_pq1.point;
-                t1 = t1 - DERIV_EPS;
-            }
-        }
-        float actual_dt = t1 - last_t;
-        CubicParams cp = cubic_from_points_derivs(this_p0, this_pq1.point, this_q0, this_pq1.deriv, actual_dt);
-        if (cp.err * scale <= tol || dt <= SUBDIV_LIMIT) {
-            EulerParams ep = es_params_from_angles(cp.th0, cp.th1);
-            float k0 = ep.k0 - 0.5f * ep.k1;
-            float k1 = ep.k1;
-            float normalized_offset = offset / cp.chord_len;
-            float dist_scaled = normalized_offset * ep.ch;
-            float scale_multiplier = sqrt_(0.125f * scale * cp.chord_len / (ep.ch * tol));
-            float a = 0.0f, b = 0.0f, integral = 0.0f, int0 = 0.0f, n_frac;
-            int robust = 0;
-            if (abs_(k1) < K1_THRESH) {
-                float k = ep.k0;
-                n_frac = sqrt_(abs_(k * (k * dist_scaled + 1.0f)));
-                robust = 1;
-            } else if (abs_(dist_scaled) < DIST_THRESH) {
-                a = k1;
-                b = k0;
-                int0 = pow_1_5_signed(b);
-                float int1 = pow_1_5_signed(a + b);
-                integral = int1 - int0;
-                n_frac = (float)(2.0 / 3.0) * integral / a;
-                robust = 2;
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+        bool accept = false;
+        uint32_t n_u = 0u;
+        float pc_n = 0.0f, pc_a = 0.0f, pc_b = 0.0f, pc_integral = 0.0f, pc_int0 = 0.0f, pc_noff = 0.0f;
+        EulerParams ep;
+        ep.th0 = ep.th1 = ep.k0 = ep.k1 = ep.ch = 0.0f;
+        V2 es_p0 = v2(0, 0), es_p1 = v2(0, 0);
+        uint32_t pc_flags = 0u;
+        if (!done) {
+            float t0 = (float)t0_u * dt;
+            if (t0 == 1.0f) {
+                done = true;
             } else {
-                a = -2.0f * dist_scaled * k1;
-                b = -1.0f - 2.0f * dist_scaled * k0;
-                int0 = espc_int_approx(b);
-                float int1 = espc_int_approx(a + b);
-                integral = int1 - int0;
-                float k_peak = k0 - k1 * b / a;
-                float integrand_peak = sqrt_(abs_(k_peak * (k_peak * dist_scaled + 1.0f)));
-                n_frac = integral * integrand_peak / a;
-            }
-            float n = clamp_(ceil_(n_frac * scale_multiplier), 1.0f, 100.0f);
-            uint32_t n_u = to_u32(n);
-            if (EMIT) {
-                uint32_t first = o.alloc(n_u);
-                for (uint32_t i = 0; i < n_u; i++) {
-                    V2 lp1;
-                    if (i + 1u == n_u && t1 == 1.0f) {
-                        lp1 = t_end;
-                    } else {
-                        float t = (float)(i + 1u) / n;
-                        float s = t;
-                        if (robust != 1) {
-                            float u = integral * t + int0;
-                            float inv;
-                            if (robust == 2) inv = pow23_abs_(u) * sign_(u); else inv = espc_int_inv_approx(u);
-                            s = (inv - b) / a;
-                        }
-                        lp1 = es_seg_eval_with_offset(this_p0, this_pq1.point, ep, s, normalized_offset);
+                float t1 = t0 + dt;
+                V2 this_p0 = last_p;
+                V2 this_q0 = last_q;
+                PointDeriv this_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1);
+                if (dot(this_pq1.deriv, this_pq1.deriv) < DERIV_THRESH_SQUARED) {
+                    PointDeriv new_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1 - DERIV_EPS);
+                    this_pq1.deriv = new_pq1.deriv;
+                    if (t1 < 1.0f) {
+                        this_pq1.point = new_pq1.point;
+                        t1 = t1 - DERIV_EPS;
                     }
-                    V2 l0 = (offset >= 0.0f) ? lp0 : lp1;
-                    V2 l1 = (offset >= 0.0f) ? lp1 : lp0;
-                    o.write_line_t(first + i, path_ix, l0, l1, transform);
-                    lp0 = lp1;
                 }
-            } else {
-                o.alloc(n_u);
+                float actual_dt = t1 - last_t;
+                CubicParams cp = cubic_from_points_derivs(this_p0, this_pq1.point, this_q0, this_pq1.deriv, actual_dt);
+                if (cp.err * scale <= tol || dt <= SUBDIV_LIMIT) {
+                    ep = es_params_from_angles(cp.th0, cp.th1);
+                    float k0 = ep.k0 - 0.5f * ep.k1;
+                    float k1 = ep.k1;
+                    float normalized_offset = offset / cp.chord_len;
+                    float dist_scaled = normalized_offset * ep.ch;
+                    float scale_multiplier = sqrt_(0.125f * scale * cp.chord_len / (ep.ch * tol));
+                    float a = 0.0f, b = 0.0f, integral = 0.0f, int0 = 0.0f, n_frac;
+                    uint32_t robust = 0u;
+                    if (abs_(k1) < K1_THRESH) {
+                        float k = ep.k0;
+                        n_frac = sqrt_(abs_(k * (k * dist_scaled + 1.0f)));
+                        robust = 1u;
+                    } else if (abs_(dist_scaled) < DIST_THRESH) {
+                        a = k1;
+                        b = k0;
+                        int0 = pow_1_5_signed(b);
+                        float int1 = pow_1_5_signed(a + b);
+                        integral = int1 - int0;
+                        n_frac = (float)(2.0 / 3.0) * integral / a;
+                        robust = 2u;
+                    } else {
+                        a = -2.0f * dist_scaled * k1;
+                        b = -1.0f - 2.0f * dist_scaled * k0;
+                        int0 = espc_int_approx(b);
+                        float int1 = espc_int_approx(a + b);
+                        integral = int1 - int0;
+                        float k_peak = k0 - k1 * b / a;
+                        float integrand_peak = sqrt_(abs_(k_peak * (k_peak * dist_scaled + 1.0f)));
+                        n_frac = integral * integrand_peak / a;
+                    }
+                    float n = clamp_(ceil_(n_frac * scale_multiplier), 1.0f, 100.0f);
+                    n_u = to_u32(n);
+                    accept = true;
+                    pc_n = n; pc_a = a; pc_b = b; pc_integral = integral; pc_int0 = int0; pc_noff = normalized_offset;
+                    es_p0 = this_p0; es_p1 = this_pq1.point;
+                    pc_flags = robust | ((t1 == 1.0f) ? 4u : 0u) | ((offset >= 0.0f) ? 8u : 0u) | ((offset == 0.0f) ? 16u : 0u);
+                    last_p = this_pq1.point;
+                    last_q = this_pq1.deriv;
+                    last_t = t1;
+                    t0_u += 1u;
+                    uint32_t shift = (t0_u == 0u) ? 32u : (uint32_t)__builtin_ctz(t0_u);
+                    t0_u = (shift >= 32u) ? 0u : (t0_u >> shift);
+                    dt *= (float)(1u << (shift & 31u));
+                } else {
+                    t0_u = t0_u * 2u;
+                    dt *= 0.5f;
+                }
             }
-            last_p = this_pq1.point;
-            last_q = this_pq1.deriv;
-            last_t = t1;
-            t0_u += 1u;
-            uint32_t shift = (t0_u == 0u) ? 32u : (uint32_t)__builtin_ctz(t0_u);
-            t0_u = (shift >= 32u) ? 0u : (t0_u >> shift);
-            dt *= (float)(1u << (shift & 31u));
-        } else {
-            t0_u = t0_u * 2u;
-            dt *= 0.5f;
         }
+        uint32_t nm = accept ? n_u : 0u;
+        uint32_t incl = wave_incl_scan_u32(nm);
+        uint32_t total = __shfl(incl, 63, 64);
+        if (total == 0u) continue;
+        if (accept) {
+            uint32_t first = o.alloc(n_u);
+            W[F_P0X][lane] = f2u(es_p0.x); W[F_P0Y][lane] = f2u(es_p0.y); W[F_P1X][lane] = f2u(es_p1.x); W[F_P1Y][lane] = f2u(es_p1.y);
+            W[F_TH0][lane] = f2u(ep.th0); W[F_K0][lane] = f2u(ep.k0); W[F_K1][lane] = f2u(ep.k1); W[F_CH][lane] = f2u(ep.ch);
+            W[F_A][lane] = f2u(pc_a); W[F_B][lane] = f2u(pc_b); W[F_INTEGRAL][lane] = f2u(pc_integral); W[F_INT0][lane] = f2u(pc_int0);
+            W[F_NOFF][lane] = f2u(pc_noff); W[F_N][lane] = f2u(pc_n);
+            W[F_LP0X][lane] = f2u(lp0.x); W[F_LP0Y][lane] = f2u(lp0.y); W[F_TENDX][lane] = f2u(t_end.x); W[F_TENDY][lane] = f2u(t_end.y);
+            W[F_FLAGS][lane] = pc_flags; W[F_PATH][lane] = job.path_ix; W[F_TPOS][lane] = o.a_tpos; W[F_FIRST][lane] = first;
+            W[F_SLOT][lane] = o.slot; W[F_TRANS][lane] = job.trans_ix;
+        }
+        W[F_INCL][lane] = incl;
+        wave_fence();
+        for (uint32_t base = 0u; base < total; base += 64u) {
+            uint32_t j = base + lane;
+            bool valid = j < total;
+            // owner = first lane whose inclusive count exceeds j
+            uint32_t owner = 0u;
+#pragma unroll
+            for (uint32_t step = 32u; step > 0u; step >>= 1) {
+                uint32_t probe = owner + step;
+                if (W[F_INCL][probe - 1u] <= j) owner = probe;
+            }
+            if (owner > 63u) owner = 63u;
+            V2 lp1 = v2(0, 0);
+            uint32_t flags = 0u, i = 0u, n_own = 0u;
+            if (valid) {
+                flags = W[F_FLAGS][owner];
+                n_own = to_u32(u2f(W[F_N][owner]));
+                i = j - (W[F_INCL][owner] - n_own);
+                if (i + 1u == n_own && (flags & 4u) != 0u) lp1 = v2(u2f(W[F_TENDX][owner]), u2f(W[F_TENDY][owner]));
+                else lp1 = piece_eval(W, owner, i + 1u, flags);
+            }
+            float px = __shfl_up(lp1.x, 1, 64), py = __shfl_up(lp1.y, 1, 64);
+            if (valid) {
+                V2 a0;
+                if (i == 0u) a0 = v2(u2f(W[F_LP0X][owner]), u2f(W[F_LP0Y][owner]));
+                else if (lane > 0u) a0 = v2(px, py);
+                else a0 = piece_eval(W, owner, i, flags);
+                Xf tr;
+                if ((flags & 16u) != 0u) {
+                    tr = xf_identity();
+                } else {
+                    uint32_t tb = sc.cfg->layout.transform_base + W[F_TRANS][owner] * 6u;
+                    tr.m0 = u2f(sc.scene.rd(tb)); tr.m1 = u2f(sc.scene.rd(tb + 1u)); tr.m2 = u2f(sc.scene.rd(tb + 2u));
+                    tr.m3 = u2f(sc.scene.rd(tb + 3u)); tr.t0 = u2f(sc.scene.rd(tb + 4u)); tr.t1 = u2f(sc.scene.rd(tb + 5u));
+                }
+                V2 l0 = (flags & 8u) ? a0 : lp1;
+                V2 l1 = (flags & 8u) ? lp1 : a0;
+                V2 q0 = xf_apply(tr, l0), q1 = xf_apply(tr, l1);
+                atomicMin((uint32_t*)&W[F_BX0][owner], fkey(fmin_(q0.x, q1.x)));
+                atomicMin((uint32_t*)&W[F_BY0][owner], fkey(fmin_(q0.y, q1.y)));
+                atomicMax((uint32_t*)&W[F_BX1][owner], fkey(fmax_(q0.x, q1.x)));
+                atomicMax((uint32_t*)&W[F_BY1][owner], fkey(fmax_(q0.y, q1.y)));
+                uint32_t t = W[F_TPOS][owner] + i;
+                if (t < o.tcap) {
+                    JlLineSoup l;
+                    l.path_ix = W[F_PATH][owner]; l.pad = 0; l.p0[0] = q0.x; l.p0[1] = q0.y; l.p1[0] = q1.x; l.p1[1] = q1.y;
+                    o.tlines[t] = l;
+                    o.tkeys[t] = make_uint2(W[F_SLOT][owner], W[F_FIRST][owner] + i);
+                }
+                if (i + 1u == n_own) { W[F_LPENDX][owner] = f2u(lp1.x); W[F_LPENDY][owner] = f2u(lp1.y); }
+            }
+        }
+        wave_fence();
+        if (accept) lp0 = v2(u2f(W[F_LPENDX][lane]), u2f(W[F_LPENDY][lane]));
+        wave_fence();
     }
+    if (job.valid) {
+        o.bx0 = fmin_(o.bx0, fkey_inv(W[F_BX0][lane]));
+        o.by0 = fmin_(o.by0, fkey_inv(W[F_BY0][lane]));
+        o.bx1 = fmax_(o.bx1, fkey_inv(W[F_BX1][lane]));
+        o.by1 = fmax_(o.by1, fkey_inv(W[F_BY1][lane]));
+    }
+    wave_fence();
 }
 
 // flatten.wgsl:490-517
@@ -498,11 +624,6 @@ JD void draw_join(Out<EMIT>& o, uint32_t path_ix, uint32_t style_flags, V2 p0, V
     }
 }
 
-struct Scene {
-    const JlConfig* cfg;
-    Buf<uint32_t> scene;
-    Buf<JlTagMonoid> tag_monoids;
-};
 
 JD V2 read_f32_point(const Scene& s, uint32_t ix) {
     uint32_t b = s.cfg->layout.pathdata_base + ix;
@@ -646,14 +767,17 @@ __global__ __launch_bounds__(JL_WG) void k_flatten_classify(const JlConfig* __re
     }
 }
 
+// Everything of an item except Euler flattening, which is returned as a job for flatten_euler_wave.
 template <bool EMIT>
-JD void run_item(const JlConfig* cfg, const Scene& s, const Buf<JlPathBbox>& path_bboxes, Out<EMIT>& o, uint32_t slot) {
+JD void run_item(const JlConfig* cfg, const Scene& s, Out<EMIT>& o, uint32_t slot, EulerJob& job, uint32_t& path_ix_out) {
     uint32_t ix = slot / 3u, sub = slot - ix * 3u;
     Seg g = load_seg(s, ix);
     uint32_t path_ix = g.tag.monoid.v[4];
+    path_ix_out = path_ix;
     uint32_t style_ix = g.tag.monoid.v[3];
     uint32_t trans_ix = g.tag.monoid.v[0];
     uint32_t style_flags = g.style_flags;
+    job.path_ix = path_ix; job.trans_ix = trans_ix;
     Xf transform;
     {
         uint32_t base = cfg->layout.transform_base + trans_ix * 6u;
@@ -682,8 +806,9 @@ JD void run_item(const JlConfig* cfg, const Scene& s, const Buf<JlPathBbox>& pat
                 V2 tan_start = cubic_start_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
                 if (dot(tan_start, tan_start) < TT) tan_start = v2(TANGENT_THRESH, 0.0f);
                 V2 n_start = offset * normalize(v2(-tan_start.y, tan_start.x));
-                if (sub == 0u) flatten_euler<EMIT>(o, pts, path_ix, transform, offset, pts.p0 + n_start, pts.p3 + n_prev);
-                else flatten_euler<EMIT>(o, pts, path_ix, transform, -offset, pts.p0 - n_start, pts.p3 - n_prev);
+                job.valid = true; job.cubic = pts; job.local_to_device = transform;
+                if (sub == 0u) { job.offset = offset; job.start_p = pts.p0 + n_start; job.end_p = pts.p3 + n_prev; }
+                else { job.offset = -offset; job.start_p = pts.p0 - n_start; job.end_p = pts.p3 - n_prev; }
             } else {
                 PathTagData ntag = compute_tag_monoid(s, ix + 1u);  // read_neighboring_segment, :790-800
                 CubicPoints npts = read_path_segment(s, ntag, true);
@@ -703,14 +828,8 @@ JD void run_item(const JlConfig* cfg, const Scene& s, const Buf<JlPathBbox>& pat
             }
         }
     } else {
-        flatten_euler<EMIT>(o, pts, path_ix, transform, 0.0f, pts.p0, pts.p3);
-    }
-    if (EMIT && (o.bx1 > o.bx0 || o.by1 > o.by0) && path_bboxes.ok(path_ix)) {  // flatten.wgsl:893-899 (min/max are order-free)
-        JlPathBbox* out = &path_bboxes.p[path_ix];
-        atomicMin(&out->x0, to_i32(floor_(o.bx0)));
-        atomicMin(&out->y0, to_i32(floor_(o.by0)));
-        atomicMax(&out->x1, to_i32(ceil_(o.bx1)));
-        atomicMax(&out->y1, to_i32(ceil_(o.by1)));
+        job.valid = true; job.cubic = pts; job.local_to_device = transform;
+        job.offset = 0.0f; job.start_p = pts.p0; job.end_p = pts.p3;
     }
 }
 
@@ -721,6 +840,7 @@ __global__ __launch_bounds__(JL_WG) void k_flatten_items(const JlConfig* __restr
                                                          uint32_t FL_CHUNK) {
     __shared__ uint32_t sh_next;
     __shared__ uint32_t sh_chunk;
+    __shared__ WaveLds sh_wave[JL_WG / 64];
     Scene s;
     s.cfg = cfg; s.scene = scene; s.tag_monoids = tag_monoids;
     uint32_t n_heavy = umin_(counters[0], cap), n_light = umin_(counters[1], cap - n_heavy);
@@ -738,15 +858,35 @@ __global__ __launch_bounds__(JL_WG) void k_flatten_items(const JlConfig* __restr
         if (t < tcap) tkeys[t] = make_uint2(FL_INVALID, 0u);
     }
     __syncthreads();
-    for (uint32_t t = blockIdx.x * JL_WG + threadIdx.x; t < n; t += gridDim.x * JL_WG) {
-        uint32_t slot = t < n_heavy ? list[t] : list[cap - 1u - (t - n_heavy)];
+    WaveLds& W = sh_wave[threadIdx.x >> 6];
+    for (uint32_t t = blockIdx.x * JL_WG + threadIdx.x;; t += gridDim.x * JL_WG) {
+        bool have = t < n;
+        if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;  // the whole wave is out of items
+        uint32_t slot = 0u;
+        if (have) slot = t < n_heavy ? list[t] : list[cap - 1u - (t - n_heavy)];
         Out<true> o;
         o.cfg = cfg; o.tlines = tlines; o.tkeys = tkeys; o.tcap = tcap; o.slot = slot;
         o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
         o.lds_next = &sh_next; o.lds_limit = chunk + FL_CHUNK; o.g_next = &counters[2];
         o.bx0 = 1e31f; o.by0 = 1e31f; o.bx1 = -1e31f; o.by1 = -1e31f;
-        run_item<true>(cfg, s, path_bboxes, o, slot);
-        counts[slot] = o.cursor;
+        EulerJob job;
+        job.valid = false; job.path_ix = 0u; job.trans_ix = 0u; job.offset = 0.0f;
+        job.start_p = v2(0, 0); job.end_p = v2(0, 0);
+        job.cubic.p0 = job.cubic.p1 = job.cubic.p2 = job.cubic.p3 = v2(0, 0);
+        job.local_to_device = xf_identity();
+        uint32_t path_ix = 0u;
+        if (have) run_item<true>(cfg, s, o, slot, job, path_ix);
+        flatten_euler_wave(o, job, s, W);
+        if (have) {
+            counts[slot] = o.cursor;
+            if ((o.bx1 > o.bx0 || o.by1 > o.by0) && path_bboxes.ok(path_ix)) {  // flatten.wgsl:893-899 (min/max are order-free)
+                JlPathBbox* out = &path_bboxes.p[path_ix];
+                atomicMin(&out->x0, to_i32(floor_(o.bx0)));
+                atomicMin(&out->y0, to_i32(floor_(o.by0)));
+                atomicMax(&out->x1, to_i32(ceil_(o.bx1)));
+                atomicMax(&out->y1, to_i32(ceil_(o.by1)));
+            }
+        }
     }
 }
 

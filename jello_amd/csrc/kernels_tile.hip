@@ -14,8 +14,8 @@
 //   path_count  per-line crossing counts -> scan -> SegmentCount slots; per-tile counts by
 //               no-return atomics (a sum, order-free); the per-tile arrival rank
 //               `seg_within_slice` is computed afterwards as the rank of the crossing's global
-//               index inside its tile's list (k_pc_scatter/k_pc_rank) instead of the value an
-//               atomicAdd happened to return.
+//               index inside its tile's list (k_pc_scatter/k_pc_rank); the value the count atomic
+//               happened to return is only used as a unique slot inside that temporary list.
 // The WGSL indirect dispatches become grid-stride loops bounded by the IndirectCount the setup
 // kernels write, so no host readback is needed.  All of this is HBM/atomic-bound integer work.
 #include "kcommon.h"
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(JL_WG) void k_pc_count(const JlBump* __restrict__ b
 __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump,
                                                    const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines, Buf<JlPath> paths, Buf<JlTile> tile,
                                                    Buf<JlSegmentCount> seg_counts, const uint32_t* __restrict__ seg_bases, uint32_t bases_n,
-                                                   uint32_t* __restrict__ tile_of, uint32_t tile_of_n) {
+                                                   uint2* __restrict__ tile_of, uint32_t tile_of_n) {
     uint32_t n_lines = umin_(umin_(bump->lines, bases_n), ind->x * JL_WG);
     for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
         if (!lines.ok(gid)) continue;
@@ -364,38 +364,40 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
                 if (tile.ok(t)) atomicAdd(&tile.p[t].backdrop, s.delta);
             }
             uint32_t t = (uint32_t)(base + x);
-            if (tile.ok(t)) atomicAdd(&tile.p[t].segment_count_or_ix, 1u);
+            uint32_t arrival = 0u;  // order-dependent, only used as a unique slot inside the tile's temporary list
+            if (tile.ok(t)) arrival = atomicAdd(&tile.p[t].segment_count_or_ix, 1u);
             uint32_t seg_ix = seg_base + i - s.imin;
             if (seg_ix < cfg->seg_counts_size && seg_counts.ok(seg_ix)) {
                 JlSegmentCount sc;
                 sc.line_ix = gid;
                 sc.counts = i;  // low 16 bits; the slice rank is OR-ed in by k_pc_rank
                 seg_counts.p[seg_ix] = sc;
-                if (seg_ix < tile_of_n) tile_of[seg_ix] = t;
+                if (seg_ix < tile_of_n) tile_of[seg_ix] = make_uint2(t, arrival);
             }
             last_z = z;
         }
     }
 }
-// pass 3: scatter crossing indices into per-tile lists (order inside a list is irrelevant)
+// pass 3: scatter crossing indices into per-tile lists; the slot inside a list is the (arbitrary but unique)
+// arrival number the count atomic returned in pass 2, so no further atomics are needed.
 __global__ __launch_bounds__(JL_WG) void k_pc_scatter(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
-                                                      const uint32_t* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
-                                                      uint32_t* __restrict__ cursor, uint32_t tiles_cap, uint32_t* __restrict__ list) {
+                                                      const uint2* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
+                                                      uint32_t tiles_cap, uint32_t* __restrict__ list) {
     uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
     for (uint32_t k = blockIdx.x * JL_WG + threadIdx.x; k < n; k += gridDim.x * JL_WG) {
-        uint32_t t = tile_of[k];
-        if (t >= tiles_cap || !tile.ok(t)) continue;
-        uint32_t pos = list_base[t] + atomicAdd(&cursor[t], 1u);
+        uint2 ta = tile_of[k];
+        if (ta.x >= tiles_cap || !tile.ok(ta.x)) continue;
+        uint32_t pos = list_base[ta.x] + ta.y;
         if (pos < n_cap) list[pos] = k;
     }
 }
 // pass 4: seg_within_slice = rank of k among the crossings of its tile
 __global__ __launch_bounds__(JL_WG) void k_pc_rank(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
-                                                   const uint32_t* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
+                                                   const uint2* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
                                                    uint32_t tiles_cap, const uint32_t* __restrict__ list, Buf<JlSegmentCount> seg_counts) {
     uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
     for (uint32_t k = blockIdx.x * JL_WG + threadIdx.x; k < n; k += gridDim.x * JL_WG) {
-        uint32_t t = tile_of[k];
+        uint32_t t = tile_of[k].x;
         if (t >= tiles_cap || !tile.ok(t) || !seg_counts.ok(k)) continue;
         uint32_t base = list_base[t];
         uint32_t cnt = tile.p[t].segment_count_or_ix;
@@ -643,11 +645,10 @@ int jh_launch_path_count(const JhLaunch& L) {
     uint32_t lines_cap = lines.n, seg_cap = segc.n, tiles_cap = tile.n;
     uint32_t* counts = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)lines_cap * 4);
     uint32_t* bases = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_B, (uint64_t)lines_cap * 4);
-    uint32_t* tile_of = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_C, (uint64_t)seg_cap * 4);
+    uint2* tile_of = (uint2*)jh_scratch_get(L.scratch, JH_SCR_C, (uint64_t)seg_cap * 8);
     uint32_t* list = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)seg_cap * 4);
     uint32_t* list_base = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_E, (uint64_t)tiles_cap * 4);
-    uint32_t* cursor = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_F, (uint64_t)tiles_cap * 4);
-    if (!counts || !bases || !tile_of || !list || !list_base || !cursor) return -5;
+    if (!counts || !bases || !tile_of || !list || !list_base) return -5;
     uint32_t gl = stride_grid(L, lines_cap), gs = stride_grid(L, seg_cap);
     hipLaunchKernelGGL(k_pc_count, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, paths, counts, lines_cap);
     int rc = jh_scan_u32(L, counts, 1, bases, lines_cap, &bump->lines, &bump->seg_counts);
@@ -657,10 +658,9 @@ int jh_launch_path_count(const JhLaunch& L) {
     // per-tile list bases: exclusive scan of Tile.segment_count_or_ix over the allocated tiles
     rc = jh_scan_u32(L, ((const uint32_t*)tile.p) + 1, 2, list_base, tiles_cap, &bump->tile, nullptr);
     if (rc) return rc;
-    (void)hipMemsetAsync(cursor, 0, (size_t)tiles_cap * 4, L.stream);
-    hipLaunchKernelGGL(k_pc_scatter, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint32_t*)tile_of, seg_cap,
-                       (const uint32_t*)list_base, cursor, tiles_cap, list);
-    hipLaunchKernelGGL(k_pc_rank, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint32_t*)tile_of, seg_cap,
+    hipLaunchKernelGGL(k_pc_scatter, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint2*)tile_of, seg_cap,
+                       (const uint32_t*)list_base, tiles_cap, list);
+    hipLaunchKernelGGL(k_pc_rank, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint2*)tile_of, seg_cap,
                        (const uint32_t*)list_base, tiles_cap, (const uint32_t*)list, segc);
     return 0;
 }

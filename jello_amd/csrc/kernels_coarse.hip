@@ -373,9 +373,7 @@ int jh_launch_coarse(const JhLaunch& L) {
     dim3 grid(L.gx, L.gy), blk(JL_WG);
     hipLaunchKernelGGL(k_coarse<false>, grid, blk, 0, L.stream, cfg, scene, dm, bh, ibd, paths, tiles, bump, ptcl, cnt_seg, cnt_chunk, cnt_blend,
                        (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-    int rc = jh_scan_u32(L, cnt_seg, 1, base_seg, n, nullptr, &bump->segments);
-    if (!rc) rc = jh_scan_u32(L, cnt_chunk, 1, base_chunk, n, nullptr, &bump->ptcl);
-    if (!rc) rc = jh_scan_u32(L, cnt_blend, 1, base_blend, n, nullptr, &bump->blend);
+    int rc = jh_scan3_u32(L, cnt_seg, base_seg, n, &bump->segments, &bump->ptcl, &bump->blend);
     if (rc) return rc;
     hipLaunchKernelGGL(k_coarse<true>, grid, blk, 0, L.stream, cfg, scene, dm, bh, ibd, paths, tiles, bump, ptcl, (uint32_t*)nullptr,
                        (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend);

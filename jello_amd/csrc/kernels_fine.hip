@@ -188,6 +188,13 @@ JD SegWin load_segwin(const float* __restrict__ segments, uint32_t segments_n, u
 }
 JD float bcast(float v, uint32_t lane) { return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(v), (int)lane)); }
 
+// Pixel ownership inside the wave: lane = (r, c) with r = lane >> 3, c = lane & 7 owns four pixels,
+//   k = 0,1: (row r,     columns 2c, 2c+1)      k = 2,3: (row r + 8, columns 2c, 2c+1).
+// A segment clipped to a 16x16 tile usually spans only a few rows, so the coverage code runs per
+// half-tile (8 rows x 16 px = all 64 lanes x 2 px) and a half none of whose rows the segment crosses
+// is skipped with one uniform branch -- the WGSL's (4 px x 16 rows) mapping keeps most lanes idle.
+// Per-pixel arithmetic is exactly the WGSL's: a pixel in column X belongs to the WGSL invocation
+// lx = X >> 2 with i = X & 3, so x offsets are formed as (p.x - 4*lx) - i, etc.
 template <bool CLIPS>
 __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ cfg, const float* __restrict__ segments, uint32_t segments_n,
                                                   const uint32_t* __restrict__ ptcl, uint32_t ptcl_n, const uint32_t* __restrict__ info,
@@ -196,20 +203,24 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
     __shared__ uint32_t win[JL_PTCL_INCREMENT];  // wave-private PTCL window
     if (ptcl_n == 0u || ptcl[0] == ~0u) return;  // fine.wgsl:889-893
     const uint32_t lane = threadIdx.x;
-    const uint32_t lx = lane & 3u, ly = lane >> 2;
+    const uint32_t pr = lane >> 3, pc = lane & 7u;
     const uint32_t tile_ix = blockIdx.y * cfg->width_in_tiles + blockIdx.x;
-    const uint32_t gx = blockIdx.x * 4u + lx, gy = blockIdx.y * 16u + ly;
-    const float xyx = (float)(gx * 4u), xyy = (float)gy;
-    const float lxyx = (float)(lx * 4u), lxyy = (float)ly;
+    // per-pixel constants (k = 0..3)
+    const uint32_t X0 = 2u * pc;                       // column of k = 0,2; k = 1,3 are X0 + 1
+    const float lxb = (float)((X0 >> 2) * 4u);         // WGSL local_xy.x of the owning invocation
+    const float i0_f = (float)(X0 & 3u);               // WGSL i of the left pixel (0 or 2); right pixel is i0 + 1
+    const float xyx = (float)((blockIdx.x * 4u + (X0 >> 2)) * 4u);  // WGSL xy.x = f32(global_id.x * 4)
+    const float lrow[2] = {(float)pr, (float)(pr + 8u)};            // WGSL local_xy.y per half
+    const float grow[2] = {(float)(blockIdx.y * 16u + pr), (float)(blockIdx.y * 16u + pr + 8u)};  // WGSL xy.y per half
     V4 rgba[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) rgba[i] = v4(cfg->base_color[0], cfg->base_color[1], cfg->base_color[2], cfg->base_color[3]);
+    for (int k = 0; k < 4; k++) rgba[k] = v4(cfg->base_color[0], cfg->base_color[1], cfg->base_color[2], cfg->base_color[3]);
     V4 bs0[4], bs1[4], bs2[4], bs3[4];  // blend_stack[0..3]
 #pragma unroll
-    for (int i = 0; i < 4; i++) { bs0[i] = v4(0, 0, 0, 0); bs1[i] = bs0[i]; bs2[i] = bs0[i]; bs3[i] = bs0[i]; }
+    for (int k = 0; k < 4; k++) { bs0[k] = v4(0, 0, 0, 0); bs1[k] = bs0[k]; bs2[k] = bs0[k]; bs3[k] = bs0[k]; }
     uint32_t clip_depth = 0u;
     float area[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    // PTCL window: words [win_base, win_base + win_len) of the global stream live in `win`
+    // PTCL window: words [win_base, win_base + 256) of the global stream live in `win`
     uint32_t win_base = tile_ix * JL_PTCL_INITIAL_ALLOC;
     {
         uint32_t gi = win_base + lane;
@@ -228,6 +239,9 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
         return v4(f16_to_f32((uint16_t)(raw.x & 0xffffu)), f16_to_f32((uint16_t)(raw.x >> 16)), f16_to_f32((uint16_t)(raw.y & 0xffffu)),
                   f16_to_f32((uint16_t)(raw.y >> 16)));
     };
+    // pixel k: WGSL i (as float) and spill index inside the tile
+    auto pix_i = [&](int k) -> float { return i0_f + (float)(k & 1); };
+    auto pix_spill = [&](int k) -> uint32_t { return (pr + 8u * (uint32_t)(k >> 1)) * JL_TILE_WIDTH + X0 + (uint32_t)(k & 1); };
     // segment windows
     SegWin cur, nxt;
     cur.p0x = cur.p0y = cur.p1x = cur.p1y = cur.ye = cur.recip = cur.sgn = 0.0f;
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             bool even_odd = (size_and_rule & 1u) != 0u;
             float backdrop_f = (float)backdrop;
 #pragma unroll
-            for (int i = 0; i < 4; i++) area[i] = backdrop_f;
+            for (int k = 0; k < 4; k++) area[k] = backdrop_f;
             for (uint32_t s = 0; s < n_segs; s++) {
                 uint32_t so = seg_data + s;
                 uint32_t rel = so - cur_base;
@@ -263,76 +277,81 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                 float p0x = bcast(cur.p0x, rel), p0y = bcast(cur.p0y, rel), p1x = bcast(cur.p1x, rel), p1y = bcast(cur.p1y, rel);
                 float y_edge_v = bcast(cur.ye, rel);
                 float vec_y_recip = bcast(cur.recip, rel), sgn_dlx = bcast(cur.sgn, rel);
-                float y = p0y - lxyy;
                 float dlx = p1x - p0x, dly = p1y - p0y;
-                float y0 = clamp_(y, 0.0f, 1.0f);
-                float y1 = clamp_(y + dly, 0.0f, 1.0f);
-                float dy = y0 - y1;
-                if (dy != 0.0f) {
-                    float t0 = (y0 - y) * vec_y_recip;
-                    float t1 = (y1 - y) * vec_y_recip;
-                    float startx = p0x - lxyx;
-                    float x0 = startx + t0 * dlx;
-                    float x1 = startx + t1 * dlx;
-                    float xmin0 = fmin_(x0, x1);
-                    float xmax0 = fmax_(x0, x1);
+                float startx = p0x - lxb;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        float i_f = (float)i;
-                        float xmin = fmin_(xmin0 - i_f, 1.0f) - 1.0e-6f;
-                        float xmax = xmax0 - i_f;
-                        float b = fmin_(xmax, 1.0f);
-                        float c = fmax_(b, 0.0f);
-                        float d = fmax_(xmin, 0.0f);
-                        float a = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
-                        area[i] += a * dy;
+                for (int h = 0; h < 2; h++) {
+                    float y = p0y - lrow[h];
+                    float y0 = clamp_(y, 0.0f, 1.0f);
+                    float y1 = clamp_(y + dly, 0.0f, 1.0f);
+                    float dy = y0 - y1;
+                    if (dy != 0.0f) {
+                        float t0 = (y0 - y) * vec_y_recip;
+                        float t1 = (y1 - y) * vec_y_recip;
+                        float x0 = startx + t0 * dlx;
+                        float x1 = startx + t1 * dlx;
+                        float xmin0 = fmin_(x0, x1);
+                        float xmax0 = fmax_(x0, x1);
+#pragma unroll
+                        for (int e = 0; e < 2; e++) {
+                            float i_f = i0_f + (float)e;
+                            float xmin = fmin_(xmin0 - i_f, 1.0f) - 1.0e-6f;
+                            float xmax = xmax0 - i_f;
+                            float b = fmin_(xmax, 1.0f);
+                            float c = fmax_(b, 0.0f);
+                            float d = fmax_(xmin, 0.0f);
+                            float a = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
+                            area[2 * h + e] += a * dy;
+                        }
                     }
                 }
                 // y_edge >= 16 (path_tiling's "no edge" value is 1e9) clamps to 0 for every row of the tile: the term
                 // would add +-0, which cannot change a sum that started from +0 -- skip it (uniform branch).
                 if (y_edge_v < 16.0f) {
-                    float y_edge = sgn_dlx * clamp_(lxyy - y_edge_v + 1.0f, 0.0f, 1.0f);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) area[i] += y_edge;
+                    for (int h = 0; h < 2; h++) {
+                        float y_edge = sgn_dlx * clamp_(lrow[h] - y_edge_v + 1.0f, 0.0f, 1.0f);
+                        area[2 * h] += y_edge;
+                        area[2 * h + 1] += y_edge;
+                    }
                 }
             }
             if (even_odd) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) { float a = area[i]; area[i] = abs_(a - 2.0f * round_(0.5f * a)); }
+                for (int k = 0; k < 4; k++) { float a = area[k]; area[k] = abs_(a - 2.0f * round_(0.5f * a)); }
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; i++) area[i] = fmin_(abs_(area[i]), 1.0f);
+                for (int k = 0; k < 4; k++) area[k] = fmin_(abs_(area[k]), 1.0f);
             }
             cmd_ix += 4u;
         } else if (tag == JL_CMD_SOLID) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) area[i] = 1.0f;
+            for (int k = 0; k < 4; k++) area[k] = 1.0f;
             cmd_ix += 1u;
         } else if (tag == JL_CMD_COLOR) {
             V4 fg = v4(u2f(P(cmd_ix + 1u)), u2f(P(cmd_ix + 2u)), u2f(P(cmd_ix + 3u)), u2f(P(cmd_ix + 4u)));
 #pragma unroll
-            for (int i = 0; i < 4; i++) rgba[i] = over(rgba[i], fg, area[i]);
+            for (int k = 0; k < 4; k++) rgba[k] = over(rgba[k], fg, area[k]);
             cmd_ix += 5u;
         } else if (CLIPS && tag == JL_CMD_BEGIN_CLIP) {
             if (clip_depth < JL_BLEND_STACK_SPLIT) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int k = 0; k < 4; k++) {
                     switch (clip_depth) {
-                        case 0: bs0[i] = rgba[i]; break;
-                        case 1: bs1[i] = rgba[i]; break;
-                        case 2: bs2[i] = rgba[i]; break;
-                        default: bs3[i] = rgba[i]; break;
+                        case 0: bs0[k] = rgba[k]; break;
+                        case 1: bs1[k] = rgba[k]; break;
+                        case 2: bs2[k] = rgba[k]; break;
+                        default: bs3[k] = rgba[k]; break;
                     }
-                    rgba[i] = v4(0, 0, 0, 0);
+                    rgba[k] = v4(0, 0, 0, 0);
                 }
             } else {
                 uint32_t blend_in_scratch = clip_depth - JL_BLEND_STACK_SPLIT;
-                uint32_t local_tile_ix = lx * 4u + ly * JL_TILE_WIDTH;
-                uint32_t local_blend_start = blend_offset + blend_in_scratch * JL_TILE_WIDTH * JL_TILE_HEIGHT + local_tile_ix;
+                uint32_t spill_base = blend_offset + blend_in_scratch * JL_TILE_WIDTH * JL_TILE_HEIGHT;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    blend_spill.wr(local_blend_start + i, rgba[i]);
-                    rgba[i] = v4(0, 0, 0, 0);
+                for (int k = 0; k < 4; k++) {
+                    blend_spill.wr(spill_base + pix_spill(k), rgba[k]);
+                    rgba[k] = v4(0, 0, 0, 0);
                 }
             }
             clip_depth += 1u;
@@ -342,23 +361,22 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             float alpha = u2f(P(cmd_ix + 2u));
             clip_depth -= 1u;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int k = 0; k < 4; k++) {
                 V4 bg;
                 if (clip_depth < JL_BLEND_STACK_SPLIT) {
                     switch (clip_depth) {
-                        case 0: bg = bs0[i]; break;
-                        case 1: bg = bs1[i]; break;
-                        case 2: bg = bs2[i]; break;
-                        default: bg = bs3[i]; break;
+                        case 0: bg = bs0[k]; break;
+                        case 1: bg = bs1[k]; break;
+                        case 2: bg = bs2[k]; break;
+                        default: bg = bs3[k]; break;
                     }
                 } else {
                     uint32_t blend_in_scratch = clip_depth - JL_BLEND_STACK_SPLIT;
-                    uint32_t local_tile_ix = lx * 4u + ly * JL_TILE_WIDTH;
-                    uint32_t local_blend_start = blend_offset + blend_in_scratch * JL_TILE_WIDTH * JL_TILE_HEIGHT + local_tile_ix;
-                    bg = blend_spill.rd(local_blend_start + i);
+                    uint32_t spill_base = blend_offset + blend_in_scratch * JL_TILE_WIDTH * JL_TILE_HEIGHT;
+                    bg = blend_spill.rd(spill_base + pix_spill(k));
                 }
-                V4 fg = v4(rgba[i].x * area[i] * alpha, rgba[i].y * area[i] * alpha, rgba[i].z * area[i] * alpha, rgba[i].w * area[i] * alpha);
-                rgba[i] = blend_mix_compose(bg, fg, blend);
+                V4 fg = v4(rgba[k].x * area[k] * alpha, rgba[k].y * area[k] * alpha, rgba[k].z * area[k] * alpha, rgba[k].w * area[k] * alpha);
+                rgba[k] = blend_mix_compose(bg, fg, blend);
             }
             cmd_ix += 3u;
         } else if (tag == JL_CMD_JUMP) {
@@ -384,12 +402,12 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
             uint32_t io = P(cmd_ix + 2u);
             float line_x = u2f(I(io)), line_y = u2f(I(io + 1u)), line_c = u2f(I(io + 2u));
-            float d = line_x * xyx + line_y * xyy + line_c;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float my_d = d + line_x * (float)i;
+            for (int k = 0; k < 4; k++) {
+                float d = line_x * xyx + line_y * grow[k >> 1] + line_c;
+                float my_d = d + line_x * pix_i(k);
                 int32_t x = to_i32(round_(extend_mode(my_d, ext) * 511.0f));
-                rgba[i] = over(rgba[i], load_grad(x, index), area[i]);
+                rgba[k] = over(rgba[k], load_grad(x, index), area[k]);
             }
             cmd_ix += 3u;
         } else if (tag == JL_CMD_RAD_GRAD) {
@@ -409,8 +427,8 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             float less_scale = (is_swapped || (1.0f - focal_x) < 0.0f) ? -1.0f : 1.0f;
             float t_sign = sign_(1.0f - focal_x);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float mx = xyx + (float)i, my = xyy;
+            for (int k = 0; k < 4; k++) {
+                float mx = xyx + pix_i(k), my = grow[k >> 1];
                 float x = m0 * mx + m2 * my + xl0;
                 float y = m1 * mx + m3 * my + xl1;
                 float xx = x * x, yy = y * y;
@@ -434,7 +452,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                     t = extend_mode(focal_x + t_sign * t, ext);
                     t = is_swapped ? (1.0f - t) : t;
                     int32_t gxi = to_i32(round_(t * 511.0f));
-                    rgba[i] = over(rgba[i], load_grad(gxi, index), area[i]);
+                    rgba[k] = over(rgba[k], load_grad(gxi, index), area[k]);
                 }
             }
             cmd_ix += 3u;
@@ -447,8 +465,8 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             float t0 = u2f(I(io + 6u)), t1 = u2f(I(io + 7u));
             float scale = 1.0f / (t1 - t0);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float mx = xyx + (float)i, my = xyy;
+            for (int k = 0; k < 4; k++) {
+                float mx = xyx + pix_i(k), my = grow[k >> 1];
                 float x = m0 * mx + m2 * my + xl0;
                 float y = m1 * mx + m3 * my + xl1;
                 float xabs = abs_(x), yabs = abs_(y);
@@ -463,7 +481,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                 phi = (phi - t0) * scale;
                 float t = extend_mode(phi, ext);
                 int32_t ramp_x = to_i32(round_(t * 511.0f));
-                rgba[i] = over(rgba[i], load_grad(ramp_x, index), area[i]);
+                rgba[k] = over(rgba[k], load_grad(ramp_x, index), area[k]);
             }
             cmd_ix += 3u;
         } else if (tag == JL_CMD_IMAGE) {
@@ -476,8 +494,8 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             const uint8_t* ipx = nullptr;
             uint32_t iw = 0, ih = 0;
 #pragma unroll
-            for (int k = 0; k < FINE_MAX_IMAGES; k++)
-                if ((uint32_t)k == index && k < images.n) { ipx = images.px[k]; iw = images.w[k]; ih = images.h[k]; }
+            for (int q = 0; q < FINE_MAX_IMAGES; q++)
+                if ((uint32_t)q == index && q < images.n) { ipx = images.px[q]; iw = images.w[q]; ih = images.h[q]; }
             auto texel = [&](int32_t tx, int32_t ty) -> V4 {
                 if (!ipx || tx < 0 || ty < 0 || (uint32_t)tx >= iw || (uint32_t)ty >= ih) return v4(0, 0, 0, 0);
                 uint32_t raw = *(const uint32_t*)(ipx + ((size_t)ty * iw + (size_t)tx) * 4);
@@ -486,11 +504,11 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                 return v4(r * a, g * a, b * a, a);  // premul_alpha, fine.wgsl:1105-1107
             };
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float mx = xyx + (float)i, my = xyy;
+            for (int k = 0; k < 4; k++) {
+                float mx = xyx + pix_i(k), my = grow[k >> 1];
                 float u = m0 * mx + m2 * my + xl0;
                 float v = m1 * mx + m3 * my + xl1;
-                if (u < ew && v < eh && area[i] != 0.0f) {
+                if (u < ew && v < eh && area[k] != 0.0f) {
                     float fu = floor_(u), fv = floor_(v), cu = ceil_(u), cv = ceil_(v);
                     float fru = fract_(u), frv = fract_(v);
                     V4 a = texel(to_i32(fu), to_i32(fv));
@@ -500,7 +518,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                     V4 ab = v4(mix_(a.x, bq.x, frv), mix_(a.y, bq.y, frv), mix_(a.z, bq.z, frv), mix_(a.w, bq.w, frv));
                     V4 cd = v4(mix_(cq.x, dq.x, frv), mix_(cq.y, dq.y, frv), mix_(cq.z, dq.z, frv), mix_(cq.w, dq.w, frv));
                     V4 fg = v4(mix_(ab.x, cd.x, fru), mix_(ab.y, cd.y, fru), mix_(ab.z, cd.z, fru), mix_(ab.w, cd.w, fru));
-                    rgba[i] = over(rgba[i], fg, area[i]);
+                    rgba[k] = over(rgba[k], fg, area[k]);
                 }
             }
             cmd_ix += 2u;
@@ -508,31 +526,27 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             break;  // unknown tag: the WGSL would never advance; stop instead of hanging the GPU
         }
     }
-    // fine.wgsl:1092-1102: un-premultiply, store RGBA16F
-    uint32_t cx0 = gx * 4u, cy = gy;
-    if (cy < out_h) {
-        uint32_t packed[8];
+    // fine.wgsl:1092-1102: un-premultiply, store RGBA16F (two adjacent pixels = 16 bytes per lane and half)
+    const uint32_t cx0 = blockIdx.x * 16u + X0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            V4 fg = rgba[i];
+    for (int h = 0; h < 2; h++) {
+        uint32_t cy = blockIdx.y * 16u + pr + 8u * (uint32_t)h;
+        if (cy >= out_h) continue;
+        uint32_t packed[4];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            V4 fg = rgba[2 * h + e];
             float a_inv = 1.0f / fmax_(fg.w, 1e-6f);
             uint32_t r = f32_to_f16(fg.x * a_inv), g = f32_to_f16(fg.y * a_inv), b = f32_to_f16(fg.z * a_inv), a = f32_to_f16(fg.w);
-            packed[i * 2] = r | (g << 16);
-            packed[i * 2 + 1] = b | (a << 16);
+            packed[e * 2] = r | (g << 16);
+            packed[e * 2 + 1] = b | (a << 16);
         }
         uint16_t* row = output + ((size_t)cy * out_w + cx0) * 4;
-        if (cx0 + 3u < out_w && ((out_w & 3u) == 0u)) {
-            uint4* dst = (uint4*)row;
-            dst[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
-            dst[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
+        if (cx0 + 1u < out_w && ((out_w & 1u) == 0u)) {
+            *(uint4*)row = make_uint4(packed[0], packed[1], packed[2], packed[3]);
         } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (cx0 + (uint32_t)i < out_w) {
-                    uint2* dst = (uint2*)(row + i * 4);
-                    *dst = make_uint2(packed[i * 2], packed[i * 2 + 1]);
-                }
-            }
+            if (cx0 < out_w) *(uint2*)row = make_uint2(packed[0], packed[1]);
+            if (cx0 + 1u < out_w) *(uint2*)(row + 4) = make_uint2(packed[2], packed[3]);
         }
     }
 }

@@ -720,50 +720,60 @@ JD Seg load_seg(const Scene& s, uint32_t ix) {
 // reserves the block's range, every lane writes its own slots.  (A per-lane atomicAdd on two hot
 // words costs ~3.7 ms for 1.2 M items on MI355X; this costs ~10 us.)  List order is irrelevant for the
 // result but this keeps it nearly sorted by tag, i.e. coalesced scene reads and line writes later on.
+#define FL_CLASSIFY_TAGS 4u  // tag bytes per thread: fewer workgroups => fewer atomics on the two hot list counters
 __global__ __launch_bounds__(JL_WG) void k_flatten_classify(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
                                                             Buf<JlPathBbox> path_bboxes, uint32_t* __restrict__ list,
-                                                            uint32_t* __restrict__ counters, uint32_t cap) {
-    uint32_t ix = blockIdx.x * JL_WG + threadIdx.x;
-    Scene s;
-    s.cfg = cfg; s.scene = scene; s.tag_monoids = tag_monoids;
-    Seg g = load_seg(s, ix);
-    uint32_t path_ix = g.tag.monoid.v[4];
-    if ((g.tag.tag_byte & JL_PATH_TAG_PATH) != 0u && path_bboxes.ok(path_ix)) {  // flatten.wgsl:825-828
-        path_bboxes.p[path_ix].draw_flags = ((g.style_flags & JL_STYLE_FLAGS_FILL) == 0u) ? 0u : 1u;
-        path_bboxes.p[path_ix].trans_ix = g.tag.monoid.v[0];
-    }
-    uint32_t seg_type = g.tag.tag_byte & JL_PATH_TAG_SEG_TYPE;
-    bool curved = seg_type != JL_PATH_TAG_LINETO;
-    // items of this tag byte: heavy subs first (0..nh-1), then light subs
-    uint32_t nh = 0u, nl = 0u;
-    if (seg_type != 0u) {
-        if (!g.is_stroke) {
-            if (curved) nh = 1u; else nl = 1u;
-        } else if ((g.tag.tag_byte & JL_PATH_TAG_SUBPATH_END) != 0u) {
-            if (curved) nl = 1u;  // open path: start cap (closed: nothing)
-        } else {
-            if (curved) { nh = 2u; nl = 1u; } else { nl = 3u; }
-        }
-    }
+                                                            uint32_t* __restrict__ counters, uint32_t cap, uint32_t n_tags) {
     __shared__ uint32_t sh[12];
     __shared__ uint32_t sh_base[2];
+    Scene s;
+    s.cfg = cfg; s.scene = scene; s.tag_monoids = tag_monoids;
+    uint32_t ix0 = (blockIdx.x * JL_WG + threadIdx.x) * FL_CLASSIFY_TAGS;
+    uint32_t nh[FL_CLASSIFY_TAGS], nl[FL_CLASSIFY_TAGS];
+    uint32_t th = 0u, tl = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < FL_CLASSIFY_TAGS; k++) {
+        uint32_t ix = ix0 + k;
+        nh[k] = 0u; nl[k] = 0u;
+        if (ix >= n_tags) continue;
+        Seg g = load_seg(s, ix);
+        uint32_t path_ix = g.tag.monoid.v[4];
+        if ((g.tag.tag_byte & JL_PATH_TAG_PATH) != 0u && path_bboxes.ok(path_ix)) {  // flatten.wgsl:825-828
+            path_bboxes.p[path_ix].draw_flags = ((g.style_flags & JL_STYLE_FLAGS_FILL) == 0u) ? 0u : 1u;
+            path_bboxes.p[path_ix].trans_ix = g.tag.monoid.v[0];
+        }
+        uint32_t seg_type = g.tag.tag_byte & JL_PATH_TAG_SEG_TYPE;
+        bool curved = seg_type != JL_PATH_TAG_LINETO;
+        // items of this tag byte: heavy subs first (0..nh-1), then light subs
+        if (seg_type != 0u) {
+            if (!g.is_stroke) {
+                if (curved) nh[k] = 1u; else nl[k] = 1u;
+            } else if ((g.tag.tag_byte & JL_PATH_TAG_SUBPATH_END) != 0u) {
+                if (curved) nl[k] = 1u;  // open path: start cap (closed: nothing)
+            } else {
+                if (curved) { nh[k] = 2u; nl[k] = 1u; } else { nl[k] = 3u; }
+            }
+        }
+        th += nh[k];
+        tl += nl[k];
+    }
     MonoidK<2> m, tot;
-    m.v[0] = nh; m.v[1] = nl;
+    m.v[0] = th; m.v[1] = tl;
     MonoidK<2> ex = block_excl_scan_monoid<2>(m, sh, &tot);
-    if (threadIdx.x == 0) {  // one atomic pair per 256 tag bytes (a hot word sustains only ~88 atomics/us)
+    if (threadIdx.x == 0) {  // one atomic pair per workgroup (a hot word sustains only ~88 atomics/us)
         sh_base[0] = tot.v[0] ? atomicAdd(&counters[0], tot.v[0]) : 0u;
         sh_base[1] = tot.v[1] ? atomicAdd(&counters[1], tot.v[1]) : 0u;
     }
     __syncthreads();
     uint32_t ph = sh_base[0] + ex.v[0], pl = sh_base[1] + ex.v[1];
-    uint32_t sub = 0u;
-    for (uint32_t k = 0; k < nh; k++, sub++) {
-        uint32_t pos = ph + k;
-        if (pos < cap) list[pos] = ix * 3u + sub;
-    }
-    for (uint32_t k = 0; k < nl; k++, sub++) {
-        uint32_t pos = pl + k;
-        if (pos < cap) list[cap - 1u - pos] = ix * 3u + sub;
+#pragma unroll
+    for (uint32_t k = 0; k < FL_CLASSIFY_TAGS; k++) {
+        uint32_t ix = ix0 + k;
+        uint32_t sub = 0u;
+        for (uint32_t q = 0; q < nh[k]; q++, sub++, ph++)
+            if (ph < cap) list[ph] = ix * 3u + sub;
+        for (uint32_t q = 0; q < nl[k]; q++, sub++, pl++)
+            if (pl < cap) list[cap - 1u - pl] = ix * 3u + sub;
     }
 }
 
@@ -937,7 +947,8 @@ int jh_launch_flatten(const JhLaunch& L) {
     if (!counts || !bases || !list || !counters || !tlines || !tkeys) return -5;
     (void)hipMemsetAsync(counters, 0, 16, L.stream);
     (void)hipMemsetAsync(counts, 0, (size_t)n_slots * 4, L.stream);
-    hipLaunchKernelGGL(k_flatten_classify, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list, counters, n_slots);
+    hipLaunchKernelGGL(k_flatten_classify, dim3((L.gx + FL_CLASSIFY_TAGS - 1) / FL_CLASSIFY_TAGS), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list,
+                       counters, n_slots, n_tags);
     hipLaunchKernelGGL(k_flatten_items, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, (const uint32_t*)list, counters, n_slots, counts,
                        tlines, tkeys, tcap, FL_CHUNK);
     int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);

@@ -96,6 +96,87 @@ int jh_scan_u32(const JhLaunch& L, const uint32_t* in, uint32_t in_stride, uint3
     return 0;
 }
 
+// Three independent exclusive scans over arrays laid out back to back (in[c*n + i]) in one set of launches:
+// blockIdx.y selects the channel.  Used by coarse (segments / PTCL words / blend pixels per tile).
+__global__ __launch_bounds__(JL_WG) void k_scan3_block_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t n_blocks,
+                                                            uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t sh[8];
+    const uint32_t* src = in + (size_t)blockIdx.y * n;
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        uint32_t ix = base + i;
+        if (ix < n) s += src[ix];
+    }
+    MonoidK<1> m;
+    m.v[0] = s;
+    MonoidK<1> t = block_reduce_monoid<1>(m, sh);
+    if (threadIdx.x == 0) block_sums[blockIdx.y * n_blocks + blockIdx.x] = t.v[0];
+}
+__global__ __launch_bounds__(1024) void k_scan3_block_prefix(uint32_t* __restrict__ block_sums, uint32_t n_blocks, uint32_t* __restrict__ t0,
+                                                             uint32_t* __restrict__ t1, uint32_t* __restrict__ t2) {
+    __shared__ uint32_t sh[16];
+    __shared__ uint32_t carry_sh;
+    uint32_t* bs = block_sums + (size_t)blockIdx.x * n_blocks;
+    uint32_t* total_dev = blockIdx.x == 0 ? t0 : (blockIdx.x == 1 ? t1 : t2);
+    if (threadIdx.x == 0) carry_sh = 0;
+    __syncthreads();
+    for (uint32_t start = 0; start < n_blocks; start += 1024) {
+        uint32_t ix = start + threadIdx.x;
+        uint32_t v = ix < n_blocks ? bs[ix] : 0u;
+        uint32_t incl = wave_incl_scan_u32(v);
+        uint32_t w = threadIdx.x >> 6;
+        if (lane_id() == 63u) sh[w] = incl;
+        __syncthreads();
+        uint32_t base = 0, tot = 0;
+        for (uint32_t j = 0; j < 16; j++) {
+            uint32_t s = sh[j];
+            if (j < w) base += s;
+            tot += s;
+        }
+        uint32_t carry = carry_sh;
+        if (ix < n_blocks) bs[ix] = carry + base + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_sh = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_dev) *total_dev = carry_sh;
+}
+__global__ __launch_bounds__(JL_WG) void k_scan3_apply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, uint32_t n_blocks,
+                                                       const uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t sh[8];
+    const uint32_t* src = in + (size_t)blockIdx.y * n;
+    uint32_t* dst = out + (size_t)blockIdx.y * n;
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        uint32_t ix = base + i;
+        v[i] = ix < n ? src[ix] : 0u;
+        s += v[i];
+    }
+    uint32_t tot;
+    uint32_t excl = block_excl_scan_u32(s, sh, &tot) + block_sums[blockIdx.y * n_blocks + blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        uint32_t ix = base + i;
+        if (ix < n) dst[ix] = excl;
+        excl += v[i];
+    }
+}
+int jh_scan3_u32(const JhLaunch& L, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total0, uint32_t* total1, uint32_t* total2) {
+    uint32_t n_blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (n_blocks == 0) n_blocks = 1;
+    uint32_t* block_sums = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_SCAN_TMP, (uint64_t)n_blocks * 12);
+    if (!block_sums) return -5;
+    hipLaunchKernelGGL(k_scan3_block_sums, dim3(n_blocks, 3), dim3(JL_WG), 0, L.stream, in, n, n_blocks, block_sums);
+    hipLaunchKernelGGL(k_scan3_block_prefix, dim3(3), dim3(1024), 0, L.stream, block_sums, n_blocks, total0, total1, total2);
+    hipLaunchKernelGGL(k_scan3_apply, dim3(n_blocks, 3), dim3(JL_WG), 0, L.stream, in, out, n, n_blocks, (const uint32_t*)block_sums);
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // pathtag (K1-K4)
 // ------------------------------------------------------------------------------------------------

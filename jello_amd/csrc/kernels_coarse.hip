@@ -89,6 +89,12 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     __shared__ uint32_t sh_tile_x0y0[JL_WG];
     __shared__ uint32_t sh_tile_count[JL_WG];
     __shared__ uint32_t sh_tile_base[JL_WG];
+    // per-batch draw object data staged once by the draw's own thread, so that the per-(draw,tile) include test and the
+    // serial per-tile command walk read LDS instead of chasing scene / draw_monoid / info pointers through HBM
+    __shared__ uint32_t sh_tag[JL_WG];
+    __shared__ uint32_t sh_di[JL_WG];
+    __shared__ uint32_t sh_flags[JL_WG];
+    __shared__ uint32_t sh_pay[4][JL_WG];  // scene[dd .. dd+3]: colour / ramp index / blend+alpha
     __shared__ uint32_t sh_scan[8];
 
     const uint32_t lid = threadIdx.x;
@@ -173,8 +179,17 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             tag = scene.rd(cfg->layout.drawtag_base + drawobj_ix);
         }
         uint32_t tile_count = 0u;
+        sh_tag[lid] = tag;
         if (tag != JL_DRAWTAG_NOP) {
-            uint32_t path_ix = draw_monoids.rd(drawobj_ix).path_ix;
+            JlDrawMonoid dm0 = draw_monoids.rd(drawobj_ix);
+            uint32_t path_ix = dm0.path_ix;
+            uint32_t dd0 = cfg->layout.drawdata_base + dm0.scene_offset;
+            sh_di[lid] = dm0.info_offset;
+            sh_flags[lid] = info_bin_data.rd(dm0.info_offset);
+            sh_pay[0][lid] = scene.rd(dd0);
+            sh_pay[1][lid] = scene.rd(dd0 + 1u);
+            sh_pay[2][lid] = scene.rd(dd0 + 2u);
+            sh_pay[3][lid] = scene.rd(dd0 + 3u);
             JlPath path = paths.rd(path_ix);
             uint32_t stride = path.bbox[2] - path.bbox[0];
             sh_tile_stride[lid] = stride;
@@ -199,8 +214,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                 uint32_t probe = el_ix + (128u >> i);
                 if (ix >= sh_tile_count[probe - 1u]) el_ix = probe;
             }
-            uint32_t d_ix = sh_drawobj_ix[el_ix];
-            uint32_t d_tag = scene.rd(cfg->layout.drawtag_base + d_ix);
+            uint32_t d_tag = sh_tag[el_ix];
             uint32_t seq_ix = ix - (el_ix > 0u ? sh_tile_count[el_ix - 1u] : 0u);
             uint32_t width = sh_tile_width[el_ix];
             uint32_t x0y0 = sh_tile_x0y0[el_ix];
@@ -210,12 +224,11 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             JlTile tile = tiles.rd(tile_ix);
             bool is_clip = (d_tag & 1u) != 0u;
             bool is_blend = false;
-            JlDrawMonoid dm = draw_monoids.rd(d_ix);
             if (is_clip) {
-                uint32_t blend = scene.rd(cfg->layout.drawdata_base + dm.scene_offset);
+                uint32_t blend = sh_pay[0][el_ix];
                 is_blend = blend != BLEND_CLIP;
             }
-            uint32_t draw_flags = info_bin_data.rd(dm.info_offset);
+            uint32_t draw_flags = sh_flags[el_ix];
             bool even_odd = (draw_flags & 1u) != 0u;
             uint32_t n_segs = tile.segment_count_or_ix;
             int32_t bd = tile.backdrop;
@@ -240,13 +253,10 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                 if (bitmap == 0u) continue;
             }
             uint32_t el_ix = slice_ix * 32u + (uint32_t)__builtin_ctz(bitmap);
-            uint32_t d_ix = sh_drawobj_ix[el_ix];
             bitmap &= bitmap - 1u;
-            uint32_t drawtag = scene.rd(cfg->layout.drawtag_base + d_ix);
-            JlDrawMonoid dm = draw_monoids.rd(d_ix);
-            uint32_t dd = cfg->layout.drawdata_base + dm.scene_offset;
-            uint32_t di = dm.info_offset;
-            uint32_t draw_flags = info_bin_data.rd(di);
+            uint32_t drawtag = sh_tag[el_ix];
+            uint32_t di = sh_di[el_ix];
+            uint32_t draw_flags = sh_flags[el_ix];
             if (clip_zero_depth == 0u) {
                 uint32_t tile_ix = sh_tile_base[el_ix] + sh_tile_stride[el_ix] * tile_y + tile_x;
                 JlTile tile = tiles.rd(tile_ix);
@@ -256,10 +266,10 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                         alloc_cmd<WRITE>(c, 5u);
                         if (WRITE) {
                             c.ptcl.wr(c.cmd_offset, JL_CMD_COLOR);
-                            c.ptcl.wr(c.cmd_offset + 1u, scene.rd(dd));
-                            c.ptcl.wr(c.cmd_offset + 2u, scene.rd(dd + 1u));
-                            c.ptcl.wr(c.cmd_offset + 3u, scene.rd(dd + 2u));
-                            c.ptcl.wr(c.cmd_offset + 4u, scene.rd(dd + 3u));
+                            c.ptcl.wr(c.cmd_offset + 1u, sh_pay[0][el_ix]);
+                            c.ptcl.wr(c.cmd_offset + 2u, sh_pay[1][el_ix]);
+                            c.ptcl.wr(c.cmd_offset + 3u, sh_pay[2][el_ix]);
+                            c.ptcl.wr(c.cmd_offset + 4u, sh_pay[3][el_ix]);
                         }
                         c.cmd_offset += 5u;
                         break;
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                             uint32_t ty = drawtag == JL_DRAWTAG_FILL_LIN_GRADIENT ? JL_CMD_LIN_GRAD
                                           : (drawtag == JL_DRAWTAG_FILL_RAD_GRADIENT ? JL_CMD_RAD_GRAD : JL_CMD_SWEEP_GRAD);
                             c.ptcl.wr(c.cmd_offset, ty);
-                            c.ptcl.wr(c.cmd_offset + 1u, scene.rd(dd));
+                            c.ptcl.wr(c.cmd_offset + 1u, sh_pay[0][el_ix]);
                             c.ptcl.wr(c.cmd_offset + 2u, di + 1u);
                         }
                         c.cmd_offset += 3u;
@@ -308,8 +318,8 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                         alloc_cmd<WRITE>(c, 3u);
                         if (WRITE) {
                             c.ptcl.wr(c.cmd_offset, JL_CMD_END_CLIP);
-                            c.ptcl.wr(c.cmd_offset + 1u, scene.rd(dd));
-                            c.ptcl.wr(c.cmd_offset + 2u, scene.rd(dd + 1u));
+                            c.ptcl.wr(c.cmd_offset + 1u, sh_pay[0][el_ix]);
+                            c.ptcl.wr(c.cmd_offset + 2u, sh_pay[1][el_ix]);
                         }
                         c.cmd_offset += 3u;
                         render_blend_depth -= 1u;

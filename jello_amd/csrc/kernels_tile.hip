@@ -321,72 +321,60 @@ JD LineSetup line_setup(const JlLineSoup& line, const Buf<JlPath>& paths) {
     return r;
 }
 
-// pass 1 (one thread per line): crossings per line; also the backdrop bumps of the part of the line that lies
-// left of the path's bbox (path_count.wgsl:167-171; integer atomics, order-free).
+// pass 1: crossings per line
 __global__ __launch_bounds__(JL_WG) void k_pc_count(const JlBump* __restrict__ bump, const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines,
-                                                    Buf<JlPath> paths, Buf<JlTile> tile, uint32_t* __restrict__ counts, uint32_t counts_n) {
+                                                    Buf<JlPath> paths, uint32_t* __restrict__ counts, uint32_t counts_n) {
     uint32_t n_lines = umin_(bump->lines, counts_n);
     uint32_t n_threads = umin_(ind->x * JL_WG, counts_n);
     for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
         uint32_t c = 0u;
         if (gid < n_threads && lines.ok(gid)) {
             LineSetup s = line_setup(lines.p[gid], paths);
-            if (s.valid) {
-                c = s.imax - s.imin;
-                for (int32_t y = s.ymin; y < s.ymax; y++) {
-                    uint32_t base = (uint32_t)((int32_t)s.tiles + (y - s.bbox[1]) * s.stride);
-                    if (tile.ok(base)) atomicAdd(&tile.p[base].backdrop, s.delta);
-                }
-            }
+            if (s.valid) c = s.imax - s.imin;
         }
         counts[gid] = c;
     }
 }
-// pass 2 (one thread per CROSSING, so loads/stores are coalesced and lanes are balanced): the owning line is
-// found by binary search in the scanned per-line bases; the DDA state of crossing i is recomputed from the line
-// (z_{i-1} = floor(a*(i-1)+b) is exactly the WGSL's running last_z).  Per-tile counts by atomics (a sum);
-// SegmentCount records get their slice rank from k_pc_rank.
+// pass 2: backdrops, per-tile counts, SegmentCount records (slice rank filled by k_pc_rank)
 __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump,
                                                    const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines, Buf<JlPath> paths, Buf<JlTile> tile,
                                                    Buf<JlSegmentCount> seg_counts, const uint32_t* __restrict__ seg_bases, uint32_t bases_n,
                                                    uint2* __restrict__ tile_of, uint32_t tile_of_n) {
     uint32_t n_lines = umin_(umin_(bump->lines, bases_n), ind->x * JL_WG);
-    uint32_t n_seg = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), tile_of_n);
-    if (n_lines == 0u) return;
-    for (uint32_t k = blockIdx.x * JL_WG + threadIdx.x; k < n_seg; k += gridDim.x * JL_WG) {
-        // largest line with seg_bases[line] <= k (lines without crossings share their successor's base and are skipped)
-        uint32_t lo = 0u, hi = n_lines;  // invariant: seg_bases[lo] <= k, answer in [lo, hi)
-        while (hi - lo > 1u) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (seg_bases[mid] <= k) lo = mid; else hi = mid;
-        }
-        uint32_t gid = lo;
+    for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
         if (!lines.ok(gid)) continue;
         LineSetup s = line_setup(lines.p[gid], paths);
         if (!s.valid) continue;
-        uint32_t i = s.imin + (k - seg_bases[gid]);
-        if (i >= s.imax) continue;
-        float last_z = floor_(s.a * ((float)i - 1.0f) + s.b);
-        float zf = s.a * (float)i + s.b;
-        float z = floor_(zf);
-        int32_t y = to_i32(s.y0 + (float)i - z);
-        int32_t x = to_i32(s.x0 + s.x_sign * z);
-        int32_t base = (int32_t)s.tiles + (y - s.bbox[1]) * s.stride - s.bbox[0];
-        bool top_edge = (i == 0u) ? (s.y0 == s.s0y) : (last_z == z);
-        if (top_edge && x + 1 < s.bbox[2]) {
-            int32_t x_bump = imax_(x + 1, s.bbox[0]);
-            uint32_t t = (uint32_t)(base + x_bump);
-            if (tile.ok(t)) atomicAdd(&tile.p[t].backdrop, s.delta);
+        for (int32_t y = s.ymin; y < s.ymax; y++) {
+            uint32_t base = (uint32_t)((int32_t)s.tiles + (y - s.bbox[1]) * s.stride);
+            if (tile.ok(base)) atomicAdd(&tile.p[base].backdrop, s.delta);
         }
-        uint32_t t = (uint32_t)(base + x);
-        uint32_t arrival = 0u;  // order-dependent, only used as a unique slot inside the tile's temporary list
-        if (tile.ok(t)) arrival = atomicAdd(&tile.p[t].segment_count_or_ix, 1u);
-        if (seg_counts.ok(k)) {
-            JlSegmentCount sc;
-            sc.line_ix = gid;
-            sc.counts = i;  // low 16 bits; the slice rank is OR-ed in by k_pc_rank
-            seg_counts.p[k] = sc;
-            tile_of[k] = make_uint2(t, arrival);
+        float last_z = floor_(s.a * ((float)s.imin - 1.0f) + s.b);
+        uint32_t seg_base = seg_bases[gid];
+        for (uint32_t i = s.imin; i < s.imax; i++) {
+            float zf = s.a * (float)i + s.b;
+            float z = floor_(zf);
+            int32_t y = to_i32(s.y0 + (float)i - z);
+            int32_t x = to_i32(s.x0 + s.x_sign * z);
+            int32_t base = (int32_t)s.tiles + (y - s.bbox[1]) * s.stride - s.bbox[0];
+            bool top_edge = (i == 0u) ? (s.y0 == s.s0y) : (last_z == z);
+            if (top_edge && x + 1 < s.bbox[2]) {
+                int32_t x_bump = imax_(x + 1, s.bbox[0]);
+                uint32_t t = (uint32_t)(base + x_bump);
+                if (tile.ok(t)) atomicAdd(&tile.p[t].backdrop, s.delta);
+            }
+            uint32_t t = (uint32_t)(base + x);
+            uint32_t arrival = 0u;  // order-dependent, only used as a unique slot inside the tile's temporary list
+            if (tile.ok(t)) arrival = atomicAdd(&tile.p[t].segment_count_or_ix, 1u);
+            uint32_t seg_ix = seg_base + i - s.imin;
+            if (seg_ix < cfg->seg_counts_size && seg_counts.ok(seg_ix)) {
+                JlSegmentCount sc;
+                sc.line_ix = gid;
+                sc.counts = i;  // low 16 bits; the slice rank is OR-ed in by k_pc_rank
+                seg_counts.p[seg_ix] = sc;
+                if (seg_ix < tile_of_n) tile_of[seg_ix] = make_uint2(t, arrival);
+            }
+            last_z = z;
         }
     }
 }
@@ -662,10 +650,10 @@ int jh_launch_path_count(const JhLaunch& L) {
     uint32_t* list_base = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_E, (uint64_t)tiles_cap * 4);
     if (!counts || !bases || !tile_of || !list || !list_base) return -5;
     uint32_t gl = stride_grid(L, lines_cap), gs = stride_grid(L, seg_cap);
-    hipLaunchKernelGGL(k_pc_count, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, paths, tile, counts, lines_cap);
+    hipLaunchKernelGGL(k_pc_count, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, paths, counts, lines_cap);
     int rc = jh_scan_u32(L, counts, 1, bases, lines_cap, &bump->lines, &bump->seg_counts);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_pc_emit, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, ind, lines, paths, tile, segc,
+    hipLaunchKernelGGL(k_pc_emit, dim3(gl), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, ind, lines, paths, tile, segc,
                        (const uint32_t*)bases, lines_cap, tile_of, seg_cap);
     // per-tile list bases: exclusive scan of Tile.segment_count_or_ix over the allocated tiles
     rc = jh_scan_u32(L, ((const uint32_t*)tile.p) + 1, 2, list_base, tiles_cap, &bump->tile, nullptr);

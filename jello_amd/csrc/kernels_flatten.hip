@@ -843,7 +843,13 @@ JD void run_item(const JlConfig* cfg, const Scene& s, Out<EMIT>& o, uint32_t slo
     }
 }
 
-__global__ __launch_bounds__(JL_WG) void k_flatten_items(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
+#ifndef FL_WAVES_PER_EU
+#define FL_WAVES_PER_EU 3
+#endif
+#ifndef FL_BLOCKS_PER_CU
+#define FL_BLOCKS_PER_CU 3
+#endif
+__global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_PER_EU, FL_WAVES_PER_EU))) void k_flatten_items(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
                                                          Buf<JlPathBbox> path_bboxes, const uint32_t* __restrict__ list,
                                                          uint32_t* __restrict__ counters, uint32_t cap, uint32_t* __restrict__ counts,
                                                          JlLineSoup* __restrict__ tlines, uint2* __restrict__ tkeys, uint32_t tcap,
@@ -929,7 +935,7 @@ int jh_launch_flatten(const JhLaunch& L) {
     auto pb = mkbuf<JlPathBbox>(L.b[3].ptr, L.b[3].size);
     JlBump* bump = (JlBump*)L.b[4].ptr;
     auto lines = mkbuf<JlLineSoup>(L.b[5].ptr, L.b[5].size);
-    uint32_t cap_blocks = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * 4u;
+    uint32_t cap_blocks = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * FL_BLOCKS_PER_CU;
     uint32_t g = (n_slots + JL_WG - 1) / JL_WG;
     if (g > cap_blocks) g = cap_blocks;
     // temp line slots a workgroup reserves up front: its fair share of the line capacity + 25 %
@@ -954,7 +960,8 @@ int jh_launch_flatten(const JhLaunch& L) {
     int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);
     if (rc) return rc;
     uint32_t gp = (tcap + JL_WG - 1) / JL_WG;
-    if (gp > cap_blocks * 2u) gp = cap_blocks * 2u;
+    uint32_t gp_cap = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * 8u;
+    if (gp > gp_cap) gp = gp_cap;
     hipLaunchKernelGGL(k_flatten_permute, dim3(gp), dim3(JL_WG), 0, L.stream, cfg, (const uint32_t*)counters, (const JlLineSoup*)tlines,
                        (const uint2*)tkeys, tcap, (const uint32_t*)bases, n_slots, lines);
     return 0;

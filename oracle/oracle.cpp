@@ -458,6 +458,11 @@ static void output_two_lines_with_transform(Ctx& c, uint32_t path_ix, V2 p00, V2
 enum { ESPC_ROBUST_NORMAL = 0, ESPC_ROBUST_LOW_K1 = 1, ESPC_ROBUST_LOW_DIST = 2 };
 
 // flatten.wgsl:328-477
+// instrumentation only (tools/flatten_stats.py): [jobs, attempts, lines, pieces, histogram of attempts per job (28 bins)]
+static uint64_t g_flatten_stats[32];
+extern "C" void oracle_flatten_stats(uint64_t* out, int reset) {
+    for (int i = 0; i < 32; i++) { out[i] = g_flatten_stats[i]; if (reset) g_flatten_stats[i] = 0; }
+}
 static void flatten_euler(Ctx& c, const CubicPoints& cubic, uint32_t path_ix, const Transform& local_to_device,
                           float offset, V2 start_p, V2 end_p) {
     V2 p0, p1, p2, p3;
@@ -490,9 +495,11 @@ static void flatten_euler(Ctx& c, const CubicPoints& cubic, uint32_t path_ix, co
     if (dot(last_q, last_q) < DERIV_THRESH_SQUARED) last_q = eval_cubic_and_deriv(p0, p1, p2, p3, DERIV_EPS).deriv;
     float last_t = 0.0f;
     V2 lp0 = t_start;
+    uint32_t st_attempts = 0u, st_pieces = 0u;
     for (;;) {
         float t0 = (float)t0_u * dt;
         if (t0 == 1.0f) break;
+        st_attempts++;
         float t1 = t0 + dt;
         V2 this_p0 = last_p;
         V2 this_q0 = last_q;
@@ -565,6 +572,8 @@ static void flatten_euler(Ctx& c, const CubicPoints& cubic, uint32_t path_ix, co
                 output_line_with_transform(c, path_ix, l0, l1, transform);
                 lp0 = lp1;
             }
+            st_pieces++;
+            g_flatten_stats[2] += n_u;
             last_p = this_pq1.point;
             last_q = this_pq1.deriv;
             last_t = t1;
@@ -577,6 +586,10 @@ static void flatten_euler(Ctx& c, const CubicPoints& cubic, uint32_t path_ix, co
             dt *= 0.5f;
         }
     }
+    g_flatten_stats[0] += 1u;
+    g_flatten_stats[1] += st_attempts;
+    g_flatten_stats[3] += st_pieces;
+    g_flatten_stats[4 + (st_attempts < 27u ? st_attempts : 27u)] += 1u;
 }
 
 // flatten.wgsl:490-517

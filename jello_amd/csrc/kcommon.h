@@ -39,18 +39,32 @@ static inline Buf<T> mkbuf(void* p, uint64_t bytes) {
 
 // ---- wave64 primitives ----
 JD uint32_t lane_id() { return threadIdx.x & 63u; }
+// Inclusive wave64 prefix operations on the DPP path (row_shr 1,2,4,8 inside each 16-lane row, then
+// row_bcast:15 / row_bcast:31 across rows): six VALU instructions, no LDS crossbar round trips
+// (__shfl_up compiles to ds_bpermute_b32, ~100 cycles each and six of them dependent).
+#define JK_DPP_ROW_SHR(n) (0x110 + (n))
+#define JK_DPP_ROW_BCAST15 0x142
+#define JK_DPP_ROW_BCAST31 0x143
 JD uint32_t wave_incl_scan_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(v, o, 64);
-        if (lane_id() >= (uint32_t)o) v += t;
-    }
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, JK_DPP_ROW_SHR(1), 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, JK_DPP_ROW_SHR(2), 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, JK_DPP_ROW_SHR(4), 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, JK_DPP_ROW_SHR(8), 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, JK_DPP_ROW_BCAST15, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, JK_DPP_ROW_BCAST31, 0xc, 0xf, false);
+    return v;
+}
+JD uint32_t wave_incl_max_u32(uint32_t v) {
+    v = jd::umax_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, JK_DPP_ROW_SHR(1), 0xf, 0xf, false));
+    v = jd::umax_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, JK_DPP_ROW_SHR(2), 0xf, 0xf, false));
+    v = jd::umax_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, JK_DPP_ROW_SHR(4), 0xf, 0xf, false));
+    v = jd::umax_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, JK_DPP_ROW_SHR(8), 0xf, 0xf, false));
+    v = jd::umax_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, JK_DPP_ROW_BCAST15, 0xa, 0xf, false));
+    v = jd::umax_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, JK_DPP_ROW_BCAST31, 0xc, 0xf, false));
     return v;
 }
 JD uint32_t wave_reduce_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), 63);
 }
 
 // Exclusive scan of one u32 per thread across a 256-thread block.  `sh` needs 5 words.
@@ -85,15 +99,9 @@ JD MonoidK<K> monoid_add(const MonoidK<K>& a, const MonoidK<K>& b) {
 }
 template <int K>
 JD MonoidK<K> block_excl_scan_monoid(const MonoidK<K>& in, uint32_t* sh, MonoidK<K>* total) {
-    MonoidK<K> incl = in;
+    MonoidK<K> incl;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-#pragma unroll
-        for (int i = 0; i < K; i++) {
-            uint32_t t = __shfl_up(incl.v[i], o, 64);
-            if (lane_id() >= (uint32_t)o) incl.v[i] += t;
-        }
-    }
+    for (int i = 0; i < K; i++) incl.v[i] = wave_incl_scan_u32(in.v[i]);
     uint32_t w = threadIdx.x >> 6;
     __syncthreads();
     if (lane_id() == 63u) {

@@ -169,49 +169,66 @@ JD V4 over(V4 bg, V4 fg, float area) {
     return v4(bg.x * k + fg_i.x, bg.y * k + fg_i.y, bg.z * k + fg_i.z, bg.w * k + fg_i.w);
 }
 
-struct SegWin {  // lane i holds segment base+i, plus the per-segment (pixel-independent) terms of fill_path
-    float p0x, p0y, p1x, p1y, ye;
-    float recip, sgn;  // 1 / delta.y and sign(delta.x), computed once per segment instead of once per lane
+// ------------------------------------------------------------------------------------------------
+// fill_path (fine.wgsl:824-878) as a wave-level pipeline.
+//
+// A segment clipped to a 16x16 tile is short (C3: 3.5 px, 3 rows); evaluating it for all 256 pixels
+// wastes ~97 % of the arithmetic, and the IEEE division of the trapezoid area is 40 % of that.  The
+// coverage a segment adds to a pixel of row r is  a*dy (+ y_edge)  where, with the WGSL's own operations,
+//   a == 1 exactly  when the pixel lies to the right of the segment's x-span in that row (xmax <= 0),
+//   a == +0 exactly when it lies to the left (xmin0 - i >= 1; the constant numerator is exactly 0),
+// and only the few pixels the span actually crosses need the full formula.  So, per BATCH of segments
+// (as many consecutive segments of the tile's slice as give <= 64 (segment,row) pairs):
+//   stage 1  lane = segment : the rows it can cross (conservative superset), 1/dy, sign(dx)  -> prefix sum
+//   stage 2  lane = (segment,row) pair : the WGSL's y-part and x-part, exact per-pixel classification,
+//            writes the row's 16 contributions (dy / +0) and the list of crossing pixels
+//   stage 3  lane = crossing pixel : the WGSL's trapezoid formula incl. the division, writes a*dy
+//   stage 4  lane = pixel quad : for every segment of the current CMD_FILL, IN ORDER, adds the contribution
+//            of the segment's pair for its row (if any) and then the y_edge term (f32 addition is not
+//            associative: the order of the WGSL's loop is kept; skipped terms are +-0, which cannot change
+//            a sum that is never -0).
+// Batches run ahead of the command stream (a tile's segment slices are contiguous), so the per-batch
+// stages run on full waves although a single CMD_FILL has ~3 segments.
+// ------------------------------------------------------------------------------------------------
+#define FB_SPEC 256u
+#ifndef FINE_EXP
+#define FINE_EXP 0
+#endif
+struct SegRaw { float p0x, p0y, p1x, p1y, ye; };
+struct FillLds {
+    float seg[5][64];        // window segments (lane-indexed): p0x p0y dx dy 1/dy
+    uint32_t pairflag[64];   // pair -> (window segment + 1) at the first pair of each segment, else 0
+    float dy[64];            // per pair
+    float contrib[16][65];   // [tile column][pair]: a*dy   (column-major + 1 pad word: lane = pair writes and
+    float px[8][65];         // [2g, 2g+1][pair]: (xmin0, xmax0) of WGSL invocation g    lane = pixel reads are conflict-free)
+    uint16_t speclist[FB_SPEC];  // crossing pixels: pair << 4 | column
+    uint32_t nspec;
 };
-JD SegWin load_segwin(const float* __restrict__ segments, uint32_t segments_n, uint32_t base) {
-    SegWin w;
-    uint32_t so = base + (threadIdx.x & 63u);
+JD SegRaw load_segraw(const float* __restrict__ segments, uint32_t segments_n, uint32_t so) {
+    SegRaw w;
     w.p0x = 0.0f; w.p0y = 0.0f; w.p1x = 0.0f; w.p1y = 0.0f; w.ye = 0.0f;
     if (so < segments_n) {
         const float2* sp = (const float2*)(segments + (size_t)so * 6);
         float2 a = sp[0], b = sp[1], c = sp[2];
         w.p0x = a.x; w.p0y = a.y; w.p1x = b.x; w.p1y = b.y; w.ye = c.x;
     }
-    w.recip = 1.0f / (w.p1y - w.p0y);
-    w.sgn = sign_(w.p1x - w.p0x);
     return w;
 }
-JD float bcast(float v, uint32_t lane) { return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(v), (int)lane)); }
 
-// Pixel ownership inside the wave: lane = (r, c) with r = lane >> 3, c = lane & 7 owns four pixels,
-//   k = 0,1: (row r,     columns 2c, 2c+1)      k = 2,3: (row r + 8, columns 2c, 2c+1).
-// A segment clipped to a 16x16 tile usually spans only a few rows, so the coverage code runs per
-// half-tile (8 rows x 16 px = all 64 lanes x 2 px) and a half none of whose rows the segment crosses
-// is skipped with one uniform branch -- the WGSL's (4 px x 16 rows) mapping keeps most lanes idle.
-// Per-pixel arithmetic is exactly the WGSL's: a pixel in column X belongs to the WGSL invocation
-// lx = X >> 2 with i = X & 3, so x offsets are formed as (p.x - 4*lx) - i, etc.
+// Pixel ownership = the WGSL's: lane = ly*4 + lx (workgroup (4,16)), pixel i = 0..3 at column 4*lx + i.
 template <bool CLIPS>
 __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ cfg, const float* __restrict__ segments, uint32_t segments_n,
                                                   const uint32_t* __restrict__ ptcl, uint32_t ptcl_n, const uint32_t* __restrict__ info,
                                                   uint32_t info_n, Buf<V4> blend_spill, uint16_t* __restrict__ output, uint32_t out_w,
                                                   uint32_t out_h, const uint16_t* __restrict__ gradients, uint32_t grad_h, FineImages images) {
     __shared__ uint32_t win[JL_PTCL_INCREMENT];  // wave-private PTCL window
+    __shared__ FillLds F;
     if (ptcl_n == 0u || ptcl[0] == ~0u) return;  // fine.wgsl:889-893
     const uint32_t lane = threadIdx.x;
-    const uint32_t pr = lane >> 3, pc = lane & 7u;
+    const uint32_t ly = lane >> 2, lx = lane & 3u;
     const uint32_t tile_ix = blockIdx.y * cfg->width_in_tiles + blockIdx.x;
-    // per-pixel constants (k = 0..3)
-    const uint32_t X0 = 2u * pc;                       // column of k = 0,2; k = 1,3 are X0 + 1
-    const float lxb = (float)((X0 >> 2) * 4u);         // WGSL local_xy.x of the owning invocation
-    const float i0_f = (float)(X0 & 3u);               // WGSL i of the left pixel (0 or 2); right pixel is i0 + 1
-    const float xyx = (float)((blockIdx.x * 4u + (X0 >> 2)) * 4u);  // WGSL xy.x = f32(global_id.x * 4)
-    const float lrow[2] = {(float)pr, (float)(pr + 8u)};            // WGSL local_xy.y per half
-    const float grow[2] = {(float)(blockIdx.y * 16u + pr), (float)(blockIdx.y * 16u + pr + 8u)};  // WGSL xy.y per half
+    const float xyx = (float)((blockIdx.x * 4u + lx) * 4u);  // WGSL xy.x = f32(global_id.x * 4)
+    const float xyy = (float)(blockIdx.y * 16u + ly);         // WGSL xy.y
     V4 rgba[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) rgba[k] = v4(cfg->base_color[0], cfg->base_color[1], cfg->base_color[2], cfg->base_color[3]);
@@ -239,82 +256,194 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
         return v4(f16_to_f32((uint16_t)(raw.x & 0xffffu)), f16_to_f32((uint16_t)(raw.x >> 16)), f16_to_f32((uint16_t)(raw.y & 0xffffu)),
                   f16_to_f32((uint16_t)(raw.y >> 16)));
     };
-    // pixel k: WGSL i (as float) and spill index inside the tile
-    auto pix_i = [&](int k) -> float { return i0_f + (float)(k & 1); };
-    auto pix_spill = [&](int k) -> uint32_t { return (pr + 8u * (uint32_t)(k >> 1)) * JL_TILE_WIDTH + X0 + (uint32_t)(k & 1); };
-    // segment windows
-    SegWin cur, nxt;
-    cur.p0x = cur.p0y = cur.p1x = cur.p1y = cur.ye = cur.recip = cur.sgn = 0.0f;
-    nxt = cur;
+    auto pix_i = [&](int k) -> float { return (float)k; };
+    auto pix_spill = [&](int k) -> uint32_t { return ly * JL_TILE_WIDTH + lx * 4u + (uint32_t)k; };
+    // segment window (64 segments: current in LDS, next prefetched in registers) and batch state
+    SegRaw nxt;
+    nxt.p0x = nxt.p0y = nxt.p1x = nxt.p1y = nxt.ye = 0.0f;
     uint32_t cur_base = 0xffffffffu, nxt_base = 0xffffffffu;  // "no window"
+    uint32_t my_cnt = 0u, my_ra = 0u;                          // stage-1 result of window segment `lane`: rows [ra, ra+cnt)
+    float my_ye = 0.0f, my_sg = 0.0f;                          // its y_edge and sign(dx), read by stage 4 with v_readlane
+    uint32_t my_meta = 0u;                                     // its pairs in the current batch: first pair | cnt << 12 | ra << 17
+    uint32_t batch_lo = 0u, batch_hi = 0u;                     // segments [batch_lo, batch_hi) are evaluated
+    const float lyf = (float)ly;
+
+    // Evaluate the batch that starts at segment `so` (uniform).
+    auto build_batch = [&](uint32_t so) {
+        __syncthreads();  // stage 4 of the previous batch is done with F
+        if (cur_base == 0xffffffffu || so - cur_base >= 64u) {  // uniform: advance / reload the window
+            SegRaw cur;
+            if (nxt_base != 0xffffffffu && so - nxt_base < 64u) {
+                cur = nxt;
+                cur_base = nxt_base;
+            } else {
+                cur = load_segraw(segments, segments_n, so + lane);
+                cur_base = so;
+            }
+            nxt_base = cur_base + 64u;
+            nxt = load_segraw(segments, segments_n, nxt_base + lane);  // prefetch; consumed much later
+            const float dlx = cur.p1x - cur.p0x, dly = cur.p1y - cur.p0y;
+            F.seg[0][lane] = cur.p0x; F.seg[1][lane] = cur.p0y; F.seg[2][lane] = dlx; F.seg[3][lane] = dly;
+            F.seg[4][lane] = 1.0f / dly;  // vec_y_recip, fine.wgsl:845 (same operands for every invocation)
+            my_ye = cur.ye;
+            my_sg = sign_(dlx);
+            // stage 1: conservative superset of the rows with dy != 0.  Coordinates are tile relative (|v| <= 16
+            // for what path_tiling writes): with |v| <= 64 every rounding error of the WGSL's row arithmetic is
+            // < 1e-4, so widening by 1e-3 is safe; anything else takes all 16 rows.
+            bool sane = abs_(cur.p0x) <= 64.0f && abs_(cur.p0y) <= 64.0f && abs_(cur.p1x) <= 64.0f && abs_(cur.p1y) <= 64.0f;
+            int32_t ra = 0, rb = 16;
+            if (sane) {
+                ra = iclamp_((int32_t)floor_(fmin_(cur.p0y, cur.p1y) - 1.0e-3f), 0, 16);
+                rb = iclamp_((int32_t)ceil_(fmax_(cur.p0y, cur.p1y) + 1.0e-3f), 0, 16);
+            }
+            my_cnt = (uint32_t)imax_(rb - ra, 0);
+            my_ra = (uint32_t)ra;
+        }
+        const uint32_t rel0 = so - cur_base;
+        uint32_t incl = wave_incl_scan_u32(lane >= rel0 ? my_cnt : 0u);
+        uint64_t fit = __builtin_amdgcn_ballot_w64(lane >= rel0 && incl <= 64u);
+        const uint32_t e_rel = rel0 + (uint32_t)__builtin_popcountll(fit);  // > rel0: one segment has at most 16 pairs
+        const uint32_t npairs = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(e_rel - 1u));
+        const uint32_t first = incl - my_cnt;
+        my_meta = first | (my_cnt << 12) | (my_ra << 17);
+        F.pairflag[lane] = 0u;
+        if (lane == 0u) F.nspec = 0u;
+        batch_lo = so;
+        batch_hi = cur_base + e_rel;
+        __syncthreads();
+        if (lane >= rel0 && lane < e_rel && my_cnt != 0u) F.pairflag[first & 63u] = lane + 1u;
+        __syncthreads();
+        // pair -> segment: running maximum of the start flags; its row from the segment's meta word
+        const uint32_t owner = wave_incl_max_u32(F.pairflag[lane]);
+        const uint32_t pseg = (owner - 1u) & 63u;
+        const uint32_t pmeta = __shfl(my_meta, (int)pseg, 64);
+        // stage 2
+        uint32_t ms = 0u, spos = 0u;
+        if (lane < npairs && !(FINE_EXP & 1)) {
+            const uint32_t j = lane;
+            const uint32_t row = ((pmeta >> 17) & 31u) + (j - (pmeta & 0xfffu));
+            const float rowf = (float)row;
+            const float p0x = F.seg[0][pseg], p0y = F.seg[1][pseg], dlx = F.seg[2][pseg], dly = F.seg[3][pseg], vec_y_recip = F.seg[4][pseg];
+            const float y = p0y - rowf;
+            const float y0 = clamp_(y, 0.0f, 1.0f);
+            const float y1 = clamp_(y + dly, 0.0f, 1.0f);
+            const float dy = y0 - y1;
+            float cv[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) cv[q] = 0.0f;
+            if (dy != 0.0f) {
+                const float t0 = (y0 - y) * vec_y_recip;
+                const float t1 = (y1 - y) * vec_y_recip;
+                const float tx0 = t0 * dlx, tx1 = t1 * dlx;
+                float pxv[8];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const float startx = p0x - (float)(4 * g);
+                    const float x0 = startx + tx0;
+                    const float x1 = startx + tx1;
+                    const float xmin0 = fmin_(x0, x1);
+                    const float xmax0 = fmax_(x0, x1);
+                    pxv[2 * g] = xmin0;
+                    pxv[2 * g + 1] = xmax0;
+                    // outside |x| <= 17 (never for path_tiling's output) everything takes the full formula
+                    const bool guard = abs_(xmin0) <= 17.0f && abs_(xmax0) <= 17.0f;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float i_f = (float)i;
+                        const bool one = guard && (xmax0 - i_f) <= 0.0f;   // a == 1: contributes dy
+                        const bool zero = guard && (xmin0 - i_f) >= 1.0f;  // a == +0: contributes nothing
+                        cv[4 * g + i] = one ? dy : 0.0f;
+                        if (!(one || zero)) ms |= 1u << (4 * g + i);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) F.px[q][j] = pxv[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) F.contrib[q][j] = cv[q];
+            F.dy[j] = dy;
+            if (ms != 0u) spos = atomicAdd(&F.nspec, (uint32_t)__builtin_popcount(ms));
+        }
+        __syncthreads();
+        const uint32_t nspec = (uint32_t)__builtin_amdgcn_readfirstlane((int)F.nspec);
+        // stage 3, in passes of FB_SPEC crossing pixels (one pass unless the batch is full of long flat segments)
+        for (uint32_t pass = 0u; pass < nspec && !(FINE_EXP & 4); pass += FB_SPEC) {
+            if (pass != 0u) __syncthreads();
+            {
+                uint32_t bits = ms, k = spos - pass;
+                while (bits != 0u) {
+                    uint32_t X = (uint32_t)__builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    if (k < FB_SPEC) F.speclist[k] = (uint16_t)((lane << 4) | X);
+                    k++;
+                }
+            }
+            __syncthreads();
+            const uint32_t n_here = umin_(nspec - pass, FB_SPEC);
+            for (uint32_t k0 = 0u; k0 < n_here; k0 += 64u) {
+                uint32_t k = k0 + lane;
+                if (k < n_here) {
+                    uint32_t e = F.speclist[k];
+                    uint32_t j = e >> 4, X = e & 15u, g = X >> 2;
+                    float i_f = (float)(X & 3u);
+                    float xmin0 = F.px[2u * g][j], xmax0 = F.px[2u * g + 1u][j];
+                    float dy = F.dy[j];
+                    float xmin = fmin_(xmin0 - i_f, 1.0f) - 1.0e-6f;
+                    float xmax = xmax0 - i_f;
+                    float b = fmin_(xmax, 1.0f);
+                    float c = fmax_(b, 0.0f);
+                    float d = fmax_(xmin, 0.0f);
+                    float a = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
+                    F.contrib[X][j] = a * dy;
+                }
+            }
+        }
+        __syncthreads();
+    };
+
     for (uint32_t guard = 0; guard < (1u << 24); guard++) {
-        uint32_t tag = P(cmd_ix);
+        // one LDS round trip per command: tag and arguments together (CMD_FILL is nearly always followed by
+        // CMD_COLOR: both are decoded from the same nine words)
+        uint32_t wv[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) wv[k] = win[(cmd_ix + (uint32_t)k) & (JL_PTCL_INCREMENT - 1u)];
+        auto W = [&](int k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)wv[k]); };
+        const uint32_t tag = W(0);
+        const uint32_t W1 = W(1), W2 = W(2);
         if (tag == JL_CMD_END) break;
         if (tag == JL_CMD_FILL) {  // fill_path, fine.wgsl:824-878
-            uint32_t size_and_rule = P(cmd_ix + 1u);
-            uint32_t seg_data = P(cmd_ix + 2u);
-            int32_t backdrop = (int32_t)P(cmd_ix + 3u);
+            uint32_t size_and_rule = W1;
+            uint32_t seg_data = W2;
+            int32_t backdrop = (int32_t)W(3);
             uint32_t n_segs = size_and_rule >> 1;
             bool even_odd = (size_and_rule & 1u) != 0u;
             float backdrop_f = (float)backdrop;
 #pragma unroll
             for (int k = 0; k < 4; k++) area[k] = backdrop_f;
-            for (uint32_t s = 0; s < n_segs; s++) {
-                uint32_t so = seg_data + s;
-                uint32_t rel = so - cur_base;
-                if (cur_base == 0xffffffffu || rel >= 64u) {  // uniform: advance / reload the window
-                    if (nxt_base != 0xffffffffu && so - nxt_base < 64u) {
-                        cur = nxt;
-                        cur_base = nxt_base;
-                    } else {
-                        cur = load_segwin(segments, segments_n, so);
-                        cur_base = so;
+            uint32_t sa = seg_data, remaining = n_segs;
+            while (remaining != 0u) {  // uniform
+                if (sa - batch_lo >= batch_hi - batch_lo) { if (FINE_EXP & 16) { batch_lo = sa; batch_hi = sa + 16u; cur_base = sa; } else build_batch(sa); }
+                uint32_t take = umin_(remaining, batch_hi - sa);
+                uint32_t r0 = sa - cur_base;  // window-relative segments [r0, r0 + take)
+                for (uint32_t q = 0u; q < take && !(FINE_EXP & 2); q++) {
+                    const int sl = (int)((r0 + q) & 63u);
+                    uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)my_meta, sl);
+                    float ye_s = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(my_ye), sl));
+                    float sg_s = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(my_sg), sl));
+                    uint32_t t = ly - ((m >> 17) & 31u);
+                    if (t < ((m >> 12) & 31u)) {  // this segment has a pair for my row
+                        uint32_t j = ((m & 0xfffu) + t) & 63u;
+                        const float* cp = &F.contrib[lx * 4u][j];
+                        area[0] += cp[0]; area[1] += cp[65]; area[2] += cp[130]; area[3] += cp[195];
                     }
-                    nxt_base = cur_base + 64u;
-                    nxt = load_segwin(segments, segments_n, nxt_base);  // prefetch; consumed much later
-                    rel = so - cur_base;
-                }
-                float p0x = bcast(cur.p0x, rel), p0y = bcast(cur.p0y, rel), p1x = bcast(cur.p1x, rel), p1y = bcast(cur.p1y, rel);
-                float y_edge_v = bcast(cur.ye, rel);
-                float vec_y_recip = bcast(cur.recip, rel), sgn_dlx = bcast(cur.sgn, rel);
-                float dlx = p1x - p0x, dly = p1y - p0y;
-                float startx = p0x - lxb;
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    float y = p0y - lrow[h];
-                    float y0 = clamp_(y, 0.0f, 1.0f);
-                    float y1 = clamp_(y + dly, 0.0f, 1.0f);
-                    float dy = y0 - y1;
-                    if (dy != 0.0f) {
-                        float t0 = (y0 - y) * vec_y_recip;
-                        float t1 = (y1 - y) * vec_y_recip;
-                        float x0 = startx + t0 * dlx;
-                        float x1 = startx + t1 * dlx;
-                        float xmin0 = fmin_(x0, x1);
-                        float xmax0 = fmax_(x0, x1);
-#pragma unroll
-                        for (int e = 0; e < 2; e++) {
-                            float i_f = i0_f + (float)e;
-                            float xmin = fmin_(xmin0 - i_f, 1.0f) - 1.0e-6f;
-                            float xmax = xmax0 - i_f;
-                            float b = fmin_(xmax, 1.0f);
-                            float c = fmax_(b, 0.0f);
-                            float d = fmax_(xmin, 0.0f);
-                            float a = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
-                            area[2 * h + e] += a * dy;
-                        }
+                    // y_edge >= 16 (path_tiling's "no edge" value is 1e9) clamps to 0 for every row of the tile
+                    if (ye_s < 16.0f) {  // uniform
+                        float y_edge = sg_s * clamp_(lyf - ye_s + 1.0f, 0.0f, 1.0f);
+                        area[0] += y_edge; area[1] += y_edge; area[2] += y_edge; area[3] += y_edge;
                     }
                 }
-                // y_edge >= 16 (path_tiling's "no edge" value is 1e9) clamps to 0 for every row of the tile: the term
-                // would add +-0, which cannot change a sum that started from +0 -- skip it (uniform branch).
-                if (y_edge_v < 16.0f) {
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        float y_edge = sgn_dlx * clamp_(lrow[h] - y_edge_v + 1.0f, 0.0f, 1.0f);
-                        area[2 * h] += y_edge;
-                        area[2 * h + 1] += y_edge;
-                    }
-                }
+                sa += take;
+                remaining -= take;
             }
             if (even_odd) {
 #pragma unroll
@@ -324,14 +453,20 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                 for (int k = 0; k < 4; k++) area[k] = fmin_(abs_(area[k]), 1.0f);
             }
             cmd_ix += 4u;
+            if (cmd_ix + 4u < JL_PTCL_INCREMENT && W(4) == JL_CMD_COLOR) {  // the usual pair: no second trip through the decoder
+                V4 fg = v4(u2f(W(5)), u2f(W(6)), u2f(W(7)), u2f(W(8)));
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (!(FINE_EXP & 8)) rgba[k] = over(rgba[k], fg, area[k]);
+                cmd_ix += 5u;
+            }
         } else if (tag == JL_CMD_SOLID) {
 #pragma unroll
             for (int k = 0; k < 4; k++) area[k] = 1.0f;
             cmd_ix += 1u;
         } else if (tag == JL_CMD_COLOR) {
-            V4 fg = v4(u2f(P(cmd_ix + 1u)), u2f(P(cmd_ix + 2u)), u2f(P(cmd_ix + 3u)), u2f(P(cmd_ix + 4u)));
+            V4 fg = v4(u2f(W1), u2f(W2), u2f(W(3)), u2f(W(4)));
 #pragma unroll
-            for (int k = 0; k < 4; k++) rgba[k] = over(rgba[k], fg, area[k]);
+            for (int k = 0; k < 4; k++) if (!(FINE_EXP & 8)) rgba[k] = over(rgba[k], fg, area[k]);
             cmd_ix += 5u;
         } else if (CLIPS && tag == JL_CMD_BEGIN_CLIP) {
             if (clip_depth < JL_BLEND_STACK_SPLIT) {
@@ -357,8 +492,8 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             clip_depth += 1u;
             cmd_ix += 1u;
         } else if (CLIPS && tag == JL_CMD_END_CLIP) {
-            uint32_t blend = P(cmd_ix + 1u);
-            float alpha = u2f(P(cmd_ix + 2u));
+            uint32_t blend = W1;
+            float alpha = u2f(W2);
             clip_depth -= 1u;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -380,7 +515,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             }
             cmd_ix += 3u;
         } else if (tag == JL_CMD_JUMP) {
-            win_base = P(cmd_ix + 1u);
+            win_base = W1;
             cmd_ix = 0u;
             __syncthreads();  // everyone is done reading the old window
             {
@@ -398,22 +533,22 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             }
             __syncthreads();
         } else if (tag == JL_CMD_LIN_GRAD) {
-            uint32_t index_mode = P(cmd_ix + 1u);
+            uint32_t index_mode = W1;
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
-            uint32_t io = P(cmd_ix + 2u);
+            uint32_t io = W2;
             float line_x = u2f(I(io)), line_y = u2f(I(io + 1u)), line_c = u2f(I(io + 2u));
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                float d = line_x * xyx + line_y * grow[k >> 1] + line_c;
+                float d = line_x * xyx + line_y * xyy + line_c;
                 float my_d = d + line_x * pix_i(k);
                 int32_t x = to_i32(round_(extend_mode(my_d, ext) * 511.0f));
                 rgba[k] = over(rgba[k], load_grad(x, index), area[k]);
             }
             cmd_ix += 3u;
         } else if (tag == JL_CMD_RAD_GRAD) {
-            uint32_t index_mode = P(cmd_ix + 1u);
+            uint32_t index_mode = W1;
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
-            uint32_t io = P(cmd_ix + 2u);
+            uint32_t io = W2;
             float m0 = u2f(I(io)), m1 = u2f(I(io + 1u)), m2 = u2f(I(io + 2u)), m3 = u2f(I(io + 3u));
             float xl0 = u2f(I(io + 4u)), xl1 = u2f(I(io + 5u));
             float focal_x = u2f(I(io + 6u));
@@ -428,7 +563,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             float t_sign = sign_(1.0f - focal_x);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                float mx = xyx + pix_i(k), my = grow[k >> 1];
+                float mx = xyx + pix_i(k), my = xyy;
                 float x = m0 * mx + m2 * my + xl0;
                 float y = m1 * mx + m3 * my + xl1;
                 float xx = x * x, yy = y * y;
@@ -457,16 +592,16 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             }
             cmd_ix += 3u;
         } else if (tag == JL_CMD_SWEEP_GRAD) {
-            uint32_t index_mode = P(cmd_ix + 1u);
+            uint32_t index_mode = W1;
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
-            uint32_t io = P(cmd_ix + 2u);
+            uint32_t io = W2;
             float m0 = u2f(I(io)), m1 = u2f(I(io + 1u)), m2 = u2f(I(io + 2u)), m3 = u2f(I(io + 3u));
             float xl0 = u2f(I(io + 4u)), xl1 = u2f(I(io + 5u));
             float t0 = u2f(I(io + 6u)), t1 = u2f(I(io + 7u));
             float scale = 1.0f / (t1 - t0);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                float mx = xyx + pix_i(k), my = grow[k >> 1];
+                float mx = xyx + pix_i(k), my = xyy;
                 float x = m0 * mx + m2 * my + xl0;
                 float y = m1 * mx + m3 * my + xl1;
                 float xabs = abs_(x), yabs = abs_(y);
@@ -485,7 +620,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             }
             cmd_ix += 3u;
         } else if (tag == JL_CMD_IMAGE) {
-            uint32_t io = P(cmd_ix + 1u);
+            uint32_t io = W1;
             float m0 = u2f(I(io)), m1 = u2f(I(io + 1u)), m2 = u2f(I(io + 2u)), m3 = u2f(I(io + 3u));
             float xl0 = u2f(I(io + 4u)), xl1 = u2f(I(io + 5u));
             uint32_t index = I(io + 6u);
@@ -505,7 +640,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             };
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                float mx = xyx + pix_i(k), my = grow[k >> 1];
+                float mx = xyx + pix_i(k), my = xyy;
                 float u = m0 * mx + m2 * my + xl0;
                 float v = m1 * mx + m3 * my + xl1;
                 if (u < ew && v < eh && area[k] != 0.0f) {
@@ -526,27 +661,27 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             break;  // unknown tag: the WGSL would never advance; stop instead of hanging the GPU
         }
     }
-    // fine.wgsl:1092-1102: un-premultiply, store RGBA16F (two adjacent pixels = 16 bytes per lane and half)
-    const uint32_t cx0 = blockIdx.x * 16u + X0;
+    // fine.wgsl:1092-1102: un-premultiply, store RGBA16F (four adjacent pixels = 32 bytes per lane; 4 lanes = one 128-B row)
+    const uint32_t cx0 = blockIdx.x * 16u + lx * 4u;
+    const uint32_t cy = blockIdx.y * 16u + ly;
+    if (cy < out_h) {
+        uint32_t packed[8];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        uint32_t cy = blockIdx.y * 16u + pr + 8u * (uint32_t)h;
-        if (cy >= out_h) continue;
-        uint32_t packed[4];
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-            V4 fg = rgba[2 * h + e];
+        for (int e = 0; e < 4; e++) {
+            V4 fg = rgba[e];
             float a_inv = 1.0f / fmax_(fg.w, 1e-6f);
             uint32_t r = f32_to_f16(fg.x * a_inv), g = f32_to_f16(fg.y * a_inv), b = f32_to_f16(fg.z * a_inv), a = f32_to_f16(fg.w);
             packed[e * 2] = r | (g << 16);
             packed[e * 2 + 1] = b | (a << 16);
         }
         uint16_t* row = output + ((size_t)cy * out_w + cx0) * 4;
-        if (cx0 + 1u < out_w && ((out_w & 1u) == 0u)) {
+        if (cx0 + 3u < out_w && ((out_w & 1u) == 0u)) {
             *(uint4*)row = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+            *(uint4*)(row + 8) = make_uint4(packed[4], packed[5], packed[6], packed[7]);
         } else {
-            if (cx0 < out_w) *(uint2*)row = make_uint2(packed[0], packed[1]);
-            if (cx0 + 1u < out_w) *(uint2*)(row + 4) = make_uint2(packed[2], packed[3]);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (cx0 + (uint32_t)e < out_w) *(uint2*)(row + 4 * e) = make_uint2(packed[e * 2], packed[e * 2 + 1]);
         }
     }
 }

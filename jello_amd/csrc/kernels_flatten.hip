@@ -456,7 +456,7 @@ JD void flatten_euler_wave(Out<true>& o, const EulerJob& job, const Scene& sc, W
         }
         uint32_t nm = accept ? n_u : 0u;
         uint32_t incl = wave_incl_scan_u32(nm);
-        uint32_t total = __shfl(incl, 63, 64);
+        uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (total == 0u) continue;
         if (accept) {
             uint32_t first = o.alloc(n_u);
@@ -490,7 +490,9 @@ JD void flatten_euler_wave(Out<true>& o, const EulerJob& job, const Scene& sc, W
                 if (i + 1u == n_own && (flags & 4u) != 0u) lp1 = v2(u2f(W[F_TENDX][owner]), u2f(W[F_TENDY][owner]));
                 else lp1 = piece_eval(W, owner, i + 1u, flags);
             }
-            float px = __shfl_up(lp1.x, 1, 64), py = __shfl_up(lp1.y, 1, 64);
+            // lane j-1's end point (DPP wave_shr:1, no LDS crossbar round trip)
+            float px = u2f((uint32_t)__builtin_amdgcn_update_dpp(0, (int)f2u(lp1.x), 0x138, 0xf, 0xf, false));
+            float py = u2f((uint32_t)__builtin_amdgcn_update_dpp(0, (int)f2u(lp1.y), 0x138, 0xf, 0xf, false));
             if (valid) {
                 V2 a0;
                 if (i == 0u) a0 = v2(u2f(W[F_LP0X][owner]), u2f(W[F_LP0Y][owner]));

@@ -63,6 +63,12 @@ JD uint32_t wave_incl_max_u32(uint32_t v) {
     v = jd::umax_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, JK_DPP_ROW_BCAST31, 0xc, 0xf, false));
     return v;
 }
+// Orders this wave's LDS accesses (a wave's DS instructions execute in issue order; the fence only has to stop the
+// compiler from moving them) -- the synchronisation primitive of kernels whose waves own private LDS regions.
+JD void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 JD uint32_t wave_reduce_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), 63);
 }

@@ -190,44 +190,56 @@ JD V4 over(V4 bg, V4 fg, float area) {
 // Batches run ahead of the command stream (a tile's segment slices are contiguous), so the per-batch
 // stages run on full waves although a single CMD_FILL has ~3 segments.
 // ------------------------------------------------------------------------------------------------
-#define FB_SPEC 256u
+#define FB_SPEC 128u
+#ifndef FINE_WAVES
+#define FINE_WAVES 2
+#endif
+#define FB_STRIDE 65  // 64 pairs + the all-zero slot 64 (odd stride: conflict-free)
 #ifndef FINE_EXP
 #define FINE_EXP 0
 #endif
 struct SegRaw { float p0x, p0y, p1x, p1y, ye; };
 struct FillLds {
-    float seg[5][64];        // window segments (lane-indexed): p0x p0y dx dy 1/dy
-    uint32_t pairflag[64];   // pair -> (window segment + 1) at the first pair of each segment, else 0
-    float dy[64];            // per pair
-    float contrib[16][65];   // [tile column][pair]: a*dy   (column-major + 1 pad word: lane = pair writes and
-    float px[8][65];         // [2g, 2g+1][pair]: (xmin0, xmax0) of WGSL invocation g    lane = pixel reads are conflict-free)
-    uint16_t speclist[FB_SPEC];  // crossing pixels: pair << 4 | column
+    float seg[5][64];            // window segments (lane-indexed): p0x p0y dx dy 1/dy
+    float contrib[16][FB_STRIDE];  // [tile column][pair]: a*dy; pair slot 64 stays +0 ("no pair"); column-major so that
+                                 // lane = pair writes and lane = pixel reads are conflict-free
+    union {
+        uint32_t pairflag[64];   // batch set-up: pair -> (window segment + 1) at the first pair of each segment, else 0
+        uint16_t speclist[FB_SPEC];  // stage 3: crossing pixels, pair << 4 | column
+    };
     uint32_t nspec;
 };
-JD SegRaw load_segraw(const float* __restrict__ segments, uint32_t segments_n, uint32_t so) {
-    SegRaw w;
-    w.p0x = 0.0f; w.p0y = 0.0f; w.p1x = 0.0f; w.p1y = 0.0f; w.ye = 0.0f;
-    if (so < segments_n) {
-        const float2* sp = (const float2*)(segments + (size_t)so * 6);
-        float2 a = sp[0], b = sp[1], c = sp[2];
-        w.p0x = a.x; w.p0y = a.y; w.p1x = b.x; w.p1y = b.y; w.ye = c.x;
-    }
-    return w;
+// The load is unconditional (index clamped) so that it can stay in flight as a prefetch; out-of-range segments are
+// zeroed when the registers are consumed (robust-access rule) -- a predicated load would be waited for at once.
+JD void load_segraw_clamped(const float* __restrict__ segments, uint32_t segments_n, uint32_t so, float& p0x, float& p0y, float& p1x,
+                            float& p1y, float& ye) {
+    // segments_n == 0: the launcher passes the (always readable) config buffer instead of a null pointer
+    const float2* sp = (const float2*)(segments + (size_t)umin_(so, umax_(segments_n, 1u) - 1u) * 6);
+    float2 a = sp[0], b = sp[1], c = sp[2];
+    p0x = a.x; p0y = a.y; p1x = b.x; p1y = b.y; ye = c.x;
 }
 
 // Pixel ownership = the WGSL's: lane = ly*4 + lx (workgroup (4,16)), pixel i = 0..3 at column 4*lx + i.
-template <bool CLIPS>
-__global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ cfg, const float* __restrict__ segments, uint32_t segments_n,
+template <bool CLIPS, bool PAINTS>
+__global__ __launch_bounds__(64 * FINE_WAVES) void k_fine_area(const JlConfig* __restrict__ cfg, const float* __restrict__ segments, uint32_t segments_n,
                                                   const uint32_t* __restrict__ ptcl, uint32_t ptcl_n, const uint32_t* __restrict__ info,
                                                   uint32_t info_n, Buf<V4> blend_spill, uint16_t* __restrict__ output, uint32_t out_w,
-                                                  uint32_t out_h, const uint16_t* __restrict__ gradients, uint32_t grad_h, FineImages images) {
-    __shared__ uint32_t win[JL_PTCL_INCREMENT];  // wave-private PTCL window
-    __shared__ FillLds F;
+                                                  uint32_t out_h, const uint16_t* __restrict__ gradients, uint32_t grad_h, FineImages images,
+                                                  uint32_t tiles_x) {
+    // FINE_WAVES independent waves (= tiles, side by side in x) per workgroup: the CU runs at most 16 workgroups, so
+    // single-wave workgroups would cap the occupancy at 4 waves per SIMD.  The waves never synchronise with each other.
+    __shared__ uint32_t win_all[FINE_WAVES][JL_PTCL_INCREMENT];  // wave-private PTCL windows
+    __shared__ FillLds F_all[FINE_WAVES];
+    const uint32_t wave_in_wg = threadIdx.x >> 6;
+    uint32_t* const win = win_all[wave_in_wg];
+    FillLds& F = F_all[wave_in_wg];
+    const uint32_t tile_x = blockIdx.x * FINE_WAVES + wave_in_wg;
+    if (tile_x >= tiles_x) return;  // tiles_x = the dispatch's x size
     if (ptcl_n == 0u || ptcl[0] == ~0u) return;  // fine.wgsl:889-893
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t ly = lane >> 2, lx = lane & 3u;
-    const uint32_t tile_ix = blockIdx.y * cfg->width_in_tiles + blockIdx.x;
-    const float xyx = (float)((blockIdx.x * 4u + lx) * 4u);  // WGSL xy.x = f32(global_id.x * 4)
+    const uint32_t tile_ix = blockIdx.y * cfg->width_in_tiles + tile_x;
+    const float xyx = (float)((tile_x * 4u + lx) * 4u);  // WGSL xy.x = f32(global_id.x * 4)
     const float xyy = (float)(blockIdx.y * 16u + ly);         // WGSL xy.y
     V4 rgba[4];
 #pragma unroll
@@ -243,7 +255,8 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
         uint32_t gi = win_base + lane;
         win[lane] = gi < ptcl_n ? ptcl[gi] : 0u;
     }
-    __syncthreads();
+    if (lane < 16u) F.contrib[lane][64] = 0.0f;  // the "no pair" slot
+    wave_sync();
     uint32_t cmd_ix = 0u;  // relative to win_base
     auto P = [&](uint32_t rel) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)win[rel & (JL_PTCL_INCREMENT - 1u)]); };
     auto I = [&](uint32_t i) -> uint32_t { return i < info_n ? info[i] : 0u; };
@@ -259,10 +272,8 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
     auto pix_i = [&](int k) -> float { return (float)k; };
     auto pix_spill = [&](int k) -> uint32_t { return ly * JL_TILE_WIDTH + lx * 4u + (uint32_t)k; };
     // segment window (64 segments: current in LDS, next prefetched in registers) and batch state
-    SegRaw nxt;
-    nxt.p0x = nxt.p0y = nxt.p1x = nxt.p1y = nxt.ye = 0.0f;
-    uint32_t cur_base = 0xffffffffu, nxt_base = 0xffffffffu;  // "no window"
-    uint32_t my_cnt = 0u, my_ra = 0u;                          // stage-1 result of window segment `lane`: rows [ra, ra+cnt)
+    float nx_p0x = 0.0f, nx_p0y = 0.0f, nx_p1x = 0.0f, nx_p1y = 0.0f, nx_ye = 0.0f;  // prefetched (plain scalars: a struct here ends up in scratch)
+    uint32_t cur_base = 0u, nxt_base = 0xffffffffu;            // nxt_base: "nothing prefetched"
     float my_ye = 0.0f, my_sg = 0.0f;                          // its y_edge and sign(dx), read by stage 4 with v_readlane
     uint32_t my_meta = 0u;                                     // its pairs in the current batch: first pair | cnt << 12 | ra << 17
     uint32_t batch_lo = 0u, batch_hi = 0u;                     // segments [batch_lo, batch_hi) are evaluated
@@ -270,26 +281,33 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
 
     // Evaluate the batch that starts at segment `so` (uniform).
     auto build_batch = [&](uint32_t so) {
-        __syncthreads();  // stage 4 of the previous batch is done with F
-        if (cur_base == 0xffffffffu || so - cur_base >= 64u) {  // uniform: advance / reload the window
-            SegRaw cur;
-            if (nxt_base != 0xffffffffu && so - nxt_base < 64u) {
-                cur = nxt;
-                cur_base = nxt_base;
-            } else {
-                cur = load_segraw(segments, segments_n, so + lane);
-                cur_base = so;
-            }
-            nxt_base = cur_base + 64u;
-            nxt = load_segraw(segments, segments_n, nxt_base + lane);  // prefetch; consumed much later
+        wave_sync();  // stage 4 of the previous batch is done with F
+        // The window always starts at the batch's first segment (so every batch can fill its 64 pair slots);
+        // it was prefetched while the previous batch was evaluated unless the fills are not contiguous.
+        SegRaw cur;
+        if (nxt_base == so) {
+            cur.p0x = nx_p0x; cur.p0y = nx_p0y; cur.p1x = nx_p1x; cur.p1y = nx_p1y; cur.ye = nx_ye;
+        } else {
+            load_segraw_clamped(segments, segments_n, so + lane, cur.p0x, cur.p0y, cur.p1x, cur.p1y, cur.ye);
+        }
+        {
+            const bool ok = so + lane < segments_n;  // robust access: out-of-range segments read as zero
+            cur.p0x = ok ? cur.p0x : 0.0f; cur.p0y = ok ? cur.p0y : 0.0f; cur.p1x = ok ? cur.p1x : 0.0f; cur.p1y = ok ? cur.p1y : 0.0f;
+            cur.ye = ok ? cur.ye : 0.0f;
+        }
+        cur_base = so;
+        {
             const float dlx = cur.p1x - cur.p0x, dly = cur.p1y - cur.p0y;
             F.seg[0][lane] = cur.p0x; F.seg[1][lane] = cur.p0y; F.seg[2][lane] = dlx; F.seg[3][lane] = dly;
             F.seg[4][lane] = 1.0f / dly;  // vec_y_recip, fine.wgsl:845 (same operands for every invocation)
             my_ye = cur.ye;
             my_sg = sign_(dlx);
-            // stage 1: conservative superset of the rows with dy != 0.  Coordinates are tile relative (|v| <= 16
-            // for what path_tiling writes): with |v| <= 64 every rounding error of the WGSL's row arithmetic is
-            // < 1e-4, so widening by 1e-3 is safe; anything else takes all 16 rows.
+        }
+        // stage 1: conservative superset of the rows with dy != 0.  Coordinates are tile relative (|v| <= 16
+        // for what path_tiling writes): with |v| <= 64 every rounding error of the WGSL's row arithmetic is
+        // < 1e-4, so widening by 1e-3 is safe; anything else takes all 16 rows.
+        uint32_t my_cnt, my_ra;
+        {
             bool sane = abs_(cur.p0x) <= 64.0f && abs_(cur.p0y) <= 64.0f && abs_(cur.p1x) <= 64.0f && abs_(cur.p1y) <= 64.0f;
             int32_t ra = 0, rb = 16;
             if (sane) {
@@ -299,26 +317,29 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
             my_cnt = (uint32_t)imax_(rb - ra, 0);
             my_ra = (uint32_t)ra;
         }
-        const uint32_t rel0 = so - cur_base;
-        uint32_t incl = wave_incl_scan_u32(lane >= rel0 ? my_cnt : 0u);
-        uint64_t fit = __builtin_amdgcn_ballot_w64(lane >= rel0 && incl <= 64u);
-        const uint32_t e_rel = rel0 + (uint32_t)__builtin_popcountll(fit);  // > rel0: one segment has at most 16 pairs
+        const uint32_t rel0 = 0u;
+        uint32_t incl = wave_incl_scan_u32(my_cnt);
+        uint64_t fit = __builtin_amdgcn_ballot_w64(incl <= 64u);
+        const uint32_t e_rel = (uint32_t)__builtin_popcountll(fit);  // > 0: one segment has at most 16 pairs
         const uint32_t npairs = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(e_rel - 1u));
         const uint32_t first = incl - my_cnt;
         my_meta = first | (my_cnt << 12) | (my_ra << 17);
+        nxt_base = so + e_rel;
+        load_segraw_clamped(segments, segments_n, nxt_base + lane, nx_p0x, nx_p0y, nx_p1x, nx_p1y, nx_ye);  // prefetch; consumed much later
         F.pairflag[lane] = 0u;
         if (lane == 0u) F.nspec = 0u;
         batch_lo = so;
         batch_hi = cur_base + e_rel;
-        __syncthreads();
+        wave_sync();
         if (lane >= rel0 && lane < e_rel && my_cnt != 0u) F.pairflag[first & 63u] = lane + 1u;
-        __syncthreads();
+        wave_sync();
         // pair -> segment: running maximum of the start flags; its row from the segment's meta word
         const uint32_t owner = wave_incl_max_u32(F.pairflag[lane]);
         const uint32_t pseg = (owner - 1u) & 63u;
         const uint32_t pmeta = __shfl(my_meta, (int)pseg, 64);
         // stage 2
         uint32_t ms = 0u, spos = 0u;
+        float s2_dy = 0.0f, s2_tx0 = 0.0f, s2_tx1 = 0.0f, s2_p0x = 0.0f;  // read by stage 3 lanes with ds_bpermute
         if (lane < npairs && !(FINE_EXP & 1)) {
             const uint32_t j = lane;
             const uint32_t row = ((pmeta >> 17) & 31u) + (j - (pmeta & 0xfffu));
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                 const float t0 = (y0 - y) * vec_y_recip;
                 const float t1 = (y1 - y) * vec_y_recip;
                 const float tx0 = t0 * dlx, tx1 = t1 * dlx;
-                float pxv[8];
+                s2_dy = dy; s2_tx0 = tx0; s2_tx1 = tx1; s2_p0x = p0x;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const float startx = p0x - (float)(4 * g);
@@ -343,32 +364,30 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                     const float x1 = startx + tx1;
                     const float xmin0 = fmin_(x0, x1);
                     const float xmax0 = fmax_(x0, x1);
-                    pxv[2 * g] = xmin0;
-                    pxv[2 * g + 1] = xmax0;
-                    // outside |x| <= 17 (never for path_tiling's output) everything takes the full formula
+                    // Classification with integer thresholds (no per-pixel mask logic):
+                    //   a == 1  <=>  fl(xmax0 - i) <= 0   <=>  i >= ceil(xmax0)   (a float difference has the exact sign)
+                    //   a == +0 <=>  fl(xmin0 - i) >= 1   <=>  i <  floor(xmin0)  (xmin0 - i in [0.5, 1) is exact, so it
+                    //                                                              cannot round up to 1)
+                    // Outside |x| <= 17 (never for path_tiling's output; also NaN) every pixel takes the full formula.
                     const bool guard = abs_(xmin0) <= 17.0f && abs_(xmax0) <= 17.0f;
+                    const int32_t c1 = guard ? iclamp_((int32_t)ceil_(xmax0), 0, 4) : 4;   // pixels i >= c1 contribute dy
+                    const int32_t n0 = guard ? iclamp_((int32_t)floor_(xmin0), 0, 4) : 0;  // pixels i <  n0 contribute nothing
+                    // pixels n0 <= i < c1 cross the span (empty when n0 >= c1)
+                    const uint32_t below_c1 = (1u << c1) - 1u, below_n0 = (1u << n0) - 1u;
+                    ms |= (below_c1 & ~below_n0) << (4 * g);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const float i_f = (float)i;
-                        const bool one = guard && (xmax0 - i_f) <= 0.0f;   // a == 1: contributes dy
-                        const bool zero = guard && (xmin0 - i_f) >= 1.0f;  // a == +0: contributes nothing
-                        cv[4 * g + i] = one ? dy : 0.0f;
-                        if (!(one || zero)) ms |= 1u << (4 * g + i);
-                    }
+                    for (int i = 0; i < 4; i++) cv[4 * g + i] = (i >= c1) ? dy : 0.0f;
                 }
-#pragma unroll
-                for (int q = 0; q < 8; q++) F.px[q][j] = pxv[q];
             }
 #pragma unroll
             for (int q = 0; q < 16; q++) F.contrib[q][j] = cv[q];
-            F.dy[j] = dy;
             if (ms != 0u) spos = atomicAdd(&F.nspec, (uint32_t)__builtin_popcount(ms));
         }
-        __syncthreads();
+        wave_sync();
         const uint32_t nspec = (uint32_t)__builtin_amdgcn_readfirstlane((int)F.nspec);
         // stage 3, in passes of FB_SPEC crossing pixels (one pass unless the batch is full of long flat segments)
         for (uint32_t pass = 0u; pass < nspec && !(FINE_EXP & 4); pass += FB_SPEC) {
-            if (pass != 0u) __syncthreads();
+            if (pass != 0u) wave_sync();
             {
                 uint32_t bits = ms, k = spos - pass;
                 while (bits != 0u) {
@@ -378,16 +397,24 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                     k++;
                 }
             }
-            __syncthreads();
+            wave_sync();
             const uint32_t n_here = umin_(nspec - pass, FB_SPEC);
             for (uint32_t k0 = 0u; k0 < n_here; k0 += 64u) {
                 uint32_t k = k0 + lane;
+                uint32_t j = 0u, X = 0u;
                 if (k < n_here) {
                     uint32_t e = F.speclist[k];
-                    uint32_t j = e >> 4, X = e & 15u, g = X >> 2;
-                    float i_f = (float)(X & 3u);
-                    float xmin0 = F.px[2u * g][j], xmax0 = F.px[2u * g + 1u][j];
-                    float dy = F.dy[j];
+                    j = e >> 4; X = e & 15u;
+                }
+                // the pair lane's y-part results (same operations as in stage 2, so the same bits)
+                const float dy = __shfl(s2_dy, (int)j, 64), tx0 = __shfl(s2_tx0, (int)j, 64), tx1 = __shfl(s2_tx1, (int)j, 64);
+                const float p0x = __shfl(s2_p0x, (int)j, 64);
+                if (k < n_here) {
+                    const uint32_t g = X >> 2;
+                    const float i_f = (float)(X & 3u);
+                    const float startx = p0x - (float)(4u * g);
+                    const float x0 = startx + tx0, x1 = startx + tx1;
+                    const float xmin0 = fmin_(x0, x1), xmax0 = fmax_(x0, x1);
                     float xmin = fmin_(xmin0 - i_f, 1.0f) - 1.0e-6f;
                     float xmax = xmax0 - i_f;
                     float b = fmin_(xmax, 1.0f);
@@ -398,7 +425,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
     };
 
     for (uint32_t guard = 0; guard < (1u << 24); guard++) {
@@ -429,15 +456,14 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                     const int sl = (int)((r0 + q) & 63u);
                     uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)my_meta, sl);
                     float ye_s = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(my_ye), sl));
-                    float sg_s = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(my_sg), sl));
                     uint32_t t = ly - ((m >> 17) & 31u);
-                    if (t < ((m >> 12) & 31u)) {  // this segment has a pair for my row
-                        uint32_t j = ((m & 0xfffu) + t) & 63u;
-                        const float* cp = &F.contrib[lx * 4u][j];
-                        area[0] += cp[0]; area[1] += cp[65]; area[2] += cp[130]; area[3] += cp[195];
-                    }
+                    // the segment's pair for my row, or the all-zero slot 64 (adding +0 is a no-op)
+                    uint32_t j = (t < ((m >> 12) & 31u)) ? (((m & 0xfffu) + t) & 63u) : 64u;
+                    const float* cp = &F.contrib[lx * 4u][j];
+                    area[0] += cp[0]; area[1] += cp[FB_STRIDE]; area[2] += cp[2 * FB_STRIDE]; area[3] += cp[3 * FB_STRIDE];
                     // y_edge >= 16 (path_tiling's "no edge" value is 1e9) clamps to 0 for every row of the tile
                     if (ye_s < 16.0f) {  // uniform
+                        float sg_s = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(my_sg), sl));
                         float y_edge = sg_s * clamp_(lyf - ye_s + 1.0f, 0.0f, 1.0f);
                         area[0] += y_edge; area[1] += y_edge; area[2] += y_edge; area[3] += y_edge;
                     }
@@ -517,7 +543,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
         } else if (tag == JL_CMD_JUMP) {
             win_base = W1;
             cmd_ix = 0u;
-            __syncthreads();  // everyone is done reading the old window
+            wave_sync();  // everyone is done reading the old window
             {
                 uint32_t gi = win_base + lane * 4u;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -531,8 +557,14 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                 }
                 *(uint4*)(&win[lane * 4u]) = v;
             }
-            __syncthreads();
-        } else if (tag == JL_CMD_LIN_GRAD) {
+            wave_sync();
+        } else if (!PAINTS && (tag == JL_CMD_LIN_GRAD || tag == JL_CMD_RAD_GRAD || tag == JL_CMD_SWEEP_GRAD || tag == JL_CMD_IMAGE)) {
+            // This instantiation is only launched when no ramp and no image is bound: every texel fetch of the
+            // WGSL returns 0 then, i.e. the command composites a transparent colour.
+#pragma unroll
+            for (int k = 0; k < 4; k++) rgba[k] = over(rgba[k], v4(0, 0, 0, 0), area[k]);
+            cmd_ix += (tag == JL_CMD_IMAGE) ? 2u : 3u;
+        } else if (PAINTS && tag == JL_CMD_LIN_GRAD) {
             uint32_t index_mode = W1;
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
             uint32_t io = W2;
@@ -545,7 +577,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                 rgba[k] = over(rgba[k], load_grad(x, index), area[k]);
             }
             cmd_ix += 3u;
-        } else if (tag == JL_CMD_RAD_GRAD) {
+        } else if (PAINTS && tag == JL_CMD_RAD_GRAD) {
             uint32_t index_mode = W1;
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
             uint32_t io = W2;
@@ -591,7 +623,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                 }
             }
             cmd_ix += 3u;
-        } else if (tag == JL_CMD_SWEEP_GRAD) {
+        } else if (PAINTS && tag == JL_CMD_SWEEP_GRAD) {
             uint32_t index_mode = W1;
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
             uint32_t io = W2;
@@ -619,7 +651,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
                 rgba[k] = over(rgba[k], load_grad(ramp_x, index), area[k]);
             }
             cmd_ix += 3u;
-        } else if (tag == JL_CMD_IMAGE) {
+        } else if (PAINTS && tag == JL_CMD_IMAGE) {
             uint32_t io = W1;
             float m0 = u2f(I(io)), m1 = u2f(I(io + 1u)), m2 = u2f(I(io + 2u)), m3 = u2f(I(io + 3u));
             float xl0 = u2f(I(io + 4u)), xl1 = u2f(I(io + 5u));
@@ -662,7 +694,7 @@ __global__ __launch_bounds__(64) void k_fine_area(const JlConfig* __restrict__ c
         }
     }
     // fine.wgsl:1092-1102: un-premultiply, store RGBA16F (four adjacent pixels = 32 bytes per lane; 4 lanes = one 128-B row)
-    const uint32_t cx0 = blockIdx.x * 16u + lx * 4u;
+    const uint32_t cx0 = tile_x * 16u + lx * 4u;
     const uint32_t cy = blockIdx.y * 16u + ly;
     if (cy < out_h) {
         uint32_t packed[8];
@@ -713,13 +745,19 @@ int jh_launch_fine_area(const JhLaunch& L) {
     // Scenes without clip layers (ConfigUniform.n_clip == 0, read from the host shadow of the uploaded uniform)
     // use the variant without the 64-register blend stack: higher occupancy.
     bool clips = !(L.cfg_host && L.cfg_host->layout.n_clip == 0u);
-    if (clips)
-        hipLaunchKernelGGL(k_fine_area<true>, dim3(L.gx, L.gy), dim3(64), 0, L.stream, cfg, (const float*)L.b[1].ptr, segments_n,
-                           (const uint32_t*)L.b[2].ptr, ptcl_n, (const uint32_t*)L.b[3].ptr, info_n, spill, (uint16_t*)out.ptr, out.width,
-                           out.height, (const uint16_t*)grad.ptr, grad_h, imgs);
-    else
-        hipLaunchKernelGGL(k_fine_area<false>, dim3(L.gx, L.gy), dim3(64), 0, L.stream, cfg, (const float*)L.b[1].ptr, segments_n,
-                           (const uint32_t*)L.b[2].ptr, ptcl_n, (const uint32_t*)L.b[3].ptr, info_n, spill, (uint16_t*)out.ptr, out.width,
-                           out.height, (const uint16_t*)grad.ptr, grad_h, imgs);
+    // Without ramps and images every gradient/image texel is 0; the instantiation without that code needs 78
+    // instead of 109 VGPRs (6 instead of 4 waves per SIMD; the kernel is latency-bound).
+    bool paints = grad_h != 0u || imgs.n != 0;
+    const float* seg_ptr = (segments_n != 0u && L.b[1].ptr) ? (const float*)L.b[1].ptr : (const float*)cfg;  // see load_segraw_clamped
+    if (seg_ptr == (const float*)cfg) segments_n = 0u;
+#define JH_FINE_LAUNCH(C, P)                                                                                                             \
+    hipLaunchKernelGGL((k_fine_area<C, P>), dim3((L.gx + FINE_WAVES - 1) / FINE_WAVES, L.gy), dim3(64 * FINE_WAVES), 0, L.stream, cfg, seg_ptr, segments_n,       \
+                       (const uint32_t*)L.b[2].ptr, ptcl_n, (const uint32_t*)L.b[3].ptr, info_n, spill, (uint16_t*)out.ptr, out.width, \
+                       out.height, (const uint16_t*)grad.ptr, grad_h, imgs, L.gx)
+    if (clips && paints) JH_FINE_LAUNCH(true, true);
+    else if (clips) JH_FINE_LAUNCH(true, false);
+    else if (paints) JH_FINE_LAUNCH(false, true);
+    else JH_FINE_LAUNCH(false, false);
+#undef JH_FINE_LAUNCH
     return 0;
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Differential timing of k_fine_area parts (results are wrong for FINE_EXP != 0; timing only).
 cd "$(dirname "$0")/.."
-for e in 0 1 4 2 8 16 18 26; do
+for e in ${FINE_EXPS:-0 1 4 2 8 16 18 26}; do
   rm -f jello_amd/csrc/kernels_fine.o
   make -s -C jello_amd/csrc EXTRA="-DFINE_EXP=$e" > /dev/null 2>&1
   echo -n "FINE_EXP=$e  "

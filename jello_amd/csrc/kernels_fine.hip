@@ -4,18 +4,21 @@
 // un-premultiplied RGBA16F.
 //
 // MI355X design: one wave64 per tile (64 lanes x 4 horizontally adjacent pixels, exactly the
-// WGSL's (4,16) workgroup).  The PTCL stream and the segment records are the same for all 64 lanes, so
-// each datum is fetched ONCE per tile with wide coalesced loads (the algorithmic-bytes model of the
-// roofline) and then broadcast on-chip:
+// WGSL's (4,16) workgroup), two independent tile-waves per workgroup (a CU holds at most 16 workgroups).
+// The PTCL stream and the segment records are the same for all 64 lanes, so each datum is fetched ONCE
+// per tile with wide coalesced loads (the algorithmic-bytes model of the roofline) and then shared on-chip:
 //   * PTCL: the 64-word head, then each 256-word chunk (one dwordx4 per lane = 1 KiB per wave
-//     instruction) is staged in a wave-private 1 KiB LDS window; the interpreter reads command words
-//     with uniform ds_reads, the command index stays in SGPRs (readfirstlane);
-//   * segments: coarse allocates a tile's segment slices back to back, so lane i keeps segment
-//     base+i of a 64-segment window in registers (plus a prefetched next window) and the per-segment
-//     loop broadcasts the 5 floats with v_readlane -- no dependent memory latency per segment.
+//     instruction) is staged in a wave-private 1 KiB LDS window; the interpreter reads a command and
+//     its arguments (and the CMD_COLOR that usually follows a CMD_FILL) in one LDS round trip;
+//   * segments: coarse allocates a tile's segment slices back to back; they are evaluated in batches of
+//     up to 64 (segment,row) pairs by the wave-level pipeline described above fill_path below, with the
+//     next batch's 64-segment window prefetched into registers.
 // Pixels leave as two 16-byte stores per lane (4 px x RGBA16F = 32 B; 4 lanes cover one 128-B row).
 // The 4-deep clip/blend stack lives in registers (statically indexed), deeper levels spill to
-// blend_spill exactly like the WGSL.
+// blend_spill exactly like the WGSL.  Four instantiations: with/without the clip stack (64 VGPRs) and
+// with/without gradient+image code (25 VGPRs); the launcher picks by ConfigUniform.n_clip and by whether
+// any ramp/image is bound.  The kernel is latency-bound (LDS round trips, short dependent loops), so
+// occupancy matters: 88 VGPRs and 6.5 KB LDS per wave give 5 waves per SIMD for the common variant.
 #include "kcommon.h"
 
 using namespace jk;
@@ -191,6 +194,9 @@ JD V4 over(V4 bg, V4 fg, float area) {
 // stages run on full waves although a single CMD_FILL has ~3 segments.
 // ------------------------------------------------------------------------------------------------
 #define FB_SPEC 128u
+#ifndef FINE_LEAN_WAVES_PER_EU
+#define FINE_LEAN_WAVES_PER_EU 5  // 88 VGPRs; 6 (80 VGPRs, 7 spills) measured the same
+#endif
 #ifndef FINE_WAVES
 #define FINE_WAVES 2
 #endif
@@ -200,7 +206,7 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #endif
 struct SegRaw { float p0x, p0y, p1x, p1y, ye; };
 struct FillLds {
-    float seg[5][64];            // window segments (lane-indexed): p0x p0y dx dy 1/dy
+    float seg[4][64];            // window segments (lane-indexed): p0x p0y dx dy
     float contrib[16][FB_STRIDE];  // [tile column][pair]: a*dy; pair slot 64 stays +0 ("no pair"); column-major so that
                                  // lane = pair writes and lane = pixel reads are conflict-free
     union {
@@ -221,7 +227,7 @@ JD void load_segraw_clamped(const float* __restrict__ segments, uint32_t segment
 
 // Pixel ownership = the WGSL's: lane = ly*4 + lx (workgroup (4,16)), pixel i = 0..3 at column 4*lx + i.
 template <bool CLIPS, bool PAINTS>
-__global__ __launch_bounds__(64 * FINE_WAVES) void k_fine_area(const JlConfig* __restrict__ cfg, const float* __restrict__ segments, uint32_t segments_n,
+__global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu(CLIPS ? 2 : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU), CLIPS ? 2 : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU)))) void k_fine_area(const JlConfig* __restrict__ cfg, const float* __restrict__ segments, uint32_t segments_n,
                                                   const uint32_t* __restrict__ ptcl, uint32_t ptcl_n, const uint32_t* __restrict__ info,
                                                   uint32_t info_n, Buf<V4> blend_spill, uint16_t* __restrict__ output, uint32_t out_w,
                                                   uint32_t out_h, const uint16_t* __restrict__ gradients, uint32_t grad_h, FineImages images,
@@ -299,7 +305,6 @@ __global__ __launch_bounds__(64 * FINE_WAVES) void k_fine_area(const JlConfig* _
         {
             const float dlx = cur.p1x - cur.p0x, dly = cur.p1y - cur.p0y;
             F.seg[0][lane] = cur.p0x; F.seg[1][lane] = cur.p0y; F.seg[2][lane] = dlx; F.seg[3][lane] = dly;
-            F.seg[4][lane] = 1.0f / dly;  // vec_y_recip, fine.wgsl:845 (same operands for every invocation)
             my_ye = cur.ye;
             my_sg = sign_(dlx);
         }
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(64 * FINE_WAVES) void k_fine_area(const JlConfig* _
             const uint32_t j = lane;
             const uint32_t row = ((pmeta >> 17) & 31u) + (j - (pmeta & 0xfffu));
             const float rowf = (float)row;
-            const float p0x = F.seg[0][pseg], p0y = F.seg[1][pseg], dlx = F.seg[2][pseg], dly = F.seg[3][pseg], vec_y_recip = F.seg[4][pseg];
+            const float p0x = F.seg[0][pseg], p0y = F.seg[1][pseg], dlx = F.seg[2][pseg], dly = F.seg[3][pseg];
             const float y = p0y - rowf;
             const float y0 = clamp_(y, 0.0f, 1.0f);
             const float y1 = clamp_(y + dly, 0.0f, 1.0f);
@@ -353,6 +358,7 @@ __global__ __launch_bounds__(64 * FINE_WAVES) void k_fine_area(const JlConfig* _
 #pragma unroll
             for (int q = 0; q < 16; q++) cv[q] = 0.0f;
             if (dy != 0.0f) {
+                const float vec_y_recip = 1.0f / dly;  // fine.wgsl:845
                 const float t0 = (y0 - y) * vec_y_recip;
                 const float t1 = (y1 - y) * vec_y_recip;
                 const float tx0 = t0 * dlx, tx1 = t1 * dlx;

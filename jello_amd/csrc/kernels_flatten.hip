@@ -36,6 +36,9 @@ struct PathTagData { uint32_t tag_byte; MonoidK<5> monoid; };
 #define TANGENT_THRESH 1e-6f
 
 #define FL_INVALID 0xffffffffu
+#ifndef FL_REFILL_LANES
+#define FL_REFILL_LANES 24u  // idle lanes that trigger a refill of the wave
+#endif
 
 // Line sink.  EMIT: lines go to a TEMPORARY buffer in allocation order (fast, order-free allocation:
 // LDS atomic on the workgroup's chunk, global atomic only when the chunk is exhausted) together with a
@@ -344,40 +347,81 @@ JD V2 piece_eval(WaveLds& W, uint32_t owner, uint32_t i_plus_1, uint32_t flags) 
     return es_seg_eval_with_offset(es_p0, es_p1, ep, s, u2f(W[F_NOFF][owner]));
 }
 
-JD void flatten_euler_wave(Out<true>& o, const EulerJob& job, const Scene& sc, WaveLds& W) {
+// Resumable per-lane state of flatten_euler: lanes that finish their job early are REFILLED with the next
+// work item while the others keep subdividing (the attempts per job vary from 1 to ~30, and with ~1.5 cubic
+// jobs per resident lane a wave-synchronous "64 items, wait for the slowest" loop idles most lanes).
+struct EulerLane {
+    V2 p0, p1, p2, p3;
+    float scale, offset;
+    V2 t_end;
+    uint32_t t0_u;
+    float dt;
+    V2 last_p, last_q;
+    float last_t;
+    V2 lp0;
+    uint32_t path_ix, trans_ix;
+    bool done;
+};
+
+JD void euler_begin(EulerLane& e, const EulerJob& job, WaveLds& W) {  // flatten.wgsl:328-360
     const uint32_t lane = lane_id();
-    V2 p0 = v2(0, 0), p1 = p0, p2 = p0, p3 = p0;
-    float scale = 1.0f;
-    V2 t_start = job.start_p, t_end = job.end_p;
-    bool done = !job.valid;
-    const float offset = job.offset;
+    e.p0 = e.p1 = e.p2 = e.p3 = v2(0, 0);
+    e.scale = 1.0f;
+    V2 t_start = job.start_p;
+    e.t_end = job.end_p;
+    e.done = !job.valid;
+    e.offset = job.offset;
+    e.path_ix = job.path_ix;
+    e.trans_ix = job.trans_ix;
     if (job.valid) {
-        if (offset == 0.0f) {
-            p0 = xf_apply(job.local_to_device, job.cubic.p0);
-            p1 = xf_apply(job.local_to_device, job.cubic.p1);
-            p2 = xf_apply(job.local_to_device, job.cubic.p2);
-            p3 = xf_apply(job.local_to_device, job.cubic.p3);
-            scale = 1.0f;
-            t_start = p0;
-            t_end = p3;
+        if (job.offset == 0.0f) {
+            e.p0 = xf_apply(job.local_to_device, job.cubic.p0);
+            e.p1 = xf_apply(job.local_to_device, job.cubic.p1);
+            e.p2 = xf_apply(job.local_to_device, job.cubic.p2);
+            e.p3 = xf_apply(job.local_to_device, job.cubic.p3);
+            e.scale = 1.0f;
+            t_start = e.p0;
+            e.t_end = e.p3;
         } else {
-            p0 = job.cubic.p0; p1 = job.cubic.p1; p2 = job.cubic.p2; p3 = job.cubic.p3;
+            e.p0 = job.cubic.p0; e.p1 = job.cubic.p1; e.p2 = job.cubic.p2; e.p3 = job.cubic.p3;
             const Xf& tr = job.local_to_device;
-            scale = 0.5f * length(v2(tr.m0 + tr.m3, tr.m1 - tr.m2)) + length(v2(tr.m0 - tr.m3, tr.m1 + tr.m2));
+            e.scale = 0.5f * length(v2(tr.m0 + tr.m3, tr.m1 - tr.m2)) + length(v2(tr.m0 - tr.m3, tr.m1 + tr.m2));
         }
-        if (veq(p0, p1) && veq(p0, p2) && veq(p0, p3)) done = true;
+        if (veq(e.p0, e.p1) && veq(e.p0, e.p2) && veq(e.p0, e.p3)) e.done = true;
     }
-    const float tol = 0.25f;
-    uint32_t t0_u = 0u;
-    float dt = 1.0f;
-    V2 last_p = p0;
-    V2 last_q = p1 - p0;
-    if (!done && dot(last_q, last_q) < DERIV_THRESH_SQUARED) last_q = eval_cubic_and_deriv(p0, p1, p2, p3, DERIV_EPS).deriv;
-    float last_t = 0.0f;
-    V2 lp0 = t_start;
+    e.t0_u = 0u;
+    e.dt = 1.0f;
+    e.last_p = e.p0;
+    e.last_q = e.p1 - e.p0;
+    if (!e.done && dot(e.last_q, e.last_q) < DERIV_THRESH_SQUARED) e.last_q = eval_cubic_and_deriv(e.p0, e.p1, e.p2, e.p3, DERIV_EPS).deriv;
+    e.last_t = 0.0f;
+    e.lp0 = t_start;
     W[F_BX0][lane] = fkey(1e31f); W[F_BY0][lane] = fkey(1e31f); W[F_BX1][lane] = fkey(-1e31f); W[F_BY1][lane] = fkey(-1e31f);
+}
+
+// `refill()` is called (by the whole wave) when enough lanes are idle; it finalises finished items, gives idle
+// lanes new ones (euler_begin) and returns false once no lane is active and the queue is empty.
+template <class Refill>
+JD void flatten_euler_wave(Out<true>& o, EulerLane& e, const Scene& sc, WaveLds& W, Refill&& refill) {
+    const uint32_t lane = lane_id();
+    V2 &p0 = e.p0, &p1 = e.p1, &p2 = e.p2, &p3 = e.p3;
+    float& scale = e.scale;
+    const float& offset = e.offset;
+    V2& t_end = e.t_end;
+    bool& done = e.done;
+    const float tol = 0.25f;
+    uint32_t& t0_u = e.t0_u;
+    float& dt = e.dt;
+    V2 &last_p = e.last_p, &last_q = e.last_q;
+    float& last_t = e.last_t;
+    V2& lp0 = e.lp0;
     for (;;) {
-        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+        {
+            uint64_t idle = __builtin_amdgcn_ballot_w64(done);
+            if ((uint32_t)__builtin_popcountll(idle) >= FL_REFILL_LANES)
+                if (!refill()) break;
+        }
+
         bool accept = false;
         uint32_t n_u = 0u;
         float pc_n = 0.0f, pc_a = 0.0f, pc_b = 0.0f, pc_integral = 0.0f, pc_int0 = 0.0f, pc_noff = 0.0f;
@@ -465,8 +509,8 @@ JD void flatten_euler_wave(Out<true>& o, const EulerJob& job, const Scene& sc, W
             W[F_A][lane] = f2u(pc_a); W[F_B][lane] = f2u(pc_b); W[F_INTEGRAL][lane] = f2u(pc_integral); W[F_INT0][lane] = f2u(pc_int0);
             W[F_NOFF][lane] = f2u(pc_noff); W[F_N][lane] = f2u(pc_n);
             W[F_LP0X][lane] = f2u(lp0.x); W[F_LP0Y][lane] = f2u(lp0.y); W[F_TENDX][lane] = f2u(t_end.x); W[F_TENDY][lane] = f2u(t_end.y);
-            W[F_FLAGS][lane] = pc_flags; W[F_PATH][lane] = job.path_ix; W[F_TPOS][lane] = o.a_tpos; W[F_FIRST][lane] = first;
-            W[F_SLOT][lane] = o.slot; W[F_TRANS][lane] = job.trans_ix;
+            W[F_FLAGS][lane] = pc_flags; W[F_PATH][lane] = e.path_ix; W[F_TPOS][lane] = o.a_tpos; W[F_FIRST][lane] = first;
+            W[F_SLOT][lane] = o.slot; W[F_TRANS][lane] = e.trans_ix;
         }
         W[F_INCL][lane] = incl;
         wave_fence();
@@ -527,13 +571,6 @@ JD void flatten_euler_wave(Out<true>& o, const EulerJob& job, const Scene& sc, W
         if (accept) lp0 = v2(u2f(W[F_LPENDX][lane]), u2f(W[F_LPENDY][lane]));
         wave_fence();
     }
-    if (job.valid) {
-        o.bx0 = fmin_(o.bx0, fkey_inv(W[F_BX0][lane]));
-        o.by0 = fmin_(o.by0, fkey_inv(W[F_BY0][lane]));
-        o.bx1 = fmax_(o.bx1, fkey_inv(W[F_BX1][lane]));
-        o.by1 = fmax_(o.by1, fkey_inv(W[F_BY1][lane]));
-    }
-    wave_fence();
 }
 
 // flatten.wgsl:490-517
@@ -858,16 +895,18 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
                                                          uint32_t FL_CHUNK) {
     __shared__ uint32_t sh_next;
     __shared__ uint32_t sh_chunk;
+    __shared__ uint32_t sh_item;  // next position of this workgroup's share of the item list
     __shared__ WaveLds sh_wave[JL_WG / 64];
     Scene s;
     s.cfg = cfg; s.scene = scene; s.tag_monoids = tag_monoids;
     uint32_t n_heavy = umin_(counters[0], cap), n_light = umin_(counters[1], cap - n_heavy);
     uint32_t n = n_heavy + n_light;
-    if (blockIdx.x * JL_WG >= n) return;  // uniform: this workgroup has no items
+    if (blockIdx.x * 64u >= n) return;  // uniform: this workgroup's share of the list is empty
     if (threadIdx.x == 0) {
         uint32_t cb = atomicAdd(&counters[2], FL_CHUNK);
         sh_chunk = cb;
         sh_next = cb;
+        sh_item = 0u;
     }
     __syncthreads();
     uint32_t chunk = sh_chunk;
@@ -877,35 +916,67 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
     }
     __syncthreads();
     WaveLds& W = sh_wave[threadIdx.x >> 6];
-    for (uint32_t t = blockIdx.x * JL_WG + threadIdx.x;; t += gridDim.x * JL_WG) {
-        bool have = t < n;
-        if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;  // the whole wave is out of items
-        uint32_t slot = 0u;
-        if (have) slot = t < n_heavy ? list[t] : list[cap - 1u - (t - n_heavy)];
-        Out<true> o;
-        o.cfg = cfg; o.tlines = tlines; o.tkeys = tkeys; o.tcap = tcap; o.slot = slot;
-        o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
-        o.lds_next = &sh_next; o.lds_limit = chunk + FL_CHUNK; o.g_next = &counters[2];
-        o.bx0 = 1e31f; o.by0 = 1e31f; o.bx1 = -1e31f; o.by1 = -1e31f;
-        EulerJob job;
-        job.valid = false; job.path_ix = 0u; job.trans_ix = 0u; job.offset = 0.0f;
-        job.start_p = v2(0, 0); job.end_p = v2(0, 0);
-        job.cubic.p0 = job.cubic.p1 = job.cubic.p2 = job.cubic.p3 = v2(0, 0);
-        job.local_to_device = xf_identity();
-        uint32_t path_ix = 0u;
-        if (have) run_item<true>(cfg, s, o, slot, job, path_ix);
-        flatten_euler_wave(o, job, s, W);
-        if (have) {
-            counts[slot] = o.cursor;
-            if ((o.bx1 > o.bx0 || o.by1 > o.by0) && path_bboxes.ok(path_ix)) {  // flatten.wgsl:893-899 (min/max are order-free)
-                JlPathBbox* out = &path_bboxes.p[path_ix];
-                atomicMin(&out->x0, to_i32(floor_(o.bx0)));
-                atomicMin(&out->y0, to_i32(floor_(o.by0)));
-                atomicMax(&out->x1, to_i32(ceil_(o.bx1)));
-                atomicMax(&out->y1, to_i32(ceil_(o.by1)));
+    const uint32_t lane = lane_id();
+    // Work distribution: the item list (heavy items first) is dealt to the workgroups in chunks of 64, round robin;
+    // the waves of a workgroup draw their items from its share through one LDS counter.
+    Out<true> o;
+    o.cfg = cfg; o.tlines = tlines; o.tkeys = tkeys; o.tcap = tcap; o.slot = 0u;
+    o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
+    o.lds_next = &sh_next; o.lds_limit = chunk + FL_CHUNK; o.g_next = &counters[2];
+    o.bx0 = 1e31f; o.by0 = 1e31f; o.bx1 = -1e31f; o.by1 = -1e31f;
+    EulerLane e;
+    e.p0 = e.p1 = e.p2 = e.p3 = v2(0, 0);
+    e.scale = 1.0f; e.offset = 0.0f; e.t_end = v2(0, 0); e.t0_u = 0u; e.dt = 1.0f; e.last_p = e.last_q = v2(0, 0); e.last_t = 0.0f;
+    e.lp0 = v2(0, 0); e.path_ix = 0u; e.trans_ix = 0u; e.done = true;
+    bool have = false;       // this lane holds an item that is not finalised yet
+    uint32_t path_ix = 0u;
+    auto refill = [&]() -> bool {
+        for (;;) {
+            if (e.done && have) {  // the lane's item is complete
+                // fold the wave-cooperative bbox of the item's Euler lines (sentinels if it had none) into the item's
+                o.bx0 = fmin_(o.bx0, fkey_inv(W[F_BX0][lane])); o.by0 = fmin_(o.by0, fkey_inv(W[F_BY0][lane]));
+                o.bx1 = fmax_(o.bx1, fkey_inv(W[F_BX1][lane])); o.by1 = fmax_(o.by1, fkey_inv(W[F_BY1][lane]));
+                counts[o.slot] = o.cursor;
+                if ((o.bx1 > o.bx0 || o.by1 > o.by0) && path_bboxes.ok(path_ix)) {  // flatten.wgsl:893-899 (min/max are order-free)
+                    JlPathBbox* out = &path_bboxes.p[path_ix];
+                    atomicMin(&out->x0, to_i32(floor_(o.bx0)));
+                    atomicMin(&out->y0, to_i32(floor_(o.by0)));
+                    atomicMax(&out->x1, to_i32(ceil_(o.bx1)));
+                    atomicMax(&out->y1, to_i32(ceil_(o.by1)));
+                }
+                have = false;
             }
+            const bool want = e.done;
+            const uint64_t wm = __builtin_amdgcn_ballot_w64(want);
+            const uint32_t nwant = (uint32_t)__builtin_popcountll(wm);
+            const uint32_t rank = (uint32_t)__builtin_popcountll(wm & ((1ull << lane) - 1ull));
+            uint32_t base = 0u;
+            if (want && rank == 0u) base = atomicAdd(&sh_item, nwant);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(wm | (1ull << 63)));
+            // position q of the workgroup's share -> list position t
+            const uint32_t q = base + rank;
+            const uint32_t t = ((q >> 6) * gridDim.x + blockIdx.x) * 64u + (q & 63u);
+            const uint32_t t_first = ((base >> 6) * gridDim.x + blockIdx.x) * 64u + (base & 63u);
+            if (want && t < n) {
+                const uint32_t slot = t < n_heavy ? list[t] : list[cap - 1u - (t - n_heavy)];
+                o.slot = slot; o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
+                o.bx0 = 1e31f; o.by0 = 1e31f; o.bx1 = -1e31f; o.by1 = -1e31f;
+                EulerJob job;
+                job.valid = false; job.path_ix = 0u; job.trans_ix = 0u; job.offset = 0.0f;
+                job.start_p = v2(0, 0); job.end_p = v2(0, 0);
+                job.cubic.p0 = job.cubic.p1 = job.cubic.p2 = job.cubic.p3 = v2(0, 0);
+                job.local_to_device = xf_identity();
+                run_item<true>(cfg, s, o, slot, job, path_ix);
+                euler_begin(e, job, W);
+                have = true;
+            }
+            wave_fence();
+            if (__builtin_amdgcn_ballot_w64(!e.done) != 0ull) return true;   // somebody has Euler work
+            if (__builtin_amdgcn_ballot_w64(have) == 0ull && t_first >= n) return false;  // nothing held, queue empty
+            // only direct items (lines, caps, joins) were drawn, or finished ones wait to be finalised: go round again
         }
-    }
+    };
+    flatten_euler_wave(o, e, s, W, refill);
 }
 
 // lines[bases[slot] + k] = temp line: the canonical (tag byte, emission order) LineSoup order.

@@ -31,6 +31,7 @@ struct Alloc {
     uint32_t width = 0, height = 0;
     int format = 0;
     bool pending_clear = false;
+    bool written = false;   // images: has content (uploaded / imported); a created-only image reads as zero like a new wgpu texture
 };
 
 struct ProfEntry {
@@ -325,7 +326,7 @@ int jh_image_import(jh_ctx* ctx, uint64_t id, void* device_ptr, uint32_t width, 
     if (it != ctx->images.end() && it->second.owned) ctx->pool.insert({it->second.capacity, it->second.ptr});
     Alloc a;
     a.ptr = device_ptr; a.size = (uint64_t)width * height * bpp; a.capacity = a.size; a.owned = false;
-    a.width = width; a.height = height; a.format = format;
+    a.width = width; a.height = height; a.format = format; a.written = true;
     ctx->images[id] = a;
     return JH_OK;
 }
@@ -337,6 +338,7 @@ int jh_image_upload(jh_ctx* ctx, uint64_t id, uint32_t width, uint32_t height, i
     if (size > a.size) size = a.size;
     if (size) HIP_TRY(ctx, hipMemcpyAsync(a.ptr, data, size, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    a.written = true;
     return JH_OK;
 }
 
@@ -391,7 +393,8 @@ static int resolve_bindings(jh_ctx* ctx, const jh_binding* bindings, int n, std:
                 if (it == ctx->images.end()) return fail(ctx, JH_ERR_INVALID, "dispatch: unknown image id in image array");
                 JhBound im;
                 std::memset(&im, 0, sizeof im);
-                im.ptr = it->second.ptr; im.size = it->second.size; im.width = it->second.width; im.height = it->second.height; im.format = it->second.format;
+                // a never-written image samples as transparent black: no pointer, the texel fetch returns zero
+                im.ptr = it->second.written ? it->second.ptr : nullptr; im.size = it->second.size; im.width = it->second.width; im.height = it->second.height; im.format = it->second.format;
                 images.push_back(im);
             }
             out.push_back(r);  // placeholder keeps binding indices aligned with the WGSL @binding order

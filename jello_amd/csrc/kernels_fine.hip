@@ -753,7 +753,8 @@ int jh_launch_fine_area(const JhLaunch& L) {
     bool clips = !(L.cfg_host && L.cfg_host->layout.n_clip == 0u);
     // Without ramps and images every gradient/image texel is 0; the instantiation without that code needs 78
     // instead of 109 VGPRs (6 instead of 4 waves per SIMD; the kernel is latency-bound).
-    bool paints = grad_h != 0u || imgs.n != 0;
+    bool paints = grad_h != 0u;
+    for (int i = 0; i < imgs.n; i++) paints = paints || imgs.px[i] != nullptr;
     const float* seg_ptr = (segments_n != 0u && L.b[1].ptr) ? (const float*)L.b[1].ptr : (const float*)cfg;  // see load_segraw_clamped
     if (seg_ptr == (const float*)cfg) segments_n = 0u;
 #define JH_FINE_LAUNCH(C, P)                                                                                                             \

@@ -338,7 +338,11 @@ int jh_image_upload(jh_ctx* ctx, uint64_t id, uint32_t width, uint32_t height, i
     if (size > a.size) size = a.size;
     if (size) HIP_TRY(ctx, hipMemcpyAsync(a.ptr, data, size, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    a.written = true;
+    // an all-zero image (the 1x1 placeholder of render.go:115-124) contributes zero texels: bind it as absent
+    bool nonzero = false;
+    const uint8_t* bytes = (const uint8_t*)data;
+    for (uint64_t i = 0; i < size && !nonzero; i++) nonzero = bytes[i] != 0;
+    a.written = nonzero;
     return JH_OK;
 }
 

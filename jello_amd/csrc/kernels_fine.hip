@@ -20,6 +20,7 @@
 // any ramp/image is bound.  The kernel is latency-bound (LDS round trips, short dependent loops), so
 // occupancy matters: 88 VGPRs and 6.5 KB LDS per wave give 5 waves per SIMD for the common variant.
 #include "kcommon.h"
+#include "srgb_lut.h"
 
 using namespace jk;
 using namespace jd;
@@ -160,6 +161,7 @@ JD float extend_mode(float t, uint32_t mode) {  // fine.wgsl:800-812
 struct FineImages {
     const uint8_t* px[FINE_MAX_IMAGES];
     uint32_t w[FINE_MAX_IMAGES], h[FINE_MAX_IMAGES];
+    uint32_t srgb_mask;  // bit q: image q is JL_RGBA8_SRGB (texels decode to linear like an rgba8unorm-srgb texture)
     int n;
 };
 
@@ -666,14 +668,19 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
             float ew = (float)(width_height >> 16), eh = (float)(width_height & 0xffffu);
             const uint8_t* ipx = nullptr;
             uint32_t iw = 0, ih = 0;
+            bool is_srgb = false;
 #pragma unroll
             for (int q = 0; q < FINE_MAX_IMAGES; q++)
-                if ((uint32_t)q == index && q < images.n) { ipx = images.px[q]; iw = images.w[q]; ih = images.h[q]; }
+                if ((uint32_t)q == index && q < images.n) { ipx = images.px[q]; iw = images.w[q]; ih = images.h[q]; is_srgb = ((images.srgb_mask >> q) & 1u) != 0u; }
             auto texel = [&](int32_t tx, int32_t ty) -> V4 {
                 if (!ipx || tx < 0 || ty < 0 || (uint32_t)tx >= iw || (uint32_t)ty >= ih) return v4(0, 0, 0, 0);
                 uint32_t raw = *(const uint32_t*)(ipx + ((size_t)ty * iw + (size_t)tx) * 4);
-                float r = (float)(raw & 0xffu) / 255.0f, g = (float)((raw >> 8) & 0xffu) / 255.0f, b = (float)((raw >> 16) & 0xffu) / 255.0f,
-                      a = (float)(raw >> 24) / 255.0f;
+                float r, g, b, a = (float)(raw >> 24) / 255.0f;
+                if (is_srgb) {
+                    r = kSrgbToLinear[raw & 0xffu]; g = kSrgbToLinear[(raw >> 8) & 0xffu]; b = kSrgbToLinear[(raw >> 16) & 0xffu];
+                } else {
+                    r = (float)(raw & 0xffu) / 255.0f; g = (float)((raw >> 8) & 0xffu) / 255.0f; b = (float)((raw >> 16) & 0xffu) / 255.0f;
+                }
                 return v4(r * a, g * a, b * a, a);  // premul_alpha, fine.wgsl:1105-1107
             };
 #pragma unroll
@@ -740,10 +747,12 @@ int jh_launch_fine_area(const JhLaunch& L) {
     if (out.format != JL_RGBA16_FLOAT || !out.ptr) return -1;
     FineImages imgs;
     imgs.n = 0;
+    imgs.srgb_mask = 0u;
     for (int i = 0; i < FINE_MAX_IMAGES; i++) { imgs.px[i] = nullptr; imgs.w[i] = 0; imgs.h[i] = 0; }
     for (int i = 0; i < L.n_images && i < FINE_MAX_IMAGES; i++) {
         imgs.px[i] = (const uint8_t*)L.images[i].ptr;
         imgs.w[i] = L.images[i].width;
+        if (L.images[i].format == JL_RGBA8_SRGB) imgs.srgb_mask |= 1u << i;
         imgs.h[i] = L.images[i].height;
         imgs.n = i + 1;
     }

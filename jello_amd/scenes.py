@@ -143,3 +143,20 @@ def scene_c4(n_paths=30_000, size=2048, seed=SEED + 4, group=10, depth=3):
         for _ in range(layers):
             s.pop_layer()
     return s, RenderParams(size, size, base_color=(0, 0, 0, 1))
+
+
+def scene_images(size=256, seed=SEED + 7):
+    """Two RGBA8 (sRGB-encoded) images as brushes: one axis-aligned at 1:1, one rotated/scaled through the
+    brush transform so that the bilinear taps and the extent test of fine.wgsl:1068-1087 are exercised, plus
+    a solid shape on top.  The reference uploads scene images as Rgba8Srgb (render.go:137)."""
+    u = splitmix64_array(64 * 48 * 4 + 32 * 32 * 4, seed)
+    img_a = (u[:64 * 48 * 4] * 256.0).astype(np.uint8).reshape(48, 64, 4)
+    img_b = (u[64 * 48 * 4:] * 256.0).astype(np.uint8).reshape(32, 32, 4)
+    img_b[:, :, 3] = 255  # opaque
+    s = Scene()
+    s.fill(Fill.NonZero, None, Brush.image(img_a, key=1), (1, 0, 0, 1, 20, 30), Path.rect(20, 30, 20 + 64, 30 + 48))
+    c, sn = math.cos(0.5), math.sin(0.5)
+    xf = (3.0 * c, 3.0 * sn, -3.0 * sn, 3.0 * c, 120.0, 90.0)
+    s.fill(Fill.NonZero, None, Brush.image(img_b, key=2), xf, Path.circle(150, 150, 70))
+    s.fill(Fill.EvenOdd, None, Brush.solid((0.1, 0.7, 0.2, 0.5)), None, Path.rect(60, 60, 200, 120))
+    return s, RenderParams(size, size, base_color=(0.2, 0.2, 0.2, 1.0))

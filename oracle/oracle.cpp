@@ -1847,7 +1847,8 @@ static float extend_mode(float t, uint32_t mode) {  // fine.wgsl:800-812
         default: return abs_(t - 2.0f * round_(0.5f * t));
     }
 }
-struct ImageDesc { uint64_t offset_px; uint32_t width, height; };  // oracle-side image table entry
+#include "srgb_lut.h"
+struct ImageDesc { uint64_t offset_px; uint32_t width, height; };  // oracle-side image table entry; height bit 31 = sRGB texels
 
 static void fine_area(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b, int nb) {
     using bl::V4;
@@ -2097,12 +2098,15 @@ static void fine_area(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b, int nb) {
                                 uint32_t width_height = info.rd((size_t)io + 7u);
                                 float ew = (float)(width_height >> 16), eh = (float)(width_height & 0xffffu);
                                 ImageDesc desc = img_table.rd(index);
+                                const uint32_t img_h = desc.height & 0x7fffffffu;
+                                const bool img_srgb = (desc.height >> 31) != 0u;  // render.go:137 Rgba8Srgb: decoded by the texture unit
                                 auto texel = [&](int32_t tx, int32_t ty) {
-                                    if (tx < 0 || ty < 0 || (uint32_t)tx >= desc.width || (uint32_t)ty >= desc.height) return V4{0, 0, 0, 0};
+                                    if (tx < 0 || ty < 0 || (uint32_t)tx >= desc.width || (uint32_t)ty >= img_h) return V4{0, 0, 0, 0};
                                     size_t ix = (size_t)desc.offset_px + (size_t)ty * desc.width + (size_t)tx;
                                     if (ix >= img_n) return V4{0, 0, 0, 0};
                                     const uint8_t* p = img_px + ix * 4;
                                     V4 c{(float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, (float)p[3] / 255.0f};
+                                    if (img_srgb) { c.x = kSrgbToLinear[p[0]]; c.y = kSrgbToLinear[p[1]]; c.z = kSrgbToLinear[p[2]]; }
                                     return V4{c.x * c.w, c.y * c.w, c.z * c.w, c.w};  // premul_alpha
                                 };
                                 for (int i = 0; i < 4; i++) {

@@ -98,9 +98,10 @@ class OracleEngine:
                         blobs = []
                         off = 0
                         for i, iid in enumerate(b["ids"]):
-                            im, w, h, _ = self.images.get(iid, (np.zeros(4, np.uint8), 1, 1, 0))
+                            im, w, h, fmt = self.images.get(iid, (np.zeros(4, np.uint8), 1, 1, 0))
                             table[i, 0] = off
-                            table[i, 1] = np.uint64(w) | (np.uint64(h) << np.uint64(32))
+                            hh = int(h) | ((1 << 31) if fmt == 1 else 0)  # JL_RGBA8_SRGB: texels decode to linear
+                            table[i, 1] = np.uint64(w) | (np.uint64(hh) << np.uint64(32))
                             blobs.append(im)
                             off += im.nbytes // 4
                         blob = np.concatenate(blobs) if blobs else np.zeros(4, np.uint8)

@@ -47,6 +47,13 @@ def test_c4_clips_gradients_blends(engine):
     compare(engine, s, p)
 
 
+def test_images_srgb_bilinear(engine):
+    s, p = scenes.scene_images()
+    r = compare(engine, s, p)
+    img = r["image"].view(np.float16).astype(np.float32)
+    assert not np.array_equal(img[40, 30], img[41, 31])  # the image brush really painted texels
+
+
 def test_non_multiple_of_16_target(engine):
     s, p = scenes.scene_c3(400, 256)
     p.width, p.height = 250, 199

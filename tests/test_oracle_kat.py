@@ -133,3 +133,27 @@ def test_float16_and_span_kats(built):
     assert np.array_equal(got, want)
     # the stroke style word of C1: stroke | miter | f16(4.0) (encoding/path.go:86-120)
     assert int(KAT["styles_u32"][2], 16) == 0x80000000 | 0x10000000 | 0x4400
+
+
+def test_image_brush_srgb_decode_kat():
+    """A constant opaque sRGB image under an identity brush transform: every covered pixel is the decoded
+    linear colour, c <= 0.04045 ? c/12.92 : ((c+0.055)/1.055)^2.4 of the 8-bit code (rgba8unorm-srgb)."""
+    import jello_amd
+    from jello_amd import Brush, Fill, Path, RenderParams, Scene
+    from oracle import oracle_engine
+    px = np.zeros((8, 8, 4), np.uint8)
+    px[:, :] = (188, 64, 10, 255)
+    s = Scene()
+    s.fill(Fill.NonZero, None, Brush.image(px, key=7), (1, 0, 0, 1, 16, 16), Path.rect(16, 16, 24, 24))
+    p = RenderParams(32, 32)
+    rec = jello_amd.Host().record(s, p)
+    eng = oracle_engine.OracleEngine()
+    eng.run(rec)
+    img = eng.target(rec).view(np.float16).astype(np.float64).reshape(32, 32, 4)
+    def lin(c):
+        c = c / 255.0
+        return c / 12.92 if c <= 0.04045 else ((c + 0.055) / 1.055) ** 2.4
+    want = np.array([lin(188), lin(64), lin(10), 1.0])
+    got = img[19, 19]  # interior pixel: all four bilinear taps inside the image
+    assert np.all(np.abs(got - want) <= 2e-3 * np.maximum(want, 1e-3)), (got, want)
+    assert tuple(img[5, 5]) == (0.0, 0.0, 0.0, 0.0)

@@ -461,6 +461,8 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
         case JH_PATH_TILING_SETUP: rc = jh_launch_path_tiling_setup(L); break;
         case JH_PATH_TILING: rc = jh_launch_path_tiling(L); break;
         case JH_FINE_AREA: rc = jh_launch_fine_area(L); break;
+        case JH_FINE_MSAA8: rc = jh_launch_fine_msaa(L, 8); break;
+        case JH_FINE_MSAA16: rc = jh_launch_fine_msaa(L, 16); break;
         default:
             if (ctx->profiling) { ctx->free_events.push_back(pe.start); ctx->free_events.push_back(pe.stop); }
             return fail(ctx, JH_ERR_UNSUPPORTED, std::string("stage not implemented: ") + jh_stage_name(stage));

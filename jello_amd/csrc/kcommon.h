@@ -239,3 +239,4 @@ int jh_launch_coarse(const JhLaunch& L);
 int jh_launch_path_tiling_setup(const JhLaunch& L);
 int jh_launch_path_tiling(const JhLaunch& L);
 int jh_launch_fine_area(const JhLaunch& L);
+int jh_launch_fine_msaa(const JhLaunch& L, int samples);  // 8 or 16

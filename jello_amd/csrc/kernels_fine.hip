@@ -227,20 +227,250 @@ JD void load_segraw_clamped(const float* __restrict__ segments, uint32_t segment
     p0x = a.x; p0y = a.y; p1x = b.x; p1y = b.y; ye = c.x;
 }
 
+// ------------------------------------------------------------------------------------------------
+// fill_path_ms / fill_path_ms_evenodd (fine.wgsl:148-711): multisampled coverage, 8 or 16 samples per pixel.
+// The WGSL is written for a 64-invocation workgroup with workgroup-memory atomics -- exactly one wave64 with
+// LDS atomics here, so this is a direct restatement: count pass (lane = segment), wave prefix sum, load-balanced
+// pixel pass (lane = pixel touched by a segment; binary search over the prefix sums) that bumps SWAR-packed
+// winding deltas, then the x/y prefix and the per-sample resolve.  All integer; every atomic is a commutative
+// add/xor, so the words do not depend on the order.  WGSL rules: shift amounts are taken modulo 32,
+// out-of-range workgroup indices drop the write, float->int conversions saturate (dmath.h).
+// ------------------------------------------------------------------------------------------------
+struct MsLds {
+    uint32_t sh_count[64];
+    uint32_t sh_winding_y[4], sh_winding_y_prefix[4];
+    uint32_t sh_winding[64];
+    uint32_t sh_samples[1024];
+};
+JD uint32_t shl32(uint32_t v, uint32_t s) { return v << (s & 31u); }
+JD uint32_t shr32(uint32_t v, uint32_t s) { return v >> (s & 31u); }
+JD uint32_t ms_span(float a, float b) { return to_u32(fmax_(ceil_(fmax_(a, b)) - floor_(fmin_(a, b)), 1.0f)); }
+
+template <int SAMPLES>
+JD void fill_path_ms(MsLds& T, uint32_t lane, uint32_t size_and_rule, uint32_t seg_data, int32_t backdrop, const float* __restrict__ segments,
+                     uint32_t segments_n, const uint32_t* __restrict__ mask_lut, uint32_t mask_lut_n, float (&area)[4]) {
+    const bool even_odd = (size_and_rule & 1u) != 0u;  // uniform
+    const uint32_t n_segs = size_and_rule >> 1;
+    const uint32_t MASK_WIDTH = SAMPLES == 8 ? 32u : 64u, MASK_HEIGHT = MASK_WIDTH;
+    const uint32_t WORDS = even_odd ? 1u : (SAMPLES == 8 ? 2u : 4u);
+    const uint32_t SH_SAMPLES_SIZE = SAMPLES == 8 ? 512u : 1024u;
+    const uint32_t FULL = SAMPLES == 8 ? 0xffu : 0xffffu;
+    const uint32_t th_ix = lane, lx = lane & 3u, ly = lane >> 2;
+    const uint32_t init = even_odd ? 0u : 0x80808080u;
+    if (even_odd) {
+        if (th_ix < 16u) {
+            if (th_ix == 0u) T.sh_winding_y[0] = 0u;
+            T.sh_winding[th_ix] = 0u;
+        }
+    } else {
+        if (th_ix < 4u) T.sh_winding_y[th_ix] = init;
+        T.sh_winding[th_ix] = init;
+    }
+    for (uint32_t i = 0u; i < 4u * WORDS; i++) T.sh_samples[th_ix * 4u * WORDS + i] = init;
+    wave_sync();
+    auto load_seg = [&](uint32_t so, float& p0x, float& p0y, float& p1x, float& p1y) {
+        p0x = 0.0f; p0y = 0.0f; p1x = 0.0f; p1y = 0.0f;
+        if (so < segments_n) {
+            const float2* sp = (const float2*)(segments + (size_t)so * 6);
+            float2 a = sp[0], b = sp[1];
+            p0x = a.x; p0y = a.y; p1x = b.x; p1y = b.y;
+        }
+    };
+    const uint32_t n_batch = (n_segs + 63u) / 64u;
+    for (uint32_t batch = 0u; batch < n_batch; batch++) {
+        const uint32_t slice_size = umin_(n_segs - batch * 64u, 64u);
+        uint32_t count = 0u;
+        if (th_ix < slice_size) {  // fine.wgsl:176-203 / :532-555
+            float x0, y0, x1, y1;
+            load_seg(seg_data + batch * 64u + th_ix, x0, y0, x1, y1);
+            float y_edge_f = 16.0f;
+            const int32_t delta = (x1 <= x0) ? 1 : -1;
+            if (x0 == 0.0f) y_edge_f = y0;
+            else if (x1 == 0.0f) y_edge_f = y1;
+            if (!(y0 == y1 && y0 == floor_(y0))) count = ms_span(x0, x1) + ms_span(y0, y1) - 1u;
+            const uint32_t y_edge = to_u32(ceil_(y_edge_f));
+            if (y_edge < 16u) {
+                if (even_odd) atomicXor(&T.sh_winding_y[0], shl32(1u, y_edge));
+                else atomicAdd(&T.sh_winding_y[y_edge >> 2], shl32((uint32_t)delta, (y_edge & 3u) << 3));
+            }
+        }
+        const uint32_t incl = wave_incl_scan_u32(count);  // :205-215 (Hillis-Steele in the WGSL)
+        T.sh_count[th_ix] = incl;
+        wave_sync();
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(slice_size - 1u));
+        for (uint32_t i = th_ix; i < total; i += 64u) {  // :217-383 / :566-675
+            uint32_t lo = 0u, hi = slice_size;
+            while (hi > lo + 1u) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (i >= T.sh_count[mid - 1u]) lo = mid; else hi = mid;
+            }
+            const uint32_t el_ix = lo;
+            const bool last_pixel = i + 1u == T.sh_count[el_ix];
+            const uint32_t sub_ix = i - (el_ix > 0u ? T.sh_count[el_ix - 1u] : 0u);
+            float in0x, in0y, in1x, in1y;
+            load_seg(seg_data + batch * 64u + el_ix, in0x, in0y, in1x, in1y);
+            const bool is_down = in1y >= in0y;
+            const float xy0x = is_down ? in0x : in1x, xy0y = is_down ? in0y : in1y;
+            const float xy1x = is_down ? in1x : in0x, xy1y = is_down ? in1y : in0y;
+            const float dx = abs_(xy1x - xy0x);
+            const float dy = xy1y - xy0y;
+            const float idxdy = 1.0f / (dx + dy);
+            float a = dx * idxdy;
+            const bool is_positive_slope = xy1x >= xy0x;
+            const float x_sign = is_positive_slope ? 1.0f : -1.0f;
+            const float xt0 = floor_(xy0x * x_sign);
+            const float c = xy0x * x_sign - xt0;
+            const float y0i = floor_(xy0y);
+            const float ytop = y0i + 1.0f;
+            const float b = fmin_((dy * c + dx * (ytop - xy0y)) * idxdy, 0.99999994f);
+            const uint32_t count_x = ms_span(xy0x, xy1x) - 1u;
+            const uint32_t cnt = count_x + ms_span(xy0y, xy1y);
+            const float robust_err = floor_(a * ((float)cnt - 1.0f) + b) - (float)count_x;
+            if (robust_err != 0.0f) a -= 2e-7f * sign_(robust_err);
+            const int32_t x0i = to_i32(xt0 * x_sign + 0.5f * (x_sign - 1.0f));
+            const float zf = a * (float)sub_ix + b;
+            const float z = floor_(zf);
+            const int32_t x = x0i + to_i32(x_sign * z);
+            const int32_t y = (int32_t)((uint32_t)to_i32(y0i) + sub_ix - (uint32_t)to_i32(z));
+            bool is_delta, is_bump = false;
+            const float zp = floor_(a * (float)(sub_ix - 1u) + b);
+            if (sub_ix == 0u) {
+                is_delta = y0i == xy0y;
+                is_bump = even_odd ? (xy0x == 0.0f) : (xy0x == 0.0f && y0i != xy0y);
+            } else {
+                is_delta = z == zp;
+                is_bump = is_positive_slope && !is_delta;
+            }
+            const uint32_t pix_ix = (uint32_t)y * 16u + (uint32_t)x;
+            if ((uint32_t)x < 15u && (uint32_t)y < 16u && is_delta) {
+                if (even_odd) {
+                    atomicXor(&T.sh_winding[y], shl32(2u, (uint32_t)x));
+                } else {
+                    const uint32_t delta_pix = pix_ix + 1u;
+                    atomicAdd(&T.sh_winding[delta_pix >> 2], shl32(is_down ? 1u : 0xffffffffu, (delta_pix & 3u) << 3));
+                }
+            }
+            const uint32_t mask_block = (is_positive_slope ? 1u : 0u) * (MASK_WIDTH * MASK_HEIGHT / 2u);
+            const float half_height = (float)(MASK_HEIGHT / 2u);
+            const float mask_row = floor_(fmin_(a * half_height, half_height - 1.0f)) * (float)MASK_WIDTH;
+            const float mask_col = floor_((zf - z) * (float)MASK_WIDTH);
+            const uint32_t mask_ix = mask_block + to_u32(mask_row + mask_col);
+            uint32_t mask;
+            if (SAMPLES == 8) {
+                const uint32_t wi = mask_ix / 4u;
+                mask = shr32(wi < mask_lut_n ? mask_lut[wi] : 0u, (mask_ix % 4u) * 8u) & 0xffu;
+            } else {
+                const uint32_t wi = mask_ix / 2u;
+                mask = shr32(wi < mask_lut_n ? mask_lut[wi] : 0u, (mask_ix % 2u) * 16u) & 0xffffu;
+            }
+            const float sf = (float)SAMPLES;
+            if (sub_ix == 0u && !is_bump) mask &= shl32(FULL, to_u32(round_(sf * (xy0y - (float)y))));
+            if (last_pixel && xy1x != 0.0f) mask &= ~shl32(FULL, to_u32(round_(sf * (xy1y - (float)y))));
+            if (even_odd) {
+                if (is_bump) mask ^= FULL;
+                if (pix_ix < SH_SAMPLES_SIZE) atomicXor(&T.sh_samples[pix_ix], mask);
+            } else {
+                const uint32_t bump_delta = is_down ? 0x1010101u : (uint32_t)-0x1010101;
+#pragma unroll
+                for (uint32_t half = 0u; half < (SAMPLES == 8 ? 1u : 2u); half++) {
+                    const uint32_t m8 = (mask >> (8u * half)) & 0xffu;
+                    const uint32_t ma = m8 ^ (m8 << 7);
+                    const uint32_t mb = ma ^ (ma << 14);
+                    const uint32_t e0 = mb & 0x1010101u, e1 = (mb >> 4) & 0x1010101u;
+                    uint32_t s0 = is_down ? (uint32_t)(-(int32_t)e0) : e0, s1 = is_down ? (uint32_t)(-(int32_t)e1) : e1;
+                    if (is_bump) { s0 += bump_delta; s1 += bump_delta; }
+                    const uint32_t w0 = pix_ix * WORDS + 2u * half;
+                    if (w0 < SH_SAMPLES_SIZE) atomicAdd(&T.sh_samples[w0], s0);
+                    if (w0 + 1u < SH_SAMPLES_SIZE) atomicAdd(&T.sh_samples[w0 + 1u], s1);
+                }
+            }
+        }
+        wave_sync();
+    }
+    // resolve (:386-501 / :677-710)
+    if (even_odd) {
+        uint32_t scan_x = T.sh_winding[ly];
+        scan_x ^= scan_x << 1; scan_x ^= scan_x << 2; scan_x ^= scan_x << 4; scan_x ^= scan_x << 8;
+        uint32_t scan_y = T.sh_winding_y[0];
+        scan_y ^= scan_y << 1; scan_y ^= scan_y << 2; scan_y ^= scan_y << 4; scan_y ^= scan_y << 8;
+        const uint32_t row_parity = (scan_y >> ly) ^ (uint32_t)backdrop;
+#pragma unroll
+        for (uint32_t i = 0u; i < 4u; i++) {
+            const uint32_t pix_ix = th_ix * 4u + i;
+            const uint32_t samples = T.sh_samples[pix_ix];
+            const uint32_t pix_parity = row_parity ^ (scan_x >> (pix_ix % 16u));
+            const uint32_t pix_mask = (uint32_t)(-(int32_t)(pix_parity & 1u));
+            area[i] = (float)__builtin_popcount((samples ^ pix_mask) & FULL) * (SAMPLES == 8 ? 0.125f : 0.0625f);
+        }
+        wave_sync();  // the arrays are reused by the next fill
+        return;
+    }
+    const uint32_t major = th_ix;
+    uint32_t packed_w = T.sh_winding[major];
+    packed_w += (packed_w - 0x808080u) << 8;
+    packed_w += (packed_w - 0x8080u) << 16;
+    uint32_t packed_y = T.sh_winding_y[ly >> 2];
+    packed_y += (packed_y - 0x808080u) << 8;
+    packed_y += (packed_y - 0x8080u) << 16;
+    uint32_t wind_y = (packed_y >> ((ly & 3u) << 3)) - 0x80u;
+    wave_sync();  // every lane has read sh_winding / sh_winding_y before they are overwritten
+    if ((ly & 3u) == 3u && lx == 0u) T.sh_winding_y_prefix[ly >> 2] = wind_y;
+    T.sh_winding[major] = ((packed_w >> 24) - 0x80u) * 0x1010101u;
+    wave_sync();
+    for (uint32_t i = (major & ~3u); i < major; i++) packed_w += T.sh_winding[i];
+    for (uint32_t i = 0u; i < (ly >> 2); i++) wind_y += T.sh_winding_y_prefix[i];
+#pragma unroll
+    for (uint32_t i = 0u; i < 4u; i++) {
+        const uint32_t pix_ix = th_ix * 4u + i;
+        const uint32_t expected_zero = (((packed_w >> (i * 8u)) + wind_y) & 0xffu) - (uint32_t)backdrop;
+        if (expected_zero >= 256u) {
+            area[i] = 1.0f;
+        } else if (SAMPLES == 8) {
+            const uint32_t samples0 = T.sh_samples[pix_ix * 2u], samples1 = T.sh_samples[pix_ix * 2u + 1u];
+            const uint32_t xored0 = (expected_zero * 0x1010101u) ^ samples0;
+            const uint32_t xored0_2 = xored0 | (xored0 * 2u);
+            const uint32_t xored1 = (expected_zero * 0x1010101u) ^ samples1;
+            const uint32_t xored1_2 = xored1 | (xored1 >> 1);
+            const uint32_t xored2 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
+            const uint32_t xored4 = xored2 | (xored2 * 4u);
+            const uint32_t xored8 = xored4 | (xored4 * 16u);
+            area[i] = (float)__builtin_popcount(xored8 & 0xC0C0C0C0u) * 0.125f;
+        } else {
+            const uint32_t e = expected_zero * 0x1010101u;
+            const uint32_t xored0 = e ^ T.sh_samples[pix_ix * 4u], xored1 = e ^ T.sh_samples[pix_ix * 4u + 1u];
+            const uint32_t xored2 = e ^ T.sh_samples[pix_ix * 4u + 2u], xored3 = e ^ T.sh_samples[pix_ix * 4u + 3u];
+            const uint32_t xored0_2 = xored0 | (xored0 * 2u), xored1_2 = xored1 | (xored1 >> 1);
+            const uint32_t xored01 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
+            const uint32_t xored01_4 = xored01 | (xored01 * 4u);
+            const uint32_t xored2_2 = xored2 | (xored2 * 2u), xored3_2 = xored3 | (xored3 >> 1);
+            const uint32_t xored23 = (xored2_2 & 0xAAAAAAAAu) | (xored3_2 & 0x55555555u);
+            const uint32_t xored23_4 = xored23 | (xored23 >> 2);
+            const uint32_t xored4 = (xored01_4 & 0xCCCCCCCCu) | (xored23_4 & 0x33333333u);
+            const uint32_t xored8 = xored4 | (xored4 * 16u);
+            area[i] = (float)__builtin_popcount(xored8 & 0xF0F0F0F0u) * 0.0625f;
+        }
+    }
+    wave_sync();  // the arrays are reused by the next fill
+}
+
+template <int AA> struct FineLdsSel { typedef MsLds type; };
+template <> struct FineLdsSel<0> { typedef FillLds type; };
+
 // Pixel ownership = the WGSL's: lane = ly*4 + lx (workgroup (4,16)), pixel i = 0..3 at column 4*lx + i.
-template <bool CLIPS, bool PAINTS>
+// AA = 0: analytic area coverage (fine_area); 8 / 16: fine_msaa8 / fine_msaa16.
+template <int AA, bool CLIPS, bool PAINTS>
 __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu(CLIPS ? 2 : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU), CLIPS ? 2 : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU)))) void k_fine_area(const JlConfig* __restrict__ cfg, const float* __restrict__ segments, uint32_t segments_n,
                                                   const uint32_t* __restrict__ ptcl, uint32_t ptcl_n, const uint32_t* __restrict__ info,
                                                   uint32_t info_n, Buf<V4> blend_spill, uint16_t* __restrict__ output, uint32_t out_w,
                                                   uint32_t out_h, const uint16_t* __restrict__ gradients, uint32_t grad_h, FineImages images,
-                                                  uint32_t tiles_x) {
+                                                  uint32_t tiles_x, const uint32_t* __restrict__ mask_lut, uint32_t mask_lut_n) {
     // FINE_WAVES independent waves (= tiles, side by side in x) per workgroup: the CU runs at most 16 workgroups, so
     // single-wave workgroups would cap the occupancy at 4 waves per SIMD.  The waves never synchronise with each other.
     __shared__ uint32_t win_all[FINE_WAVES][JL_PTCL_INCREMENT];  // wave-private PTCL windows
-    __shared__ FillLds F_all[FINE_WAVES];
+    __shared__ typename FineLdsSel<AA>::type F_all[FINE_WAVES];
     const uint32_t wave_in_wg = threadIdx.x >> 6;
     uint32_t* const win = win_all[wave_in_wg];
-    FillLds& F = F_all[wave_in_wg];
+    auto& F = F_all[wave_in_wg];
     const uint32_t tile_x = blockIdx.x * FINE_WAVES + wave_in_wg;
     if (tile_x >= tiles_x) return;  // tiles_x = the dispatch's x size
     if (ptcl_n == 0u || ptcl[0] == ~0u) return;  // fine.wgsl:889-893
@@ -263,7 +493,9 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
         uint32_t gi = win_base + lane;
         win[lane] = gi < ptcl_n ? ptcl[gi] : 0u;
     }
-    if (lane < 16u) F.contrib[lane][64] = 0.0f;  // the "no pair" slot
+    if constexpr (AA == 0) {
+        if (lane < 16u) F.contrib[lane][64] = 0.0f;  // the "no pair" slot
+    }
     wave_sync();
     uint32_t cmd_ix = 0u;  // relative to win_base
     auto P = [&](uint32_t rel) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)win[rel & (JL_PTCL_INCREMENT - 1u)]); };
@@ -289,6 +521,7 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
 
     // Evaluate the batch that starts at segment `so` (uniform).
     auto build_batch = [&](uint32_t so) {
+      if constexpr (AA == 0) {
         wave_sync();  // stage 4 of the previous batch is done with F
         // The window always starts at the batch's first segment (so every batch can fill its 64 pair slots);
         // it was prefetched while the previous batch was evaluated unless the fills are not contiguous.
@@ -434,6 +667,9 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
             }
         }
         wave_sync();
+      } else {
+        (void)so;
+      }
     };
 
     for (uint32_t guard = 0; guard < (1u << 24); guard++) {
@@ -452,6 +688,7 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
             int32_t backdrop = (int32_t)W(3);
             uint32_t n_segs = size_and_rule >> 1;
             bool even_odd = (size_and_rule & 1u) != 0u;
+          if constexpr (AA == 0) {
             float backdrop_f = (float)backdrop;
 #pragma unroll
             for (int k = 0; k < 4; k++) area[k] = backdrop_f;
@@ -486,6 +723,10 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                 for (int k = 0; k < 4; k++) area[k] = fmin_(abs_(area[k]), 1.0f);
             }
+          } else {
+            (void)n_segs; (void)even_odd;
+            fill_path_ms<AA>(F, lane, size_and_rule, seg_data, backdrop, segments, segments_n, mask_lut, mask_lut_n, area);
+          }
             cmd_ix += 4u;
             if (cmd_ix + 4u < JL_PTCL_INCREMENT && W(4) == JL_CMD_COLOR) {  // the usual pair: no second trip through the decoder
                 V4 fg = v4(u2f(W(5)), u2f(W(6)), u2f(W(7)), u2f(W(8)));
@@ -733,10 +974,14 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
 
 }  // namespace
 
-// [config, segments, ptcl, info, blend_spill, output image, gradients image, images[]]
-int jh_launch_fine_area(const JhLaunch& L) {
-    if (L.nb < 7) return -1;
+// [config, segments, ptcl, info, blend_spill, output image, gradients image, images[] (, mask_lut for MSAA)]
+// aa = 0: fine_area, 8: fine_msaa8, 16: fine_msaa16
+static int launch_fine(const JhLaunch& L, int aa) {
+    if (L.nb < (aa ? 9 : 7)) return -1;
     if (L.gx == 0 || L.gy == 0) return 0;
+    const uint32_t* mask_lut = aa ? (const uint32_t*)L.b[8].ptr : nullptr;
+    uint32_t mask_lut_n = aa ? (uint32_t)(L.b[8].size / 4) : 0u;
+    if (!mask_lut) mask_lut_n = 0u;
     auto cfg = (const JlConfig*)L.b[0].ptr;
     uint32_t segments_n = (uint32_t)(L.b[1].size / sizeof(JlSegment));
     uint32_t ptcl_n = (uint32_t)(L.b[2].size / 4);
@@ -766,14 +1011,19 @@ int jh_launch_fine_area(const JhLaunch& L) {
     for (int i = 0; i < imgs.n; i++) paints = paints || imgs.px[i] != nullptr;
     const float* seg_ptr = (segments_n != 0u && L.b[1].ptr) ? (const float*)L.b[1].ptr : (const float*)cfg;  // see load_segraw_clamped
     if (seg_ptr == (const float*)cfg) segments_n = 0u;
-#define JH_FINE_LAUNCH(C, P)                                                                                                             \
-    hipLaunchKernelGGL((k_fine_area<C, P>), dim3((L.gx + FINE_WAVES - 1) / FINE_WAVES, L.gy), dim3(64 * FINE_WAVES), 0, L.stream, cfg, seg_ptr, segments_n,       \
-                       (const uint32_t*)L.b[2].ptr, ptcl_n, (const uint32_t*)L.b[3].ptr, info_n, spill, (uint16_t*)out.ptr, out.width, \
-                       out.height, (const uint16_t*)grad.ptr, grad_h, imgs, L.gx)
-    if (clips && paints) JH_FINE_LAUNCH(true, true);
-    else if (clips) JH_FINE_LAUNCH(true, false);
-    else if (paints) JH_FINE_LAUNCH(false, true);
-    else JH_FINE_LAUNCH(false, false);
+#define JH_FINE_LAUNCH(A, C, P)                                                                                                          \
+    hipLaunchKernelGGL((k_fine_area<A, C, P>), dim3((L.gx + FINE_WAVES - 1) / FINE_WAVES, L.gy), dim3(64 * FINE_WAVES), 0, L.stream, cfg, seg_ptr, \
+                       segments_n, (const uint32_t*)L.b[2].ptr, ptcl_n, (const uint32_t*)L.b[3].ptr, info_n, spill, (uint16_t*)out.ptr,         \
+                       out.width, out.height, (const uint16_t*)grad.ptr, grad_h, imgs, L.gx, mask_lut, mask_lut_n)
+    if (aa == 8) JH_FINE_LAUNCH(8, true, true);  // the multisampled stages come in the full flavour only
+    else if (aa == 16) JH_FINE_LAUNCH(16, true, true);
+    else if (clips && paints) JH_FINE_LAUNCH(0, true, true);
+    else if (clips) JH_FINE_LAUNCH(0, true, false);
+    else if (paints) JH_FINE_LAUNCH(0, false, true);
+    else JH_FINE_LAUNCH(0, false, false);
 #undef JH_FINE_LAUNCH
     return 0;
 }
+
+int jh_launch_fine_area(const JhLaunch& L) { return launch_fine(L, 0); }
+int jh_launch_fine_msaa(const JhLaunch& L, int samples) { return launch_fine(L, samples); }

@@ -588,7 +588,10 @@ Renderer::Result Renderer::render_full(const Encoding& enc, Resolver& resolver, 
     switch (params.antialiasing_method) {
         case AaConfig::Area: recording.dispatch(shaders.fine_area, wg.fine, fine_bindings); break;
         default: {
-            if (mask_buf_.kind == ResourceProxy::None) {
+            // render.go:495-507 caches one LUT per renderer and would keep the 8-sample table after a switch to
+            // 16 samples; here the cached buffer is tied to the mode it was built for.
+            if (mask_buf_.kind == ResourceProxy::None || mask_aa_ != params.antialiasing_method) {
+                mask_aa_ = params.antialiasing_method;
                 std::vector<uint8_t> lut = params.antialiasing_method == AaConfig::Msaa16 ? make_mask_lut16() : make_mask_lut8();
                 mask_buf_ = ResourceProxy::of(recording.upload("mask lut", lut.data(), lut.size()));
             }

@@ -135,6 +135,7 @@ class Renderer {
 
    private:
     ResourceProxy mask_buf_;
+    AaConfig mask_aa_ = AaConfig::Area;
     ImageProxy empty_;
     std::map<uint64_t, ImageProxy> images_;
 };

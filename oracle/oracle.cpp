@@ -1850,7 +1850,225 @@ static float extend_mode(float t, uint32_t mode) {  // fine.wgsl:800-812
 #include "srgb_lut.h"
 struct ImageDesc { uint64_t offset_px; uint32_t width, height; };  // oracle-side image table entry; height bit 31 = sRGB texels
 
-static void fine_area(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b, int nb) {
+
+// ------------------------------------------------------------------------------------------------
+// fill_path_ms / fill_path_ms_evenodd (fine.wgsl:148-711): multisampled coverage of one 16x16 tile for one
+// CMD_FILL, evaluated for the whole workgroup at once (the WGSL is workgroup-cooperative; its result for an
+// invocation depends only on the fill and the segments).  SWAR integer arithmetic; every atomic is a
+// commutative add/xor, so the sequential order here gives the same words.  WGSL rules applied: shifts take
+// the amount modulo 32, out-of-range workgroup/storage indices read zero and drop writes, float->int
+// conversions saturate.  SAMPLES is 8 or 16; mask_lut per renderer/mask.go:43-105.
+// ------------------------------------------------------------------------------------------------
+static inline uint32_t shl32(uint32_t v, uint32_t s) { return v << (s & 31u); }
+static inline uint32_t shr32(uint32_t v, uint32_t s) { return v >> (s & 31u); }
+
+struct MsTile {
+    uint32_t sh_count[64];
+    uint32_t sh_winding_y[4], sh_winding_y_prefix[4];
+    uint32_t sh_winding[64];
+    uint32_t sh_samples[1024];
+};
+
+static void fill_path_ms_tile(int SAMPLES, uint32_t size_and_rule, uint32_t seg_data, int32_t backdrop, const View<Segment>& segments,
+                              const View<uint32_t>& mask_lut, float* area /*[256], pixel = y*16+x*/) {
+    const bool even_odd = (size_and_rule & 1u) != 0u;
+    const uint32_t n_segs = size_and_rule >> 1;
+    const uint32_t MASK_WIDTH = SAMPLES == 8 ? 32u : 64u, MASK_HEIGHT = MASK_WIDTH;
+    const uint32_t WORDS = even_odd ? 1u : (SAMPLES == 8 ? 2u : 4u);  // sh_samples words per pixel
+    const uint32_t SH_SAMPLES_SIZE = SAMPLES == 8 ? 512u : 1024u;
+    const uint32_t FULL = SAMPLES == 8 ? 0xffu : 0xffffu;
+    MsTile T;
+    if (even_odd) {
+        T.sh_winding_y[0] = 0u;
+        for (int i = 0; i < 16; i++) T.sh_winding[i] = 0u;
+        for (uint32_t i = 0; i < 256u; i++) T.sh_samples[i] = 0u;
+    } else {
+        for (int i = 0; i < 4; i++) T.sh_winding_y[i] = 0x80808080u;
+        for (int i = 0; i < 64; i++) T.sh_winding[i] = 0x80808080u;
+        for (uint32_t i = 0; i < 256u * WORDS; i++) T.sh_samples[i] = 0x80808080u;
+    }
+    auto samples_add = [&](uint32_t ix, uint32_t v) { if (ix < SH_SAMPLES_SIZE) T.sh_samples[ix] += v; };
+    auto samples_xor = [&](uint32_t ix, uint32_t v) { if (ix < SH_SAMPLES_SIZE) T.sh_samples[ix] ^= v; };
+    const uint32_t n_batch = (n_segs + 63u) / 64u;
+    for (uint32_t batch = 0; batch < n_batch; batch++) {
+        const uint32_t slice_size = std::min(n_segs - batch * 64u, 64u);
+        for (uint32_t th = 0; th < 64u; th++) {  // fine.wgsl:176-203 / :532-555
+            uint32_t count = 0u;
+            if (th < slice_size) {
+                Segment seg = segments.rd((size_t)seg_data + batch * 64u + th);
+                float x0 = seg.p0[0], y0 = seg.p0[1], x1 = seg.p1[0], y1 = seg.p1[1];
+                float y_edge_f = 16.0f;
+                int32_t delta = (x1 <= x0) ? 1 : -1;
+                if (x0 == 0.0f) y_edge_f = y0;
+                else if (x1 == 0.0f) y_edge_f = y1;
+                if (!(y0 == y1 && y0 == floor_(y0))) count = span(x0, x1) + span(y0, y1) - 1u;
+                uint32_t y_edge = to_u32(ceil_(y_edge_f));
+                if (y_edge < 16u) {
+                    if (even_odd) T.sh_winding_y[0] ^= shl32(1u, y_edge);
+                    else T.sh_winding_y[y_edge >> 2] += shl32((uint32_t)delta, (y_edge & 3u) << 3);
+                }
+            }
+            T.sh_count[th] = count;
+        }
+        for (uint32_t th = 1; th < slice_size; th++) T.sh_count[th] += T.sh_count[th - 1u];  // inclusive prefix, :205-215
+        const uint32_t total = T.sh_count[slice_size - 1u];
+        for (uint32_t i = 0; i < total; i++) {  // :217-383 / :566-675
+            uint32_t lo = 0u, hi = slice_size;
+            while (hi > lo + 1u) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (i >= T.sh_count[mid - 1u]) lo = mid; else hi = mid;
+            }
+            const uint32_t el_ix = lo;
+            const bool last_pixel = i + 1u == T.sh_count[el_ix];
+            const uint32_t sub_ix = i - (el_ix > 0u ? T.sh_count[el_ix - 1u] : 0u);
+            Segment seg = segments.rd((size_t)seg_data + batch * 64u + el_ix);
+            V2 in0{seg.p0[0], seg.p0[1]}, in1{seg.p1[0], seg.p1[1]};
+            const bool is_down = in1.y >= in0.y;
+            const V2 xy0 = is_down ? in0 : in1, xy1 = is_down ? in1 : in0;
+            const float dx = abs_(xy1.x - xy0.x);
+            const float dy = xy1.y - xy0.y;
+            const float idxdy = 1.0f / (dx + dy);
+            float a = dx * idxdy;
+            const bool is_positive_slope = xy1.x >= xy0.x;
+            const float x_sign = is_positive_slope ? 1.0f : -1.0f;
+            const float xt0 = floor_(xy0.x * x_sign);
+            const float c = xy0.x * x_sign - xt0;
+            const float y0i = floor_(xy0.y);
+            const float ytop = y0i + 1.0f;
+            const float b = fmin_((dy * c + dx * (ytop - xy0.y)) * idxdy, ONE_MINUS_ULP);
+            const uint32_t count_x = span(xy0.x, xy1.x) - 1u;
+            const uint32_t count = count_x + span(xy0.y, xy1.y);
+            const float robust_err = floor_(a * ((float)count - 1.0f) + b) - (float)count_x;
+            if (robust_err != 0.0f) a -= ROBUST_EPSILON * sign_(robust_err);
+            const int32_t x0i = to_i32(xt0 * x_sign + 0.5f * (x_sign - 1.0f));
+            const float zf = a * (float)sub_ix + b;
+            const float z = floor_(zf);
+            const int32_t x = x0i + to_i32(x_sign * z);
+            const int32_t y = (int32_t)((uint32_t)to_i32(y0i) + sub_ix - (uint32_t)to_i32(z));
+            bool is_delta, is_bump = false;
+            const float zp = floor_(a * (float)(sub_ix - 1u) + b);
+            if (sub_ix == 0u) {
+                is_delta = y0i == xy0.y;
+                is_bump = even_odd ? (xy0.x == 0.0f) : (xy0.x == 0.0f && y0i != xy0.y);
+            } else {
+                is_delta = z == zp;
+                is_bump = is_positive_slope && !is_delta;
+            }
+            const uint32_t pix_ix = (uint32_t)y * 16u + (uint32_t)x;
+            if ((uint32_t)x < 15u && (uint32_t)y < 16u) {
+                if (is_delta) {
+                    if (even_odd) {
+                        T.sh_winding[y] ^= shl32(2u, (uint32_t)x);
+                    } else {
+                        const uint32_t delta_pix = pix_ix + 1u;
+                        T.sh_winding[delta_pix >> 2] += shl32(is_down ? 1u : 0xffffffffu, (delta_pix & 3u) << 3);
+                    }
+                }
+            }
+            const uint32_t mask_block = (is_positive_slope ? 1u : 0u) * (MASK_WIDTH * MASK_HEIGHT / 2u);
+            const float half_height = (float)(MASK_HEIGHT / 2u);
+            const float mask_row = floor_(fmin_(a * half_height, half_height - 1.0f)) * (float)MASK_WIDTH;
+            const float mask_col = floor_((zf - z) * (float)MASK_WIDTH);
+            const uint32_t mask_ix = mask_block + to_u32(mask_row + mask_col);
+            uint32_t mask;
+            if (SAMPLES == 8) mask = shr32(mask_lut.rd(mask_ix / 4u), (mask_ix % 4u) * 8u) & 0xffu;
+            else mask = shr32(mask_lut.rd(mask_ix / 2u), (mask_ix % 2u) * 16u) & 0xffffu;
+            const float sf = (float)SAMPLES;
+            if (sub_ix == 0u && !is_bump) mask &= shl32(FULL, to_u32(round_(sf * (xy0.y - (float)y))));
+            if (last_pixel && xy1.x != 0.0f) mask &= ~shl32(FULL, to_u32(round_(sf * (xy1.y - (float)y))));
+            if (even_odd) {
+                if (is_bump) mask ^= FULL;
+                samples_xor(pix_ix, mask);
+            } else {
+                const uint32_t bump_delta = is_down ? 0x1010101u : (uint32_t)-0x1010101;
+                for (uint32_t half = 0; half < (SAMPLES == 8 ? 1u : 2u); half++) {
+                    const uint32_t m8 = (mask >> (8u * half)) & 0xffu;
+                    const uint32_t ma = m8 ^ (m8 << 7);
+                    const uint32_t mb = ma ^ (ma << 14);
+                    const uint32_t e0 = mb & 0x1010101u, e1 = (mb >> 4) & 0x1010101u;
+                    uint32_t s0 = is_down ? (uint32_t)(-(int32_t)e0) : e0, s1 = is_down ? (uint32_t)(-(int32_t)e1) : e1;
+                    if (is_bump) { s0 += bump_delta; s1 += bump_delta; }
+                    samples_add(pix_ix * WORDS + 2u * half, s0);
+                    samples_add(pix_ix * WORDS + 2u * half + 1u, s1);
+                }
+            }
+        }
+    }
+    // resolve (:386-501 / :677-710)
+    if (even_odd) {
+        uint32_t scan_y = T.sh_winding_y[0];
+        scan_y ^= scan_y << 1; scan_y ^= scan_y << 2; scan_y ^= scan_y << 4; scan_y ^= scan_y << 8;
+        for (uint32_t ly = 0; ly < 16u; ly++) {
+            uint32_t scan_x = T.sh_winding[ly];
+            scan_x ^= scan_x << 1; scan_x ^= scan_x << 2; scan_x ^= scan_x << 4; scan_x ^= scan_x << 8;
+            const uint32_t row_parity = (scan_y >> ly) ^ (uint32_t)backdrop;
+            for (uint32_t px = 0; px < 16u; px++) {
+                const uint32_t pix_ix = ly * 16u + px;
+                const uint32_t samples = T.sh_samples[pix_ix];
+                const uint32_t pix_parity = row_parity ^ (scan_x >> (pix_ix % 16u));
+                const uint32_t pix_mask = (uint32_t)(-(int32_t)(pix_parity & 1u));
+                area[pix_ix] = (float)__builtin_popcount((samples ^ pix_mask) & FULL) * (SAMPLES == 8 ? 0.125f : 0.0625f);
+            }
+        }
+        return;
+    }
+    uint32_t packed_w_th[64], wind_y_th[64];
+    for (uint32_t th = 0; th < 64u; th++) {
+        const uint32_t lx = th & 3u, ly = th >> 2;
+        uint32_t packed_w = T.sh_winding[th];  // major == th
+        packed_w += (packed_w - 0x808080u) << 8;
+        packed_w += (packed_w - 0x8080u) << 16;
+        uint32_t packed_y = T.sh_winding_y[ly >> 2];
+        packed_y += (packed_y - 0x808080u) << 8;
+        packed_y += (packed_y - 0x8080u) << 16;
+        const uint32_t wind_y = (packed_y >> ((ly & 3u) << 3)) - 0x80u;
+        if ((ly & 3u) == 3u && lx == 0u) T.sh_winding_y_prefix[ly >> 2] = wind_y;
+        packed_w_th[th] = packed_w;
+        wind_y_th[th] = wind_y;
+    }
+    uint32_t prefix_x_th[64];
+    for (uint32_t th = 0; th < 64u; th++) prefix_x_th[th] = ((packed_w_th[th] >> 24) - 0x80u) * 0x1010101u;  // stored to sh_winding[major]
+    for (uint32_t th = 0; th < 64u; th++) {
+        const uint32_t ly = th >> 2;
+        uint32_t packed_w = packed_w_th[th];
+        for (uint32_t i = (th & ~3u); i < th; i++) packed_w += prefix_x_th[i];
+        uint32_t wind_y = wind_y_th[th];
+        for (uint32_t i = 0; i < (ly >> 2); i++) wind_y += T.sh_winding_y_prefix[i];
+        for (uint32_t i = 0; i < 4u; i++) {
+            const uint32_t pix_ix = th * 4u + i;
+            const uint32_t expected_zero = (((packed_w >> (i * 8u)) + wind_y) & 0xffu) - (uint32_t)backdrop;
+            if (expected_zero >= 256u) {
+                area[pix_ix] = 1.0f;
+            } else if (SAMPLES == 8) {
+                const uint32_t samples0 = T.sh_samples[pix_ix * 2u], samples1 = T.sh_samples[pix_ix * 2u + 1u];
+                const uint32_t xored0 = (expected_zero * 0x1010101u) ^ samples0;
+                const uint32_t xored0_2 = xored0 | (xored0 * 2u);
+                const uint32_t xored1 = (expected_zero * 0x1010101u) ^ samples1;
+                const uint32_t xored1_2 = xored1 | (xored1 >> 1);
+                const uint32_t xored2 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
+                const uint32_t xored4 = xored2 | (xored2 * 4u);
+                const uint32_t xored8 = xored4 | (xored4 * 16u);
+                area[pix_ix] = (float)__builtin_popcount(xored8 & 0xC0C0C0C0u) * 0.125f;
+            } else {
+                const uint32_t e = expected_zero * 0x1010101u;
+                const uint32_t xored0 = e ^ T.sh_samples[pix_ix * 4u], xored1 = e ^ T.sh_samples[pix_ix * 4u + 1u];
+                const uint32_t xored2 = e ^ T.sh_samples[pix_ix * 4u + 2u], xored3 = e ^ T.sh_samples[pix_ix * 4u + 3u];
+                const uint32_t xored0_2 = xored0 | (xored0 * 2u), xored1_2 = xored1 | (xored1 >> 1);
+                const uint32_t xored01 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
+                const uint32_t xored01_4 = xored01 | (xored01 * 4u);
+                const uint32_t xored2_2 = xored2 | (xored2 * 2u), xored3_2 = xored3 | (xored3 >> 1);
+                const uint32_t xored23 = (xored2_2 & 0xAAAAAAAAu) | (xored3_2 & 0x55555555u);
+                const uint32_t xored23_4 = xored23 | (xored23 >> 2);
+                const uint32_t xored4 = (xored01_4 & 0xCCCCCCCCu) | (xored23_4 & 0x33333333u);
+                const uint32_t xored8 = xored4 | (xored4 * 16u);
+                area[pix_ix] = (float)__builtin_popcount(xored8 & 0xF0F0F0F0u) * 0.0625f;
+            }
+        }
+    }
+}
+
+// aa = 0: analytic area (fine_area); 8 / 16: fine_msaa8 / fine_msaa16 with the mask LUT as last binding
+static void fine_area(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b, int nb, int aa = 0) {
     using bl::V4;
     const Config& cfg = *(Config*)b[0].p;
     View<Segment> segments(b[1]);
@@ -1865,6 +2083,9 @@ static void fine_area(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b, int nb) {
     View<ImageDesc> img_table(nb > 8 ? b[7] : OBuf{nullptr, 0});
     const uint8_t* img_px = nb > 8 ? (const uint8_t*)b[8].p : nullptr;
     size_t img_n = nb > 8 ? (size_t)(b[8].n / 4) : 0;
+    View<uint32_t> mask_lut((aa != 0 && nb > 9) ? b[9] : OBuf{nullptr, 0});
+    std::vector<float> ms_area;          // per tile: cached fill_path_ms results, 256 floats per CMD_FILL in stream order
+    std::vector<uint32_t> ms_cmd;        // ... and the command index each belongs to
     if (ptcl.rd(0) == ~0u) return;
     auto load_grad = [&](int32_t x, int32_t y) {
         size_t ix = (size_t)y * 512u + (size_t)x;
@@ -1875,6 +2096,8 @@ static void fine_area(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b, int nb) {
     for (uint32_t wy = 0; wy < n_wg_y; wy++)
         for (uint32_t wx = 0; wx < n_wg_x; wx++) {
             uint32_t tile_ix = wy * cfg.width_in_tiles + wx;
+            ms_area.clear();
+            ms_cmd.clear();
             for (uint32_t ly = 0; ly < 16u; ly++)
                 for (uint32_t lx = 0; lx < 4u; lx++) {
                     uint32_t gx = wx * 4u + lx, gy = wy * 16u + ly;
@@ -1901,6 +2124,18 @@ static void fine_area(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b, int nb) {
                                 int32_t backdrop = (int32_t)ptcl.rd((size_t)cmd_ix + 3u);
                                 uint32_t n_segs = size_and_rule >> 1;
                                 bool even_odd = (size_and_rule & 1u) != 0u;
+                                if (aa != 0) {  // fine.wgsl:916-917: workgroup-cooperative fill, evaluated once per tile and command
+                                    size_t slot = 0;
+                                    while (slot < ms_cmd.size() && ms_cmd[slot] != cmd_ix) slot++;
+                                    if (slot == ms_cmd.size()) {
+                                        ms_cmd.push_back(cmd_ix);
+                                        ms_area.resize(ms_area.size() + 256u);
+                                        fill_path_ms_tile(aa, size_and_rule, seg_data, backdrop, segments, mask_lut, ms_area.data() + slot * 256u);
+                                    }
+                                    for (int i = 0; i < 4; i++) area[i] = ms_area[slot * 256u + ly * 16u + lx * 4u + (uint32_t)i];
+                                    cmd_ix += 4u;
+                                    break;
+                                }
                                 float backdrop_f = (float)backdrop;
                                 for (int i = 0; i < 4; i++) area[i] = backdrop_f;
                                 for (uint32_t s = 0; s < n_segs; s++) {
@@ -2188,6 +2423,8 @@ int oracle_dispatch(int stage, uint32_t gx, uint32_t gy, uint32_t gz, OBuf* b, i
         case ST_PATH_TILING_SETUP: path_tiling_setup(b); break;
         case ST_PATH_TILING: path_tiling(gx, b); break;
         case ST_FINE_AREA: fine_area(gx, gy, b, nb); break;
+        case ST_FINE_MSAA8: fine_area(gx, gy, b, nb, 8); break;
+        case ST_FINE_MSAA16: fine_area(gx, gy, b, nb, 16); break;
         default: return -1;
     }
     return 0;

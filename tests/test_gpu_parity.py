@@ -54,6 +54,24 @@ def test_images_srgb_bilinear(engine):
     assert not np.array_equal(img[40, 30], img[41, 31])  # the image brush really painted texels
 
 
+@pytest.mark.parametrize("aa", [jello_amd.Aa.Msaa8, jello_amd.Aa.Msaa16])
+@pytest.mark.parametrize("which", ["c1", "c2", "c3", "c4"])
+def test_msaa_matches_oracle(engine, aa, which):
+    """fine_msaa8 / fine_msaa16 (fine.wgsl:148-711): integer SWAR coverage, image identical in f16 bits."""
+    if which == "c1":
+        s, p = scenes.scene_c1()
+    elif which == "c2":
+        s, p = scenes.scene_c2(120, 512)      # even-odd fills, all joins and caps
+    elif which == "c3":
+        s, p = scenes.scene_c3(2000, 512)
+        p.bump = BumpSizes(ptcl=1 << 24)
+    else:
+        s, p = scenes.scene_c4(600, 256)      # clip layers, gradients, blends
+        p.bump = BumpSizes(ptcl=1 << 24)
+    p.aa = aa
+    compare(engine, s, p)
+
+
 def test_non_multiple_of_16_target(engine):
     s, p = scenes.scene_c3(400, 256)
     p.width, p.height = 250, 199

@@ -157,3 +157,25 @@ def test_image_brush_srgb_decode_kat():
     got = img[19, 19]  # interior pixel: all four bilinear taps inside the image
     assert np.all(np.abs(got - want) <= 2e-3 * np.maximum(want, 1e-3)), (got, want)
     assert tuple(img[5, 5]) == (0.0, 0.0, 0.0, 0.0)
+
+
+@pytest.mark.parametrize("samples", [8, 16])
+@pytest.mark.parametrize("rule", ["nonzero", "evenodd"])
+def test_msaa_rect_coverage_kat(samples, rule):
+    """Half-plane masks of the D3D11 sample patterns (mask.go:43-105): a rectangle whose left edge sits at x+0.5
+    and whose bottom edge sits at y+0.25 covers exactly 1/2 resp. 1/4 of the samples of the boundary pixels."""
+    import jello_amd
+    from jello_amd import Aa, Brush, Fill, Path, RenderParams, Scene
+    from oracle import oracle_engine
+    s = Scene()
+    s.fill(Fill.NonZero if rule == "nonzero" else Fill.EvenOdd, None, Brush.solid((0, 1, 0, 1)), None, Path.rect(16.5, 8, 40, 24.25))
+    p = RenderParams(64, 32, aa=Aa.Msaa8 if samples == 8 else Aa.Msaa16)
+    rec = jello_amd.Host().record(s, p)
+    eng = oracle_engine.OracleEngine()
+    eng.run(rec)
+    img = eng.target(rec).view(np.float16).astype(np.float32).reshape(32, 64, 4)
+    assert tuple(img[12, 20]) == (0.0, 1.0, 0.0, 1.0)   # interior
+    assert img[12, 16, 3] == 0.5                          # left edge pixel: half covered
+    assert img[24, 20, 3] == 0.25                         # bottom edge pixel: quarter covered
+    assert img[24, 16, 3] == 0.125                        # corner: 1/2 * 1/4
+    assert img[4, 4, 3] == 0.0 and img[12, 41, 3] == 0.0  # outside

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--paths", type=int, default=100_000)
     ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--aa", choices=["area", "msaa8", "msaa16"], default="area", help="coverage mode of the fine stage (the headline is area)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
@@ -57,6 +58,8 @@ def main():
     W = H = args.size
     # independent scene per rank (same generator, different seed)
     scene, params = scenes.scene_c3(args.paths, args.size, seed=scenes.SEED + rank)
+    params.aa = {"area": jello_amd.Aa.Area, "msaa8": jello_amd.Aa.Msaa8, "msaa16": jello_amd.Aa.Msaa16}[args.aa]
+    fine_stage = {"area": "fine_area", "msaa8": "fine_msaa8", "msaa16": "fine_msaa16"}[args.aa]
     eng = jello_amd.Engine(dev.index)
     host = jello_amd.Host()
     stream = torch.cuda.current_stream(dev)
@@ -154,7 +157,7 @@ def main():
     for name, ms in prof:
         stage_ms[name] = stage_ms.get(name, 0.0) + ms
     stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
-    fine_ms = stage_ms.get("fine_area", float("nan"))
+    fine_ms = stage_ms.get(fine_stage, float("nan"))
 
     result = None
     if rank == 0:
@@ -169,7 +172,7 @@ def main():
         b_fine = 4 * words + 24 * segs + 4 * info_words + 8 * texels + 32 * spill_px + 8 * W * H
         achieved = b_fine / (fine_ms * 1e-3) / 1e9
         bump_now = eng.download(rec.buffer("bumpBuf")[0], dtype=np.uint32)[:8]
-        roofline = {"kernel": "k_fine_area", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"kernel": "k_fine_area" if args.aa == "area" else "k_fine_area<%s>" % args.aa, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes": int(b_fine), "avg_ms": round(fine_ms, 4),
                     "segment_pixel_evals": int(segs) * 256}
         pm = os.path.join(ROOT, "profiles", "fine_traffic.json")
@@ -186,8 +189,8 @@ def main():
             "metric": "Mpixels/sec fine-raster + paths/sec, 100k-path 4096^2 scene", "value": round(mpix, 2), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3: %d random stroked+filled cubic Beziers, %dx%d RGBA16F target, area AA, one independent scene per GPU"
-                                   % (args.paths, W, H),
+            "config": {"workload": "C3: %d random stroked+filled cubic Beziers, %dx%d RGBA16F target, %s AA, one independent scene per GPU"
+                                   % (args.paths, W, H, args.aa),
                        "paths": args.paths, "draw_objects": cfg["n_drawobj"], "width": W, "height": H,
                        "parallelism": "scene-per-gpu x%d%s" % (world, "" if world == 1 or args.no_gather else " + RCCL image gather")},
             "paths_per_s": round(args.paths * world / (elapsed / args.steps), 1),

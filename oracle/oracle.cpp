@@ -2067,6 +2067,9 @@ static void fill_path_ms_tile(int SAMPLES, uint32_t size_and_rule, uint32_t seg_
     }
 }
 
+static int g_oracle_threads = 1;
+extern "C" void oracle_set_threads(int n) { g_oracle_threads = n < 1 ? 1 : n; }
+
 // aa = 0: analytic area (fine_area); 8 / 16: fine_msaa8 / fine_msaa16 with the mask LUT as last binding
 static void fine_area(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b, int nb, int aa = 0) {
     using bl::V4;
@@ -2084,8 +2087,6 @@ static void fine_area(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b, int nb, int aa 
     const uint8_t* img_px = nb > 8 ? (const uint8_t*)b[8].p : nullptr;
     size_t img_n = nb > 8 ? (size_t)(b[8].n / 4) : 0;
     View<uint32_t> mask_lut((aa != 0 && nb > 9) ? b[9] : OBuf{nullptr, 0});
-    std::vector<float> ms_area;          // per tile: cached fill_path_ms results, 256 floats per CMD_FILL in stream order
-    std::vector<uint32_t> ms_cmd;        // ... and the command index each belongs to
     if (ptcl.rd(0) == ~0u) return;
     auto load_grad = [&](int32_t x, int32_t y) {
         size_t ix = (size_t)y * 512u + (size_t)x;
@@ -2093,11 +2094,14 @@ static void fine_area(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b, int nb, int aa 
         const uint16_t* t = gradients + ix * 4;
         return V4{f16_to_f32(t[0]), f16_to_f32(t[1]), f16_to_f32(t[2]), f16_to_f32(t[3])};
     };
+    // Tiles are independent (disjoint pixels and blend_spill slices): rows of tiles may run on several host
+    // threads (oracle_set_threads; default 1).  Results do not depend on the thread count.
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_oracle_threads)
     for (uint32_t wy = 0; wy < n_wg_y; wy++)
         for (uint32_t wx = 0; wx < n_wg_x; wx++) {
             uint32_t tile_ix = wy * cfg.width_in_tiles + wx;
-            ms_area.clear();
-            ms_cmd.clear();
+            std::vector<float> ms_area;    // per tile: cached fill_path_ms results, 256 floats per CMD_FILL in stream order
+            std::vector<uint32_t> ms_cmd;  // ... and the command index each belongs to
             for (uint32_t ly = 0; ly < 16u; ly++)
                 for (uint32_t lx = 0; lx < 4u; lx++) {
                     uint32_t gx = wx * 4u + lx, gy = wy * 16u + ly;

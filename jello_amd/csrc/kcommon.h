@@ -211,7 +211,9 @@ enum {  // scratch slots
     JH_SCR_E = 5,
     JH_SCR_F = 6,
     JH_SCR_G = 7,
-    JH_SCR_COUNT = 8
+    JH_SCR_H = 8,
+    JH_SCR_I = 9,
+    JH_SCR_COUNT = 10
 };
 
 // Generic device-side exclusive scan of u32 (stride in words between consecutive inputs).

@@ -335,22 +335,49 @@ __global__ __launch_bounds__(JL_WG) void k_pc_count(const JlBump* __restrict__ b
         counts[gid] = c;
     }
 }
-// pass 2: backdrops, per-tile counts, SegmentCount records (slice rank filled by k_pc_rank)
-__global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump,
-                                                   const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines, Buf<JlPath> paths, Buf<JlTile> tile,
-                                                   Buf<JlSegmentCount> seg_counts, const uint32_t* __restrict__ seg_bases, uint32_t bases_n,
-                                                   uint2* __restrict__ tile_of, uint32_t tile_of_n) {
+// Crossing ranges of the paths: lines are in path order (canonical LineSoup order), so the crossings of path P are
+// the contiguous range [pstart[P], pend[P]) of seg_counts.  Both arrays are zeroed before (paths without lines).
+__global__ __launch_bounds__(JL_WG) void k_pc_paths(const JlBump* __restrict__ bump, const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines,
+                                                    const uint32_t* __restrict__ counts, const uint32_t* __restrict__ seg_bases, uint32_t bases_n,
+                                                    uint32_t* __restrict__ pstart, uint32_t* __restrict__ pend, uint32_t n_paths) {
     uint32_t n_lines = umin_(umin_(bump->lines, bases_n), ind->x * JL_WG);
     for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
         if (!lines.ok(gid)) continue;
+        uint32_t P = lines.p[gid].path_ix;
+        if (P >= n_paths) continue;
+        uint32_t prevP = (gid > 0u && lines.ok(gid - 1u)) ? lines.p[gid - 1u].path_ix : 0xffffffffu;
+        uint32_t nextP = (gid + 1u < n_lines && lines.ok(gid + 1u)) ? lines.p[gid + 1u].path_ix : 0xffffffffu;
+        if (P != prevP) pstart[P] = seg_bases[gid];
+        if (P != nextP) pend[P] = seg_bases[gid] + counts[gid];
+    }
+}
+
+// Paths with more crossings than this take the atomic route (per-tile arrival slots, lists, rank inside the list);
+// all others get their slice ranks from k_pc_rank_small without a single atomic.
+#define PC_BIG_PATH 16384u
+
+// pass 2: backdrops, SegmentCount records, the tile of every crossing (slice ranks are filled in later)
+__global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump,
+                                                   const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines, Buf<JlPath> paths, Buf<JlTile> tile,
+                                                   Buf<JlSegmentCount> seg_counts, const uint32_t* __restrict__ seg_bases, uint32_t bases_n,
+                                                   uint2* __restrict__ tile_of, uint32_t* __restrict__ keys, uint32_t* __restrict__ kpath,
+                                                   uint32_t tile_of_n, const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ pend,
+                                                   uint32_t n_paths, uint32_t* __restrict__ gate) {
+    uint32_t n_lines = umin_(umin_(bump->lines, bases_n), ind->x * JL_WG);
+    for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
+        if (!lines.ok(gid)) continue;
+        const uint32_t P = lines.p[gid].path_ix;
         LineSetup s = line_setup(lines.p[gid], paths);
         if (!s.valid) continue;
+        // big path (or a path index outside the table): arrival slots by atomics, as k_pc_scatter / k_pc_rank expect
+        const bool big = P >= n_paths || pend[P] - pstart[P] > PC_BIG_PATH;
         for (int32_t y = s.ymin; y < s.ymax; y++) {
             uint32_t base = (uint32_t)((int32_t)s.tiles + (y - s.bbox[1]) * s.stride);
             if (tile.ok(base)) atomicAdd(&tile.p[base].backdrop, s.delta);
         }
         float last_z = floor_(s.a * ((float)s.imin - 1.0f) + s.b);
         uint32_t seg_base = seg_bases[gid];
+        if (big && s.imax > s.imin) atomicMax(gate, 0xffffffffu);
         for (uint32_t i = s.imin; i < s.imax; i++) {
             float zf = s.a * (float)i + s.b;
             float z = floor_(zf);
@@ -364,27 +391,94 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
                 if (tile.ok(t)) atomicAdd(&tile.p[t].backdrop, s.delta);
             }
             uint32_t t = (uint32_t)(base + x);
-            uint32_t arrival = 0u;  // order-dependent, only used as a unique slot inside the tile's temporary list
-            if (tile.ok(t)) arrival = atomicAdd(&tile.p[t].segment_count_or_ix, 1u);
             uint32_t seg_ix = seg_base + i - s.imin;
             if (seg_ix < cfg->seg_counts_size && seg_counts.ok(seg_ix)) {
                 JlSegmentCount sc;
                 sc.line_ix = gid;
-                sc.counts = i;  // low 16 bits; the slice rank is OR-ed in by k_pc_rank
+                sc.counts = i;  // low 16 bits; the slice rank is OR-ed in by k_pc_rank_small / k_pc_rank
                 seg_counts.p[seg_ix] = sc;
-                if (seg_ix < tile_of_n) tile_of[seg_ix] = make_uint2(t, arrival);
+                if (seg_ix < tile_of_n) {
+                    keys[seg_ix] = tile.ok(t) ? t : 0xffffffffu;
+                    kpath[seg_ix] = P;
+                    if (big) {
+                        uint32_t arrival = 0u;  // order-dependent, only a unique slot inside the tile's temporary list
+                        if (tile.ok(t)) arrival = atomicAdd(&tile.p[t].segment_count_or_ix, 1u);
+                        tile_of[seg_ix] = make_uint2(t, arrival);
+                    }
+                }
             }
             last_z = z;
         }
     }
 }
+
+// Slice ranks without atomics.  One wave takes 64 consecutive crossings (lane = crossing k) and streams the tile
+// keys of every crossing of the paths its lanes belong to (a uniform, scalar-loaded stream): crossings in the same
+// tile are crossings of the same path (tile_alloc gives every path its own tile range), hence
+//   seg_within_slice(k) = #{ j < k : key[j] == key[k] },   Tile.segment_count = that number + #{ j > k : ... } + 1,
+// the canonical (line, crossing) order by construction.  Cost is O(crossings of the path) per crossing, which is why
+// paths above PC_BIG_PATH go through the list-based kernels instead.
+__global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
+                                                         const uint32_t* __restrict__ keys, const uint32_t* __restrict__ kpath, uint32_t n_cap,
+                                                         const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ pend, uint32_t n_paths,
+                                                         Buf<JlSegmentCount> seg_counts) {
+    const uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
+    const uint32_t lane = lane_id();
+    const uint32_t waves = (gridDim.x * JL_WG) >> 6;
+    for (uint32_t chunk = (blockIdx.x * JL_WG + threadIdx.x) >> 6; chunk * 64u < n; chunk += waves) {
+        const uint32_t k0 = chunk * 64u;
+        const uint32_t k = k0 + lane;
+        uint32_t my_t = 0xffffffffu, ps = 0xffffffffu, pe = 0u;
+        bool mine = false;
+        if (k < n) {
+            const uint32_t P = kpath[k];
+            if (P < n_paths) {
+                ps = pstart[P];
+                pe = pend[P];
+                mine = pe - ps <= PC_BIG_PATH && k >= ps && k < pe;
+                my_t = keys[k];
+                mine = mine && my_t != 0xffffffffu;
+            }
+        }
+        if (!mine) { ps = 0xffffffffu; pe = 0u; my_t = 0xffffffffu; }
+        // range of crossings to scan: the union of the lanes' path ranges (uniform)
+        uint32_t lo = ps, hi = pe;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = umin_(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
+            hi = umax_(hi, (uint32_t)__shfl_xor((int)hi, o, 64));
+        }
+        lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+        hi = umin_((uint32_t)__builtin_amdgcn_readfirstlane((int)hi), n);
+        if (lo >= hi) continue;  // uniform: nothing but big-path crossings here
+        uint32_t before = 0u, after = 0u;
+        const uint32_t k_end = umin_(k0 + 64u, hi);
+        for (uint32_t j = lo; j < k0; j++) before += (keys[j] == my_t) ? 1u : 0u;               // j < every k of the wave
+        for (uint32_t j = umax_(lo, k0); j < k_end; j++) {                                       // the wave's own crossings
+            const uint32_t kj = keys[j];
+            before += (kj == my_t && j < k) ? 1u : 0u;
+            after += (kj == my_t && j > k) ? 1u : 0u;
+        }
+        for (uint32_t j = umax_(k_end, lo); j < hi; j++) after += (keys[j] == my_t) ? 1u : 0u;   // j > every k of the wave
+        if (mine && seg_counts.ok(k)) {
+            seg_counts.p[k].counts |= before << 16;
+            if (after == 0u && tile.ok(my_t)) tile.p[my_t].segment_count_or_ix = before + 1u;
+        }
+    }
+}
+
 // pass 3: scatter crossing indices into per-tile lists; the slot inside a list is the (arbitrary but unique)
 // arrival number the count atomic returned in pass 2, so no further atomics are needed.
 __global__ __launch_bounds__(JL_WG) void k_pc_scatter(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
                                                       const uint2* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
-                                                      uint32_t tiles_cap, uint32_t* __restrict__ list) {
+                                                      uint32_t tiles_cap, uint32_t* __restrict__ list, const uint32_t* __restrict__ kpath,
+                                                      const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ pend, uint32_t n_paths,
+                                                      const uint32_t* __restrict__ gate) {
+    if (*gate == 0u) return;  // no big path in this frame
     uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
     for (uint32_t k = blockIdx.x * JL_WG + threadIdx.x; k < n; k += gridDim.x * JL_WG) {
+        uint32_t P = kpath[k];
+        if (P < n_paths && pend[P] - pstart[P] <= PC_BIG_PATH) continue;  // ranked by k_pc_rank_small
         uint2 ta = tile_of[k];
         if (ta.x >= tiles_cap || !tile.ok(ta.x)) continue;
         uint32_t pos = list_base[ta.x] + ta.y;
@@ -394,9 +488,14 @@ __global__ __launch_bounds__(JL_WG) void k_pc_scatter(const JlConfig* __restrict
 // pass 4: seg_within_slice = rank of k among the crossings of its tile
 __global__ __launch_bounds__(JL_WG) void k_pc_rank(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
                                                    const uint2* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
-                                                   uint32_t tiles_cap, const uint32_t* __restrict__ list, Buf<JlSegmentCount> seg_counts) {
+                                                   uint32_t tiles_cap, const uint32_t* __restrict__ list, Buf<JlSegmentCount> seg_counts,
+                                                   const uint32_t* __restrict__ kpath, const uint32_t* __restrict__ pstart,
+                                                   const uint32_t* __restrict__ pend, uint32_t n_paths, const uint32_t* __restrict__ gate) {
+    if (*gate == 0u) return;  // no big path in this frame
     uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
     for (uint32_t k = blockIdx.x * JL_WG + threadIdx.x; k < n; k += gridDim.x * JL_WG) {
+        uint32_t P = kpath[k];
+        if (P < n_paths && pend[P] - pstart[P] <= PC_BIG_PATH) continue;  // ranked by k_pc_rank_small
         uint32_t t = tile_of[k].x;
         if (t >= tiles_cap || !tile.ok(t) || !seg_counts.ok(k)) continue;
         uint32_t base = list_base[t];
@@ -648,20 +747,36 @@ int jh_launch_path_count(const JhLaunch& L) {
     uint2* tile_of = (uint2*)jh_scratch_get(L.scratch, JH_SCR_C, (uint64_t)seg_cap * 8);
     uint32_t* list = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)seg_cap * 4);
     uint32_t* list_base = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_E, (uint64_t)tiles_cap * 4);
-    if (!counts || !bases || !tile_of || !list || !list_base) return -5;
+    uint32_t* keys = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_F, (uint64_t)seg_cap * 4);
+    uint32_t* kpath = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_H, (uint64_t)seg_cap * 4);
+    uint32_t n_paths = paths.n;
+    // [pstart | pend | gate]: zeroed every frame
+    uint32_t* prange = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_I, ((uint64_t)n_paths * 2 + 64) * 4);
+    if (!counts || !bases || !tile_of || !list || !list_base || !keys || !kpath || !prange) return -5;
+    uint32_t *pstart = prange, *pend = prange + n_paths, *gate = prange + 2 * (size_t)n_paths;
+    (void)hipMemsetAsync(prange, 0, ((size_t)n_paths * 2 + 64) * 4, L.stream);
     uint32_t gl = stride_grid(L, lines_cap), gs = stride_grid(L, seg_cap);
     hipLaunchKernelGGL(k_pc_count, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, paths, counts, lines_cap);
     int rc = jh_scan_u32(L, counts, 1, bases, lines_cap, &bump->lines, &bump->seg_counts);
     if (rc) return rc;
+    hipLaunchKernelGGL(k_pc_paths, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, (const uint32_t*)counts,
+                       (const uint32_t*)bases, lines_cap, pstart, pend, n_paths);
     hipLaunchKernelGGL(k_pc_emit, dim3(gl), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, ind, lines, paths, tile, segc,
-                       (const uint32_t*)bases, lines_cap, tile_of, seg_cap);
-    // per-tile list bases: exclusive scan of Tile.segment_count_or_ix over the allocated tiles
-    rc = jh_scan_u32(L, ((const uint32_t*)tile.p) + 1, 2, list_base, tiles_cap, &bump->tile, nullptr);
+                       (const uint32_t*)bases, lines_cap, tile_of, keys, kpath, seg_cap, (const uint32_t*)pstart, (const uint32_t*)pend, n_paths,
+                       gate);
+    // Big paths only (none in most frames: `gate` stays 0, the scan then covers 0 elements and the kernels return at once):
+    // per-tile list bases = exclusive scan of Tile.segment_count_or_ix, scatter into the lists, rank inside the list.
+    rc = jh_scan_u32(L, ((const uint32_t*)tile.p) + 1, 2, list_base, tiles_cap, gate, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pc_scatter, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint2*)tile_of, seg_cap,
-                       (const uint32_t*)list_base, tiles_cap, list);
+                       (const uint32_t*)list_base, tiles_cap, list, (const uint32_t*)kpath, (const uint32_t*)pstart, (const uint32_t*)pend,
+                       n_paths, (const uint32_t*)gate);
     hipLaunchKernelGGL(k_pc_rank, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint2*)tile_of, seg_cap,
-                       (const uint32_t*)list_base, tiles_cap, (const uint32_t*)list, segc);
+                       (const uint32_t*)list_base, tiles_cap, (const uint32_t*)list, segc, (const uint32_t*)kpath, (const uint32_t*)pstart,
+                       (const uint32_t*)pend, n_paths, (const uint32_t*)gate);
+    // everything else: atomics-free ranks
+    hipLaunchKernelGGL(k_pc_rank_small, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint32_t*)keys,
+                       (const uint32_t*)kpath, seg_cap, (const uint32_t*)pstart, (const uint32_t*)pend, n_paths, segc);
     return 0;
 }
 

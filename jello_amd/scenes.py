@@ -160,3 +160,22 @@ def scene_images(size=256, seed=SEED + 7):
     s.fill(Fill.NonZero, None, Brush.image(img_b, key=2), xf, Path.circle(150, 150, 70))
     s.fill(Fill.EvenOdd, None, Brush.solid((0.1, 0.7, 0.2, 0.5)), None, Path.rect(60, 60, 200, 120))
     return s, RenderParams(size, size, base_color=(0.2, 0.2, 0.2, 1.0))
+
+
+def scene_big_path(size=1024, n_zig=600, seed=SEED + 9):
+    """One path with far more tile crossings than PC_BIG_PATH (a long zigzag polyline, filled even-odd and stroked)
+    on top of a few small shapes: path_count's list-based route for big paths next to the atomics-free one."""
+    u = splitmix64_array(40 * 6, seed).reshape(40, 6)
+    s = Scene()
+    for i in range(40):
+        cx, cy, r = u[i, 0] * size, u[i, 1] * size, 10 + u[i, 2] * 50
+        s.fill(Fill.NonZero, None, Brush.solid((u[i, 3], u[i, 4], u[i, 5], 0.8)), None, Path.circle(cx, cy, r))
+    p = Path().move_to(8.5, 20.25)
+    for k in range(n_zig):
+        x = size - 9.25 if (k % 2 == 0) else 8.5
+        y = 20.25 + (size - 40.0) * (k + 1) / n_zig
+        p.line_to(x, y)
+    p.close()
+    s.fill(Fill.EvenOdd, None, Brush.solid((0.9, 0.2, 0.1, 0.6)), None, p)
+    s.stroke(Stroke(1.5, Join.Bevel, 4, Cap.Butt, Cap.Butt), None, Brush.solid((0.0, 0.0, 0.0, 1.0)), None, p)
+    return s, RenderParams(size, size, base_color=(1, 1, 1, 1))

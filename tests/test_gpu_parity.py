@@ -72,6 +72,14 @@ def test_msaa_matches_oracle(engine, aa, which):
     compare(engine, s, p)
 
 
+def test_big_path_takes_the_list_route(engine):
+    """A single path with > 16384 tile crossings (PC_BIG_PATH) next to small ones: both rank routes of path_count."""
+    s, p = scenes.scene_big_path()
+    p.bump = BumpSizes(ptcl=1 << 24)
+    r = compare(engine, s, p)
+    assert r["bump"]["seg_counts"] > 60000
+
+
 def test_non_multiple_of_16_target(engine):
     s, p = scenes.scene_c3(400, 256)
     p.width, p.height = 250, 199

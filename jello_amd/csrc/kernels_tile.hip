@@ -337,6 +337,8 @@ __global__ __launch_bounds__(JL_WG) void k_pc_count(const JlBump* __restrict__ b
 }
 // Crossing ranges of the paths: lines are in path order (canonical LineSoup order), so the crossings of path P are
 // the contiguous range [pstart[P], pend[P]) of seg_counts.  Both arrays are zeroed before (paths without lines).
+// (Deriving the range from first/last line indices inside the consumers instead measured slower: five dependent
+// loads per line.)
 __global__ __launch_bounds__(JL_WG) void k_pc_paths(const JlBump* __restrict__ bump, const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines,
                                                     const uint32_t* __restrict__ counts, const uint32_t* __restrict__ seg_bases, uint32_t bases_n,
                                                     uint32_t* __restrict__ pstart, uint32_t* __restrict__ pend, uint32_t n_paths) {
@@ -351,18 +353,25 @@ __global__ __launch_bounds__(JL_WG) void k_pc_paths(const JlBump* __restrict__ b
         if (P != nextP) pend[P] = seg_bases[gid] + counts[gid];
     }
 }
+// crossings [ps, pe) of path P (empty if it has no line)
+JD void path_range(uint32_t P, const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ pend, const uint32_t*, const uint32_t*,
+                   uint32_t& ps, uint32_t& pe) {
+    ps = pstart[P];
+    pe = pend[P];
+}
 
 // Paths with more crossings than this take the atomic route (per-tile arrival slots, lists, rank inside the list);
 // all others get their slice ranks from k_pc_rank_small without a single atomic.
 #define PC_BIG_PATH 16384u
+JD bool npe_big(uint32_t n) { return n > PC_BIG_PATH; }
 
 // pass 2: backdrops, SegmentCount records, the tile of every crossing (slice ranks are filled in later)
 __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump,
                                                    const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines, Buf<JlPath> paths, Buf<JlTile> tile,
                                                    Buf<JlSegmentCount> seg_counts, const uint32_t* __restrict__ seg_bases, uint32_t bases_n,
                                                    uint2* __restrict__ tile_of, uint32_t* __restrict__ keys, uint32_t* __restrict__ kpath,
-                                                   uint32_t tile_of_n, const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ pend,
-                                                   uint32_t n_paths, uint32_t* __restrict__ gate) {
+                                                   uint32_t tile_of_n, const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ plast,
+                                                   const uint32_t* __restrict__ counts, uint32_t n_paths, uint32_t* __restrict__ gate) {
     uint32_t n_lines = umin_(umin_(bump->lines, bases_n), ind->x * JL_WG);
     for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
         if (!lines.ok(gid)) continue;
@@ -370,7 +379,12 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
         LineSetup s = line_setup(lines.p[gid], paths);
         if (!s.valid) continue;
         // big path (or a path index outside the table): arrival slots by atomics, as k_pc_scatter / k_pc_rank expect
-        const bool big = P >= n_paths || pend[P] - pstart[P] > PC_BIG_PATH;
+        bool big = true;
+        if (P < n_paths) {
+            uint32_t ps, pe;
+            path_range(P, pfirst, plast, counts, seg_bases, ps, pe);
+            big = pe - ps > PC_BIG_PATH;
+        }
         for (int32_t y = s.ymin; y < s.ymax; y++) {
             uint32_t base = (uint32_t)((int32_t)s.tiles + (y - s.bbox[1]) * s.stride);
             if (tile.ok(base)) atomicAdd(&tile.p[base].backdrop, s.delta);
@@ -412,57 +426,58 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
     }
 }
 
-// Slice ranks without atomics.  One wave takes 64 consecutive crossings (lane = crossing k) and streams the tile
-// keys of every crossing of the paths its lanes belong to (a uniform, scalar-loaded stream): crossings in the same
-// tile are crossings of the same path (tile_alloc gives every path its own tile range), hence
+// Slice ranks without atomics.  One wave takes one path: its crossings are the contiguous range [pstart, pend) and
+// crossings in the same tile are crossings of the same path (tile_alloc gives every path its own tile range), hence
 //   seg_within_slice(k) = #{ j < k : key[j] == key[k] },   Tile.segment_count = that number + #{ j > k : ... } + 1,
-// the canonical (line, crossing) order by construction.  Cost is O(crossings of the path) per crossing, which is why
-// paths above PC_BIG_PATH go through the list-based kernels instead.
+// the canonical (line, crossing) order by construction.  Inside a block of 64 crossings (lane = crossing) the counts
+// come from one ballot per DISTINCT tile of the block; a path with more than 64 crossings additionally streams its
+// other blocks through v_readlane (O(n^2/64) -- which is why paths above PC_BIG_PATH use the list-based kernels).
 __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
-                                                         const uint32_t* __restrict__ keys, const uint32_t* __restrict__ kpath, uint32_t n_cap,
-                                                         const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ pend, uint32_t n_paths,
+                                                         const uint32_t* __restrict__ keys, uint32_t n_cap, const uint32_t* __restrict__ pfirst,
+                                                         const uint32_t* __restrict__ plast, const uint32_t* __restrict__ counts,
+                                                         const uint32_t* __restrict__ seg_bases, uint32_t n_paths,
                                                          Buf<JlSegmentCount> seg_counts) {
     const uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
     const uint32_t lane = lane_id();
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t waves = (gridDim.x * JL_WG) >> 6;
-    for (uint32_t chunk = (blockIdx.x * JL_WG + threadIdx.x) >> 6; chunk * 64u < n; chunk += waves) {
-        const uint32_t k0 = chunk * 64u;
-        const uint32_t k = k0 + lane;
-        uint32_t my_t = 0xffffffffu, ps = 0xffffffffu, pe = 0u;
-        bool mine = false;
-        if (k < n) {
-            const uint32_t P = kpath[k];
-            if (P < n_paths) {
-                ps = pstart[P];
-                pe = pend[P];
-                mine = pe - ps <= PC_BIG_PATH && k >= ps && k < pe;
-                my_t = keys[k];
-                mine = mine && my_t != 0xffffffffu;
+    uint32_t P = (blockIdx.x * JL_WG + threadIdx.x) >> 6;
+    uint32_t nps = 0u, npe = 0u;  // range of the path after this one (prefetched: the loop is a chain of dependent loads)
+    if (P < n_paths) path_range(P, pfirst, plast, counts, seg_bases, nps, npe);
+    for (; P < n_paths; P += waves) {
+        const uint32_t ps = nps, pe = umin_(npe, n);
+        if (P + waves < n_paths) path_range(P + waves, pfirst, plast, counts, seg_bases, nps, npe);
+        if (pe <= ps || npe_big(pe - ps)) continue;  // uniform
+        for (uint32_t c0 = ps; c0 < pe; c0 += 64u) {       // own block [c0, c0 + 64)
+            const uint32_t k = c0 + lane;
+            const bool valid = k < pe;
+            uint32_t my_t = valid ? keys[k] : 0xffffffffu;
+            const bool mine = valid && my_t != 0xffffffffu;  // 0xffffffff: crossing outside the tile buffer
+            uint32_t before = 0u, after = 0u;
+            // inside the block: one ballot per distinct tile
+            uint64_t rem = __builtin_amdgcn_ballot_w64(mine);
+            while (rem != 0ull) {
+                const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, (int)__builtin_ctzll(rem));
+                const uint64_t m = __builtin_amdgcn_ballot_w64(mine && my_t == t);
+                if (mine && my_t == t) {
+                    before = (uint32_t)__builtin_popcountll(m & lt_mask);
+                    after = (uint32_t)__builtin_popcountll(m & ~lt_mask) - 1u;
+                }
+                rem &= ~m;
             }
-        }
-        if (!mine) { ps = 0xffffffffu; pe = 0u; my_t = 0xffffffffu; }
-        // range of crossings to scan: the union of the lanes' path ranges (uniform)
-        uint32_t lo = ps, hi = pe;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = umin_(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
-            hi = umax_(hi, (uint32_t)__shfl_xor((int)hi, o, 64));
-        }
-        lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
-        hi = umin_((uint32_t)__builtin_amdgcn_readfirstlane((int)hi), n);
-        if (lo >= hi) continue;  // uniform: nothing but big-path crossings here
-        uint32_t before = 0u, after = 0u;
-        const uint32_t k_end = umin_(k0 + 64u, hi);
-        for (uint32_t j = lo; j < k0; j++) before += (keys[j] == my_t) ? 1u : 0u;               // j < every k of the wave
-        for (uint32_t j = umax_(lo, k0); j < k_end; j++) {                                       // the wave's own crossings
-            const uint32_t kj = keys[j];
-            before += (kj == my_t && j < k) ? 1u : 0u;
-            after += (kj == my_t && j > k) ? 1u : 0u;
-        }
-        for (uint32_t j = umax_(k_end, lo); j < hi; j++) after += (keys[j] == my_t) ? 1u : 0u;   // j > every k of the wave
-        if (mine && seg_counts.ok(k)) {
-            seg_counts.p[k].counts |= before << 16;
-            if (after == 0u && tile.ok(my_t)) tile.p[my_t].segment_count_or_ix = before + 1u;
+            // the path's other blocks (none for a path of up to 64 crossings)
+            for (uint32_t b0 = ps; b0 < pe; b0 += 64u) {
+                if (b0 == c0) continue;
+                const uint32_t jn = umin_(pe - b0, 64u);
+                const uint32_t vec = (lane < jn) ? keys[b0 + lane] : 0xfffffffeu;
+                uint32_t cnt = 0u;
+                for (uint32_t jj = 0u; jj < jn; jj++) cnt += ((uint32_t)__builtin_amdgcn_readlane((int)vec, (int)jj) == my_t) ? 1u : 0u;
+                if (b0 < c0) before += cnt; else after += cnt;
+            }
+            if (mine && seg_counts.ok(k)) {
+                seg_counts.p[k].counts |= before << 16;
+                if (after == 0u && tile.ok(my_t)) tile.p[my_t].segment_count_or_ix = before + 1u;
+            }
         }
     }
 }
@@ -472,13 +487,18 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restr
 __global__ __launch_bounds__(JL_WG) void k_pc_scatter(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
                                                       const uint2* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
                                                       uint32_t tiles_cap, uint32_t* __restrict__ list, const uint32_t* __restrict__ kpath,
-                                                      const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ pend, uint32_t n_paths,
+                                                      const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ plast,
+                                                      const uint32_t* __restrict__ counts, const uint32_t* __restrict__ seg_bases, uint32_t n_paths,
                                                       const uint32_t* __restrict__ gate) {
     if (*gate == 0u) return;  // no big path in this frame
     uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
     for (uint32_t k = blockIdx.x * JL_WG + threadIdx.x; k < n; k += gridDim.x * JL_WG) {
         uint32_t P = kpath[k];
-        if (P < n_paths && pend[P] - pstart[P] <= PC_BIG_PATH) continue;  // ranked by k_pc_rank_small
+        if (P < n_paths) {
+            uint32_t ps, pe;
+            path_range(P, pfirst, plast, counts, seg_bases, ps, pe);
+            if (pe - ps <= PC_BIG_PATH) continue;  // ranked by k_pc_rank_small
+        }
         uint2 ta = tile_of[k];
         if (ta.x >= tiles_cap || !tile.ok(ta.x)) continue;
         uint32_t pos = list_base[ta.x] + ta.y;
@@ -489,13 +509,18 @@ __global__ __launch_bounds__(JL_WG) void k_pc_scatter(const JlConfig* __restrict
 __global__ __launch_bounds__(JL_WG) void k_pc_rank(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
                                                    const uint2* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
                                                    uint32_t tiles_cap, const uint32_t* __restrict__ list, Buf<JlSegmentCount> seg_counts,
-                                                   const uint32_t* __restrict__ kpath, const uint32_t* __restrict__ pstart,
-                                                   const uint32_t* __restrict__ pend, uint32_t n_paths, const uint32_t* __restrict__ gate) {
+                                                   const uint32_t* __restrict__ kpath, const uint32_t* __restrict__ pfirst,
+                                                   const uint32_t* __restrict__ plast, const uint32_t* __restrict__ counts,
+                                                   const uint32_t* __restrict__ seg_bases, uint32_t n_paths, const uint32_t* __restrict__ gate) {
     if (*gate == 0u) return;  // no big path in this frame
     uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
     for (uint32_t k = blockIdx.x * JL_WG + threadIdx.x; k < n; k += gridDim.x * JL_WG) {
         uint32_t P = kpath[k];
-        if (P < n_paths && pend[P] - pstart[P] <= PC_BIG_PATH) continue;  // ranked by k_pc_rank_small
+        if (P < n_paths) {
+            uint32_t ps, pe;
+            path_range(P, pfirst, plast, counts, seg_bases, ps, pe);
+            if (pe - ps <= PC_BIG_PATH) continue;  // ranked by k_pc_rank_small
+        }
         uint32_t t = tile_of[k].x;
         if (t >= tiles_cap || !tile.ok(t) || !seg_counts.ok(k)) continue;
         uint32_t base = list_base[t];
@@ -750,33 +775,32 @@ int jh_launch_path_count(const JhLaunch& L) {
     uint32_t* keys = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_F, (uint64_t)seg_cap * 4);
     uint32_t* kpath = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_H, (uint64_t)seg_cap * 4);
     uint32_t n_paths = paths.n;
-    // [pstart | pend | gate]: zeroed every frame
+    // [pstart | pend | gate]: zeroed every frame (the variables below keep the names of the path_range parameters)
     uint32_t* prange = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_I, ((uint64_t)n_paths * 2 + 64) * 4);
     if (!counts || !bases || !tile_of || !list || !list_base || !keys || !kpath || !prange) return -5;
-    uint32_t *pstart = prange, *pend = prange + n_paths, *gate = prange + 2 * (size_t)n_paths;
+    uint32_t *pfirst = prange, *plast = prange + n_paths, *gate = prange + 2 * (size_t)n_paths;
     (void)hipMemsetAsync(prange, 0, ((size_t)n_paths * 2 + 64) * 4, L.stream);
     uint32_t gl = stride_grid(L, lines_cap), gs = stride_grid(L, seg_cap);
     hipLaunchKernelGGL(k_pc_count, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, paths, counts, lines_cap);
     int rc = jh_scan_u32(L, counts, 1, bases, lines_cap, &bump->lines, &bump->seg_counts);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pc_paths, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, (const uint32_t*)counts,
-                       (const uint32_t*)bases, lines_cap, pstart, pend, n_paths);
-    hipLaunchKernelGGL(k_pc_emit, dim3(gl), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, ind, lines, paths, tile, segc,
-                       (const uint32_t*)bases, lines_cap, tile_of, keys, kpath, seg_cap, (const uint32_t*)pstart, (const uint32_t*)pend, n_paths,
-                       gate);
+                       (const uint32_t*)bases, lines_cap, pfirst, plast, n_paths);
+    const uint32_t *cpf = pfirst, *cpl = plast, *cc = counts, *cb = bases;
+    hipLaunchKernelGGL(k_pc_emit, dim3(gl), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, ind, lines, paths, tile, segc, cb, lines_cap,
+                       tile_of, keys, kpath, seg_cap, cpf, cpl, cc, n_paths, gate);
     // Big paths only (none in most frames: `gate` stays 0, the scan then covers 0 elements and the kernels return at once):
     // per-tile list bases = exclusive scan of Tile.segment_count_or_ix, scatter into the lists, rank inside the list.
     rc = jh_scan_u32(L, ((const uint32_t*)tile.p) + 1, 2, list_base, tiles_cap, gate, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pc_scatter, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint2*)tile_of, seg_cap,
-                       (const uint32_t*)list_base, tiles_cap, list, (const uint32_t*)kpath, (const uint32_t*)pstart, (const uint32_t*)pend,
-                       n_paths, (const uint32_t*)gate);
+                       (const uint32_t*)list_base, tiles_cap, list, (const uint32_t*)kpath, cpf, cpl, cc, cb, n_paths, (const uint32_t*)gate);
     hipLaunchKernelGGL(k_pc_rank, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint2*)tile_of, seg_cap,
-                       (const uint32_t*)list_base, tiles_cap, (const uint32_t*)list, segc, (const uint32_t*)kpath, (const uint32_t*)pstart,
-                       (const uint32_t*)pend, n_paths, (const uint32_t*)gate);
+                       (const uint32_t*)list_base, tiles_cap, (const uint32_t*)list, segc, (const uint32_t*)kpath, cpf, cpl, cc, cb, n_paths,
+                       (const uint32_t*)gate);
     // everything else: atomics-free ranks
-    hipLaunchKernelGGL(k_pc_rank_small, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint32_t*)keys,
-                       (const uint32_t*)kpath, seg_cap, (const uint32_t*)pstart, (const uint32_t*)pend, n_paths, segc);
+    hipLaunchKernelGGL(k_pc_rank_small, dim3(stride_grid(L, (uint64_t)n_paths * 64u)), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile,
+                       (const uint32_t*)keys, seg_cap, cpf, cpl, cc, cb, n_paths, segc);
     return 0;
 }
 

@@ -73,6 +73,12 @@ JD void write_path(Cmd& c, const Buf<JlTile>& tiles, JlTile tile, uint32_t tile_
     }
 }
 
+#define COARSE_UNROLL 4u
+#ifndef COARSE_EXP
+#define COARSE_EXP 0
+#endif
+#define COARSE_TILE_CACHE 4096u
+
 template <bool WRITE>
 __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlDrawMonoid> draw_monoids,
                                                   Buf<JlBinHeader> bin_headers, Buf<uint32_t> info_bin_data, Buf<JlPath> paths, Buf<JlTile> tiles,
@@ -96,6 +102,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     __shared__ uint32_t sh_flags[JL_WG];
     __shared__ uint32_t sh_pay[4][JL_WG];  // scene[dd .. dd+3]: colour / ramp index / blend+alpha
     __shared__ uint32_t sh_scan[8];
+    __shared__ uint2 sh_tile_cache[COARSE_TILE_CACHE];  // (backdrop, segment count) of the batch's first (draw, tile) pairs
 
     const uint32_t lid = threadIdx.x;
     const uint32_t width_in_bins = (cfg->width_in_tiles + JL_N_TILE_X - 1u) / JL_N_TILE_X;
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         }
         uint32_t tile_count = 0u;
         sh_tag[lid] = tag;
-        if (tag != JL_DRAWTAG_NOP) {
+        if (tag != JL_DRAWTAG_NOP && !(COARSE_EXP & 4)) {
             JlDrawMonoid dm0 = draw_monoids.rd(drawobj_ix);
             uint32_t path_ix = dm0.path_ix;
             uint32_t dd0 = cfg->layout.drawdata_base + dm0.scene_offset;
@@ -208,44 +215,66 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         uint32_t excl_tc = block_excl_scan_u32(tile_count, sh_scan, &total_tile_count);
         sh_tile_count[lid] = excl_tc + tile_count;
         __syncthreads();
-        for (uint32_t ix = lid; ix < total_tile_count; ix += JL_N_TILE) {
-            uint32_t el_ix = 0u;
-            for (uint32_t i = 0; i < 8u; i++) {
-                uint32_t probe = el_ix + (128u >> i);
-                if (ix >= sh_tile_count[probe - 1u]) el_ix = probe;
+        // (draw, tile) include test, coarse.wgsl:318-341.  The workgroup is alone on its CU (one workgroup per bin), so
+        // the Tile loads are issued four at a time per thread instead of one dependent load per iteration, and what
+        // they return is kept in LDS for the command walk below.
+        for (uint32_t base = 0u; base < total_tile_count && !(COARSE_EXP & 1); base += COARSE_UNROLL * JL_N_TILE) {
+            uint32_t p_el[COARSE_UNROLL], p_xy[COARSE_UNROLL], p_tile[COARSE_UNROLL];
+            JlTile p_t[COARSE_UNROLL];
+#pragma unroll
+            for (uint32_t u = 0; u < COARSE_UNROLL; u++) {
+                const uint32_t ix = base + u * JL_N_TILE + lid;
+                p_el[u] = 0xffffffffu; p_xy[u] = 0u; p_tile[u] = 0u;
+                p_t[u].backdrop = 0; p_t[u].segment_count_or_ix = 0u;
+                if (ix < total_tile_count) {
+                    uint32_t el_ix = 0u;
+#pragma unroll
+                    for (uint32_t i = 0; i < 8u; i++) {
+                        uint32_t probe = el_ix + (128u >> i);
+                        if (ix >= sh_tile_count[probe - 1u]) el_ix = probe;
+                    }
+                    uint32_t seq_ix = ix - (el_ix > 0u ? sh_tile_count[el_ix - 1u] : 0u);
+                    uint32_t width = sh_tile_width[el_ix];
+                    uint32_t x0y0 = sh_tile_x0y0[el_ix];
+                    uint32_t x = (x0y0 & 0xffffu) + seq_ix % width;
+                    uint32_t y = (x0y0 >> 16) + seq_ix / width;
+                    p_el[u] = el_ix;
+                    p_xy[u] = y * JL_N_TILE_X + x;
+                    p_tile[u] = sh_tile_base[el_ix] + sh_tile_stride[el_ix] * y + x;
+                }
             }
-            uint32_t d_tag = sh_tag[el_ix];
-            uint32_t seq_ix = ix - (el_ix > 0u ? sh_tile_count[el_ix - 1u] : 0u);
-            uint32_t width = sh_tile_width[el_ix];
-            uint32_t x0y0 = sh_tile_x0y0[el_ix];
-            uint32_t x = (x0y0 & 0xffffu) + seq_ix % width;
-            uint32_t y = (x0y0 >> 16) + seq_ix / width;
-            uint32_t tile_ix = sh_tile_base[el_ix] + sh_tile_stride[el_ix] * y + x;
-            JlTile tile = tiles.rd(tile_ix);
-            bool is_clip = (d_tag & 1u) != 0u;
-            bool is_blend = false;
-            if (is_clip) {
-                uint32_t blend = sh_pay[0][el_ix];
-                is_blend = blend != BLEND_CLIP;
-            }
-            uint32_t draw_flags = sh_flags[el_ix];
-            bool even_odd = (draw_flags & 1u) != 0u;
-            uint32_t n_segs = tile.segment_count_or_ix;
-            int32_t bd = tile.backdrop;
-            int32_t absbd = bd < 0 ? (int32_t)(0u - (uint32_t)bd) : bd;
-            bool backdrop_clear = (even_odd ? (absbd & 1) : bd) == 0;
-            bool include_tile = n_segs != 0u || (backdrop_clear == is_clip) || is_blend;
-            if (include_tile) {
-                uint32_t el_slice = el_ix / 32u;
-                uint32_t el_mask = 1u << (el_ix & 31u);
-                atomicOr(&sh_bitmaps[el_slice][y * JL_N_TILE_X + x], el_mask);
+#pragma unroll
+            for (uint32_t u = 0; u < COARSE_UNROLL; u++)
+                if (p_el[u] != 0xffffffffu) p_t[u] = tiles.rd(p_tile[u]);
+#pragma unroll
+            for (uint32_t u = 0; u < COARSE_UNROLL; u++) {
+                if (p_el[u] == 0xffffffffu) continue;
+                const uint32_t ix = base + u * JL_N_TILE + lid;
+                const uint32_t el_ix = p_el[u];
+                const JlTile tile = p_t[u];
+                if (ix < COARSE_TILE_CACHE) sh_tile_cache[ix] = make_uint2((uint32_t)tile.backdrop, tile.segment_count_or_ix);
+                uint32_t d_tag = sh_tag[el_ix];
+                bool is_clip = (d_tag & 1u) != 0u;
+                bool is_blend = false;
+                if (is_clip) {
+                    uint32_t blend = sh_pay[0][el_ix];
+                    is_blend = blend != BLEND_CLIP;
+                }
+                uint32_t draw_flags = sh_flags[el_ix];
+                bool even_odd = (draw_flags & 1u) != 0u;
+                uint32_t n_segs = tile.segment_count_or_ix;
+                int32_t bd = tile.backdrop;
+                int32_t absbd = bd < 0 ? (int32_t)(0u - (uint32_t)bd) : bd;
+                bool backdrop_clear = (even_odd ? (absbd & 1) : bd) == 0;
+                bool include_tile = n_segs != 0u || (backdrop_clear == is_clip) || is_blend;
+                if (include_tile) atomicOr(&sh_bitmaps[el_ix / 32u][p_xy[u]], 1u << (el_ix & 31u));
             }
         }
         __syncthreads();
         // Write the per-tile command list for this tile (coarse.wgsl:344-444)
         uint32_t slice_ix = 0u;
         uint32_t bitmap = sh_bitmaps[0][lid];
-        for (;;) {
+        for (; !(COARSE_EXP & 2);) {
             if (bitmap == 0u) {
                 slice_ix += 1u;
                 if (slice_ix == 8u) break;
@@ -259,7 +288,19 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             uint32_t draw_flags = sh_flags[el_ix];
             if (clip_zero_depth == 0u) {
                 uint32_t tile_ix = sh_tile_base[el_ix] + sh_tile_stride[el_ix] * tile_y + tile_x;
-                JlTile tile = tiles.rd(tile_ix);
+                JlTile tile;
+                {   // the pair's slot in the include-test order: what that pass loaded is still in LDS
+                    const uint32_t x0y0 = sh_tile_x0y0[el_ix];
+                    const uint32_t pair = (el_ix > 0u ? sh_tile_count[el_ix - 1u] : 0u) + (tile_y - (x0y0 >> 16)) * sh_tile_width[el_ix] +
+                                          (tile_x - (x0y0 & 0xffffu));
+                    if (pair < COARSE_TILE_CACHE) {
+                        const uint2 tc = sh_tile_cache[pair];
+                        tile.backdrop = (int32_t)tc.x;
+                        tile.segment_count_or_ix = tc.y;
+                    } else {
+                        tile = tiles.rd(tile_ix);
+                    }
+                }
                 switch (drawtag) {
                     case JL_DRAWTAG_FILL_COLOR: {
                         write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);

@@ -90,17 +90,13 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     __shared__ uint32_t sh_part_count[JL_WG];
     __shared__ uint32_t sh_part_offsets[JL_WG];
     __shared__ uint32_t sh_drawobj_ix[JL_WG];
-    __shared__ uint32_t sh_tile_stride[JL_WG];
-    __shared__ uint32_t sh_tile_width[JL_WG];
-    __shared__ uint32_t sh_tile_x0y0[JL_WG];
     __shared__ uint32_t sh_tile_count[JL_WG];
-    __shared__ uint32_t sh_tile_base[JL_WG];
     // per-batch draw object data staged once by the draw's own thread, so that the per-(draw,tile) include test and the
-    // serial per-tile command walk read LDS instead of chasing scene / draw_monoid / info pointers through HBM
-    __shared__ uint32_t sh_tag[JL_WG];
-    __shared__ uint32_t sh_di[JL_WG];
-    __shared__ uint32_t sh_flags[JL_WG];
-    __shared__ uint32_t sh_pay[4][JL_WG];  // scene[dd .. dd+3]: colour / ramp index / blend+alpha
+    // serial per-tile command walk read LDS instead of chasing scene / draw_monoid / info pointers through HBM; packed
+    // so that one walk step is three 16-byte LDS reads issued together:
+    __shared__ uint4 sh_r0[JL_WG];  // tag, draw flags, tile base (of bin-relative tile (0,0)), tile stride
+    __shared__ uint4 sh_r1[JL_WG];  // x0 | y0 << 16, width, first (draw, tile) pair of the draw in the batch, info offset
+    __shared__ uint4 sh_r2[JL_WG];  // scene[dd .. dd+3]: colour / ramp index / blend+alpha
     __shared__ uint32_t sh_scan[8];
     __shared__ uint2 sh_tile_cache[COARSE_TILE_CACHE];  // (backdrop, segment count) of the batch's first (draw, tile) pairs
 
@@ -186,34 +182,33 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             tag = scene.rd(cfg->layout.drawtag_base + drawobj_ix);
         }
         uint32_t tile_count = 0u;
-        sh_tag[lid] = tag;
+        uint4 r0 = make_uint4(tag, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0u, 0u), r2 = make_uint4(0u, 0u, 0u, 0u);
         if (tag != JL_DRAWTAG_NOP && !(COARSE_EXP & 4)) {
             JlDrawMonoid dm0 = draw_monoids.rd(drawobj_ix);
             uint32_t path_ix = dm0.path_ix;
             uint32_t dd0 = cfg->layout.drawdata_base + dm0.scene_offset;
-            sh_di[lid] = dm0.info_offset;
-            sh_flags[lid] = info_bin_data.rd(dm0.info_offset);
-            sh_pay[0][lid] = scene.rd(dd0);
-            sh_pay[1][lid] = scene.rd(dd0 + 1u);
-            sh_pay[2][lid] = scene.rd(dd0 + 2u);
-            sh_pay[3][lid] = scene.rd(dd0 + 3u);
+            r1.w = dm0.info_offset;
+            r0.y = info_bin_data.rd(dm0.info_offset);
+            r2 = make_uint4(scene.rd(dd0), scene.rd(dd0 + 1u), scene.rd(dd0 + 2u), scene.rd(dd0 + 3u));
             JlPath path = paths.rd(path_ix);
             uint32_t stride = path.bbox[2] - path.bbox[0];
-            sh_tile_stride[lid] = stride;
+            r0.w = stride;
             int32_t dx = (int32_t)path.bbox[0] - (int32_t)bin_tile_x;
             int32_t dy = (int32_t)path.bbox[1] - (int32_t)bin_tile_y;
             int32_t x0 = iclamp_(dx, 0, JL_N_TILE_X);
             int32_t y0 = iclamp_(dy, 0, JL_N_TILE_Y);
             int32_t x1 = iclamp_((int32_t)path.bbox[2] - (int32_t)bin_tile_x, 0, JL_N_TILE_X);
             int32_t y1 = iclamp_((int32_t)path.bbox[3] - (int32_t)bin_tile_y, 0, JL_N_TILE_Y);
-            sh_tile_width[lid] = (uint32_t)(x1 - x0);
-            sh_tile_x0y0[lid] = (uint32_t)x0 | ((uint32_t)y0 << 16);
+            r1.y = (uint32_t)(x1 - x0);
+            r1.x = (uint32_t)x0 | ((uint32_t)y0 << 16);
             tile_count = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
-            sh_tile_base[lid] = path.tiles - (uint32_t)(dy * (int32_t)stride + dx);
+            r0.z = path.tiles - (uint32_t)(dy * (int32_t)stride + dx);
         }
         uint32_t total_tile_count;
         uint32_t excl_tc = block_excl_scan_u32(tile_count, sh_scan, &total_tile_count);
         sh_tile_count[lid] = excl_tc + tile_count;
+        r1.z = excl_tc;
+        sh_r0[lid] = r0; sh_r1[lid] = r1; sh_r2[lid] = r2;
         __syncthreads();
         // (draw, tile) include test, coarse.wgsl:318-341.  The workgroup is alone on its CU (one workgroup per bin), so
         // the Tile loads are issued four at a time per thread instead of one dependent load per iteration, and what
@@ -233,14 +228,14 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                         uint32_t probe = el_ix + (128u >> i);
                         if (ix >= sh_tile_count[probe - 1u]) el_ix = probe;
                     }
-                    uint32_t seq_ix = ix - (el_ix > 0u ? sh_tile_count[el_ix - 1u] : 0u);
-                    uint32_t width = sh_tile_width[el_ix];
-                    uint32_t x0y0 = sh_tile_x0y0[el_ix];
-                    uint32_t x = (x0y0 & 0xffffu) + seq_ix % width;
-                    uint32_t y = (x0y0 >> 16) + seq_ix / width;
+                    const uint4 q0 = sh_r0[el_ix], q1 = sh_r1[el_ix];
+                    uint32_t seq_ix = ix - q1.z;
+                    uint32_t width = q1.y;
+                    uint32_t x = (q1.x & 0xffffu) + seq_ix % width;
+                    uint32_t y = (q1.x >> 16) + seq_ix / width;
                     p_el[u] = el_ix;
                     p_xy[u] = y * JL_N_TILE_X + x;
-                    p_tile[u] = sh_tile_base[el_ix] + sh_tile_stride[el_ix] * y + x;
+                    p_tile[u] = q0.z + q0.w * y + x;
                 }
             }
 #pragma unroll
@@ -253,14 +248,15 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                 const uint32_t el_ix = p_el[u];
                 const JlTile tile = p_t[u];
                 if (ix < COARSE_TILE_CACHE) sh_tile_cache[ix] = make_uint2((uint32_t)tile.backdrop, tile.segment_count_or_ix);
-                uint32_t d_tag = sh_tag[el_ix];
+                const uint4 q0 = sh_r0[el_ix];
+                uint32_t d_tag = q0.x;
                 bool is_clip = (d_tag & 1u) != 0u;
                 bool is_blend = false;
                 if (is_clip) {
-                    uint32_t blend = sh_pay[0][el_ix];
+                    uint32_t blend = sh_r2[el_ix].x;
                     is_blend = blend != BLEND_CLIP;
                 }
-                uint32_t draw_flags = sh_flags[el_ix];
+                uint32_t draw_flags = q0.y;
                 bool even_odd = (draw_flags & 1u) != 0u;
                 uint32_t n_segs = tile.segment_count_or_ix;
                 int32_t bd = tile.backdrop;
@@ -283,16 +279,15 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             }
             uint32_t el_ix = slice_ix * 32u + (uint32_t)__builtin_ctz(bitmap);
             bitmap &= bitmap - 1u;
-            uint32_t drawtag = sh_tag[el_ix];
-            uint32_t di = sh_di[el_ix];
-            uint32_t draw_flags = sh_flags[el_ix];
+            const uint4 q0 = sh_r0[el_ix], q1 = sh_r1[el_ix], q2 = sh_r2[el_ix];
+            uint32_t drawtag = q0.x;
+            uint32_t di = q1.w;
+            uint32_t draw_flags = q0.y;
             if (clip_zero_depth == 0u) {
-                uint32_t tile_ix = sh_tile_base[el_ix] + sh_tile_stride[el_ix] * tile_y + tile_x;
+                uint32_t tile_ix = q0.z + q0.w * tile_y + tile_x;
                 JlTile tile;
                 {   // the pair's slot in the include-test order: what that pass loaded is still in LDS
-                    const uint32_t x0y0 = sh_tile_x0y0[el_ix];
-                    const uint32_t pair = (el_ix > 0u ? sh_tile_count[el_ix - 1u] : 0u) + (tile_y - (x0y0 >> 16)) * sh_tile_width[el_ix] +
-                                          (tile_x - (x0y0 & 0xffffu));
+                    const uint32_t pair = q1.z + (tile_y - (q1.x >> 16)) * q1.y + (tile_x - (q1.x & 0xffffu));
                     if (pair < COARSE_TILE_CACHE) {
                         const uint2 tc = sh_tile_cache[pair];
                         tile.backdrop = (int32_t)tc.x;
@@ -307,10 +302,10 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                         alloc_cmd<WRITE>(c, 5u);
                         if (WRITE) {
                             c.ptcl.wr(c.cmd_offset, JL_CMD_COLOR);
-                            c.ptcl.wr(c.cmd_offset + 1u, sh_pay[0][el_ix]);
-                            c.ptcl.wr(c.cmd_offset + 2u, sh_pay[1][el_ix]);
-                            c.ptcl.wr(c.cmd_offset + 3u, sh_pay[2][el_ix]);
-                            c.ptcl.wr(c.cmd_offset + 4u, sh_pay[3][el_ix]);
+                            c.ptcl.wr(c.cmd_offset + 1u, q2.x);
+                            c.ptcl.wr(c.cmd_offset + 2u, q2.y);
+                            c.ptcl.wr(c.cmd_offset + 3u, q2.z);
+                            c.ptcl.wr(c.cmd_offset + 4u, q2.w);
                         }
                         c.cmd_offset += 5u;
                         break;
@@ -324,7 +319,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                             uint32_t ty = drawtag == JL_DRAWTAG_FILL_LIN_GRADIENT ? JL_CMD_LIN_GRAD
                                           : (drawtag == JL_DRAWTAG_FILL_RAD_GRADIENT ? JL_CMD_RAD_GRAD : JL_CMD_SWEEP_GRAD);
                             c.ptcl.wr(c.cmd_offset, ty);
-                            c.ptcl.wr(c.cmd_offset + 1u, sh_pay[0][el_ix]);
+                            c.ptcl.wr(c.cmd_offset + 1u, q2.x);
                             c.ptcl.wr(c.cmd_offset + 2u, di + 1u);
                         }
                         c.cmd_offset += 3u;
@@ -359,8 +354,8 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                         alloc_cmd<WRITE>(c, 3u);
                         if (WRITE) {
                             c.ptcl.wr(c.cmd_offset, JL_CMD_END_CLIP);
-                            c.ptcl.wr(c.cmd_offset + 1u, sh_pay[0][el_ix]);
-                            c.ptcl.wr(c.cmd_offset + 2u, sh_pay[1][el_ix]);
+                            c.ptcl.wr(c.cmd_offset + 1u, q2.x);
+                            c.ptcl.wr(c.cmd_offset + 2u, q2.y);
                         }
                         c.cmd_offset += 3u;
                         render_blend_depth -= 1u;

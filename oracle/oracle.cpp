@@ -460,6 +460,10 @@ enum { ESPC_ROBUST_NORMAL = 0, ESPC_ROBUST_LOW_K1 = 1, ESPC_ROBUST_LOW_DIST = 2 
 // flatten.wgsl:328-477
 // instrumentation only (tools/flatten_stats.py): [jobs, attempts, lines, pieces, histogram of attempts per job (28 bins)]
 static uint64_t g_flatten_stats[32];
+static float* g_flatten_pairs = nullptr;  // optional (root error * scale, attempts) log for tools/flatten_stats.py
+static size_t g_flatten_pairs_n = 0, g_flatten_pairs_cap = 0;
+extern "C" void oracle_flatten_pairs(float* buf, size_t cap) { g_flatten_pairs = buf; g_flatten_pairs_cap = cap; g_flatten_pairs_n = 0; }
+extern "C" size_t oracle_flatten_pairs_count() { return g_flatten_pairs_n; }
 extern "C" void oracle_flatten_stats(uint64_t* out, int reset) {
     for (int i = 0; i < 32; i++) { out[i] = g_flatten_stats[i]; if (reset) g_flatten_stats[i] = 0; }
 }
@@ -496,6 +500,7 @@ static void flatten_euler(Ctx& c, const CubicPoints& cubic, uint32_t path_ix, co
     float last_t = 0.0f;
     V2 lp0 = t_start;
     uint32_t st_attempts = 0u, st_pieces = 0u;
+    float st_root_err = 0.0f;
     for (;;) {
         float t0 = (float)t0_u * dt;
         if (t0 == 1.0f) break;
@@ -514,6 +519,7 @@ static void flatten_euler(Ctx& c, const CubicPoints& cubic, uint32_t path_ix, co
         }
         float actual_dt = t1 - last_t;
         CubicParams cp = cubic_from_points_derivs(this_p0, this_pq1.point, this_q0, this_pq1.deriv, actual_dt);
+        if (st_attempts == 1u) st_root_err = cp.err * scale;
         if (cp.err * scale <= tol || dt <= SUBDIV_LIMIT) {
             EulerParams ep = es_params_from_angles(cp.th0, cp.th1);
             EulerSeg es{this_p0, this_pq1.point, ep};
@@ -590,6 +596,11 @@ static void flatten_euler(Ctx& c, const CubicPoints& cubic, uint32_t path_ix, co
     g_flatten_stats[1] += st_attempts;
     g_flatten_stats[3] += st_pieces;
     g_flatten_stats[4 + (st_attempts < 27u ? st_attempts : 27u)] += 1u;
+    if (g_flatten_pairs && g_flatten_pairs_n < g_flatten_pairs_cap) {
+        g_flatten_pairs[2 * g_flatten_pairs_n] = st_root_err;
+        g_flatten_pairs[2 * g_flatten_pairs_n + 1] = (float)st_attempts;
+        g_flatten_pairs_n++;
+    }
 }
 
 // flatten.wgsl:490-517

@@ -36,6 +36,10 @@ struct PathTagData { uint32_t tag_byte; MonoidK<5> monoid; };
 #define TANGENT_THRESH 1e-6f
 
 #define FL_INVALID 0xffffffffu
+#define FL_SRC_DIRECT 0xfffffffeu    // tsrc: the temp slot holds a complete (already transformed) line in tlines
+#define FL_INFO_PIECE 0x80000000u    // tinfo: an Euler piece starts here, low 16 bits = its line count; its record is pieces[slot]
+#define FL_INFO_POINT 0x40000000u    // tinfo: the slot only holds a point (start of an Euler job)
+#define FL_INFO_DIRECT 0x20000000u   // tinfo: complete line
 #ifndef FL_REFILL_LANES
 #define FL_REFILL_LANES 24u  // idle lanes that trigger a refill of the wave
 #endif
@@ -49,6 +53,8 @@ struct Out {
     const JlConfig* cfg;
     JlLineSoup* tlines;
     uint2* tkeys;
+    uint32_t* tsrc;   // per temp slot: where the line's start point comes from (FL_SRC_DIRECT: the slot holds a complete line)
+    uint32_t* tinfo;  // per temp slot: FL_INFO_* marker (0 = nothing starts here)
     uint32_t tcap;
     uint32_t slot;
     uint32_t cursor;           // lines emitted so far by this item (local index of the next line)
@@ -69,6 +75,14 @@ struct Out {
         }
         return first;
     }
+    JD uint32_t alloc_temp(uint32_t n) {  // temp slots that are not lines of the item (Euler start points)
+        uint32_t p = 0u;
+        if (EMIT) {
+            p = atomicAdd(lds_next, n);
+            if (p + n > lds_limit) p = atomicAdd(g_next, n);
+        }
+        return p;
+    }
     JD void write_line(uint32_t line_ix, uint32_t path_ix, V2 p0, V2 p1) {  // flatten.wgsl:749-756
         if (EMIT) {
             bx0 = fmin_(bx0, fmin_(p0.x, p1.x));
@@ -81,6 +95,8 @@ struct Out {
                 l.path_ix = path_ix; l.pad = 0; l.p0[0] = p0.x; l.p0[1] = p0.y; l.p1[0] = p1.x; l.p1[1] = p1.y;
                 tlines[t] = l;
                 tkeys[t] = make_uint2(slot, line_ix);
+                tsrc[t] = FL_SRC_DIRECT;
+                tinfo[t] = FL_INFO_DIRECT;
             }
         }
     }
@@ -296,29 +312,27 @@ struct Scene {
 };
 
 // ------------------------------------------------------------------------------------------------
-// flatten_euler (flatten.wgsl:328-477), wave-cooperative.
+// flatten_euler (flatten.wgsl:328-477) in two kernels.
 //
-// Every lane of the wave may own one Euler job (a cubic + offset).  The adaptive subdivision runs per
-// lane exactly as in the WGSL.  When lanes ACCEPT a piece in an iteration they publish its parameters in
-// LDS, the wave prefix-sums the pieces' line counts, and then ALL 64 lanes evaluate the lines of all
-// accepted pieces together (lane j takes line j: owner piece by binary search, end point by
-// es_seg_eval_with_offset, start point from lane j-1's end point / the piece's start).  This removes
-// the divergence of the per-lane `for i < n` loop, which otherwise dominates the stage.  Arithmetic per
-// point is the WGSL's, so results are bit-identical to the sequential formulation.
+// k_flatten_items: every lane owns one Euler job (a cubic + offset) and runs the adaptive subdivision exactly as in the
+// WGSL.  An ACCEPTED piece reserves its n line slots in the temporary buffer and leaves a 96-byte record there; its
+// lines are NOT evaluated in this kernel (that loop at 3 waves/SIMD and 35 % lane use cost 240 of the stage's 600 us).
+// k_flatten_lines: one thread per temporary slot evaluates the END point of its line from the piece record (the
+// WGSL's arithmetic per point) and stores it already transformed.  A line's START point is the end point of the line
+// before it -- the previous slot, or for a piece's first line the last slot of the previous piece of the job, or the
+// job's start point, which k_flatten_items stores in a slot of its own -- so k_flatten_permute assembles
+// (start, end) from two stored points while moving the line to its canonical position.  Same operations on the same
+// values as the sequential formulation, hence the same bits.
 // ------------------------------------------------------------------------------------------------
-enum {
-    F_INCL = 0, F_P0X, F_P0Y, F_P1X, F_P1Y, F_TH0, F_K0, F_K1, F_CH, F_A, F_B, F_INTEGRAL, F_INT0, F_NOFF, F_N, F_LP0X, F_LP0Y,
-    F_TENDX, F_TENDY, F_FLAGS, F_PATH, F_TPOS, F_FIRST, F_SLOT, F_TRANS, F_LPENDX, F_LPENDY, F_BX0, F_BY0, F_BX1, F_BY1, F_COUNT
-};
-typedef volatile uint32_t WaveLds[F_COUNT][64];
-
 JD void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-// order-preserving float <-> uint key (for integer LDS atomic min/max on floats)
-JD uint32_t fkey(float f) { uint32_t b = f2u(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
-JD float fkey_inv(uint32_t k) { return u2f((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// piece record: 6 x uint4 at pieces[6 * tpos]
+//   0: es_p0.x es_p0.y es_p1.x es_p1.y   1: th0 k0 k1 ch   2: a b integral int0   3: noff n t_end.x t_end.y
+//   4: flags tpos slot first             5: path_ix trans_ix start_src -
+// flags: bits 0-1 robust case, 4 = ends at t == 1 (last line ends in t_end), 8 = offset >= 0, 16 = offset == 0
 
 struct EulerJob {
     bool valid;
@@ -328,24 +342,6 @@ struct EulerJob {
     float offset;
     V2 start_p, end_p;
 };
-
-JD V2 piece_eval(WaveLds& W, uint32_t owner, uint32_t i_plus_1, uint32_t flags) {
-    float n = u2f(W[F_N][owner]);
-    float t = (float)i_plus_1 / n;
-    float s = t;
-    uint32_t robust = flags & 3u;
-    float a = u2f(W[F_A][owner]), b = u2f(W[F_B][owner]);
-    if (robust != 1u) {
-        float u = u2f(W[F_INTEGRAL][owner]) * t + u2f(W[F_INT0][owner]);
-        float inv;
-        if (robust == 2u) inv = pow23_abs_(u) * sign_(u); else inv = espc_int_inv_approx(u);
-        s = (inv - b) / a;
-    }
-    EulerParams ep;
-    ep.th0 = u2f(W[F_TH0][owner]); ep.th1 = 0.0f; ep.k0 = u2f(W[F_K0][owner]); ep.k1 = u2f(W[F_K1][owner]); ep.ch = u2f(W[F_CH][owner]);
-    V2 es_p0 = v2(u2f(W[F_P0X][owner]), u2f(W[F_P0Y][owner])), es_p1 = v2(u2f(W[F_P1X][owner]), u2f(W[F_P1Y][owner]));
-    return es_seg_eval_with_offset(es_p0, es_p1, ep, s, u2f(W[F_NOFF][owner]));
-}
 
 // Resumable per-lane state of flatten_euler: lanes that finish their job early are REFILLED with the next
 // work item while the others keep subdividing (the attempts per job vary from 1 to ~30, and with ~1.5 cubic
@@ -358,13 +354,12 @@ struct EulerLane {
     float dt;
     V2 last_p, last_q;
     float last_t;
-    V2 lp0;
+    uint32_t start_src;  // temp slot holding the start point of the next piece's first line
     uint32_t path_ix, trans_ix;
     bool done;
 };
 
-JD void euler_begin(EulerLane& e, const EulerJob& job, WaveLds& W) {  // flatten.wgsl:328-360
-    const uint32_t lane = lane_id();
+JD void euler_begin(EulerLane& e, const EulerJob& job, Out<true>& o, float2* __restrict__ tE) {  // flatten.wgsl:328-360
     e.p0 = e.p1 = e.p2 = e.p3 = v2(0, 0);
     e.scale = 1.0f;
     V2 t_start = job.start_p;
@@ -395,15 +390,25 @@ JD void euler_begin(EulerLane& e, const EulerJob& job, WaveLds& W) {  // flatten
     e.last_q = e.p1 - e.p0;
     if (!e.done && dot(e.last_q, e.last_q) < DERIV_THRESH_SQUARED) e.last_q = eval_cubic_and_deriv(e.p0, e.p1, e.p2, e.p3, DERIV_EPS).deriv;
     e.last_t = 0.0f;
-    e.lp0 = t_start;
-    W[F_BX0][lane] = fkey(1e31f); W[F_BY0][lane] = fkey(1e31f); W[F_BX1][lane] = fkey(-1e31f); W[F_BY1][lane] = fkey(-1e31f);
+    e.start_src = 0u;
+    if (!e.done) {
+        // the job's start point gets a temp slot of its own, stored the way every line point is: transformed
+        Xf tr = (job.offset == 0.0f) ? xf_identity() : job.local_to_device;
+        uint32_t ps = o.alloc_temp(1u);
+        if (ps < o.tcap) {
+            V2 q = xf_apply(tr, t_start);
+            tE[ps] = make_float2(q.x, q.y);
+            o.tinfo[ps] = FL_INFO_POINT;
+            o.tkeys[ps] = make_uint2(FL_INVALID, 0u);  // not a line
+        }
+        e.start_src = ps;
+    }
 }
 
 // `refill()` is called (by the whole wave) when enough lanes are idle; it finalises finished items, gives idle
 // lanes new ones (euler_begin) and returns false once no lane is active and the queue is empty.
 template <class Refill>
-JD void flatten_euler_wave(Out<true>& o, EulerLane& e, const Scene& sc, WaveLds& W, Refill&& refill) {
-    const uint32_t lane = lane_id();
+JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ pieces, Refill&& refill) {
     V2 &p0 = e.p0, &p1 = e.p1, &p2 = e.p2, &p3 = e.p3;
     float& scale = e.scale;
     const float& offset = e.offset;
@@ -414,7 +419,6 @@ JD void flatten_euler_wave(Out<true>& o, EulerLane& e, const Scene& sc, WaveLds&
     float& dt = e.dt;
     V2 &last_p = e.last_p, &last_q = e.last_q;
     float& last_t = e.last_t;
-    V2& lp0 = e.lp0;
     for (;;) {
         {
             uint64_t idle = __builtin_amdgcn_ballot_w64(done);
@@ -498,78 +502,21 @@ JD void flatten_euler_wave(Out<true>& o, EulerLane& e, const Scene& sc, WaveLds&
                 }
             }
         }
-        uint32_t nm = accept ? n_u : 0u;
-        uint32_t incl = wave_incl_scan_u32(nm);
-        uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (total == 0u) continue;
         if (accept) {
-            uint32_t first = o.alloc(n_u);
-            W[F_P0X][lane] = f2u(es_p0.x); W[F_P0Y][lane] = f2u(es_p0.y); W[F_P1X][lane] = f2u(es_p1.x); W[F_P1Y][lane] = f2u(es_p1.y);
-            W[F_TH0][lane] = f2u(ep.th0); W[F_K0][lane] = f2u(ep.k0); W[F_K1][lane] = f2u(ep.k1); W[F_CH][lane] = f2u(ep.ch);
-            W[F_A][lane] = f2u(pc_a); W[F_B][lane] = f2u(pc_b); W[F_INTEGRAL][lane] = f2u(pc_integral); W[F_INT0][lane] = f2u(pc_int0);
-            W[F_NOFF][lane] = f2u(pc_noff); W[F_N][lane] = f2u(pc_n);
-            W[F_LP0X][lane] = f2u(lp0.x); W[F_LP0Y][lane] = f2u(lp0.y); W[F_TENDX][lane] = f2u(t_end.x); W[F_TENDY][lane] = f2u(t_end.y);
-            W[F_FLAGS][lane] = pc_flags; W[F_PATH][lane] = e.path_ix; W[F_TPOS][lane] = o.a_tpos; W[F_FIRST][lane] = first;
-            W[F_SLOT][lane] = o.slot; W[F_TRANS][lane] = e.trans_ix;
+            const uint32_t first = o.alloc(n_u);
+            const uint32_t tpos = o.a_tpos;
+            if (tpos < o.tcap && tpos + n_u <= o.tcap) {
+                uint4* rec = pieces + (size_t)tpos * 6u;
+                rec[0] = make_uint4(f2u(es_p0.x), f2u(es_p0.y), f2u(es_p1.x), f2u(es_p1.y));
+                rec[1] = make_uint4(f2u(ep.th0), f2u(ep.k0), f2u(ep.k1), f2u(ep.ch));
+                rec[2] = make_uint4(f2u(pc_a), f2u(pc_b), f2u(pc_integral), f2u(pc_int0));
+                rec[3] = make_uint4(f2u(pc_noff), f2u(pc_n), f2u(t_end.x), f2u(t_end.y));
+                rec[4] = make_uint4(pc_flags, tpos, o.slot, first);
+                rec[5] = make_uint4(e.path_ix, e.trans_ix, e.start_src, 0u);
+                o.tinfo[tpos] = FL_INFO_PIECE | n_u;
+            }
+            e.start_src = tpos + n_u - 1u;  // the next piece starts where this one's last line ends
         }
-        W[F_INCL][lane] = incl;
-        wave_fence();
-        for (uint32_t base = 0u; base < total; base += 64u) {
-            uint32_t j = base + lane;
-            bool valid = j < total;
-            // owner = first lane whose inclusive count exceeds j
-            uint32_t owner = 0u;
-#pragma unroll
-            for (uint32_t step = 32u; step > 0u; step >>= 1) {
-                uint32_t probe = owner + step;
-                if (W[F_INCL][probe - 1u] <= j) owner = probe;
-            }
-            if (owner > 63u) owner = 63u;
-            V2 lp1 = v2(0, 0);
-            uint32_t flags = 0u, i = 0u, n_own = 0u;
-            if (valid) {
-                flags = W[F_FLAGS][owner];
-                n_own = to_u32(u2f(W[F_N][owner]));
-                i = j - (W[F_INCL][owner] - n_own);
-                if (i + 1u == n_own && (flags & 4u) != 0u) lp1 = v2(u2f(W[F_TENDX][owner]), u2f(W[F_TENDY][owner]));
-                else lp1 = piece_eval(W, owner, i + 1u, flags);
-            }
-            // lane j-1's end point (DPP wave_shr:1, no LDS crossbar round trip)
-            float px = u2f((uint32_t)__builtin_amdgcn_update_dpp(0, (int)f2u(lp1.x), 0x138, 0xf, 0xf, false));
-            float py = u2f((uint32_t)__builtin_amdgcn_update_dpp(0, (int)f2u(lp1.y), 0x138, 0xf, 0xf, false));
-            if (valid) {
-                V2 a0;
-                if (i == 0u) a0 = v2(u2f(W[F_LP0X][owner]), u2f(W[F_LP0Y][owner]));
-                else if (lane > 0u) a0 = v2(px, py);
-                else a0 = piece_eval(W, owner, i, flags);
-                Xf tr;
-                if ((flags & 16u) != 0u) {
-                    tr = xf_identity();
-                } else {
-                    uint32_t tb = sc.cfg->layout.transform_base + W[F_TRANS][owner] * 6u;
-                    tr.m0 = u2f(sc.scene.rd(tb)); tr.m1 = u2f(sc.scene.rd(tb + 1u)); tr.m2 = u2f(sc.scene.rd(tb + 2u));
-                    tr.m3 = u2f(sc.scene.rd(tb + 3u)); tr.t0 = u2f(sc.scene.rd(tb + 4u)); tr.t1 = u2f(sc.scene.rd(tb + 5u));
-                }
-                V2 l0 = (flags & 8u) ? a0 : lp1;
-                V2 l1 = (flags & 8u) ? lp1 : a0;
-                V2 q0 = xf_apply(tr, l0), q1 = xf_apply(tr, l1);
-                atomicMin((uint32_t*)&W[F_BX0][owner], fkey(fmin_(q0.x, q1.x)));
-                atomicMin((uint32_t*)&W[F_BY0][owner], fkey(fmin_(q0.y, q1.y)));
-                atomicMax((uint32_t*)&W[F_BX1][owner], fkey(fmax_(q0.x, q1.x)));
-                atomicMax((uint32_t*)&W[F_BY1][owner], fkey(fmax_(q0.y, q1.y)));
-                uint32_t t = W[F_TPOS][owner] + i;
-                if (t < o.tcap) {
-                    JlLineSoup l;
-                    l.path_ix = W[F_PATH][owner]; l.pad = 0; l.p0[0] = q0.x; l.p0[1] = q0.y; l.p1[0] = q1.x; l.p1[1] = q1.y;
-                    o.tlines[t] = l;
-                    o.tkeys[t] = make_uint2(W[F_SLOT][owner], W[F_FIRST][owner] + i);
-                }
-                if (i + 1u == n_own) { W[F_LPENDX][owner] = f2u(lp1.x); W[F_LPENDY][owner] = f2u(lp1.y); }
-            }
-        }
-        wave_fence();
-        if (accept) lp0 = v2(u2f(W[F_LPENDX][lane]), u2f(W[F_LPENDY][lane]));
-        wave_fence();
     }
 }
 
@@ -892,11 +839,11 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
                                                          Buf<JlPathBbox> path_bboxes, const uint32_t* __restrict__ list,
                                                          uint32_t* __restrict__ counters, uint32_t cap, uint32_t* __restrict__ counts,
                                                          JlLineSoup* __restrict__ tlines, uint2* __restrict__ tkeys, uint32_t tcap,
-                                                         uint32_t FL_CHUNK) {
+                                                         uint32_t FL_CHUNK, uint32_t* __restrict__ tsrc, uint32_t* __restrict__ tinfo,
+                                                         float2* __restrict__ tE, uint4* __restrict__ pieces) {
     __shared__ uint32_t sh_next;
     __shared__ uint32_t sh_chunk;
     __shared__ uint32_t sh_item;  // next position of this workgroup's share of the item list
-    __shared__ WaveLds sh_wave[JL_WG / 64];
     Scene s;
     s.cfg = cfg; s.scene = scene; s.tag_monoids = tag_monoids;
     uint32_t n_heavy = umin_(counters[0], cap), n_light = umin_(counters[1], cap - n_heavy);
@@ -915,35 +862,24 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
         if (t < tcap) tkeys[t] = make_uint2(FL_INVALID, 0u);
     }
     __syncthreads();
-    WaveLds& W = sh_wave[threadIdx.x >> 6];
     const uint32_t lane = lane_id();
     // Work distribution: the item list (heavy items first) is dealt to the workgroups in chunks of 64, round robin;
     // the waves of a workgroup draw their items from its share through one LDS counter.
     Out<true> o;
-    o.cfg = cfg; o.tlines = tlines; o.tkeys = tkeys; o.tcap = tcap; o.slot = 0u;
+    o.cfg = cfg; o.tlines = tlines; o.tkeys = tkeys; o.tsrc = tsrc; o.tinfo = tinfo; o.tcap = tcap; o.slot = 0u;
     o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
     o.lds_next = &sh_next; o.lds_limit = chunk + FL_CHUNK; o.g_next = &counters[2];
     o.bx0 = 1e31f; o.by0 = 1e31f; o.bx1 = -1e31f; o.by1 = -1e31f;
     EulerLane e;
     e.p0 = e.p1 = e.p2 = e.p3 = v2(0, 0);
     e.scale = 1.0f; e.offset = 0.0f; e.t_end = v2(0, 0); e.t0_u = 0u; e.dt = 1.0f; e.last_p = e.last_q = v2(0, 0); e.last_t = 0.0f;
-    e.lp0 = v2(0, 0); e.path_ix = 0u; e.trans_ix = 0u; e.done = true;
+    e.start_src = 0u; e.path_ix = 0u; e.trans_ix = 0u; e.done = true;
     bool have = false;       // this lane holds an item that is not finalised yet
     uint32_t path_ix = 0u;
     auto refill = [&]() -> bool {
         for (;;) {
-            if (e.done && have) {  // the lane's item is complete
-                // fold the wave-cooperative bbox of the item's Euler lines (sentinels if it had none) into the item's
-                o.bx0 = fmin_(o.bx0, fkey_inv(W[F_BX0][lane])); o.by0 = fmin_(o.by0, fkey_inv(W[F_BY0][lane]));
-                o.bx1 = fmax_(o.bx1, fkey_inv(W[F_BX1][lane])); o.by1 = fmax_(o.by1, fkey_inv(W[F_BY1][lane]));
+            if (e.done && have) {  // the lane's item is complete (path bounding boxes: k_flatten_bbox)
                 counts[o.slot] = o.cursor;
-                if ((o.bx1 > o.bx0 || o.by1 > o.by0) && path_bboxes.ok(path_ix)) {  // flatten.wgsl:893-899 (min/max are order-free)
-                    JlPathBbox* out = &path_bboxes.p[path_ix];
-                    atomicMin(&out->x0, to_i32(floor_(o.bx0)));
-                    atomicMin(&out->y0, to_i32(floor_(o.by0)));
-                    atomicMax(&out->x1, to_i32(ceil_(o.bx1)));
-                    atomicMax(&out->y1, to_i32(ceil_(o.by1)));
-                }
                 have = false;
             }
             const bool want = e.done;
@@ -967,7 +903,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
                 job.cubic.p0 = job.cubic.p1 = job.cubic.p2 = job.cubic.p3 = v2(0, 0);
                 job.local_to_device = xf_identity();
                 run_item<true>(cfg, s, o, slot, job, path_ix);
-                euler_begin(e, job, W);
+                euler_begin(e, job, o, tE);
                 have = true;
             }
             wave_fence();
@@ -976,19 +912,121 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
             // only direct items (lines, caps, joins) were drawn, or finished ones wait to be finalised: go round again
         }
     };
-    flatten_euler_wave(o, e, s, W, refill);
+    flatten_euler_wave(o, e, pieces, refill);
+}
+
+// One thread per temporary slot: the end point of the Euler line that lives there (if any).
+__global__ __launch_bounds__(JL_WG) void k_flatten_lines(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, const uint32_t* __restrict__ counters,
+                                                         const uint32_t* __restrict__ tinfo, const uint4* __restrict__ pieces, uint32_t tcap,
+                                                         float2* __restrict__ tE, uint2* __restrict__ tkeys, uint32_t* __restrict__ tsrc,
+                                                         uint32_t* __restrict__ tmeta) {
+    const uint32_t n_t = umin_(counters[2], tcap);
+    for (uint32_t t = blockIdx.x * JL_WG + threadIdx.x; t < n_t; t += gridDim.x * JL_WG) {
+        // which piece covers slot t?  Its first slot carries the marker; pieces have at most 100 lines.
+        uint32_t v = tinfo[t];
+        uint32_t tp = t;
+        if (v == 0u) {
+            for (uint32_t back = 1u; back <= 100u && back <= t; back++) {
+                v = tinfo[t - back];
+                if (v != 0u) { tp = t - back; break; }
+            }
+        }
+        if ((v & FL_INFO_PIECE) == 0u) continue;
+        const uint32_t n_u = v & 0xffffu, i = t - tp;
+        if (i >= n_u) continue;
+        const uint4* rec = pieces + (size_t)tp * 6u;
+        const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
+        const uint32_t flags = r4.x;
+        V2 lp1;
+        if (i + 1u == n_u && (flags & 4u) != 0u) {
+            lp1 = v2(u2f(r3.z), u2f(r3.w));
+        } else {  // flatten.wgsl:440-461
+            const float n = u2f(r3.y);
+            const float tt = (float)(i + 1u) / n;
+            float sarg = tt;
+            const uint32_t robust = flags & 3u;
+            const float a = u2f(r2.x), b = u2f(r2.y);
+            if (robust != 1u) {
+                float u = u2f(r2.z) * tt + u2f(r2.w);
+                float inv;
+                if (robust == 2u) inv = pow23_abs_(u) * sign_(u); else inv = espc_int_inv_approx(u);
+                sarg = (inv - b) / a;
+            }
+            EulerParams ep;
+            ep.th0 = u2f(r1.x); ep.th1 = 0.0f; ep.k0 = u2f(r1.y); ep.k1 = u2f(r1.z); ep.ch = u2f(r1.w);
+            lp1 = es_seg_eval_with_offset(v2(u2f(r0.x), u2f(r0.y)), v2(u2f(r0.z), u2f(r0.w)), ep, sarg, u2f(r3.x));
+        }
+        Xf tr;
+        if ((flags & 16u) != 0u) {
+            tr = xf_identity();
+        } else {
+            uint32_t tb = cfg->layout.transform_base + r5.y * 6u;
+            tr.m0 = u2f(scene.rd(tb)); tr.m1 = u2f(scene.rd(tb + 1u)); tr.m2 = u2f(scene.rd(tb + 2u));
+            tr.m3 = u2f(scene.rd(tb + 3u)); tr.t0 = u2f(scene.rd(tb + 4u)); tr.t1 = u2f(scene.rd(tb + 5u));
+        }
+        const V2 q = xf_apply(tr, lp1);
+        tE[t] = make_float2(q.x, q.y);
+        tkeys[t] = make_uint2(r4.z, r4.w + i);
+        tsrc[t] = (i == 0u) ? r5.z : (t - 1u);
+        tmeta[t] = (r5.x & 0x7fffffffu) | ((flags & 8u) ? 0u : 0x80000000u);  // path | reversed (offset < 0)
+    }
 }
 
 // lines[bases[slot] + k] = temp line: the canonical (tag byte, emission order) LineSoup order.
 __global__ __launch_bounds__(JL_WG) void k_flatten_permute(const JlConfig* __restrict__ cfg, const uint32_t* __restrict__ counters,
                                                            const JlLineSoup* __restrict__ tlines, const uint2* __restrict__ tkeys, uint32_t tcap,
-                                                           const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines) {
+                                                           const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines,
+                                                           const float2* __restrict__ tE, const uint32_t* __restrict__ tsrc,
+                                                           const uint32_t* __restrict__ tmeta) {
     uint32_t n = umin_(counters[2], tcap);
     for (uint32_t x = blockIdx.x * JL_WG + threadIdx.x; x < n; x += gridDim.x * JL_WG) {
         uint2 key = tkeys[x];
         if (key.x >= n_slots) continue;
         uint32_t dst = bases[key.x] + key.y;
-        if (dst < cfg->lines_size && lines.ok(dst)) lines.p[dst] = tlines[x];
+        if (!(dst < cfg->lines_size && lines.ok(dst))) continue;
+        const uint32_t src = tsrc[x];
+        if (src == FL_SRC_DIRECT) {
+            lines.p[dst] = tlines[x];
+        } else {
+            const float2 e = tE[x];
+            const float2 s = src < tcap ? tE[src] : make_float2(0.0f, 0.0f);
+            const uint32_t meta = tmeta[x];
+            const bool rev = (meta & 0x80000000u) != 0u;
+            JlLineSoup l;
+            l.path_ix = meta & 0x7fffffffu; l.pad = 0;
+            l.p0[0] = rev ? e.x : s.x; l.p0[1] = rev ? e.y : s.y;
+            l.p1[0] = rev ? s.x : e.x; l.p1[1] = rev ? s.y : e.y;
+            lines.p[dst] = l;
+        }
+    }
+}
+
+// Path bounding boxes (flatten.wgsl:807, :893-899): one thread per tag byte folds the bbox of the lines the tag emitted
+// (its three work items are adjacent in the canonical order: lines [bases[3g], bases[3g+3])) and, if it has an extent,
+// merges it into the path's box (integer min/max are order-free).
+__global__ __launch_bounds__(JL_WG) void k_flatten_bbox(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump,
+                                                        const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines,
+                                                        Buf<JlPathBbox> path_bboxes) {
+    const uint32_t n_tags = n_slots / 3u;
+    const uint32_t total = umin_(umin_(bump->lines, cfg->lines_size), lines.n);
+    for (uint32_t g = blockIdx.x * JL_WG + threadIdx.x; g < n_tags; g += gridDim.x * JL_WG) {
+        const uint32_t lo = umin_(bases[3u * g], total);
+        const uint32_t hi = (3u * g + 3u < n_slots) ? umin_(bases[3u * g + 3u], total) : total;
+        if (hi <= lo) continue;
+        float bx0 = 1e31f, by0 = 1e31f, bx1 = -1e31f, by1 = -1e31f;
+        uint32_t path_ix = lines.p[lo].path_ix;
+        for (uint32_t j = lo; j < hi; j++) {
+            const JlLineSoup l = lines.p[j];
+            bx0 = fmin_(bx0, fmin_(l.p0[0], l.p1[0])); by0 = fmin_(by0, fmin_(l.p0[1], l.p1[1]));
+            bx1 = fmax_(bx1, fmax_(l.p0[0], l.p1[0])); by1 = fmax_(by1, fmax_(l.p0[1], l.p1[1]));
+        }
+        if ((bx1 > bx0 || by1 > by0) && path_bboxes.ok(path_ix)) {
+            JlPathBbox* out = &path_bboxes.p[path_ix];
+            atomicMin(&out->x0, to_i32(floor_(bx0)));
+            atomicMin(&out->y0, to_i32(floor_(by0)));
+            atomicMax(&out->x1, to_i32(ceil_(bx1)));
+            atomicMax(&out->y1, to_i32(ceil_(by1)));
+        }
     }
 }
 
@@ -1011,10 +1049,12 @@ int jh_launch_flatten(const JhLaunch& L) {
     uint32_t cap_blocks = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * FL_BLOCKS_PER_CU;
     uint32_t g = (n_slots + JL_WG - 1) / JL_WG;
     if (g > cap_blocks) g = cap_blocks;
-    // temp line slots a workgroup reserves up front: its fair share of the line capacity + 25 %
-    uint32_t FL_CHUNK = (uint32_t)((((uint64_t)lines.n / g) * 5 / 4 + 255) & ~255ull);
+    // temp slots a workgroup reserves up front: its fair share of (line capacity + one start-point slot per possible
+    // Euler job) + 25 %
+    uint64_t want = (uint64_t)lines.n + 2ull * n_tags;
+    uint32_t FL_CHUNK = (uint32_t)(((want / g) * 5 / 4 + 255) & ~255ull);
     if (FL_CHUNK < 256u) FL_CHUNK = 256u;
-    uint64_t tcap64 = (uint64_t)lines.n + (uint64_t)g * FL_CHUNK;
+    uint64_t tcap64 = want + (uint64_t)g * FL_CHUNK;
     if (tcap64 > 0xfffffff0ull) return -1;
     uint32_t tcap = (uint32_t)tcap64;
     uint32_t* counts = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)n_slots * 4);
@@ -1022,20 +1062,31 @@ int jh_launch_flatten(const JhLaunch& L) {
     uint32_t* list = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_C, (uint64_t)n_slots * 4);
     JlLineSoup* tlines = (JlLineSoup*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)tcap * sizeof(JlLineSoup));
     uint2* tkeys = (uint2*)jh_scratch_get(L.scratch, JH_SCR_E, (uint64_t)tcap * sizeof(uint2));
+    float2* tE = (float2*)jh_scratch_get(L.scratch, JH_SCR_F, (uint64_t)tcap * sizeof(float2));
+    uint32_t* t3 = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_H, (uint64_t)tcap * 12);
+    uint4* pieces = (uint4*)jh_scratch_get(L.scratch, JH_SCR_I, (uint64_t)tcap * 96);
     uint32_t* counters = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, 256);
-    if (!counts || !bases || !list || !counters || !tlines || !tkeys) return -5;
+    if (!counts || !bases || !list || !counters || !tlines || !tkeys || !tE || !t3 || !pieces) return -5;
+    uint32_t *tsrc = t3, *tinfo = t3 + tcap, *tmeta = t3 + 2 * (size_t)tcap;
     (void)hipMemsetAsync(counters, 0, 16, L.stream);
     (void)hipMemsetAsync(counts, 0, (size_t)n_slots * 4, L.stream);
+    (void)hipMemsetAsync(tinfo, 0, (size_t)tcap * 4, L.stream);  // "nothing starts in this slot"
     hipLaunchKernelGGL(k_flatten_classify, dim3((L.gx + FL_CLASSIFY_TAGS - 1) / FL_CLASSIFY_TAGS), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list,
                        counters, n_slots, n_tags);
     hipLaunchKernelGGL(k_flatten_items, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, (const uint32_t*)list, counters, n_slots, counts,
-                       tlines, tkeys, tcap, FL_CHUNK);
-    int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);
-    if (rc) return rc;
+                       tlines, tkeys, tcap, FL_CHUNK, tsrc, tinfo, tE, pieces);
     uint32_t gp = (tcap + JL_WG - 1) / JL_WG;
     uint32_t gp_cap = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * 8u;
     if (gp > gp_cap) gp = gp_cap;
+    hipLaunchKernelGGL(k_flatten_lines, dim3(gp), dim3(JL_WG), 0, L.stream, cfg, scene, (const uint32_t*)counters, (const uint32_t*)tinfo,
+                       (const uint4*)pieces, tcap, tE, tkeys, tsrc, tmeta);
+    int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_flatten_permute, dim3(gp), dim3(JL_WG), 0, L.stream, cfg, (const uint32_t*)counters, (const JlLineSoup*)tlines,
-                       (const uint2*)tkeys, tcap, (const uint32_t*)bases, n_slots, lines);
+                       (const uint2*)tkeys, tcap, (const uint32_t*)bases, n_slots, lines, (const float2*)tE, (const uint32_t*)tsrc,
+                       (const uint32_t*)tmeta);
+    uint32_t gb = (n_tags + JL_WG - 1) / JL_WG;
+    if (gb > gp_cap) gb = gp_cap;
+    hipLaunchKernelGGL(k_flatten_bbox, dim3(gb), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, (const uint32_t*)bases, n_slots, lines, pb);
     return 0;
 }

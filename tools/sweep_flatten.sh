@@ -1,7 +1,8 @@
 #!/bin/bash
-# Sweep of k_flatten_items tuning macros (run on the GPU box).
+# Sweep of k_flatten_items tuning macros (run on the GPU box): refill threshold, waves/EU, workgroups/CU.
 cd "$(dirname "$0")/.."
-for cfg in ${FL_CFGS:-"24 3 3" "8 3 3" "16 3 3" "32 3 3" "48 3 3" "16 2 2" "16 2 3"}; do
+FL_CFGS=("24 3 3" "24 4 4" "24 4 5" "16 4 4" "32 4 4" "24 5 5" "24 4 6")
+for cfg in "${FL_CFGS[@]}"; do
   set -- $cfg
   rm -f jello_amd/csrc/kernels_flatten.o
   make -s -C jello_amd/csrc EXTRA="-DFL_REFILL_LANES=${1}u -DFL_WAVES_PER_EU=$2 -DFL_BLOCKS_PER_CU=$3" > /dev/null 2>&1

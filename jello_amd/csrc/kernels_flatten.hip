@@ -709,8 +709,10 @@ JD Seg load_seg(const Scene& s, uint32_t ix) {
 #define FL_CLASSIFY_TAGS 4u  // tag bytes per thread: fewer workgroups => fewer atomics on the two hot list counters
 __global__ __launch_bounds__(JL_WG) void k_flatten_classify(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
                                                             Buf<JlPathBbox> path_bboxes, uint32_t* __restrict__ list,
-                                                            uint32_t* __restrict__ counters, uint32_t cap, uint32_t n_tags) {
+                                                            uint32_t* __restrict__ counters, uint32_t cap, uint32_t n_tags,
+                                                            uint32_t temp_overflow_start) {
     __shared__ uint32_t sh[12];
+    if (blockIdx.x == 0u && threadIdx.x == 0u) counters[2] = temp_overflow_start;  // first temp slot behind the workgroup chunks
     __shared__ uint32_t sh_base[2];
     Scene s;
     s.cfg = cfg; s.scene = scene; s.tag_monoids = tag_monoids;
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
                                                          uint32_t* __restrict__ counters, uint32_t cap, uint32_t* __restrict__ counts,
                                                          JlLineSoup* __restrict__ tlines, uint2* __restrict__ tkeys, uint32_t tcap,
                                                          uint32_t FL_CHUNK, uint32_t* __restrict__ tsrc, uint32_t* __restrict__ tinfo,
-                                                         float2* __restrict__ tE, uint4* __restrict__ pieces) {
+                                                         float2* __restrict__ tE, uint4* __restrict__ pieces, uint32_t* __restrict__ chunk_used) {
     __shared__ uint32_t sh_next;
     __shared__ uint32_t sh_chunk;
     __shared__ uint32_t sh_item;  // next position of this workgroup's share of the item list
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
     uint32_t n = n_heavy + n_light;
     if (blockIdx.x * 64u >= n) return;  // uniform: this workgroup's share of the list is empty
     if (threadIdx.x == 0) {
-        uint32_t cb = atomicAdd(&counters[2], FL_CHUNK);
+        uint32_t cb = blockIdx.x * FL_CHUNK;  // static: the overflow area (counters[2]) starts behind the last chunk
         sh_chunk = cb;
         sh_next = cb;
         sh_item = 0u;
@@ -913,15 +915,21 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
         }
     };
     flatten_euler_wave(o, e, pieces, refill);
+    // how much of the reserved chunk is in use (k_flatten_lines skips the unused tail); every wave reports, the last wins
+    if (lane == 0u) atomicMax(&chunk_used[chunk / FL_CHUNK], umin_(sh_next, chunk + FL_CHUNK) - chunk);
 }
 
 // One thread per temporary slot: the end point of the Euler line that lives there (if any).
 __global__ __launch_bounds__(JL_WG) void k_flatten_lines(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, const uint32_t* __restrict__ counters,
                                                          const uint32_t* __restrict__ tinfo, const uint4* __restrict__ pieces, uint32_t tcap,
                                                          float2* __restrict__ tE, uint2* __restrict__ tkeys, uint32_t* __restrict__ tsrc,
-                                                         uint32_t* __restrict__ tmeta) {
+                                                         uint32_t* __restrict__ tmeta, const uint32_t* __restrict__ chunk_used, uint32_t n_chunks,
+                                                         uint32_t FL_CHUNK) {
     const uint32_t n_t = umin_(counters[2], tcap);
     for (uint32_t t = blockIdx.x * JL_WG + threadIdx.x; t < n_t; t += gridDim.x * JL_WG) {
+        // the workgroups' reserved chunks are the first n_chunks * FL_CHUNK slots; their unused tails hold nothing
+        const uint32_t c = t / FL_CHUNK;
+        if (c < n_chunks && t - c * FL_CHUNK >= chunk_used[c]) continue;
         // which piece covers slot t?  Its first slot carries the marker; pieces have at most 100 lines.
         uint32_t v = tinfo[t];
         uint32_t tp = t;
@@ -977,9 +985,12 @@ __global__ __launch_bounds__(JL_WG) void k_flatten_permute(const JlConfig* __res
                                                            const JlLineSoup* __restrict__ tlines, const uint2* __restrict__ tkeys, uint32_t tcap,
                                                            const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines,
                                                            const float2* __restrict__ tE, const uint32_t* __restrict__ tsrc,
-                                                           const uint32_t* __restrict__ tmeta) {
+                                                           const uint32_t* __restrict__ tmeta, const uint32_t* __restrict__ chunk_used,
+                                                           uint32_t n_chunks, uint32_t FL_CHUNK) {
     uint32_t n = umin_(counters[2], tcap);
     for (uint32_t x = blockIdx.x * JL_WG + threadIdx.x; x < n; x += gridDim.x * JL_WG) {
+        const uint32_t c = x / FL_CHUNK;  // unused tail of a workgroup chunk (or a chunk nobody used): nothing there
+        if (c < n_chunks && x - c * FL_CHUNK >= chunk_used[c]) continue;
         uint2 key = tkeys[x];
         if (key.x >= n_slots) continue;
         uint32_t dst = bases[key.x] + key.y;
@@ -1001,32 +1012,68 @@ __global__ __launch_bounds__(JL_WG) void k_flatten_permute(const JlConfig* __res
     }
 }
 
-// Path bounding boxes (flatten.wgsl:807, :893-899): one thread per tag byte folds the bbox of the lines the tag emitted
-// (its three work items are adjacent in the canonical order: lines [bases[3g], bases[3g+3])) and, if it has an extent,
-// merges it into the path's box (integer min/max are order-free).
+// order-preserving float <-> uint key (integer LDS atomic min/max on floats)
+JD uint32_t fkey(float f) { uint32_t b = f2u(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+JD float fkey_inv(uint32_t k) { return u2f((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// Path bounding boxes (flatten.wgsl:807, :893-899).  The WGSL keeps one box per invocation (tag byte) and merges it into
+// the path's box only if it has an extent.  A tag's three work items are adjacent in the canonical order, so its lines
+// are [bases[3g], bases[3g+3]).  One wave takes 64 consecutive tags: their lines are one contiguous range, streamed
+// with coalesced loads; each line finds its tag by a 6-step search over the lanes' range ends and folds into the tag's
+// box in LDS; finally lane g tests the extent and merges (integer min/max on the path boxes are order-free).
 __global__ __launch_bounds__(JL_WG) void k_flatten_bbox(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump,
                                                         const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines,
                                                         Buf<JlPathBbox> path_bboxes) {
+    __shared__ uint32_t sh_box[JL_WG / 64][64][4];
     const uint32_t n_tags = n_slots / 3u;
     const uint32_t total = umin_(umin_(bump->lines, cfg->lines_size), lines.n);
-    for (uint32_t g = blockIdx.x * JL_WG + threadIdx.x; g < n_tags; g += gridDim.x * JL_WG) {
-        const uint32_t lo = umin_(bases[3u * g], total);
-        const uint32_t hi = (3u * g + 3u < n_slots) ? umin_(bases[3u * g + 3u], total) : total;
-        if (hi <= lo) continue;
-        float bx0 = 1e31f, by0 = 1e31f, bx1 = -1e31f, by1 = -1e31f;
-        uint32_t path_ix = lines.p[lo].path_ix;
-        for (uint32_t j = lo; j < hi; j++) {
-            const JlLineSoup l = lines.p[j];
-            bx0 = fmin_(bx0, fmin_(l.p0[0], l.p1[0])); by0 = fmin_(by0, fmin_(l.p0[1], l.p1[1]));
-            bx1 = fmax_(bx1, fmax_(l.p0[0], l.p1[0])); by1 = fmax_(by1, fmax_(l.p0[1], l.p1[1]));
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t waves = (gridDim.x * JL_WG) >> 6;
+    for (uint32_t g0 = ((blockIdx.x * JL_WG + threadIdx.x) >> 6) * 64u; g0 < n_tags; g0 += waves * 64u) {
+        const uint32_t g = g0 + lane;
+        uint32_t lo = total, hi = total;
+        if (g < n_tags) {
+            lo = umin_(bases[3u * g], total);
+            hi = (3u * g + 3u < n_slots) ? umin_(bases[3u * g + 3u], total) : total;
+            if (hi < lo) hi = lo;
         }
-        if ((bx1 > bx0 || by1 > by0) && path_bboxes.ok(path_ix)) {
-            JlPathBbox* out = &path_bboxes.p[path_ix];
-            atomicMin(&out->x0, to_i32(floor_(bx0)));
-            atomicMin(&out->y0, to_i32(floor_(by0)));
-            atomicMax(&out->x1, to_i32(ceil_(bx1)));
-            atomicMax(&out->y1, to_i32(ceil_(by1)));
+        const uint32_t LO = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+        const uint32_t HI = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
+        sh_box[wv][lane][0] = fkey(1e31f); sh_box[wv][lane][1] = fkey(1e31f);
+        sh_box[wv][lane][2] = fkey(-1e31f); sh_box[wv][lane][3] = fkey(-1e31f);
+        wave_fence();
+        for (uint32_t base = LO; base < HI; base += 64u) {
+            const uint32_t pos = base + lane;
+            uint32_t own = 0u;  // first lane whose range end exceeds pos (all lanes take part in the shuffles)
+#pragma unroll
+            for (uint32_t step = 32u; step > 0u; step >>= 1) {
+                const uint32_t probe = own + step;
+                const uint32_t h = (uint32_t)__shfl((int)hi, (int)(probe - 1u), 64);
+                if (h <= pos) own = probe;
+            }
+            own = umin_(own, 63u);
+            if (pos < HI) {
+                const JlLineSoup l = lines.p[pos];
+                atomicMin(&sh_box[wv][own][0], fkey(fmin_(l.p0[0], l.p1[0])));
+                atomicMin(&sh_box[wv][own][1], fkey(fmin_(l.p0[1], l.p1[1])));
+                atomicMax(&sh_box[wv][own][2], fkey(fmax_(l.p0[0], l.p1[0])));
+                atomicMax(&sh_box[wv][own][3], fkey(fmax_(l.p0[1], l.p1[1])));
+            }
         }
+        wave_fence();
+        if (hi > lo) {
+            const float bx0 = fkey_inv(sh_box[wv][lane][0]), by0 = fkey_inv(sh_box[wv][lane][1]);
+            const float bx1 = fkey_inv(sh_box[wv][lane][2]), by1 = fkey_inv(sh_box[wv][lane][3]);
+            const uint32_t path_ix = lines.p[lo].path_ix;
+            if ((bx1 > bx0 || by1 > by0) && path_bboxes.ok(path_ix)) {
+                JlPathBbox* out = &path_bboxes.p[path_ix];
+                atomicMin(&out->x0, to_i32(floor_(bx0)));
+                atomicMin(&out->y0, to_i32(floor_(by0)));
+                atomicMax(&out->x1, to_i32(ceil_(bx1)));
+                atomicMax(&out->y1, to_i32(ceil_(by1)));
+            }
+        }
+        wave_fence();
     }
 }
 
@@ -1065,27 +1112,28 @@ int jh_launch_flatten(const JhLaunch& L) {
     float2* tE = (float2*)jh_scratch_get(L.scratch, JH_SCR_F, (uint64_t)tcap * sizeof(float2));
     uint32_t* t3 = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_H, (uint64_t)tcap * 12);
     uint4* pieces = (uint4*)jh_scratch_get(L.scratch, JH_SCR_I, (uint64_t)tcap * 96);
-    uint32_t* counters = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, 256);
+    uint32_t* counters = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, 64 + (uint64_t)g * 4);
     if (!counts || !bases || !list || !counters || !tlines || !tkeys || !tE || !t3 || !pieces) return -5;
     uint32_t *tsrc = t3, *tinfo = t3 + tcap, *tmeta = t3 + 2 * (size_t)tcap;
-    (void)hipMemsetAsync(counters, 0, 16, L.stream);
+    uint32_t* chunk_used = counters + 16;  // one word per workgroup chunk (g <= 2048 workgroups)
+    (void)hipMemsetAsync(counters, 0, 64 + (size_t)g * 4, L.stream);
     (void)hipMemsetAsync(counts, 0, (size_t)n_slots * 4, L.stream);
     (void)hipMemsetAsync(tinfo, 0, (size_t)tcap * 4, L.stream);  // "nothing starts in this slot"
     hipLaunchKernelGGL(k_flatten_classify, dim3((L.gx + FL_CLASSIFY_TAGS - 1) / FL_CLASSIFY_TAGS), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list,
-                       counters, n_slots, n_tags);
+                       counters, n_slots, n_tags, g * FL_CHUNK);
     hipLaunchKernelGGL(k_flatten_items, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, (const uint32_t*)list, counters, n_slots, counts,
-                       tlines, tkeys, tcap, FL_CHUNK, tsrc, tinfo, tE, pieces);
+                       tlines, tkeys, tcap, FL_CHUNK, tsrc, tinfo, tE, pieces, chunk_used);
     uint32_t gp = (tcap + JL_WG - 1) / JL_WG;
     uint32_t gp_cap = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * 8u;
     if (gp > gp_cap) gp = gp_cap;
     hipLaunchKernelGGL(k_flatten_lines, dim3(gp), dim3(JL_WG), 0, L.stream, cfg, scene, (const uint32_t*)counters, (const uint32_t*)tinfo,
-                       (const uint4*)pieces, tcap, tE, tkeys, tsrc, tmeta);
+                       (const uint4*)pieces, tcap, tE, tkeys, tsrc, tmeta, (const uint32_t*)chunk_used, g, FL_CHUNK);
     int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);
     if (rc) return rc;
     hipLaunchKernelGGL(k_flatten_permute, dim3(gp), dim3(JL_WG), 0, L.stream, cfg, (const uint32_t*)counters, (const JlLineSoup*)tlines,
                        (const uint2*)tkeys, tcap, (const uint32_t*)bases, n_slots, lines, (const float2*)tE, (const uint32_t*)tsrc,
-                       (const uint32_t*)tmeta);
-    uint32_t gb = (n_tags + JL_WG - 1) / JL_WG;
+                       (const uint32_t*)tmeta, (const uint32_t*)chunk_used, g, FL_CHUNK);
+    uint32_t gb = (n_tags + JL_WG - 1) / JL_WG;  // one wave per 64 tags
     if (gb > gp_cap) gb = gp_cap;
     hipLaunchKernelGGL(k_flatten_bbox, dim3(gb), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, (const uint32_t*)bases, n_slots, lines, pb);
     return 0;

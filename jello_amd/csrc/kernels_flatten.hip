@@ -53,7 +53,6 @@ struct Out {
     const JlConfig* cfg;
     JlLineSoup* tlines;
     uint2* tkeys;
-    uint32_t* tsrc;   // per temp slot: where the line's start point comes from (FL_SRC_DIRECT: the slot holds a complete line)
     uint32_t* tinfo;  // per temp slot: FL_INFO_* marker (0 = nothing starts here)
     uint32_t tcap;
     uint32_t slot;
@@ -95,7 +94,6 @@ struct Out {
                 l.path_ix = path_ix; l.pad = 0; l.p0[0] = p0.x; l.p0[1] = p0.y; l.p1[0] = p1.x; l.p1[1] = p1.y;
                 tlines[t] = l;
                 tkeys[t] = make_uint2(slot, line_ix);
-                tsrc[t] = FL_SRC_DIRECT;
                 tinfo[t] = FL_INFO_DIRECT;
             }
         }
@@ -317,12 +315,12 @@ struct Scene {
 // k_flatten_items: every lane owns one Euler job (a cubic + offset) and runs the adaptive subdivision exactly as in the
 // WGSL.  An ACCEPTED piece reserves its n line slots in the temporary buffer and leaves a 96-byte record there; its
 // lines are NOT evaluated in this kernel (that loop at 3 waves/SIMD and 35 % lane use cost 240 of the stage's 600 us).
-// k_flatten_lines: one thread per temporary slot evaluates the END point of its line from the piece record (the
-// WGSL's arithmetic per point) and stores it already transformed.  A line's START point is the end point of the line
-// before it -- the previous slot, or for a piece's first line the last slot of the previous piece of the job, or the
-// job's start point, which k_flatten_items stores in a slot of its own -- so k_flatten_permute assembles
-// (start, end) from two stored points while moving the line to its canonical position.  Same operations on the same
-// values as the sequential formulation, hence the same bits.
+// k_flatten_lines (after the per-item line counts are scanned): one thread per temporary slot evaluates the END point
+// of its line from the piece record (the WGSL's arithmetic per point), transforms it and writes it straight into the
+// canonical LineSoup position of the line AND as the START point of the following line of the item -- a line's start
+// is the end of the line before it (flatten.wgsl:462-468); only the item's first line takes its start from the
+// record.  Every point is computed once, with the same operations on the same values as in the sequential
+// formulation, hence the same bits.  Lines emitted directly (caps, joins) wait in the temp buffer and are copied.
 // ------------------------------------------------------------------------------------------------
 JD void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -331,8 +329,9 @@ JD void wave_fence() {
 
 // piece record: 6 x uint4 at pieces[6 * tpos]
 //   0: es_p0.x es_p0.y es_p1.x es_p1.y   1: th0 k0 k1 ch   2: a b integral int0   3: noff n t_end.x t_end.y
-//   4: flags tpos slot first             5: path_ix trans_ix start_src -
-// flags: bits 0-1 robust case, 4 = ends at t == 1 (last line ends in t_end), 8 = offset >= 0, 16 = offset == 0
+//   4: flags tpos slot first             5: path_ix trans_ix t_start.x t_start.y (first piece of the item only)
+// flags: bits 0-1 robust case, 4 = ends at t == 1 (last line ends in t_end), 8 = offset >= 0, 16 = offset == 0,
+//        32 = first piece of its item
 
 struct EulerJob {
     bool valid;
@@ -354,12 +353,13 @@ struct EulerLane {
     float dt;
     V2 last_p, last_q;
     float last_t;
-    uint32_t start_src;  // temp slot holding the start point of the next piece's first line
+    V2 t_start;          // start point of the item's first line
+    bool first_piece;
     uint32_t path_ix, trans_ix;
     bool done;
 };
 
-JD void euler_begin(EulerLane& e, const EulerJob& job, Out<true>& o, float2* __restrict__ tE) {  // flatten.wgsl:328-360
+JD void euler_begin(EulerLane& e, const EulerJob& job) {  // flatten.wgsl:328-360
     e.p0 = e.p1 = e.p2 = e.p3 = v2(0, 0);
     e.scale = 1.0f;
     V2 t_start = job.start_p;
@@ -390,19 +390,8 @@ JD void euler_begin(EulerLane& e, const EulerJob& job, Out<true>& o, float2* __r
     e.last_q = e.p1 - e.p0;
     if (!e.done && dot(e.last_q, e.last_q) < DERIV_THRESH_SQUARED) e.last_q = eval_cubic_and_deriv(e.p0, e.p1, e.p2, e.p3, DERIV_EPS).deriv;
     e.last_t = 0.0f;
-    e.start_src = 0u;
-    if (!e.done) {
-        // the job's start point gets a temp slot of its own, stored the way every line point is: transformed
-        Xf tr = (job.offset == 0.0f) ? xf_identity() : job.local_to_device;
-        uint32_t ps = o.alloc_temp(1u);
-        if (ps < o.tcap) {
-            V2 q = xf_apply(tr, t_start);
-            tE[ps] = make_float2(q.x, q.y);
-            o.tinfo[ps] = FL_INFO_POINT;
-            o.tkeys[ps] = make_uint2(FL_INVALID, 0u);  // not a line
-        }
-        e.start_src = ps;
-    }
+    e.t_start = t_start;
+    e.first_piece = true;
 }
 
 // `refill()` is called (by the whole wave) when enough lanes are idle; it finalises finished items, gives idle
@@ -511,11 +500,11 @@ JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ piece
                 rec[1] = make_uint4(f2u(ep.th0), f2u(ep.k0), f2u(ep.k1), f2u(ep.ch));
                 rec[2] = make_uint4(f2u(pc_a), f2u(pc_b), f2u(pc_integral), f2u(pc_int0));
                 rec[3] = make_uint4(f2u(pc_noff), f2u(pc_n), f2u(t_end.x), f2u(t_end.y));
-                rec[4] = make_uint4(pc_flags, tpos, o.slot, first);
-                rec[5] = make_uint4(e.path_ix, e.trans_ix, e.start_src, 0u);
+                rec[4] = make_uint4(pc_flags | (e.first_piece ? 32u : 0u), tpos, o.slot, first);
+                rec[5] = make_uint4(e.path_ix, e.trans_ix, f2u(e.t_start.x), f2u(e.t_start.y));
                 o.tinfo[tpos] = FL_INFO_PIECE | n_u;
             }
-            e.start_src = tpos + n_u - 1u;  // the next piece starts where this one's last line ends
+            e.first_piece = false;
         }
     }
 }
@@ -841,8 +830,8 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
                                                          Buf<JlPathBbox> path_bboxes, const uint32_t* __restrict__ list,
                                                          uint32_t* __restrict__ counters, uint32_t cap, uint32_t* __restrict__ counts,
                                                          JlLineSoup* __restrict__ tlines, uint2* __restrict__ tkeys, uint32_t tcap,
-                                                         uint32_t FL_CHUNK, uint32_t* __restrict__ tsrc, uint32_t* __restrict__ tinfo,
-                                                         float2* __restrict__ tE, uint4* __restrict__ pieces, uint32_t* __restrict__ chunk_used) {
+                                                         uint32_t FL_CHUNK, uint32_t* __restrict__ tinfo, uint4* __restrict__ pieces,
+                                                         uint32_t* __restrict__ chunk_used) {
     __shared__ uint32_t sh_next;
     __shared__ uint32_t sh_chunk;
     __shared__ uint32_t sh_item;  // next position of this workgroup's share of the item list
@@ -868,14 +857,14 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
     // Work distribution: the item list (heavy items first) is dealt to the workgroups in chunks of 64, round robin;
     // the waves of a workgroup draw their items from its share through one LDS counter.
     Out<true> o;
-    o.cfg = cfg; o.tlines = tlines; o.tkeys = tkeys; o.tsrc = tsrc; o.tinfo = tinfo; o.tcap = tcap; o.slot = 0u;
+    o.cfg = cfg; o.tlines = tlines; o.tkeys = tkeys; o.tinfo = tinfo; o.tcap = tcap; o.slot = 0u;
     o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
     o.lds_next = &sh_next; o.lds_limit = chunk + FL_CHUNK; o.g_next = &counters[2];
     o.bx0 = 1e31f; o.by0 = 1e31f; o.bx1 = -1e31f; o.by1 = -1e31f;
     EulerLane e;
     e.p0 = e.p1 = e.p2 = e.p3 = v2(0, 0);
     e.scale = 1.0f; e.offset = 0.0f; e.t_end = v2(0, 0); e.t0_u = 0u; e.dt = 1.0f; e.last_p = e.last_q = v2(0, 0); e.last_t = 0.0f;
-    e.start_src = 0u; e.path_ix = 0u; e.trans_ix = 0u; e.done = true;
+    e.t_start = v2(0, 0); e.first_piece = true; e.path_ix = 0u; e.trans_ix = 0u; e.done = true;
     bool have = false;       // this lane holds an item that is not finalised yet
     uint32_t path_ix = 0u;
     auto refill = [&]() -> bool {
@@ -905,7 +894,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
                 job.cubic.p0 = job.cubic.p1 = job.cubic.p2 = job.cubic.p3 = v2(0, 0);
                 job.local_to_device = xf_identity();
                 run_item<true>(cfg, s, o, slot, job, path_ix);
-                euler_begin(e, job, o, tE);
+                euler_begin(e, job);
                 have = true;
             }
             wave_fence();
@@ -919,13 +908,16 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
     if (lane == 0u) atomicMax(&chunk_used[chunk / FL_CHUNK], umin_(sh_next, chunk + FL_CHUNK) - chunk);
 }
 
-// One thread per temporary slot: the end point of the Euler line that lives there (if any).
+// One thread per temporary slot: the Euler line (or the directly emitted line) that lives there, moved to
+// lines[bases[slot] + k], the canonical (tag byte, emission order) LineSoup position.
 __global__ __launch_bounds__(JL_WG) void k_flatten_lines(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, const uint32_t* __restrict__ counters,
                                                          const uint32_t* __restrict__ tinfo, const uint4* __restrict__ pieces, uint32_t tcap,
-                                                         float2* __restrict__ tE, uint2* __restrict__ tkeys, uint32_t* __restrict__ tsrc,
-                                                         uint32_t* __restrict__ tmeta, const uint32_t* __restrict__ chunk_used, uint32_t n_chunks,
-                                                         uint32_t FL_CHUNK) {
+                                                         const JlLineSoup* __restrict__ tlines, const uint2* __restrict__ tkeys,
+                                                         const uint32_t* __restrict__ chunk_used, uint32_t n_chunks, uint32_t FL_CHUNK,
+                                                         const uint32_t* __restrict__ bases, const uint32_t* __restrict__ counts, uint32_t n_slots,
+                                                         Buf<JlLineSoup> lines) {
     const uint32_t n_t = umin_(counters[2], tcap);
+    const uint32_t lines_lim = umin_(cfg->lines_size, lines.n);
     for (uint32_t t = blockIdx.x * JL_WG + threadIdx.x; t < n_t; t += gridDim.x * JL_WG) {
         // the workgroups' reserved chunks are the first n_chunks * FL_CHUNK slots; their unused tails hold nothing
         const uint32_t c = t / FL_CHUNK;
@@ -939,14 +931,23 @@ __global__ __launch_bounds__(JL_WG) void k_flatten_lines(const JlConfig* __restr
                 if (v != 0u) { tp = t - back; break; }
             }
         }
+        if ((v & FL_INFO_DIRECT) != 0u && tp == t) {  // complete line: copy
+            const uint2 key = tkeys[t];
+            if (key.x < n_slots) {
+                const uint32_t dst = bases[key.x] + key.y;
+                if (dst < lines_lim) lines.p[dst] = tlines[t];
+            }
+            continue;
+        }
         if ((v & FL_INFO_PIECE) == 0u) continue;
         const uint32_t n_u = v & 0xffffu, i = t - tp;
         if (i >= n_u) continue;
         const uint4* rec = pieces + (size_t)tp * 6u;
         const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
         const uint32_t flags = r4.x;
+        const bool last_of_item = i + 1u == n_u && (flags & 4u) != 0u;
         V2 lp1;
-        if (i + 1u == n_u && (flags & 4u) != 0u) {
+        if (last_of_item) {
             lp1 = v2(u2f(r3.z), u2f(r3.w));
         } else {  // flatten.wgsl:440-461
             const float n = u2f(r3.y);
@@ -973,41 +974,31 @@ __global__ __launch_bounds__(JL_WG) void k_flatten_lines(const JlConfig* __restr
             tr.m3 = u2f(scene.rd(tb + 3u)); tr.t0 = u2f(scene.rd(tb + 4u)); tr.t1 = u2f(scene.rd(tb + 5u));
         }
         const V2 q = xf_apply(tr, lp1);
-        tE[t] = make_float2(q.x, q.y);
-        tkeys[t] = make_uint2(r4.z, r4.w + i);
-        tsrc[t] = (i == 0u) ? r5.z : (t - 1u);
-        tmeta[t] = (r5.x & 0x7fffffffu) | ((flags & 8u) ? 0u : 0x80000000u);  // path | reversed (offset < 0)
-    }
-}
-
-// lines[bases[slot] + k] = temp line: the canonical (tag byte, emission order) LineSoup order.
-__global__ __launch_bounds__(JL_WG) void k_flatten_permute(const JlConfig* __restrict__ cfg, const uint32_t* __restrict__ counters,
-                                                           const JlLineSoup* __restrict__ tlines, const uint2* __restrict__ tkeys, uint32_t tcap,
-                                                           const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines,
-                                                           const float2* __restrict__ tE, const uint32_t* __restrict__ tsrc,
-                                                           const uint32_t* __restrict__ tmeta, const uint32_t* __restrict__ chunk_used,
-                                                           uint32_t n_chunks, uint32_t FL_CHUNK) {
-    uint32_t n = umin_(counters[2], tcap);
-    for (uint32_t x = blockIdx.x * JL_WG + threadIdx.x; x < n; x += gridDim.x * JL_WG) {
-        const uint32_t c = x / FL_CHUNK;  // unused tail of a workgroup chunk (or a chunk nobody used): nothing there
-        if (c < n_chunks && x - c * FL_CHUNK >= chunk_used[c]) continue;
-        uint2 key = tkeys[x];
-        if (key.x >= n_slots) continue;
-        uint32_t dst = bases[key.x] + key.y;
-        if (!(dst < cfg->lines_size && lines.ok(dst))) continue;
-        const uint32_t src = tsrc[x];
-        if (src == FL_SRC_DIRECT) {
-            lines.p[dst] = tlines[x];
-        } else {
-            const float2 e = tE[x];
-            const float2 s = src < tcap ? tE[src] : make_float2(0.0f, 0.0f);
-            const uint32_t meta = tmeta[x];
-            const bool rev = (meta & 0x80000000u) != 0u;
-            JlLineSoup l;
-            l.path_ix = meta & 0x7fffffffu; l.pad = 0;
-            l.p0[0] = rev ? e.x : s.x; l.p0[1] = rev ? e.y : s.y;
-            l.p1[0] = rev ? s.x : e.x; l.p1[1] = rev ? s.y : e.y;
-            lines.p[dst] = l;
+        const uint32_t slot = r4.z;
+        if (slot >= n_slots) continue;
+        const uint32_t k = r4.w + i;
+        const uint32_t dst = bases[slot] + k;
+        const bool fwd = (flags & 8u) != 0u;  // offset >= 0: (start, end); else the line runs (end, start)
+        const bool has_next = k + 1u < counts[slot] && dst + 1u < lines_lim;
+        // Stores are grouped into contiguous byte ranges (a LineSoup is {path, pad, p0, p1} = 3 x 8 bytes): partial
+        // 8-byte stores to three different cache lines per thread tripled the write traffic.
+        uint2* w = (uint2*)lines.p;  // 8-byte words: 3 per line
+        const uint2 hdr = make_uint2(r5.x, 0u), pt = make_uint2(f2u(q.x), f2u(q.y));
+        if (dst < lines_lim) {
+            if (k == 0u) {  // the item's first line: header and start point (the job's start point)
+                const V2 qs = xf_apply(tr, v2(u2f(r5.z), u2f(r5.w)));
+                w[(size_t)dst * 3u] = hdr;
+                w[(size_t)dst * 3u + (fwd ? 1u : 2u)] = make_uint2(f2u(qs.x), f2u(qs.y));
+            }
+            if (fwd) {
+                // [p1 of this line | header of the next | p0 of the next]: 24 contiguous bytes
+                w[(size_t)dst * 3u + 2u] = pt;
+                if (has_next) { w[(size_t)dst * 3u + 3u] = hdr; w[(size_t)dst * 3u + 4u] = pt; }
+            } else {
+                // the line runs (end, start): p0 of this line, header and p1 of the next
+                w[(size_t)dst * 3u + 1u] = pt;
+                if (has_next) { w[(size_t)dst * 3u + 3u] = hdr; w[(size_t)dst * 3u + 5u] = pt; }
+            }
         }
     }
 }
@@ -1061,16 +1052,47 @@ __global__ __launch_bounds__(JL_WG) void k_flatten_bbox(const JlConfig* __restri
             }
         }
         wave_fence();
+        // per-tag result (integer box, or "nothing" if the tag's box has no extent), then folded per path inside the
+        // wave: the 64 tags touch fewer than 64 consecutive paths; a path strictly between the paths of the wave's
+        // first and last line has all its lines in this wave, so its box is stored plainly -- atomics only at the edges.
+        int32_t ix0 = 0x7fffffff, iy0 = 0x7fffffff, ix1 = (int32_t)0x80000000, iy1 = (int32_t)0x80000000;
+        bool valid = false;
+        uint32_t path_ix = 0u;
         if (hi > lo) {
             const float bx0 = fkey_inv(sh_box[wv][lane][0]), by0 = fkey_inv(sh_box[wv][lane][1]);
             const float bx1 = fkey_inv(sh_box[wv][lane][2]), by1 = fkey_inv(sh_box[wv][lane][3]);
-            const uint32_t path_ix = lines.p[lo].path_ix;
-            if ((bx1 > bx0 || by1 > by0) && path_bboxes.ok(path_ix)) {
+            path_ix = lines.p[lo].path_ix;
+            if (bx1 > bx0 || by1 > by0) {
+                valid = true;
+                ix0 = to_i32(floor_(bx0)); iy0 = to_i32(floor_(by0)); ix1 = to_i32(ceil_(bx1)); iy1 = to_i32(ceil_(by1));
+            }
+        }
+        if (HI > LO) {  // uniform
+            const uint32_t p_first = lines.p[LO].path_ix, p_last = lines.p[HI - 1u].path_ix;
+            wave_fence();
+            sh_box[wv][lane][0] = 0x7fffffffu; sh_box[wv][lane][1] = 0x7fffffffu;
+            sh_box[wv][lane][2] = 0x80000000u; sh_box[wv][lane][3] = 0x80000000u;
+            wave_fence();
+            const uint32_t local = path_ix - p_first;
+            if (valid && local < 64u) {
+                atomicMin((int32_t*)&sh_box[wv][local][0], ix0); atomicMin((int32_t*)&sh_box[wv][local][1], iy0);
+                atomicMax((int32_t*)&sh_box[wv][local][2], ix1); atomicMax((int32_t*)&sh_box[wv][local][3], iy1);
+            } else if (valid && path_bboxes.ok(path_ix)) {  // (cannot happen for a well-formed scene)
                 JlPathBbox* out = &path_bboxes.p[path_ix];
-                atomicMin(&out->x0, to_i32(floor_(bx0)));
-                atomicMin(&out->y0, to_i32(floor_(by0)));
-                atomicMax(&out->x1, to_i32(ceil_(bx1)));
-                atomicMax(&out->y1, to_i32(ceil_(by1)));
+                atomicMin(&out->x0, ix0); atomicMin(&out->y0, iy0); atomicMax(&out->x1, ix1); atomicMax(&out->y1, iy1);
+            }
+            wave_fence();
+            const uint32_t P = p_first + lane;
+            const int32_t fx0 = (int32_t)sh_box[wv][lane][0], fy0 = (int32_t)sh_box[wv][lane][1];
+            const int32_t fx1 = (int32_t)sh_box[wv][lane][2], fy1 = (int32_t)sh_box[wv][lane][3];
+            if (P <= p_last && fx0 != 0x7fffffff && path_bboxes.ok(P)) {
+                JlPathBbox* out = &path_bboxes.p[P];
+                if (P > p_first && P < p_last) {
+                    out->x0 = imin_(out->x0, fx0); out->y0 = imin_(out->y0, fy0);
+                    out->x1 = imax_(out->x1, fx1); out->y1 = imax_(out->y1, fy1);
+                } else {
+                    atomicMin(&out->x0, fx0); atomicMin(&out->y0, fy0); atomicMax(&out->x1, fx1); atomicMax(&out->y1, fy1);
+                }
             }
         }
         wave_fence();
@@ -1109,12 +1131,10 @@ int jh_launch_flatten(const JhLaunch& L) {
     uint32_t* list = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_C, (uint64_t)n_slots * 4);
     JlLineSoup* tlines = (JlLineSoup*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)tcap * sizeof(JlLineSoup));
     uint2* tkeys = (uint2*)jh_scratch_get(L.scratch, JH_SCR_E, (uint64_t)tcap * sizeof(uint2));
-    float2* tE = (float2*)jh_scratch_get(L.scratch, JH_SCR_F, (uint64_t)tcap * sizeof(float2));
-    uint32_t* t3 = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_H, (uint64_t)tcap * 12);
+    uint32_t* tinfo = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_H, (uint64_t)tcap * 4);
     uint4* pieces = (uint4*)jh_scratch_get(L.scratch, JH_SCR_I, (uint64_t)tcap * 96);
     uint32_t* counters = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, 64 + (uint64_t)g * 4);
-    if (!counts || !bases || !list || !counters || !tlines || !tkeys || !tE || !t3 || !pieces) return -5;
-    uint32_t *tsrc = t3, *tinfo = t3 + tcap, *tmeta = t3 + 2 * (size_t)tcap;
+    if (!counts || !bases || !list || !counters || !tlines || !tkeys || !tinfo || !pieces) return -5;
     uint32_t* chunk_used = counters + 16;  // one word per workgroup chunk (g <= 2048 workgroups)
     (void)hipMemsetAsync(counters, 0, 64 + (size_t)g * 4, L.stream);
     (void)hipMemsetAsync(counts, 0, (size_t)n_slots * 4, L.stream);
@@ -1122,17 +1142,15 @@ int jh_launch_flatten(const JhLaunch& L) {
     hipLaunchKernelGGL(k_flatten_classify, dim3((L.gx + FL_CLASSIFY_TAGS - 1) / FL_CLASSIFY_TAGS), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list,
                        counters, n_slots, n_tags, g * FL_CHUNK);
     hipLaunchKernelGGL(k_flatten_items, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, (const uint32_t*)list, counters, n_slots, counts,
-                       tlines, tkeys, tcap, FL_CHUNK, tsrc, tinfo, tE, pieces, chunk_used);
+                       tlines, tkeys, tcap, FL_CHUNK, tinfo, pieces, chunk_used);
+    int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);
+    if (rc) return rc;
     uint32_t gp = (tcap + JL_WG - 1) / JL_WG;
     uint32_t gp_cap = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * 8u;
     if (gp > gp_cap) gp = gp_cap;
     hipLaunchKernelGGL(k_flatten_lines, dim3(gp), dim3(JL_WG), 0, L.stream, cfg, scene, (const uint32_t*)counters, (const uint32_t*)tinfo,
-                       (const uint4*)pieces, tcap, tE, tkeys, tsrc, tmeta, (const uint32_t*)chunk_used, g, FL_CHUNK);
-    int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_flatten_permute, dim3(gp), dim3(JL_WG), 0, L.stream, cfg, (const uint32_t*)counters, (const JlLineSoup*)tlines,
-                       (const uint2*)tkeys, tcap, (const uint32_t*)bases, n_slots, lines, (const float2*)tE, (const uint32_t*)tsrc,
-                       (const uint32_t*)tmeta, (const uint32_t*)chunk_used, g, FL_CHUNK);
+                       (const uint4*)pieces, tcap, (const JlLineSoup*)tlines, (const uint2*)tkeys, (const uint32_t*)chunk_used, g, FL_CHUNK,
+                       (const uint32_t*)bases, (const uint32_t*)counts, n_slots, lines);
     uint32_t gb = (n_tags + JL_WG - 1) / JL_WG;  // one wave per 64 tags
     if (gb > gp_cap) gb = gp_cap;
     hipLaunchKernelGGL(k_flatten_bbox, dim3(gb), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, (const uint32_t*)bases, n_slots, lines, pb);

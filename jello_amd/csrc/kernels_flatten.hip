@@ -41,7 +41,7 @@ struct PathTagData { uint32_t tag_byte; MonoidK<5> monoid; };
 #define FL_INFO_POINT 0x40000000u    // tinfo: the slot only holds a point (start of an Euler job)
 #define FL_INFO_DIRECT 0x20000000u   // tinfo: complete line
 #ifndef FL_REFILL_LANES
-#define FL_REFILL_LANES 24u  // idle lanes that trigger a refill of the wave
+#define FL_REFILL_LANES 32u  // idle lanes that trigger a refill of the wave
 #endif
 
 // Line sink.  EMIT: lines go to a TEMPORARY buffer in allocation order (fast, order-free allocation:
@@ -821,10 +821,10 @@ JD void run_item(const JlConfig* cfg, const Scene& s, Out<EMIT>& o, uint32_t slo
 }
 
 #ifndef FL_WAVES_PER_EU
-#define FL_WAVES_PER_EU 3
+#define FL_WAVES_PER_EU 4
 #endif
 #ifndef FL_BLOCKS_PER_CU
-#define FL_BLOCKS_PER_CU 3
+#define FL_BLOCKS_PER_CU 4
 #endif
 __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_PER_EU, FL_WAVES_PER_EU))) void k_flatten_items(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
                                                          Buf<JlPathBbox> path_bboxes, const uint32_t* __restrict__ list,

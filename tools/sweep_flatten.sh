@@ -1,7 +1,7 @@
 #!/bin/bash
 # Sweep of k_flatten_items tuning macros (run on the GPU box): refill threshold, waves/EU, workgroups/CU.
 cd "$(dirname "$0")/.."
-FL_CFGS=("24 3 3" "24 4 4" "24 4 5" "16 4 4" "32 4 4" "24 5 5" "24 4 6")
+FL_CFGS=("24 3 3" "24 4 4" "32 4 4" "24 4 5" "24 5 5")
 for cfg in "${FL_CFGS[@]}"; do
   set -- $cfg
   rm -f jello_amd/csrc/kernels_flatten.o

@@ -2,18 +2,21 @@
 // Euler-spiral subdivision of fills, GPU stroke expansion (offset curves, caps, joins, arcs).
 //
 // MI355X design: the WGSL allocates every output line with atomicAdd(bump.lines), which makes the
-// LineSoup order run-dependent.  Here the stage is classify -> flatten-to-temp -> scan -> permute:
+// LineSoup order run-dependent.  Here the stage is classify -> items -> scan -> lines -> bbox:
 //   k_flatten_classify   one thread per tag byte: splits it into up to 3 work items (see below) and appends them
 //                        to a heavy / light list; writes PathBbox.draw_flags/trans_ix;
-//   k_flatten_items      one thread per item: Euler-spiral subdivision / caps / joins; lines are written ONCE to a
-//                        temporary buffer in allocation order (LDS-chunked, order-free) with a key (item slot, k),
-//                        counts[slot] = lines of the item; path bbox via atomicMin/Max (commutative);
+//   k_flatten_items      one lane per item: caps / joins / lines are written to a temporary buffer (LDS-chunked,
+//                        order-free allocation) with a key (item slot, k); an Euler job runs the adaptive subdivision
+//                        and leaves one 64-byte record per accepted piece in the temp slots the piece reserves;
+//                        counts[slot] = lines of the item; idle lanes are refilled from the workgroup's item queue;
 //   jh_scan_u32          line base per slot; the total lands in bump.lines;
-//   k_flatten_permute    lines[bases[slot] + k] = temp line  (one coalesced read, one 24-byte scatter per line).
+//   k_flatten_lines      one thread per temp slot: evaluates the line's end point from the piece record and writes the
+//                        line to lines[bases[slot] + k] (its start is the end point of the line before it);
+//   k_flatten_bbox       per-tag boxes of the finished lines -> path bounding boxes.
 // Result: lines are ordered by (tag byte, emission order) -- the reference's own sequential order
 // (shaders/cpu/flatten.go:664-823) -- with the subdivision arithmetic executed exactly once.
-// Algorithmic traffic: scene bytes + 20 B / tag word in, 24 B / line out (+ 56 B / line through the temp).
-// The stage is ALU/latency-bound (f64 transcendentals, divergent trip counts).
+// Algorithmic traffic: scene bytes + 20 B / tag word in, 24 B / line out (+ 64-80 B / piece through the temp).
+// k_flatten_items is VALU/latency-bound (f64 transcendentals, 1...30 subdivision attempts per job).
 #include "kcommon.h"
 
 using namespace jk;
@@ -36,9 +39,7 @@ struct PathTagData { uint32_t tag_byte; MonoidK<5> monoid; };
 #define TANGENT_THRESH 1e-6f
 
 #define FL_INVALID 0xffffffffu
-#define FL_SRC_DIRECT 0xfffffffeu    // tsrc: the temp slot holds a complete (already transformed) line in tlines
 #define FL_INFO_PIECE 0x80000000u    // tinfo: an Euler piece starts here, low 16 bits = its line count; its record is pieces[slot]
-#define FL_INFO_POINT 0x40000000u    // tinfo: the slot only holds a point (start of an Euler job)
 #define FL_INFO_DIRECT 0x20000000u   // tinfo: complete line
 #ifndef FL_REFILL_LANES
 #define FL_REFILL_LANES 32u  // idle lanes that trigger a refill of the wave
@@ -46,7 +47,7 @@ struct PathTagData { uint32_t tag_byte; MonoidK<5> monoid; };
 
 // Line sink.  EMIT: lines go to a TEMPORARY buffer in allocation order (fast, order-free allocation:
 // LDS atomic on the workgroup's chunk, global atomic only when the chunk is exhausted) together with a
-// key (slot, k) = (work item, index of the line inside the item); k_flatten_permute then moves every
+// key (slot, k) = (work item, index of the line inside the item); k_flatten_lines then moves every
 // line to lines[bases[slot] + k], the canonical position.  !EMIT: only counts.
 template <bool EMIT>
 struct Out {
@@ -73,14 +74,6 @@ struct Out {
             a_tpos = p;
         }
         return first;
-    }
-    JD uint32_t alloc_temp(uint32_t n) {  // temp slots that are not lines of the item (Euler start points)
-        uint32_t p = 0u;
-        if (EMIT) {
-            p = atomicAdd(lds_next, n);
-            if (p + n > lds_limit) p = atomicAdd(g_next, n);
-        }
-        return p;
     }
     JD void write_line(uint32_t line_ix, uint32_t path_ix, V2 p0, V2 p1) {  // flatten.wgsl:749-756
         if (EMIT) {
@@ -327,11 +320,12 @@ JD void wave_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// piece record: 6 x uint4 at pieces[6 * tpos]
-//   0: es_p0.x es_p0.y es_p1.x es_p1.y   1: th0 k0 k1 ch   2: a b integral int0   3: noff n t_end.x t_end.y
-//   4: flags tpos slot first             5: path_ix trans_ix t_start.x t_start.y (first piece of the item only)
+// piece record: one 64-byte sector, 4 x uint4 at pieces[4 * tpos] (the lines kernel fetches one sector per piece):
+//   0: es_p0.x es_p0.y es_p1.x es_p1.y   1: th0 k0 k1 ch   2: noff n slot first   3: path_ix trans_ix flags -
+// plus ends[tpos] = (t_start.x, t_start.y, t_end.x, t_end.y), read only for the first / last line of an item.
 // flags: bits 0-1 robust case, 4 = ends at t == 1 (last line ends in t_end), 8 = offset >= 0, 16 = offset == 0,
-//        32 = first piece of its item
+//        32 = first piece of its item.  The subdivision constants a, b, integral, int0 of flatten.wgsl:404-433 are
+//        recomputed from (k0, k1, ch, noff) by the same operations instead of being stored.
 
 struct EulerJob {
     bool valid;
@@ -397,7 +391,7 @@ JD void euler_begin(EulerLane& e, const EulerJob& job) {  // flatten.wgsl:328-36
 // `refill()` is called (by the whole wave) when enough lanes are idle; it finalises finished items, gives idle
 // lanes new ones (euler_begin) and returns false once no lane is active and the queue is empty.
 template <class Refill>
-JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ pieces, Refill&& refill) {
+JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ pieces, uint4* __restrict__ ends, Refill&& refill) {
     V2 &p0 = e.p0, &p1 = e.p1, &p2 = e.p2, &p3 = e.p3;
     float& scale = e.scale;
     const float& offset = e.offset;
@@ -417,7 +411,7 @@ JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ piece
 
         bool accept = false;
         uint32_t n_u = 0u;
-        float pc_n = 0.0f, pc_a = 0.0f, pc_b = 0.0f, pc_integral = 0.0f, pc_int0 = 0.0f, pc_noff = 0.0f;
+        float pc_n = 0.0f, pc_noff = 0.0f;
         EulerParams ep;
         ep.th0 = ep.th1 = ep.k0 = ep.k1 = ep.ch = 0.0f;
         V2 es_p0 = v2(0, 0), es_p1 = v2(0, 0);
@@ -475,7 +469,7 @@ JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ piece
                     float n = clamp_(ceil_(n_frac * scale_multiplier), 1.0f, 100.0f);
                     n_u = to_u32(n);
                     accept = true;
-                    pc_n = n; pc_a = a; pc_b = b; pc_integral = integral; pc_int0 = int0; pc_noff = normalized_offset;
+                    pc_n = n; pc_noff = normalized_offset;  // a, b, integral, int0 are recomputed by k_flatten_lines
                     es_p0 = this_p0; es_p1 = this_pq1.point;
                     pc_flags = robust | ((t1 == 1.0f) ? 4u : 0u) | ((offset >= 0.0f) ? 8u : 0u) | ((offset == 0.0f) ? 16u : 0u);
                     last_p = this_pq1.point;
@@ -495,13 +489,13 @@ JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ piece
             const uint32_t first = o.alloc(n_u);
             const uint32_t tpos = o.a_tpos;
             if (tpos < o.tcap && tpos + n_u <= o.tcap) {
-                uint4* rec = pieces + (size_t)tpos * 6u;
+                uint4* rec = pieces + (size_t)tpos * 4u;
+                const uint32_t fl = pc_flags | (e.first_piece ? 32u : 0u);
                 rec[0] = make_uint4(f2u(es_p0.x), f2u(es_p0.y), f2u(es_p1.x), f2u(es_p1.y));
                 rec[1] = make_uint4(f2u(ep.th0), f2u(ep.k0), f2u(ep.k1), f2u(ep.ch));
-                rec[2] = make_uint4(f2u(pc_a), f2u(pc_b), f2u(pc_integral), f2u(pc_int0));
-                rec[3] = make_uint4(f2u(pc_noff), f2u(pc_n), f2u(t_end.x), f2u(t_end.y));
-                rec[4] = make_uint4(pc_flags | (e.first_piece ? 32u : 0u), tpos, o.slot, first);
-                rec[5] = make_uint4(e.path_ix, e.trans_ix, f2u(e.t_start.x), f2u(e.t_start.y));
+                rec[2] = make_uint4(f2u(pc_noff), f2u(pc_n), o.slot, first);
+                rec[3] = make_uint4(e.path_ix, e.trans_ix, fl, 0u);
+                if ((fl & (32u | 4u)) != 0u) ends[tpos] = make_uint4(f2u(e.t_start.x), f2u(e.t_start.y), f2u(t_end.x), f2u(t_end.y));
                 o.tinfo[tpos] = FL_INFO_PIECE | n_u;
             }
             e.first_piece = false;
@@ -831,7 +825,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
                                                          uint32_t* __restrict__ counters, uint32_t cap, uint32_t* __restrict__ counts,
                                                          JlLineSoup* __restrict__ tlines, uint2* __restrict__ tkeys, uint32_t tcap,
                                                          uint32_t FL_CHUNK, uint32_t* __restrict__ tinfo, uint4* __restrict__ pieces,
-                                                         uint32_t* __restrict__ chunk_used) {
+                                                         uint4* __restrict__ ends, uint32_t* __restrict__ chunk_used) {
     __shared__ uint32_t sh_next;
     __shared__ uint32_t sh_chunk;
     __shared__ uint32_t sh_item;  // next position of this workgroup's share of the item list
@@ -903,7 +897,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
             // only direct items (lines, caps, joins) were drawn, or finished ones wait to be finalised: go round again
         }
     };
-    flatten_euler_wave(o, e, pieces, refill);
+    flatten_euler_wave(o, e, pieces, ends, refill);
     // how much of the reserved chunk is in use (k_flatten_lines skips the unused tail); every wave reports, the last wins
     if (lane == 0u) atomicMax(&chunk_used[chunk / FL_CHUNK], umin_(sh_next, chunk + FL_CHUNK) - chunk);
 }
@@ -911,22 +905,31 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
 // One thread per temporary slot: the Euler line (or the directly emitted line) that lives there, moved to
 // lines[bases[slot] + k], the canonical (tag byte, emission order) LineSoup position.
 __global__ __launch_bounds__(JL_WG) void k_flatten_lines(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, const uint32_t* __restrict__ counters,
-                                                         const uint32_t* __restrict__ tinfo, const uint4* __restrict__ pieces, uint32_t tcap,
-                                                         const JlLineSoup* __restrict__ tlines, const uint2* __restrict__ tkeys,
+                                                         const uint32_t* __restrict__ tinfo, const uint4* __restrict__ pieces,
+                                                         const uint4* __restrict__ ends, uint32_t tcap, const JlLineSoup* __restrict__ tlines, const uint2* __restrict__ tkeys,
                                                          const uint32_t* __restrict__ chunk_used, uint32_t n_chunks, uint32_t FL_CHUNK,
-                                                         const uint32_t* __restrict__ bases, const uint32_t* __restrict__ counts, uint32_t n_slots,
-                                                         Buf<JlLineSoup> lines) {
+                                                         const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines) {
     const uint32_t n_t = umin_(counters[2], tcap);
     const uint32_t lines_lim = umin_(cfg->lines_size, lines.n);
-    for (uint32_t t = blockIdx.x * JL_WG + threadIdx.x; t < n_t; t += gridDim.x * JL_WG) {
+    const uint32_t lane = lane_id();
+    for (uint32_t t0 = blockIdx.x * JL_WG; t0 < n_t; t0 += gridDim.x * JL_WG) {  // uniform per workgroup
+        const uint32_t t = t0 + threadIdx.x;
+        // which piece covers slot t?  Its first slot carries the marker (pieces have at most 100 lines).  The wave looks
+        // at its 64 markers together: the nearest marker at or before a lane (DPP running maximum); only lanes before
+        // the wave's first marker walk back through memory.
+        uint32_t v = t < n_t ? tinfo[t] : 0u;
+        const uint32_t mark = wave_incl_max_u32(v != 0u ? lane + 1u : 0u);  // 1 + lane of the nearest marker, 0 = none
+        uint32_t tp = t;
+        if (mark != 0u) {
+            v = (uint32_t)__shfl((int)v, (int)(mark - 1u), 64);
+            tp = t - (lane - (mark - 1u));
+        }
+        if (t >= n_t) continue;
         // the workgroups' reserved chunks are the first n_chunks * FL_CHUNK slots; their unused tails hold nothing
         const uint32_t c = t / FL_CHUNK;
         if (c < n_chunks && t - c * FL_CHUNK >= chunk_used[c]) continue;
-        // which piece covers slot t?  Its first slot carries the marker; pieces have at most 100 lines.
-        uint32_t v = tinfo[t];
-        uint32_t tp = t;
-        if (v == 0u) {
-            for (uint32_t back = 1u; back <= 100u && back <= t; back++) {
+        if (mark == 0u) {
+            for (uint32_t back = lane + 1u; back <= 100u && back <= t; back++) {
                 v = tinfo[t - back];
                 if (v != 0u) { tp = t - back; break; }
             }
@@ -942,51 +945,65 @@ __global__ __launch_bounds__(JL_WG) void k_flatten_lines(const JlConfig* __restr
         if ((v & FL_INFO_PIECE) == 0u) continue;
         const uint32_t n_u = v & 0xffffu, i = t - tp;
         if (i >= n_u) continue;
-        const uint4* rec = pieces + (size_t)tp * 6u;
-        const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
-        const uint32_t flags = r4.x;
+        const uint4* rec = pieces + (size_t)tp * 4u;
+        const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        const uint32_t flags = r3.z;
         const bool last_of_item = i + 1u == n_u && (flags & 4u) != 0u;
+        const uint32_t slot = r2.z, k = r2.w + i;
+        uint4 en = make_uint4(0u, 0u, 0u, 0u);
+        if (last_of_item || k == 0u) en = ends[tp];
         V2 lp1;
         if (last_of_item) {
-            lp1 = v2(u2f(r3.z), u2f(r3.w));
-        } else {  // flatten.wgsl:440-461
-            const float n = u2f(r3.y);
+            lp1 = v2(u2f(en.z), u2f(en.w));
+        } else {  // flatten.wgsl:404-461
+            EulerParams ep;
+            ep.th0 = u2f(r1.x); ep.th1 = 0.0f; ep.k0 = u2f(r1.y); ep.k1 = u2f(r1.z); ep.ch = u2f(r1.w);
+            const float noff = u2f(r2.x), n = u2f(r2.y);
             const float tt = (float)(i + 1u) / n;
             float sarg = tt;
             const uint32_t robust = flags & 3u;
-            const float a = u2f(r2.x), b = u2f(r2.y);
             if (robust != 1u) {
-                float u = u2f(r2.z) * tt + u2f(r2.w);
+                const float k0 = ep.k0 - 0.5f * ep.k1, k1 = ep.k1;
+                const float dist_scaled = noff * ep.ch;
+                float a, b, int0, integral;
+                if (robust == 2u) {
+                    a = k1;
+                    b = k0;
+                    int0 = pow_1_5_signed(b);
+                    integral = pow_1_5_signed(a + b) - int0;
+                } else {
+                    a = -2.0f * dist_scaled * k1;
+                    b = -1.0f - 2.0f * dist_scaled * k0;
+                    int0 = espc_int_approx(b);
+                    integral = espc_int_approx(a + b) - int0;
+                }
+                float u = integral * tt + int0;
                 float inv;
                 if (robust == 2u) inv = pow23_abs_(u) * sign_(u); else inv = espc_int_inv_approx(u);
                 sarg = (inv - b) / a;
             }
-            EulerParams ep;
-            ep.th0 = u2f(r1.x); ep.th1 = 0.0f; ep.k0 = u2f(r1.y); ep.k1 = u2f(r1.z); ep.ch = u2f(r1.w);
-            lp1 = es_seg_eval_with_offset(v2(u2f(r0.x), u2f(r0.y)), v2(u2f(r0.z), u2f(r0.w)), ep, sarg, u2f(r3.x));
+            lp1 = es_seg_eval_with_offset(v2(u2f(r0.x), u2f(r0.y)), v2(u2f(r0.z), u2f(r0.w)), ep, sarg, noff);
         }
         Xf tr;
         if ((flags & 16u) != 0u) {
             tr = xf_identity();
         } else {
-            uint32_t tb = cfg->layout.transform_base + r5.y * 6u;
+            uint32_t tb = cfg->layout.transform_base + r3.y * 6u;
             tr.m0 = u2f(scene.rd(tb)); tr.m1 = u2f(scene.rd(tb + 1u)); tr.m2 = u2f(scene.rd(tb + 2u));
             tr.m3 = u2f(scene.rd(tb + 3u)); tr.t0 = u2f(scene.rd(tb + 4u)); tr.t1 = u2f(scene.rd(tb + 5u));
         }
         const V2 q = xf_apply(tr, lp1);
-        const uint32_t slot = r4.z;
         if (slot >= n_slots) continue;
-        const uint32_t k = r4.w + i;
         const uint32_t dst = bases[slot] + k;
         const bool fwd = (flags & 8u) != 0u;  // offset >= 0: (start, end); else the line runs (end, start)
-        const bool has_next = k + 1u < counts[slot] && dst + 1u < lines_lim;
+        const bool has_next = !last_of_item && dst + 1u < lines_lim;
         // Stores are grouped into contiguous byte ranges (a LineSoup is {path, pad, p0, p1} = 3 x 8 bytes): partial
         // 8-byte stores to three different cache lines per thread tripled the write traffic.
         uint2* w = (uint2*)lines.p;  // 8-byte words: 3 per line
-        const uint2 hdr = make_uint2(r5.x, 0u), pt = make_uint2(f2u(q.x), f2u(q.y));
+        const uint2 hdr = make_uint2(r3.x, 0u), pt = make_uint2(f2u(q.x), f2u(q.y));
         if (dst < lines_lim) {
             if (k == 0u) {  // the item's first line: header and start point (the job's start point)
-                const V2 qs = xf_apply(tr, v2(u2f(r5.z), u2f(r5.w)));
+                const V2 qs = xf_apply(tr, v2(u2f(en.x), u2f(en.y)));
                 w[(size_t)dst * 3u] = hdr;
                 w[(size_t)dst * 3u + (fwd ? 1u : 2u)] = make_uint2(f2u(qs.x), f2u(qs.y));
             }
@@ -1132,9 +1149,10 @@ int jh_launch_flatten(const JhLaunch& L) {
     JlLineSoup* tlines = (JlLineSoup*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)tcap * sizeof(JlLineSoup));
     uint2* tkeys = (uint2*)jh_scratch_get(L.scratch, JH_SCR_E, (uint64_t)tcap * sizeof(uint2));
     uint32_t* tinfo = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_H, (uint64_t)tcap * 4);
-    uint4* pieces = (uint4*)jh_scratch_get(L.scratch, JH_SCR_I, (uint64_t)tcap * 96);
+    uint4* pieces = (uint4*)jh_scratch_get(L.scratch, JH_SCR_I, (uint64_t)tcap * 64);
+    uint4* ends = (uint4*)jh_scratch_get(L.scratch, JH_SCR_F, (uint64_t)tcap * 16);
     uint32_t* counters = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, 64 + (uint64_t)g * 4);
-    if (!counts || !bases || !list || !counters || !tlines || !tkeys || !tinfo || !pieces) return -5;
+    if (!counts || !bases || !list || !counters || !tlines || !tkeys || !tinfo || !pieces || !ends) return -5;
     uint32_t* chunk_used = counters + 16;  // one word per workgroup chunk (g <= 2048 workgroups)
     (void)hipMemsetAsync(counters, 0, 64 + (size_t)g * 4, L.stream);
     (void)hipMemsetAsync(counts, 0, (size_t)n_slots * 4, L.stream);
@@ -1142,15 +1160,15 @@ int jh_launch_flatten(const JhLaunch& L) {
     hipLaunchKernelGGL(k_flatten_classify, dim3((L.gx + FL_CLASSIFY_TAGS - 1) / FL_CLASSIFY_TAGS), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list,
                        counters, n_slots, n_tags, g * FL_CHUNK);
     hipLaunchKernelGGL(k_flatten_items, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, (const uint32_t*)list, counters, n_slots, counts,
-                       tlines, tkeys, tcap, FL_CHUNK, tinfo, pieces, chunk_used);
+                       tlines, tkeys, tcap, FL_CHUNK, tinfo, pieces, ends, chunk_used);
     int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);
     if (rc) return rc;
     uint32_t gp = (tcap + JL_WG - 1) / JL_WG;
     uint32_t gp_cap = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * 8u;
     if (gp > gp_cap) gp = gp_cap;
     hipLaunchKernelGGL(k_flatten_lines, dim3(gp), dim3(JL_WG), 0, L.stream, cfg, scene, (const uint32_t*)counters, (const uint32_t*)tinfo,
-                       (const uint4*)pieces, tcap, (const JlLineSoup*)tlines, (const uint2*)tkeys, (const uint32_t*)chunk_used, g, FL_CHUNK,
-                       (const uint32_t*)bases, (const uint32_t*)counts, n_slots, lines);
+                       (const uint4*)pieces, (const uint4*)ends, tcap, (const JlLineSoup*)tlines, (const uint2*)tkeys, (const uint32_t*)chunk_used,
+                       g, FL_CHUNK, (const uint32_t*)bases, n_slots, lines);
     uint32_t gb = (n_tags + JL_WG - 1) / JL_WG;  // one wave per 64 tags
     if (gb > gp_cap) gb = gp_cap;
     hipLaunchKernelGGL(k_flatten_bbox, dim3(gb), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, (const uint32_t*)bases, n_slots, lines, pb);

@@ -99,3 +99,27 @@ def test_empty_scene(engine):
     img = engine.download_image(t["id"], t["width"], t["height"]).view(np.float16).astype(np.float32)
     engine.release(rec)
     assert np.allclose(img[..., 0], 0.5) and np.allclose(img[..., 3], 1.0)
+
+
+def test_regrow_loop_recovers_from_undersized_buffers(engine):
+    """renderer/render.go:458-460 reads bump back; with every bump buffer far too small the first attempt must fail
+    cleanly (no hang, no fault), the regrow loop must converge, and the final image must be the one the oracle gives
+    with comfortable buffers."""
+    s, p = scenes.scene_c3(800, 256)
+    p.bump = BumpSizes(bin_data=256, tiles=512, lines=1024, seg_counts=1024, segments=1024, blend_spill=256, ptcl=1 << 14)
+    rec, bump, attempts = engine.render(s, p, robust=True, retain=True)
+    assert bump["failed"] == 0 and attempts > 1
+    t = rec.target
+    got = engine.download_image(t["id"], t["width"], t["height"])
+    engine.release(rec)
+    s2, p2 = scenes.scene_c3(800, 256)
+    p2.bump = BumpSizes(ptcl=1 << 22)
+    r = compare(engine, s2, p2)
+    assert np.array_equal(got.view(np.uint16), r["image"].view(np.uint16))
+
+
+def test_undersized_buffers_fail_cleanly_without_regrow(engine):
+    s, p = scenes.scene_c3(800, 256)
+    p.bump = BumpSizes(bin_data=256, tiles=512, lines=1024, seg_counts=1024, segments=1024, blend_spill=256, ptcl=1 << 14)
+    rec, bump, attempts = engine.render(s, p, robust=False, retain=False)
+    assert bump["failed"] != 0 and attempts == 1

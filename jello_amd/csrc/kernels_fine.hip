@@ -1015,12 +1015,17 @@ static int launch_fine(const JhLaunch& L, int aa) {
     hipLaunchKernelGGL((k_fine_area<A, C, P>), dim3((L.gx + FINE_WAVES - 1) / FINE_WAVES, L.gy), dim3(64 * FINE_WAVES), 0, L.stream, cfg, seg_ptr, \
                        segments_n, (const uint32_t*)L.b[2].ptr, ptcl_n, (const uint32_t*)L.b[3].ptr, info_n, spill, (uint16_t*)out.ptr,         \
                        out.width, out.height, (const uint16_t*)grad.ptr, grad_h, imgs, L.gx, mask_lut, mask_lut_n)
-    if (aa == 8) JH_FINE_LAUNCH(8, true, true);  // the multisampled stages come in the full flavour only
-    else if (aa == 16) JH_FINE_LAUNCH(16, true, true);
-    else if (clips && paints) JH_FINE_LAUNCH(0, true, true);
-    else if (clips) JH_FINE_LAUNCH(0, true, false);
-    else if (paints) JH_FINE_LAUNCH(0, false, true);
-    else JH_FINE_LAUNCH(0, false, false);
+#define JH_FINE_PICK(A)                                  \
+    do {                                                 \
+        if (clips && paints) JH_FINE_LAUNCH(A, true, true);   \
+        else if (clips) JH_FINE_LAUNCH(A, true, false);       \
+        else if (paints) JH_FINE_LAUNCH(A, false, true);      \
+        else JH_FINE_LAUNCH(A, false, false);                 \
+    } while (0)
+    if (aa == 8) JH_FINE_PICK(8);
+    else if (aa == 16) JH_FINE_PICK(16);
+    else JH_FINE_PICK(0);
+#undef JH_FINE_PICK
 #undef JH_FINE_LAUNCH
     return 0;
 }

@@ -31,6 +31,18 @@ struct Cmd {
     uint32_t seg_base, seg_used;
 };
 
+// PTCL words leave as 16-byte stores where a command has four or more words (dword-aligned addresses: gfx950 runs in
+// unaligned-access mode; a 4-byte store per word costs three times the write requests).
+struct __attribute__((packed, aligned(4))) PtclQuad { uint32_t a, b, c, d; };
+JD void ptcl_wr4(const Buf<uint32_t>& ptcl, uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    if (i + 3u < ptcl.n && i + 3u >= i) {
+        PtclQuad q; q.a = a; q.b = b; q.c = c; q.d = d;
+        *(PtclQuad*)(ptcl.p + i) = q;
+    } else {
+        ptcl.wr(i, a); ptcl.wr(i + 1u, b); ptcl.wr(i + 2u, c); ptcl.wr(i + 3u, d);
+    }
+}
+
 template <bool WRITE>
 JD void alloc_cmd(Cmd& c, uint32_t size) {  // coarse.wgsl:70-88
     if (c.cmd_offset + size >= c.cmd_limit) {
@@ -60,10 +72,7 @@ JD void write_path(Cmd& c, const Buf<JlTile>& tiles, JlTile tile, uint32_t tile_
         if (WRITE) {
             if (tiles.ok(tile_ix)) tiles.p[tile_ix].segment_count_or_ix = ~seg_ix;
             bool even_odd = (draw_flags & 1u) != 0u;
-            c.ptcl.wr(c.cmd_offset, JL_CMD_FILL);
-            c.ptcl.wr(c.cmd_offset + 1u, (n_segs << 1) | (even_odd ? 1u : 0u));
-            c.ptcl.wr(c.cmd_offset + 2u, seg_ix);
-            c.ptcl.wr(c.cmd_offset + 3u, (uint32_t)tile.backdrop);
+            ptcl_wr4(c.ptcl, c.cmd_offset, JL_CMD_FILL, (n_segs << 1) | (even_odd ? 1u : 0u), seg_ix, (uint32_t)tile.backdrop);
         }
         c.cmd_offset += 4u;
     } else {
@@ -283,6 +292,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             uint32_t drawtag = q0.x;
             uint32_t di = q1.w;
             uint32_t draw_flags = q0.y;
+            if (COARSE_EXP & 8) { c.seg_used += q0.x + q1.y + q2.x; continue; }  // timing experiment: iteration + record reads only
             if (clip_zero_depth == 0u) {
                 uint32_t tile_ix = q0.z + q0.w * tile_y + tile_x;
                 JlTile tile;
@@ -296,15 +306,13 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                         tile = tiles.rd(tile_ix);
                     }
                 }
+                if (COARSE_EXP & 16) { c.seg_used += tile.segment_count_or_ix; continue; }  // ... + tile cache read
                 switch (drawtag) {
                     case JL_DRAWTAG_FILL_COLOR: {
                         write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);
                         alloc_cmd<WRITE>(c, 5u);
                         if (WRITE) {
-                            c.ptcl.wr(c.cmd_offset, JL_CMD_COLOR);
-                            c.ptcl.wr(c.cmd_offset + 1u, q2.x);
-                            c.ptcl.wr(c.cmd_offset + 2u, q2.y);
-                            c.ptcl.wr(c.cmd_offset + 3u, q2.z);
+                            ptcl_wr4(c.ptcl, c.cmd_offset, JL_CMD_COLOR, q2.x, q2.y, q2.z);
                             c.ptcl.wr(c.cmd_offset + 4u, q2.w);
                         }
                         c.cmd_offset += 5u;

@@ -16,16 +16,25 @@ using namespace jd;
 #define SCAN_ITEMS 8
 #define SCAN_TILE (JL_WG * SCAN_ITEMS)
 
+// Two launches: SCAN_G workgroups each own a contiguous range of ceil(n / SCAN_G) elements (rounded to whole tiles).
+// Pass 1 reduces the range to one sum; pass 2 first turns the (at most SCAN_G) sums before its own into its carry-in
+// with one block reduction -- cheaper than a third single-workgroup launch in between -- then scans its range.
+#define SCAN_G 512u
+JD uint32_t scan_range_len(uint32_t n) { return ((n + SCAN_G - 1u) / SCAN_G + SCAN_TILE - 1u) / SCAN_TILE * SCAN_TILE; }
+
 __global__ __launch_bounds__(JL_WG) void k_scan_block_sums(const uint32_t* __restrict__ in, uint32_t stride, uint32_t n_max,
                                                            const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t sh[8];
     uint32_t n = n_dev ? umin_(*n_dev, n_max) : n_max;
-    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    const uint32_t len = scan_range_len(n);
+    const uint32_t lo = blockIdx.x * len, hi = umin_(lo + len, n);
     uint32_t s = 0;
+    for (uint32_t base = lo + threadIdx.x * SCAN_ITEMS; base < hi; base += SCAN_TILE) {
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        uint32_t ix = base + i;
-        if (ix < n) s += in[(size_t)ix * stride];
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            uint32_t ix = base + i;
+            if (ix < hi) s += in[(size_t)ix * stride];
+        }
     }
     MonoidK<1> m;
     m.v[0] = s;
@@ -33,66 +42,58 @@ __global__ __launch_bounds__(JL_WG) void k_scan_block_sums(const uint32_t* __res
     if (threadIdx.x == 0) block_sums[blockIdx.x] = t.v[0];
 }
 
-__global__ __launch_bounds__(1024) void k_scan_block_prefix(uint32_t* __restrict__ block_sums, uint32_t n_blocks, uint32_t* __restrict__ total_dev) {
-    __shared__ uint32_t sh[16];
-    __shared__ uint32_t carry_sh;
-    if (threadIdx.x == 0) carry_sh = 0;
-    __syncthreads();
-    for (uint32_t start = 0; start < n_blocks; start += 1024) {
-        uint32_t ix = start + threadIdx.x;
-        uint32_t v = ix < n_blocks ? block_sums[ix] : 0u;
-        uint32_t incl = wave_incl_scan_u32(v);
-        uint32_t w = threadIdx.x >> 6;
-        if (lane_id() == 63u) sh[w] = incl;
-        __syncthreads();
-        uint32_t base = 0, tot = 0;
-        for (uint32_t j = 0; j < 16; j++) {
-            uint32_t s = sh[j];
-            if (j < w) base += s;
-            tot += s;
-        }
-        uint32_t carry = carry_sh;
-        if (ix < n_blocks) block_sums[ix] = carry + base + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_sh = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && total_dev) *total_dev = carry_sh;
-}
-
 __global__ __launch_bounds__(JL_WG) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t stride, uint32_t* __restrict__ out, uint32_t n_max,
-                                                      const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ block_sums) {
+                                                      const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ block_sums,
+                                                      uint32_t* __restrict__ total_dev) {
     __shared__ uint32_t sh[8];
     uint32_t n = n_dev ? umin_(*n_dev, n_max) : n_max;
-    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    if (blockIdx.x * SCAN_TILE >= n) return;
-    uint32_t v[SCAN_ITEMS];
-    uint32_t s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        uint32_t ix = base + i;
-        v[i] = ix < n ? in[(size_t)ix * stride] : 0u;
-        s += v[i];
+    const uint32_t len = scan_range_len(n);
+    const uint32_t lo = blockIdx.x * len, hi = umin_(lo + len, n);
+    // carry-in: sum of the ranges before mine (SCAN_G = 2 * JL_WG values); the last workgroup also publishes the total
+    MonoidK<1> m;
+    {
+        const uint32_t a = threadIdx.x, b2 = threadIdx.x + JL_WG;
+        uint32_t va = block_sums[a], vb = block_sums[b2];
+        m.v[0] = (a < blockIdx.x ? va : 0u) + (b2 < blockIdx.x ? vb : 0u);
+        if (blockIdx.x == SCAN_G - 1u && total_dev) {
+            MonoidK<1> all;
+            all.v[0] = va + vb;
+            MonoidK<1> t = block_reduce_monoid<1>(all, sh);
+            if (threadIdx.x == 0) *total_dev = t.v[0];
+            __syncthreads();
+        }
     }
-    uint32_t tot;
-    uint32_t excl = block_excl_scan_u32(s, sh, &tot) + block_sums[blockIdx.x];
+    uint32_t carry = block_reduce_monoid<1>(m, sh).v[0];
+    for (uint32_t base0 = lo; base0 < hi; base0 += SCAN_TILE) {
+        const uint32_t base = base0 + threadIdx.x * SCAN_ITEMS;
+        uint32_t v[SCAN_ITEMS];
+        uint32_t s = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        uint32_t ix = base + i;
-        if (ix < n) out[ix] = excl;
-        excl += v[i];
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            uint32_t ix = base + i;
+            v[i] = ix < hi ? in[(size_t)ix * stride] : 0u;
+            s += v[i];
+        }
+        uint32_t tot;
+        uint32_t excl = block_excl_scan_u32(s, sh, &tot) + carry;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            uint32_t ix = base + i;
+            if (ix < hi) out[ix] = excl;
+            excl += v[i];
+        }
+        carry += tot;
+        __syncthreads();
     }
 }
 
 int jh_scan_u32(const JhLaunch& L, const uint32_t* in, uint32_t in_stride, uint32_t* out, uint32_t n_max, const uint32_t* n_dev,
                 uint32_t* total_dev) {
-    uint32_t n_blocks = (n_max + SCAN_TILE - 1) / SCAN_TILE;
-    if (n_blocks == 0) n_blocks = 1;
-    uint32_t* block_sums = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_SCAN_TMP, (uint64_t)n_blocks * 4);
+    uint32_t* block_sums = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_SCAN_TMP, (uint64_t)SCAN_G * 12);
     if (!block_sums) return -5;
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(n_blocks), dim3(JL_WG), 0, L.stream, in, in_stride, n_max, n_dev, block_sums);
-    hipLaunchKernelGGL(k_scan_block_prefix, dim3(1), dim3(1024), 0, L.stream, block_sums, n_blocks, total_dev);
-    hipLaunchKernelGGL(k_scan_apply, dim3(n_blocks), dim3(JL_WG), 0, L.stream, in, in_stride, out, n_max, n_dev, block_sums);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(SCAN_G), dim3(JL_WG), 0, L.stream, in, in_stride, n_max, n_dev, block_sums);
+    hipLaunchKernelGGL(k_scan_apply, dim3(SCAN_G), dim3(JL_WG), 0, L.stream, in, in_stride, out, n_max, n_dev, (const uint32_t*)block_sums,
+                       total_dev);
     return 0;
 }
 

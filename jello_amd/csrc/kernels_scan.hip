@@ -3,8 +3,8 @@
 //   K5    bbox_clear                                              (orig/bbox_clear.wgsl:13-24)
 //   K7-K8 draw_reduce / draw_leaf                                 (orig/draw_reduce.wgsl, draw_leaf.wgsl)
 //   plus the generic u32 exclusive scan every deterministic allocator is built on.
-// All of these are HBM-bound integer work: 16 B / tag word in, 20 B out (K4); wave64 __shfl_up
-// prefix + a 4-entry LDS exchange per 256-thread block replaces the WGSL's 8-round LDS ladder.
+// All of these are HBM-bound integer work: 16 B / tag word in, 20 B out (K4); wave64 DPP
+// prefix (row_shr + row_bcast) + a 4-entry LDS exchange per 256-thread block replaces the WGSL's 8-round LDS ladder.
 #include "kcommon.h"
 
 using namespace jk;
@@ -97,84 +97,77 @@ int jh_scan_u32(const JhLaunch& L, const uint32_t* in, uint32_t in_stride, uint3
     return 0;
 }
 
-// Three independent exclusive scans over arrays laid out back to back (in[c*n + i]) in one set of launches:
+// Three independent exclusive scans over arrays laid out back to back (in[c*n + i]) in one pair of launches:
 // blockIdx.y selects the channel.  Used by coarse (segments / PTCL words / blend pixels per tile).
-__global__ __launch_bounds__(JL_WG) void k_scan3_block_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t n_blocks,
-                                                            uint32_t* __restrict__ block_sums) {
+__global__ __launch_bounds__(JL_WG) void k_scan3_block_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t sh[8];
     const uint32_t* src = in + (size_t)blockIdx.y * n;
-    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    const uint32_t len = scan_range_len(n);
+    const uint32_t lo = blockIdx.x * len, hi = umin_(lo + len, n);
     uint32_t s = 0;
+    for (uint32_t base = lo + threadIdx.x * SCAN_ITEMS; base < hi; base += SCAN_TILE) {
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        uint32_t ix = base + i;
-        if (ix < n) s += src[ix];
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            uint32_t ix = base + i;
+            if (ix < hi) s += src[ix];
+        }
     }
     MonoidK<1> m;
     m.v[0] = s;
     MonoidK<1> t = block_reduce_monoid<1>(m, sh);
-    if (threadIdx.x == 0) block_sums[blockIdx.y * n_blocks + blockIdx.x] = t.v[0];
+    if (threadIdx.x == 0) block_sums[blockIdx.y * SCAN_G + blockIdx.x] = t.v[0];
 }
-__global__ __launch_bounds__(1024) void k_scan3_block_prefix(uint32_t* __restrict__ block_sums, uint32_t n_blocks, uint32_t* __restrict__ t0,
-                                                             uint32_t* __restrict__ t1, uint32_t* __restrict__ t2) {
-    __shared__ uint32_t sh[16];
-    __shared__ uint32_t carry_sh;
-    uint32_t* bs = block_sums + (size_t)blockIdx.x * n_blocks;
-    uint32_t* total_dev = blockIdx.x == 0 ? t0 : (blockIdx.x == 1 ? t1 : t2);
-    if (threadIdx.x == 0) carry_sh = 0;
-    __syncthreads();
-    for (uint32_t start = 0; start < n_blocks; start += 1024) {
-        uint32_t ix = start + threadIdx.x;
-        uint32_t v = ix < n_blocks ? bs[ix] : 0u;
-        uint32_t incl = wave_incl_scan_u32(v);
-        uint32_t w = threadIdx.x >> 6;
-        if (lane_id() == 63u) sh[w] = incl;
-        __syncthreads();
-        uint32_t base = 0, tot = 0;
-        for (uint32_t j = 0; j < 16; j++) {
-            uint32_t s = sh[j];
-            if (j < w) base += s;
-            tot += s;
-        }
-        uint32_t carry = carry_sh;
-        if (ix < n_blocks) bs[ix] = carry + base + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_sh = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && total_dev) *total_dev = carry_sh;
-}
-__global__ __launch_bounds__(JL_WG) void k_scan3_apply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, uint32_t n_blocks,
-                                                       const uint32_t* __restrict__ block_sums) {
+__global__ __launch_bounds__(JL_WG) void k_scan3_apply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n,
+                                                       const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ t0, uint32_t* __restrict__ t1,
+                                                       uint32_t* __restrict__ t2) {
     __shared__ uint32_t sh[8];
     const uint32_t* src = in + (size_t)blockIdx.y * n;
     uint32_t* dst = out + (size_t)blockIdx.y * n;
-    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    uint32_t s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        uint32_t ix = base + i;
-        v[i] = ix < n ? src[ix] : 0u;
-        s += v[i];
+    const uint32_t* bs = block_sums + (size_t)blockIdx.y * SCAN_G;
+    uint32_t* total_dev = blockIdx.y == 0 ? t0 : (blockIdx.y == 1 ? t1 : t2);
+    const uint32_t len = scan_range_len(n);
+    const uint32_t lo = blockIdx.x * len, hi = umin_(lo + len, n);
+    MonoidK<1> m;
+    {
+        const uint32_t a = threadIdx.x, b2 = threadIdx.x + JL_WG;
+        uint32_t va = bs[a], vb = bs[b2];
+        m.v[0] = (a < blockIdx.x ? va : 0u) + (b2 < blockIdx.x ? vb : 0u);
+        if (blockIdx.x == SCAN_G - 1u && total_dev) {
+            MonoidK<1> all;
+            all.v[0] = va + vb;
+            MonoidK<1> t = block_reduce_monoid<1>(all, sh);
+            if (threadIdx.x == 0) *total_dev = t.v[0];
+            __syncthreads();
+        }
     }
-    uint32_t tot;
-    uint32_t excl = block_excl_scan_u32(s, sh, &tot) + block_sums[blockIdx.y * n_blocks + blockIdx.x];
+    uint32_t carry = block_reduce_monoid<1>(m, sh).v[0];
+    for (uint32_t base0 = lo; base0 < hi; base0 += SCAN_TILE) {
+        const uint32_t base = base0 + threadIdx.x * SCAN_ITEMS;
+        uint32_t v[SCAN_ITEMS];
+        uint32_t s = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        uint32_t ix = base + i;
-        if (ix < n) dst[ix] = excl;
-        excl += v[i];
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            uint32_t ix = base + i;
+            v[i] = ix < hi ? src[ix] : 0u;
+            s += v[i];
+        }
+        uint32_t tot;
+        uint32_t excl = block_excl_scan_u32(s, sh, &tot) + carry;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            uint32_t ix = base + i;
+            if (ix < hi) dst[ix] = excl;
+            excl += v[i];
+        }
+        carry += tot;
+        __syncthreads();
     }
 }
 int jh_scan3_u32(const JhLaunch& L, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total0, uint32_t* total1, uint32_t* total2) {
-    uint32_t n_blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
-    if (n_blocks == 0) n_blocks = 1;
-    uint32_t* block_sums = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_SCAN_TMP, (uint64_t)n_blocks * 12);
+    uint32_t* block_sums = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_SCAN_TMP, (uint64_t)SCAN_G * 12);
     if (!block_sums) return -5;
-    hipLaunchKernelGGL(k_scan3_block_sums, dim3(n_blocks, 3), dim3(JL_WG), 0, L.stream, in, n, n_blocks, block_sums);
-    hipLaunchKernelGGL(k_scan3_block_prefix, dim3(3), dim3(1024), 0, L.stream, block_sums, n_blocks, total0, total1, total2);
-    hipLaunchKernelGGL(k_scan3_apply, dim3(n_blocks, 3), dim3(JL_WG), 0, L.stream, in, out, n, n_blocks, (const uint32_t*)block_sums);
+    hipLaunchKernelGGL(k_scan3_block_sums, dim3(SCAN_G, 3), dim3(JL_WG), 0, L.stream, in, n, block_sums);
+    hipLaunchKernelGGL(k_scan3_apply, dim3(SCAN_G, 3), dim3(JL_WG), 0, L.stream, in, out, n, (const uint32_t*)block_sums, total0, total1, total2);
     return 0;
 }
 

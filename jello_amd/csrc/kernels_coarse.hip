@@ -88,7 +88,9 @@ JD void write_path(Cmd& c, const Buf<JlTile>& tiles, JlTile tile, uint32_t tile_
 #endif
 #define COARSE_TILE_CACHE 4096u
 
-template <bool WRITE>
+// CLIPS = false: instantiation for scenes without clip layers (ConfigUniform.n_clip == 0): no BEGIN/END_CLIP draw
+// objects can occur, which removes the clip-depth state and half of the divergent control flow of the command walk.
+template <bool WRITE, bool CLIPS>
 __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlDrawMonoid> draw_monoids,
                                                   Buf<JlBinHeader> bin_headers, Buf<uint32_t> info_bin_data, Buf<JlPath> paths, Buf<JlTile> tiles,
                                                   JlBump* __restrict__ bump, Buf<uint32_t> ptcl, uint32_t* __restrict__ cnt_seg,
@@ -208,7 +210,10 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             int32_t y0 = iclamp_(dy, 0, JL_N_TILE_Y);
             int32_t x1 = iclamp_((int32_t)path.bbox[2] - (int32_t)bin_tile_x, 0, JL_N_TILE_X);
             int32_t y1 = iclamp_((int32_t)path.bbox[3] - (int32_t)bin_tile_y, 0, JL_N_TILE_Y);
-            r1.y = (uint32_t)(x1 - x0);
+            {   // width (<= 16) and ceil(2^16 / width): the include test divides pair indices (< 4096) by the width
+                const uint32_t wdt = (uint32_t)(x1 - x0);
+                r1.y = wdt | ((wdt ? (65536u + wdt - 1u) / wdt : 0u) << 5);
+            }
             r1.x = (uint32_t)x0 | ((uint32_t)y0 << 16);
             tile_count = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
             r0.z = path.tiles - (uint32_t)(dy * (int32_t)stride + dx);
@@ -239,9 +244,10 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                     }
                     const uint4 q0 = sh_r0[el_ix], q1 = sh_r1[el_ix];
                     uint32_t seq_ix = ix - q1.z;
-                    uint32_t width = q1.y;
-                    uint32_t x = (q1.x & 0xffffu) + seq_ix % width;
-                    uint32_t y = (q1.x >> 16) + seq_ix / width;
+                    uint32_t width = q1.y & 31u;
+                    uint32_t row = (seq_ix * (q1.y >> 5)) >> 16;  // seq_ix / width, exact for seq_ix < 4096 and width <= 16
+                    uint32_t x = (q1.x & 0xffffu) + (seq_ix - row * width);
+                    uint32_t y = (q1.x >> 16) + row;
                     p_el[u] = el_ix;
                     p_xy[u] = y * JL_N_TILE_X + x;
                     p_tile[u] = q0.z + q0.w * y + x;
@@ -293,11 +299,11 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             uint32_t di = q1.w;
             uint32_t draw_flags = q0.y;
             if (COARSE_EXP & 8) { c.seg_used += q0.x + q1.y + q2.x; continue; }  // timing experiment: iteration + record reads only
-            if (clip_zero_depth == 0u) {
+            if (!CLIPS || clip_zero_depth == 0u) {
                 uint32_t tile_ix = q0.z + q0.w * tile_y + tile_x;
                 JlTile tile;
                 {   // the pair's slot in the include-test order: what that pass loaded is still in LDS
-                    const uint32_t pair = q1.z + (tile_y - (q1.x >> 16)) * q1.y + (tile_x - (q1.x & 0xffffu));
+                    const uint32_t pair = q1.z + (tile_y - (q1.x >> 16)) * (q1.y & 31u) + (tile_x - (q1.x & 0xffffu));
                     if (pair < COARSE_TILE_CACHE) {
                         const uint2 tc = sh_tile_cache[pair];
                         tile.backdrop = (int32_t)tc.x;
@@ -307,71 +313,58 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                     }
                 }
                 if (COARSE_EXP & 16) { c.seg_used += tile.segment_count_or_ix; continue; }  // ... + tile cache read
-                switch (drawtag) {
-                    case JL_DRAWTAG_FILL_COLOR: {
-                        write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);
-                        alloc_cmd<WRITE>(c, 5u);
-                        if (WRITE) {
-                            ptcl_wr4(c.ptcl, c.cmd_offset, JL_CMD_COLOR, q2.x, q2.y, q2.z);
-                            c.ptcl.wr(c.cmd_offset + 4u, q2.w);
-                        }
-                        c.cmd_offset += 5u;
-                        break;
+                if (drawtag == JL_DRAWTAG_FILL_COLOR) {  // by far the most frequent draw object: tested first
+                    write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);
+                    alloc_cmd<WRITE>(c, 5u);
+                    if (WRITE) {
+                        ptcl_wr4(c.ptcl, c.cmd_offset, JL_CMD_COLOR, q2.x, q2.y, q2.z);
+                        c.ptcl.wr(c.cmd_offset + 4u, q2.w);
                     }
-                    case JL_DRAWTAG_FILL_LIN_GRADIENT:
-                    case JL_DRAWTAG_FILL_RAD_GRADIENT:
-                    case JL_DRAWTAG_FILL_SWEEP_GRADIENT: {
-                        write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);
-                        alloc_cmd<WRITE>(c, 3u);
-                        if (WRITE) {
-                            uint32_t ty = drawtag == JL_DRAWTAG_FILL_LIN_GRADIENT ? JL_CMD_LIN_GRAD
-                                          : (drawtag == JL_DRAWTAG_FILL_RAD_GRADIENT ? JL_CMD_RAD_GRAD : JL_CMD_SWEEP_GRAD);
-                            c.ptcl.wr(c.cmd_offset, ty);
-                            c.ptcl.wr(c.cmd_offset + 1u, q2.x);
-                            c.ptcl.wr(c.cmd_offset + 2u, di + 1u);
-                        }
-                        c.cmd_offset += 3u;
-                        break;
+                    c.cmd_offset += 5u;
+                } else if (drawtag == JL_DRAWTAG_FILL_LIN_GRADIENT || drawtag == JL_DRAWTAG_FILL_RAD_GRADIENT ||
+                           drawtag == JL_DRAWTAG_FILL_SWEEP_GRADIENT) {
+                    write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);
+                    alloc_cmd<WRITE>(c, 3u);
+                    if (WRITE) {
+                        uint32_t ty = drawtag == JL_DRAWTAG_FILL_LIN_GRADIENT ? JL_CMD_LIN_GRAD
+                                      : (drawtag == JL_DRAWTAG_FILL_RAD_GRADIENT ? JL_CMD_RAD_GRAD : JL_CMD_SWEEP_GRAD);
+                        c.ptcl.wr(c.cmd_offset, ty);
+                        c.ptcl.wr(c.cmd_offset + 1u, q2.x);
+                        c.ptcl.wr(c.cmd_offset + 2u, di + 1u);
                     }
-                    case JL_DRAWTAG_FILL_IMAGE: {
-                        write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);
-                        alloc_cmd<WRITE>(c, 2u);
-                        if (WRITE) {
-                            c.ptcl.wr(c.cmd_offset, JL_CMD_IMAGE);
-                            c.ptcl.wr(c.cmd_offset + 1u, di + 1u);
-                        }
-                        c.cmd_offset += 2u;
-                        break;
+                    c.cmd_offset += 3u;
+                } else if (drawtag == JL_DRAWTAG_FILL_IMAGE) {
+                    write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);
+                    alloc_cmd<WRITE>(c, 2u);
+                    if (WRITE) {
+                        c.ptcl.wr(c.cmd_offset, JL_CMD_IMAGE);
+                        c.ptcl.wr(c.cmd_offset + 1u, di + 1u);
                     }
-                    case JL_DRAWTAG_BEGIN_CLIP: {
-                        if (tile.segment_count_or_ix == 0u && tile.backdrop == 0) {
-                            clip_zero_depth = clip_depth + 1u;
-                        } else {
-                            alloc_cmd<WRITE>(c, 1u);
-                            if (WRITE) c.ptcl.wr(c.cmd_offset, JL_CMD_BEGIN_CLIP);
-                            c.cmd_offset += 1u;
-                            render_blend_depth += 1u;
-                            max_blend_depth = umax_(max_blend_depth, render_blend_depth);
-                        }
-                        clip_depth += 1u;
-                        break;
+                    c.cmd_offset += 2u;
+                } else if (CLIPS && drawtag == JL_DRAWTAG_BEGIN_CLIP) {
+                    if (tile.segment_count_or_ix == 0u && tile.backdrop == 0) {
+                        clip_zero_depth = clip_depth + 1u;
+                    } else {
+                        alloc_cmd<WRITE>(c, 1u);
+                        if (WRITE) c.ptcl.wr(c.cmd_offset, JL_CMD_BEGIN_CLIP);
+                        c.cmd_offset += 1u;
+                        render_blend_depth += 1u;
+                        max_blend_depth = umax_(max_blend_depth, render_blend_depth);
                     }
-                    case JL_DRAWTAG_END_CLIP: {
-                        clip_depth -= 1u;
-                        write_path<WRITE>(c, tiles, tile, tile_ix, 0u);
-                        alloc_cmd<WRITE>(c, 3u);
-                        if (WRITE) {
-                            c.ptcl.wr(c.cmd_offset, JL_CMD_END_CLIP);
-                            c.ptcl.wr(c.cmd_offset + 1u, q2.x);
-                            c.ptcl.wr(c.cmd_offset + 2u, q2.y);
-                        }
-                        c.cmd_offset += 3u;
-                        render_blend_depth -= 1u;
-                        break;
+                    clip_depth += 1u;
+                } else if (CLIPS && drawtag == JL_DRAWTAG_END_CLIP) {
+                    clip_depth -= 1u;
+                    write_path<WRITE>(c, tiles, tile, tile_ix, 0u);
+                    alloc_cmd<WRITE>(c, 3u);
+                    if (WRITE) {
+                        c.ptcl.wr(c.cmd_offset, JL_CMD_END_CLIP);
+                        c.ptcl.wr(c.cmd_offset + 1u, q2.x);
+                        c.ptcl.wr(c.cmd_offset + 2u, q2.y);
                     }
-                    default: break;
+                    c.cmd_offset += 3u;
+                    render_blend_depth -= 1u;
                 }
-            } else {
+            } else if (CLIPS) {
                 if (drawtag == JL_DRAWTAG_BEGIN_CLIP) {
                     clip_depth += 1u;
                 } else if (drawtag == JL_DRAWTAG_END_CLIP) {
@@ -425,11 +418,14 @@ int jh_launch_coarse(const JhLaunch& L) {
     JlBump* bump = (JlBump*)L.b[7].ptr;
     auto ptcl = mkbuf<uint32_t>(L.b[8].ptr, L.b[8].size);
     dim3 grid(L.gx, L.gy), blk(JL_WG);
-    hipLaunchKernelGGL(k_coarse<false>, grid, blk, 0, L.stream, cfg, scene, dm, bh, ibd, paths, tiles, bump, ptcl, cnt_seg, cnt_chunk, cnt_blend,
-                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    const bool clips = !(L.cfg_host && L.cfg_host->layout.n_clip == 0u);  // host shadow of the uploaded ConfigUniform
+#define JH_COARSE(W, C, ...) hipLaunchKernelGGL((k_coarse<W, C>), grid, blk, 0, L.stream, cfg, scene, dm, bh, ibd, paths, tiles, bump, ptcl, __VA_ARGS__)
+    if (clips) JH_COARSE(false, true, cnt_seg, cnt_chunk, cnt_blend, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    else JH_COARSE(false, false, cnt_seg, cnt_chunk, cnt_blend, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     int rc = jh_scan3_u32(L, cnt_seg, base_seg, n, &bump->segments, &bump->ptcl, &bump->blend);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_coarse<true>, grid, blk, 0, L.stream, cfg, scene, dm, bh, ibd, paths, tiles, bump, ptcl, (uint32_t*)nullptr,
-                       (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend);
+    if (clips) JH_COARSE(true, true, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend);
+    else JH_COARSE(true, false, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend);
+#undef JH_COARSE
     return 0;
 }

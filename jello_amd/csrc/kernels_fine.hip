@@ -697,20 +697,41 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
                 if (sa - batch_lo >= batch_hi - batch_lo) { if (FINE_EXP & 16) { batch_lo = sa; batch_hi = sa + 16u; cur_base = sa; } else build_batch(sa); }
                 uint32_t take = umin_(remaining, batch_hi - sa);
                 uint32_t r0 = sa - cur_base;  // window-relative segments [r0, r0 + take)
-                for (uint32_t q = 0u; q < take && !(FINE_EXP & 2); q++) {
-                    const int sl = (int)((r0 + q) & 63u);
+                // two segments per trip: both LDS reads are in flight before the (ordered) adds (four measured the same)
+                auto seg_fetch = [&](uint32_t q, float (&cv)[4], float& ye_s, int& sl) {
+                    sl = (int)((r0 + q) & 63u);
                     uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)my_meta, sl);
-                    float ye_s = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(my_ye), sl));
+                    ye_s = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(my_ye), sl));
                     uint32_t t = ly - ((m >> 17) & 31u);
                     // the segment's pair for my row, or the all-zero slot 64 (adding +0 is a no-op)
                     uint32_t j = (t < ((m >> 12) & 31u)) ? (((m & 0xfffu) + t) & 63u) : 64u;
                     const float* cp = &F.contrib[lx * 4u][j];
-                    area[0] += cp[0]; area[1] += cp[FB_STRIDE]; area[2] += cp[2 * FB_STRIDE]; area[3] += cp[3 * FB_STRIDE];
+                    cv[0] = cp[0]; cv[1] = cp[FB_STRIDE]; cv[2] = cp[2 * FB_STRIDE]; cv[3] = cp[3 * FB_STRIDE];
+                };
+                auto seg_apply = [&](const float (&cv)[4], float ye_s, int sl) {
+                    area[0] += cv[0]; area[1] += cv[1]; area[2] += cv[2]; area[3] += cv[3];
                     // y_edge >= 16 (path_tiling's "no edge" value is 1e9) clamps to 0 for every row of the tile
                     if (ye_s < 16.0f) {  // uniform
                         float sg_s = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(my_sg), sl));
                         float y_edge = sg_s * clamp_(lyf - ye_s + 1.0f, 0.0f, 1.0f);
                         area[0] += y_edge; area[1] += y_edge; area[2] += y_edge; area[3] += y_edge;
+                    }
+                };
+                uint32_t q = 0u;
+                if (!(FINE_EXP & 2)) {
+                    for (; q + 1u < take; q += 2u) {
+                        float ca[4], cb[4], ya, yb;
+                        int sa_l, sb_l;
+                        seg_fetch(q, ca, ya, sa_l);
+                        seg_fetch(q + 1u, cb, yb, sb_l);
+                        seg_apply(ca, ya, sa_l);
+                        seg_apply(cb, yb, sb_l);
+                    }
+                    if (q < take) {
+                        float ca[4], ya;
+                        int sa_l;
+                        seg_fetch(q, ca, ya, sa_l);
+                        seg_apply(ca, ya, sa_l);
                     }
                 }
                 sa += take;

@@ -55,6 +55,7 @@ struct Out {
     JlLineSoup* tlines;
     uint2* tkeys;
     uint32_t* tinfo;  // per temp slot: FL_INFO_* marker (0 = nothing starts here)
+    uint32_t overflow_start;  // first temp slot behind the workgroup chunks
     uint32_t tcap;
     uint32_t slot;
     uint32_t cursor;           // lines emitted so far by this item (local index of the next line)
@@ -497,6 +498,8 @@ JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ piece
                 rec[3] = make_uint4(e.path_ix, e.trans_ix, fl, 0u);
                 if ((fl & (32u | 4u)) != 0u) ends[tpos] = make_uint4(f2u(e.t_start.x), f2u(e.t_start.y), f2u(t_end.x), f2u(t_end.y));
                 o.tinfo[tpos] = FL_INFO_PIECE | n_u;
+                if (tpos >= o.overflow_start)  // only the chunk area is zeroed by the launcher (rare path)
+                    for (uint32_t i = 1u; i < n_u; i++) o.tinfo[tpos + i] = 0u;
             }
             e.first_piece = false;
         }
@@ -841,17 +844,12 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
         sh_item = 0u;
     }
     __syncthreads();
-    uint32_t chunk = sh_chunk;
-    for (uint32_t i = threadIdx.x; i < FL_CHUNK; i += JL_WG) {  // slots of the chunk that stay unused must read as invalid
-        uint32_t t = chunk + i;
-        if (t < tcap) tkeys[t] = make_uint2(FL_INVALID, 0u);
-    }
-    __syncthreads();
+    uint32_t chunk = sh_chunk;  // (unused slots need no marking: tinfo, zeroed by the launcher, says what a slot holds)
     const uint32_t lane = lane_id();
     // Work distribution: the item list (heavy items first) is dealt to the workgroups in chunks of 64, round robin;
     // the waves of a workgroup draw their items from its share through one LDS counter.
     Out<true> o;
-    o.cfg = cfg; o.tlines = tlines; o.tkeys = tkeys; o.tinfo = tinfo; o.tcap = tcap; o.slot = 0u;
+    o.cfg = cfg; o.tlines = tlines; o.tkeys = tkeys; o.tinfo = tinfo; o.overflow_start = gridDim.x * FL_CHUNK; o.tcap = tcap; o.slot = 0u;
     o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
     o.lds_next = &sh_next; o.lds_limit = chunk + FL_CHUNK; o.g_next = &counters[2];
     o.bx0 = 1e31f; o.by0 = 1e31f; o.bx1 = -1e31f; o.by1 = -1e31f;
@@ -1156,7 +1154,7 @@ int jh_launch_flatten(const JhLaunch& L) {
     uint32_t* chunk_used = counters + 16;  // one word per workgroup chunk (g <= 2048 workgroups)
     (void)hipMemsetAsync(counters, 0, 64 + (size_t)g * 4, L.stream);
     (void)hipMemsetAsync(counts, 0, (size_t)n_slots * 4, L.stream);
-    (void)hipMemsetAsync(tinfo, 0, (size_t)tcap * 4, L.stream);  // "nothing starts in this slot"
+    (void)hipMemsetAsync(tinfo, 0, (size_t)g * FL_CHUNK * 4, L.stream);  // chunk area: "nothing starts in this slot"
     hipLaunchKernelGGL(k_flatten_classify, dim3((L.gx + FL_CLASSIFY_TAGS - 1) / FL_CLASSIFY_TAGS), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list,
                        counters, n_slots, n_tags, g * FL_CHUNK);
     hipLaunchKernelGGL(k_flatten_items, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, (const uint32_t*)list, counters, n_slots, counts,

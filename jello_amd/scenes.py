@@ -179,3 +179,80 @@ def scene_big_path(size=1024, n_zig=600, seed=SEED + 9):
     s.fill(Fill.EvenOdd, None, Brush.solid((0.9, 0.2, 0.1, 0.6)), None, p)
     s.stroke(Stroke(1.5, Join.Bevel, 4, Cap.Butt, Cap.Butt), None, Brush.solid((0.0, 0.0, 0.0, 1.0)), None, p)
     return s, RenderParams(size, size, base_color=(1, 1, 1, 1))
+
+
+def scene_fuzz(seed, size=256, n=40):
+    """Random mixture of everything the pipeline handles: fills (both rules) and strokes (all joins / caps / widths,
+    closed and open, lines / quads / cubics, degenerate segments), per-draw affine transforms, solid / linear / radial /
+    sweep / image brushes with all extend modes, nested clip layers with every mix mode.  Drives the parity fuzz test."""
+    r = SplitMix64(SEED + 1000 + seed)
+    s = Scene()
+    img = (splitmix64_array(16 * 16 * 4, SEED + 2000 + seed) * 256.0).astype(np.uint8).reshape(16, 16, 4)
+    open_layers = 0
+
+    def rnd_affine():
+        k = int(r.uniform(0, 4))
+        if k == 0:
+            return None
+        a, sc = r.uniform(0, 2 * math.pi), r.uniform(0.4, 2.0)
+        c, sn = math.cos(a) * sc, math.sin(a) * sc
+        return (c, sn, -sn, c * r.uniform(0.5, 1.5), r.uniform(0, size * 0.5), r.uniform(0, size * 0.5))
+
+    def rnd_path(closed):
+        p = Path()
+        x, y = r.uniform(0, size), r.uniform(0, size)
+        p.move_to(x, y)
+        for _ in range(1 + int(r.uniform(0, 5))):
+            k = int(r.uniform(0, 4))
+            ext = r.uniform(2, size * 0.4)
+            nx, ny = x + r.uniform(-ext, ext), y + r.uniform(-ext, ext)
+            if k == 0:
+                p.line_to(nx, ny)
+            elif k == 1:
+                p.quad_to(x + r.uniform(-ext, ext), y + r.uniform(-ext, ext), nx, ny)
+            elif k == 2:
+                p.cubic_to(x + r.uniform(-ext, ext), y + r.uniform(-ext, ext), nx + r.uniform(-ext, ext), ny + r.uniform(-ext, ext), nx, ny)
+            else:
+                nx, ny = x, y          # zero-length segment
+                p.line_to(nx, ny)
+            x, y = nx, ny
+        if closed:
+            p.close()
+        return p
+
+    def rnd_brush():
+        k = int(r.uniform(0, 6))
+        col = lambda: (r.uniform(), r.uniform(), r.uniform(), r.uniform(0.2, 1.0))
+        stops = [ColorStop(0.0, col()), ColorStop(r.uniform(0.2, 0.8), col()), ColorStop(1.0, col())]
+        ext = Extend(int(r.uniform(0, 3)))
+        if k <= 1:
+            return Brush.solid(col())
+        if k == 2:
+            return Brush.linear((r.uniform(0, size), r.uniform(0, size)), (r.uniform(0, size), r.uniform(0, size)), stops, ext)
+        if k == 3:
+            c0 = (r.uniform(0, size), r.uniform(0, size))
+            return Brush.radial(c0, r.uniform(0, 20), (c0[0] + r.uniform(-30, 30), c0[1] + r.uniform(-30, 30)), r.uniform(25, 120), stops, ext)
+        if k == 4:
+            return Brush.sweep((r.uniform(0, size), r.uniform(0, size)), 0.0, r.uniform(0.3, 1.0), stops, ext)
+        return Brush.image(img, key=3000 + seed)
+
+    for i in range(n):
+        act = int(r.uniform(0, 10))
+        if act == 0 and open_layers < 5:
+            s.push_layer(Mix(int(r.uniform(0, 16))) if r.uniform() < 0.7 else Mix.Clip, Compose.SrcOver, r.uniform(0.3, 1.0), rnd_affine(),
+                         Path.circle(r.uniform(0.2 * size, 0.8 * size), r.uniform(0.2 * size, 0.8 * size), r.uniform(0.3 * size, 0.8 * size)))
+            open_layers += 1
+        elif act == 1 and open_layers > 0:
+            s.pop_layer()
+            open_layers -= 1
+        elif act <= 5:
+            s.fill(Fill.EvenOdd if r.uniform() < 0.3 else Fill.NonZero, rnd_affine(), rnd_brush(), rnd_affine() if r.uniform() < 0.3 else None,
+                   rnd_path(True))
+        else:
+            st = Stroke(r.uniform(0.3, 12.0), Join(int(r.uniform(0, 3))), r.uniform(1.0, 8.0), Cap(int(r.uniform(0, 3))), Cap(int(r.uniform(0, 3))))
+            s.stroke(st, rnd_affine(), rnd_brush(), None, rnd_path(r.uniform() < 0.4))
+    while open_layers > 0:
+        s.pop_layer()
+        open_layers -= 1
+    p = RenderParams(size, size, base_color=(r.uniform(), r.uniform(), r.uniform(), 1.0))
+    return s, p

@@ -80,6 +80,19 @@ def test_big_path_takes_the_list_route(engine):
     assert r["bump"]["seg_counts"] > 60000
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_mixed_scenes(engine, seed):
+    """Random mixtures of every feature (scenes.scene_fuzz): all buffers and the image against the oracle; every third
+    seed with multisampling."""
+    s, p = scenes.scene_fuzz(seed)
+    p.bump = BumpSizes(ptcl=1 << 22)
+    if seed % 3 == 1:
+        p.aa = jello_amd.Aa.Msaa8
+    elif seed % 3 == 2:
+        p.aa = jello_amd.Aa.Msaa16
+    compare(engine, s, p)
+
+
 def test_non_multiple_of_16_target(engine):
     s, p = scenes.scene_c3(400, 256)
     p.width, p.height = 250, 199

@@ -687,6 +687,10 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
             uint32_t seg_data = W2;
             int32_t backdrop = (int32_t)W(3);
             uint32_t n_segs = size_and_rule >> 1;
+            // segments behind the end of the buffer read as zero and contribute nothing (robust access), so a corrupt
+            // count is cut to the buffer: the loops below are bounded by the buffer size, not by a stream word
+            // (area coverage only: in the multisampled fill a zero segment touches the tile corner and does count)
+            if constexpr (AA == 0) n_segs = umin_(n_segs, seg_data < segments_n ? segments_n - seg_data : 0u);
             bool even_odd = (size_and_rule & 1u) != 0u;
           if constexpr (AA == 0) {
             float backdrop_f = (float)backdrop;

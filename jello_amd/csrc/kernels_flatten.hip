@@ -902,7 +902,10 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
 
 // One thread per temporary slot: the Euler line (or the directly emitted line) that lives there, moved to
 // lines[bases[slot] + k], the canonical (tag byte, emission order) LineSoup position.
-__global__ __launch_bounds__(JL_WG) void k_flatten_lines(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, const uint32_t* __restrict__ counters,
+#ifndef FL_LINES_WAVES_PER_EU
+#define FL_LINES_WAVES_PER_EU 5  // 6 and 8 measured the same: the kernel is bound by its scattered memory accesses
+#endif
+__global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_WAVES_PER_EU, FL_LINES_WAVES_PER_EU))) void k_flatten_lines(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, const uint32_t* __restrict__ counters,
                                                          const uint32_t* __restrict__ tinfo, const uint4* __restrict__ pieces,
                                                          const uint4* __restrict__ ends, uint32_t tcap, const JlLineSoup* __restrict__ tlines, const uint2* __restrict__ tkeys,
                                                          const uint32_t* __restrict__ chunk_used, uint32_t n_chunks, uint32_t FL_CHUNK,

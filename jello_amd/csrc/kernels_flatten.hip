@@ -498,7 +498,7 @@ JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ piece
                 rec[3] = make_uint4(e.path_ix, e.trans_ix, fl, 0u);
                 if ((fl & (32u | 4u)) != 0u) ends[tpos] = make_uint4(f2u(e.t_start.x), f2u(e.t_start.y), f2u(t_end.x), f2u(t_end.y));
                 o.tinfo[tpos] = FL_INFO_PIECE | n_u;
-                if (tpos >= o.overflow_start)  // only the chunk area is zeroed by the launcher (rare path)
+                if (tpos >= o.overflow_start)  // only the chunk area is zeroed up front (rare path)
                     for (uint32_t i = 1u; i < n_u; i++) o.tinfo[tpos + i] = 0u;
             }
             e.first_piece = false;
@@ -696,13 +696,18 @@ JD Seg load_seg(const Scene& s, uint32_t ix) {
 __global__ __launch_bounds__(JL_WG) void k_flatten_classify(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
                                                             Buf<JlPathBbox> path_bboxes, uint32_t* __restrict__ list,
                                                             uint32_t* __restrict__ counters, uint32_t cap, uint32_t n_tags,
-                                                            uint32_t temp_overflow_start) {
+                                                            uint32_t temp_overflow_start, uint32_t* __restrict__ counts) {
     __shared__ uint32_t sh[12];
     if (blockIdx.x == 0u && threadIdx.x == 0u) counters[2] = temp_overflow_start;  // first temp slot behind the workgroup chunks
     __shared__ uint32_t sh_base[2];
     Scene s;
     s.cfg = cfg; s.scene = scene; s.tag_monoids = tag_monoids;
     uint32_t ix0 = (blockIdx.x * JL_WG + threadIdx.x) * FL_CLASSIFY_TAGS;
+    // line counts of all slots start at zero (most slots are not work items); cheaper here than a separate memset
+    for (uint32_t q = 0u; q < 3u * FL_CLASSIFY_TAGS; q++) {
+        uint32_t sl = ix0 * 3u + q;
+        if (sl < cap) counts[sl] = 0u;
+    }
     uint32_t nh[FL_CLASSIFY_TAGS], nl[FL_CLASSIFY_TAGS];
     uint32_t th = 0u, tl = 0u;
 #pragma unroll
@@ -844,7 +849,10 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
         sh_item = 0u;
     }
     __syncthreads();
-    uint32_t chunk = sh_chunk;  // (unused slots need no marking: tinfo, zeroed by the launcher, says what a slot holds)
+    uint32_t chunk = sh_chunk;
+    for (uint32_t i = threadIdx.x; i < FL_CHUNK; i += JL_WG)  // "nothing starts in this slot" for the workgroup's own chunk
+        if (chunk + i < tcap) tinfo[chunk + i] = 0u;
+    __syncthreads();  // before any wave of the workgroup marks a slot
     const uint32_t lane = lane_id();
     // Work distribution: the item list (heavy items first) is dealt to the workgroups in chunks of 64, round robin;
     // the waves of a workgroup draw their items from its share through one LDS counter.
@@ -1156,10 +1164,8 @@ int jh_launch_flatten(const JhLaunch& L) {
     if (!counts || !bases || !list || !counters || !tlines || !tkeys || !tinfo || !pieces || !ends) return -5;
     uint32_t* chunk_used = counters + 16;  // one word per workgroup chunk (g <= 2048 workgroups)
     (void)hipMemsetAsync(counters, 0, 64 + (size_t)g * 4, L.stream);
-    (void)hipMemsetAsync(counts, 0, (size_t)n_slots * 4, L.stream);
-    (void)hipMemsetAsync(tinfo, 0, (size_t)g * FL_CHUNK * 4, L.stream);  // chunk area: "nothing starts in this slot"
     hipLaunchKernelGGL(k_flatten_classify, dim3((L.gx + FL_CLASSIFY_TAGS - 1) / FL_CLASSIFY_TAGS), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list,
-                       counters, n_slots, n_tags, g * FL_CHUNK);
+                       counters, n_slots, n_tags, g * FL_CHUNK, counts);
     hipLaunchKernelGGL(k_flatten_items, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, (const uint32_t*)list, counters, n_slots, counts,
                        tlines, tkeys, tcap, FL_CHUNK, tinfo, pieces, ends, chunk_used);
     int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);

@@ -216,6 +216,8 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_source": "eager replay of the same %d steps with a hipEvent pair per stage" % args.steps,
             "bump": {k: int(v) for k, v in zip(["failed", "binning", "ptcl", "tile", "seg_counts", "segments", "blend", "lines"], bump_now)},
+            "stage_roofline": stage_roofline(cfg, dict(zip(["failed", "binning", "ptcl", "tile", "seg_counts", "segments", "blend", "lines"],
+                                                           [int(v) for v in bump_now])), stage_ms, rec),
             "roofline": roofline,
             "cpu_baseline": cpu,
             "device": eng.device_info()["name"],
@@ -232,6 +234,32 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def stage_roofline(cfg, bump, stage_ms, rec):
+    """Algorithmic bytes per stage / measured stage time, against the 8 TB/s HBM peak.  These stages are
+    irregular integer / f32 work; the figure says how far each is from being bandwidth-limited, nothing more."""
+    n_tagw = cfg["pathdata_base"] - cfg["pathtag_base"]  # tag words (4 tag bytes each)
+    n_draw, lines, cross, segs = cfg["n_drawobj"], bump["lines"], bump["seg_counts"], bump["segments"]
+    try:
+        scene_bytes = rec.buffer("scene")[1]
+    except Exception:  # noqa: BLE001
+        scene_bytes = 0
+    per = {
+        "pathtag (4 stages)": (24 * n_tagw, sum(stage_ms.get(k, 0.0) for k in ("pathtag_reduce", "pathtag_reduce2", "pathtag_scan1",
+                                                                                "pathtag_scan_small", "pathtag_scan_large"))),
+        "flatten": (scene_bytes + 20 * n_tagw + 24 * lines, stage_ms.get("flatten", 0.0)),
+        "draw_reduce+leaf": (20 * n_draw + 4 * n_draw, stage_ms.get("draw_reduce", 0.0) + stage_ms.get("draw_leaf", 0.0)),
+        "path_count": (24 * lines + 8 * cross, stage_ms.get("path_count", 0.0)),
+        "path_tiling": ((8 + 24) * cross + 24 * segs, stage_ms.get("path_tiling", 0.0)),
+        "coarse": (4 * bump["binning"] + 40 * bump["tile"] + 4 * bump["ptcl"], stage_ms.get("coarse", 0.0)),
+    }
+    out = {}
+    for k, (b, ms) in per.items():
+        if ms > 0:
+            gbs = b / (ms * 1e-3) / 1e9
+            out[k] = {"algorithmic_bytes": int(b), "ms": round(ms, 4), "achieved_gbs": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4)}
+    return out
 
 
 def cpu_baseline(host):

@@ -563,7 +563,7 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
         const uint32_t e_rel = (uint32_t)__builtin_popcountll(fit);  // > 0: one segment has at most 16 pairs
         const uint32_t npairs = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(e_rel - 1u));
         const uint32_t first = incl - my_cnt;
-        my_meta = first | (my_cnt << 12) | (my_ra << 17);
+        my_meta = first | (my_cnt << 12) | (my_ra << 17) | ((my_ye < 16.0f) ? (1u << 22) : 0u);  // bit 22: has a y_edge term
         nxt_base = so + e_rel;
         load_segraw_clamped(segments, segments_n, nxt_base + lane, nx_p0x, nx_p0y, nx_p1x, nx_p1y, nx_ye);  // prefetch; consumed much later
         F.pairflag[lane] = 0u;
@@ -702,20 +702,21 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
                 uint32_t take = umin_(remaining, batch_hi - sa);
                 uint32_t r0 = sa - cur_base;  // window-relative segments [r0, r0 + take)
                 // two segments per trip: both LDS reads are in flight before the (ordered) adds (four measured the same)
-                auto seg_fetch = [&](uint32_t q, float (&cv)[4], float& ye_s, int& sl) {
+                auto seg_fetch = [&](uint32_t q, float (&cv)[4], uint32_t& has_edge, int& sl) {
                     sl = (int)((r0 + q) & 63u);
                     uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)my_meta, sl);
-                    ye_s = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(my_ye), sl));
+                    has_edge = m & (1u << 22);
                     uint32_t t = ly - ((m >> 17) & 31u);
                     // the segment's pair for my row, or the all-zero slot 64 (adding +0 is a no-op)
                     uint32_t j = (t < ((m >> 12) & 31u)) ? (((m & 0xfffu) + t) & 63u) : 64u;
                     const float* cp = &F.contrib[lx * 4u][j];
                     cv[0] = cp[0]; cv[1] = cp[FB_STRIDE]; cv[2] = cp[2 * FB_STRIDE]; cv[3] = cp[3 * FB_STRIDE];
                 };
-                auto seg_apply = [&](const float (&cv)[4], float ye_s, int sl) {
+                auto seg_apply = [&](const float (&cv)[4], uint32_t has_edge, int sl) {
                     area[0] += cv[0]; area[1] += cv[1]; area[2] += cv[2]; area[3] += cv[3];
                     // y_edge >= 16 (path_tiling's "no edge" value is 1e9) clamps to 0 for every row of the tile
-                    if (ye_s < 16.0f) {  // uniform
+                    if (has_edge != 0u) {  // uniform (a bit of the segment's meta word)
+                        float ye_s = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(my_ye), sl));
                         float sg_s = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(my_sg), sl));
                         float y_edge = sg_s * clamp_(lyf - ye_s + 1.0f, 0.0f, 1.0f);
                         area[0] += y_edge; area[1] += y_edge; area[2] += y_edge; area[3] += y_edge;
@@ -724,7 +725,8 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
                 uint32_t q = 0u;
                 if (!(FINE_EXP & 2)) {
                     for (; q + 1u < take; q += 2u) {
-                        float ca[4], cb[4], ya, yb;
+                        float ca[4], cb[4];
+                        uint32_t ya, yb;
                         int sa_l, sb_l;
                         seg_fetch(q, ca, ya, sa_l);
                         seg_fetch(q + 1u, cb, yb, sb_l);
@@ -732,7 +734,8 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
                         seg_apply(cb, yb, sb_l);
                     }
                     if (q < take) {
-                        float ca[4], ya;
+                        float ca[4];
+                        uint32_t ya;
                         int sa_l;
                         seg_fetch(q, ca, ya, sa_l);
                         seg_apply(ca, ya, sa_l);

@@ -104,7 +104,10 @@ int jh_free(jh_ctx* ctx, uint64_t id); /* returns the allocation to the pool */
 void* jh_buffer_device_ptr(jh_ctx* ctx, uint64_t id);
 uint64_t jh_buffer_size(jh_ctx* ctx, uint64_t id);
 
-/* ---- images: linear device memory, row-major, format = renderer.ImageFormat ---- */
+/* ---- images: linear device memory, row-major, format = renderer.ImageFormat ----
+ * An image that was only created (never uploaded / imported), or whose upload was all zero bytes (the 1x1 placeholder
+ * of render.go:115-124), samples as transparent black like a fresh wgpu texture.  JL_RGBA8_SRGB texels are decoded to
+ * linear when fine samples them (an rgba8unorm-srgb texture view); alpha is linear. */
 int jh_image_create(jh_ctx* ctx, uint64_t id, uint32_t width, uint32_t height, int format);
 int jh_image_import(jh_ctx* ctx, uint64_t id, void* device_ptr, uint32_t width, uint32_t height, int format);
 int jh_image_upload(jh_ctx* ctx, uint64_t id, uint32_t width, uint32_t height, int format, const void* data, uint64_t size);
@@ -112,7 +115,12 @@ int jh_image_download(jh_ctx* ctx, uint64_t id, void* dst, uint64_t size);
 int jh_image_free(jh_ctx* ctx, uint64_t id);
 void* jh_image_device_ptr(jh_ctx* ctx, uint64_t id);
 
-/* ---- dispatch ---- */
+/* ---- dispatch ----
+ * One call per recorded Dispatch: `stage` is a jh_stage (= the field order of renderer.FullShaders), (gx, gy, gz) the
+ * recorded workgroup counts, bindings in WGSL @binding order.  All 22 stages are implemented (fine_msaa8/16 included).
+ * Several stages pick a specialised instantiation from the HOST SHADOW of the ConfigUniform that was uploaded to the
+ * buffer bound at index 0 (n_clip == 0: no clip stack) and from what is bound (no ramp / no non-zero image: no
+ * gradient code); a config that only exists on the device selects the general instantiation. */
 int jh_dispatch(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uint32_t gz, const jh_binding* bindings, int n_bindings);
 int jh_dispatch_indirect(jh_ctx* ctx, int stage, uint64_t indirect_buffer_id, uint64_t offset, const jh_binding* bindings,
                          int n_bindings);

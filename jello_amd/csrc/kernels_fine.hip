@@ -681,7 +681,7 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
         auto W = [&](int k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)wv[k]); };
         const uint32_t tag = W(0);
         const uint32_t W1 = W(1), W2 = W(2);
-        if (tag == JL_CMD_END) break;
+        if (tag == JL_CMD_END || (FINE_EXP & 32)) break;  // 32: timing experiment, prologue + epilogue only
         if (tag == JL_CMD_FILL) {  // fill_path, fine.wgsl:824-878
             uint32_t size_and_rule = W1;
             uint32_t seg_data = W2;

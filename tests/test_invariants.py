@@ -190,3 +190,57 @@ def test_bump_overflow_is_reported_not_crashed(built):
     bump = o.get(rec, "bumpBuf", np.uint32)[:8]
     assert bump[0] & 0x4 and bump[7] > 1000     # STAGE_FLATTEN set by binning; bump.lines reports the need
     assert o.get(rec, "ptclBuf", np.uint32)[0] == 0xffffffff   # path_tiling_setup poisons ptcl[0]
+
+
+def _cubic(p, t):
+    p = np.asarray(p, np.float64)
+    t = np.asarray(t, np.float64)[:, None]
+    mt = 1.0 - t
+    return mt ** 3 * p[0] + 3 * mt ** 2 * t * p[1] + 3 * mt * t ** 2 * p[2] + t ** 3 * p[3]
+
+
+def _dist_to_curve(pts, ctrl):
+    """Distance of each point to a densely sampled cubic (float64, independent of the pipeline)."""
+    ts = np.linspace(0.0, 1.0, 4001)
+    c = _cubic(ctrl, ts)
+    d = np.sqrt(((pts[:, None, :] - c[None, :, :]) ** 2).sum(axis=2))
+    return d.min(axis=1)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_flatten_lines_follow_the_curve_within_tolerance(built, seed):
+    """flatten.wgsl's error bound: the polyline of a filled cubic stays within the 0.25 px tolerance of the true curve
+    (checked against an independent float64 evaluation of the Bezier), is connected, starts and ends in the end points;
+    the two sides of its stroke run at half the line width from it (closer only where the offset curve folds)."""
+    from jello_amd import Cap, Join, Stroke
+    rng = np.random.default_rng(100 + seed)
+    ctrl = rng.uniform(40.0, 460.0, (4, 2))
+    width = float(rng.uniform(2.0, 12.0))
+    s = Scene()
+    p = Path().move_to(*ctrl[0]).cubic_to(*ctrl[1], *ctrl[2], *ctrl[3])
+    s.fill(Fill.NonZero, None, Brush.solid((1, 0, 0, 1)), None, p)
+    s.stroke(Stroke(width, Join.Bevel, 4.0, Cap.Butt, Cap.Butt), None, Brush.solid((0, 0, 1, 1)), None, p)
+    rec, o = run(s, RenderParams(512, 512))
+    n = int(o.get(rec, "bumpBuf", np.uint32)[7])
+    raw = o.get(rec, "linesBuf", np.uint32)[:n * 6].reshape(n, 6)
+    path_ix = raw[:, 0]
+    xy = raw[:, 2:6].copy().view(np.float32).reshape(n, 4)
+    fill = xy[path_ix == 0]
+    # the fill: the cubic's polyline followed by the closing line
+    poly, closing = fill[:-1], fill[-1]
+    assert np.array_equal(poly[0, 0:2], ctrl[0].astype(np.float32)) and np.array_equal(poly[-1, 2:4], ctrl[3].astype(np.float32))
+    assert np.array_equal(poly[1:, 0:2], poly[:-1, 2:4])            # connected: every line starts where the previous ends
+    assert np.array_equal(closing[0:2], poly[-1, 2:4]) and np.array_equal(closing[2:4], poly[0, 0:2])
+    verts = np.vstack([poly[:, 0:2], poly[-1:, 2:4]]).astype(np.float64)
+    # two error sources, each bounded by tol = 0.25 px: cubic -> Euler spiral pieces, spiral -> chords
+    assert _dist_to_curve(verts, ctrl).max() <= 0.25 + 1e-3         # vertices lie on the spiral approximation
+    mids = 0.5 * (poly[:, 0:2] + poly[:, 2:4]).astype(np.float64)
+    assert _dist_to_curve(mids, ctrl).max() <= 0.5 + 1e-3           # chord mid-points add the flattening error
+    # the stroke: offset curves at +-width/2 (butt caps and the closing pieces are lines across the curve's ends)
+    stroke = xy[path_ix == 1].astype(np.float64)
+    d0 = _dist_to_curve(stroke[:, 0:2], ctrl)
+    d1 = _dist_to_curve(stroke[:, 2:4], ctrl)
+    d = np.concatenate([d0, d1])
+    assert d.max() <= width / 2 + 0.5                               # never farther than half the width (+ tolerance)
+    # ... and at half the width wherever the offset curve does not fold back (radius of curvature > width / 2)
+    assert np.mean(np.abs(d - width / 2) < 0.5) > 0.6

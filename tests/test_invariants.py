@@ -244,3 +244,52 @@ def test_flatten_lines_follow_the_curve_within_tolerance(built, seed):
     assert d.max() <= width / 2 + 0.5                               # never farther than half the width (+ tolerance)
     # ... and at half the width wherever the offset curve does not fold back (radius of curvature > width / 2)
     assert np.mean(np.abs(d - width / 2) < 0.5) > 0.6
+
+
+def _supersampled_coverage(poly, size, rule, ss=8):
+    """Independent coverage: winding number of ss x ss sample points per pixel against the polygon (float64)."""
+    n = size * ss
+    c = (np.arange(n) + 0.5) / ss
+    px, py = np.meshgrid(c, c)
+    wind = np.zeros((n, n), np.int32)
+    pts = np.asarray(poly, np.float64)
+    for a, b in zip(pts, np.roll(pts, -1, axis=0)):
+        (x0, y0), (x1, y1) = a, b
+        if y0 == y1:
+            continue
+        up = (y0 <= py) & (y1 > py)
+        dn = (y1 <= py) & (y0 > py)
+        t = (py - y0) / (y1 - y0)
+        xi = x0 + t * (x1 - x0)
+        wind += (up & (xi > px)).astype(np.int32) - (dn & (xi > px)).astype(np.int32)
+    inside = (wind != 0) if rule == "nonzero" else (wind % 2 != 0)
+    return inside.reshape(size, ss, size, ss).mean(axis=(1, 3))
+
+
+@pytest.mark.parametrize("rule", ["nonzero", "evenodd"])
+@pytest.mark.parametrize("aa", ["area", "msaa8", "msaa16"])
+def test_coverage_matches_supersampling(built, rule, aa):
+    """End to end (flatten ... fine): the alpha of a self-intersecting polygon filled with an opaque colour equals the
+    geometric pixel coverage, computed independently by 8x8 supersampling of the winding number."""
+    from jello_amd import Aa
+    rng = np.random.default_rng(7)
+    size = 96
+    poly = rng.uniform(6.0, size - 6.0, (9, 2))      # 9 random vertices: self-intersecting star-like polygon
+    p = Path().move_to(*poly[0])
+    for v in poly[1:]:
+        p.line_to(*v)
+    p.close()
+    s = Scene()
+    s.fill(Fill.NonZero if rule == "nonzero" else Fill.EvenOdd, None, Brush.solid((1, 1, 1, 1)), None, p)
+    params = RenderParams(size, size, aa={"area": Aa.Area, "msaa8": Aa.Msaa8, "msaa16": Aa.Msaa16}[aa])
+    rec, o = run(s, params)
+    alpha = f16img(o, rec).reshape(size, size, 4)[:, :, 3].astype(np.float64)
+    want = _supersampled_coverage(poly.astype(np.float32).astype(np.float64), size, rule)
+    err = np.abs(alpha - want)
+    if aa == "area":
+        # analytic area coverage is exact except where edges cross inside a pixel (signed areas of overlapping lobes are
+        # summed and clamped): a handful of pixels; measured p99 0.009, mean 0.0003
+        assert np.percentile(err, 99) < 0.02 and err.mean() < 0.001
+    else:
+        assert err.max() <= (0.25 if aa == "msaa8" else 0.18)   # 8 / 16 samples against 64; measured 0.20 / 0.14
+        assert err.mean() < 0.004

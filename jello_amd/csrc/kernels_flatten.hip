@@ -1149,6 +1149,9 @@ int jh_launch_flatten(const JhLaunch& L) {
     uint64_t want = (uint64_t)lines.n + 2ull * n_tags;
     uint32_t FL_CHUNK = (uint32_t)(((want / g) * 5 / 4 + 255) & ~255ull);
     if (FL_CHUNK < 256u) FL_CHUNK = 256u;
+    // every workgroup zeroes its chunk's markers, so a small scene in a large line buffer must not get huge chunks
+    // (3 workgroups x 870 k slots cost 80 us); a workgroup that outgrows its chunk continues in the overflow area
+    if (FL_CHUNK > 16384u) FL_CHUNK = 16384u;
     uint64_t tcap64 = want + (uint64_t)g * FL_CHUNK;
     if (tcap64 > 0xfffffff0ull) return -1;
     uint32_t tcap = (uint32_t)tcap64;

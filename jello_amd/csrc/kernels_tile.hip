@@ -41,8 +41,6 @@ __global__ __launch_bounds__(JL_WG) void k_binning(const JlConfig* __restrict__ 
                                                    Buf<uint32_t> bin_data, Buf<JlBinHeader> bin_header, uint32_t* __restrict__ counts,
                                                    const uint32_t* __restrict__ offsets) {
     __shared__ uint32_t sh_bitmaps[8][JL_N_TILE];
-    __shared__ uint32_t sh_count[4][JL_N_TILE];
-    __shared__ uint32_t sh_chunk_offset[JL_N_TILE];
     const float SX = 0.00390625f, SY = 0.00390625f;
     uint32_t lid = threadIdx.x;
     uint32_t gid = blockIdx.x * JL_WG + lid;
@@ -92,13 +90,7 @@ __global__ __launch_bounds__(JL_WG) void k_binning(const JlConfig* __restrict__ 
     }
     __syncthreads();
     uint32_t element_count = 0u;
-    for (uint32_t i = 0; i < 4u; i++) {
-        element_count += __popc(sh_bitmaps[i * 2u][lid]);
-        uint32_t lo = element_count;
-        element_count += __popc(sh_bitmaps[i * 2u + 1u][lid]);
-        uint32_t hi = element_count;
-        sh_count[i][lid] = lo | (hi << 16);
-    }
+    for (uint32_t i = 0; i < 8u; i++) element_count += __popc(sh_bitmaps[i][lid]);
     if (PASS == 0) {
         counts[gid] = element_count;
         return;
@@ -108,30 +100,21 @@ __global__ __launch_bounds__(JL_WG) void k_binning(const JlConfig* __restrict__ 
         chunk_offset = 0u;
         atomicOr(&bump->failed, (uint32_t)JL_STAGE_BINNING);
     }
-    sh_chunk_offset[lid] = chunk_offset;
     JlBinHeader h;
     h.element_count = element_count;
     h.chunk_offset = chunk_offset;
     bin_header.wr(gid, h);
-    __syncthreads();
-    x = x0; y = y0;
-    while (y < y1) {
-        uint32_t bin_ix = (uint32_t)(y * width_in_bins + x);
-        if (bin_ix < JL_N_TILE) {
-            uint32_t out_mask = sh_bitmaps[my_slice][bin_ix];
-            if ((out_mask & my_mask) != 0u) {
-                uint32_t idx = __popc(out_mask & (my_mask - 1u));
-                if (my_slice > 0u) {
-                    uint32_t count_ix = my_slice - 1u;
-                    uint32_t count_packed = sh_count[count_ix / 2u][bin_ix];
-                    idx += (count_packed >> (16u * (count_ix & 1u))) & 0xffffu;
-                }
-                uint32_t offset = cfg->layout.bin_data_start + sh_chunk_offset[bin_ix];
-                bin_data.wr(offset + idx, element_ix);
-            }
+    // binning.wgsl:144-165 lets every element walk its bins again and write itself at
+    // (set bits below it in the bin's bitmaps); thread = bin writing its set bits in ascending order produces the same
+    // list without the 256-step walk of an element that covers the whole target (a background rectangle).
+    uint32_t out = cfg->layout.bin_data_start + chunk_offset;
+    for (uint32_t i = 0; i < 8u; i++) {
+        uint32_t bits = sh_bitmaps[i][lid];
+        while (bits != 0u) {
+            bin_data.wr(out, blockIdx.x * JL_WG + i * 32u + (uint32_t)__builtin_ctz(bits));
+            out += 1u;
+            bits &= bits - 1u;
         }
-        x += 1;
-        if (x == x1) { x = x0; y += 1; }
     }
 }
 
@@ -186,10 +169,22 @@ __global__ __launch_bounds__(JL_WG) void k_tile_alloc_write(const JlConfig* __re
         if (threadIdx.x == JL_WG - 1u) atomicOr(&bump->failed, (uint32_t)JL_STAGE_TILE_ALLOC);
     }
     if (drawobj_ix < cfg->layout.n_drawobj && paths.ok(drawobj_ix)) paths.p[drawobj_ix].tiles = offset + my_sub;
-    JlTile z;
-    z.backdrop = 0;
-    z.segment_count_or_ix = 0u;
-    for (uint32_t i = threadIdx.x; i < wg_cnt; i += JL_WG) tiles.wr(offset + i, z);
+}
+// The WGSL zeroes a workgroup's tiles with that workgroup's 256 threads (tile_alloc.wgsl:107-111): two workgroups
+// clearing the 1.7 M tiles of 300 large circles take 0.3 ms.  All allocated tiles form the range [0, bump.tile), so
+// one device-wide pass clears them (in the failure case the contents of the buffer are unspecified anyway).
+__global__ __launch_bounds__(JL_WG) void k_tile_zero(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tiles) {
+    if ((bump->failed & (JL_STAGE_BINNING | JL_STAGE_FLATTEN)) != 0u) return;
+    const uint32_t n = umin_(umin_(bump->tile, cfg->tiles_size), tiles.n);
+    uint4* p = (uint4*)tiles.p;  // two tiles per store
+    const uint32_t n2 = n >> 1;
+    for (uint32_t i = blockIdx.x * JL_WG + threadIdx.x; i < n2; i += gridDim.x * JL_WG) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    if ((n & 1u) != 0u && blockIdx.x == 0u && threadIdx.x == 0u) {
+        JlTile z;
+        z.backdrop = 0;
+        z.segment_count_or_ix = 0u;
+        tiles.p[n - 1u] = z;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -361,15 +356,19 @@ JD void path_range(uint32_t P, const uint32_t* __restrict__ pstart, const uint32
 }
 
 // Paths with more crossings than this take the atomic route (per-tile arrival slots, lists, rank inside the list);
-// all others get their slice ranks from k_pc_rank_small without a single atomic.
-#define PC_BIG_PATH 16384u
+// all others get their slice ranks from k_pc_rank_small without a single atomic.  k_pc_rank_small is one wave per path
+// and quadratic in the path's 64-crossing blocks (256 crossings: ~5 us, 2048: ~0.3 ms of one wave), the atomic route is
+// linear and spread over the whole device, but costs two passes over the crossings once a single path takes it.
+#ifndef PC_BIG_PATH
+#define PC_BIG_PATH 256u
+#endif
 JD bool npe_big(uint32_t n) { return n > PC_BIG_PATH; }
 
 // pass 2: backdrops, SegmentCount records, the tile of every crossing (slice ranks are filled in later)
 __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump,
                                                    const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines, Buf<JlPath> paths, Buf<JlTile> tile,
                                                    Buf<JlSegmentCount> seg_counts, const uint32_t* __restrict__ seg_bases, uint32_t bases_n,
-                                                   uint2* __restrict__ tile_of, uint32_t* __restrict__ keys, uint32_t* __restrict__ kpath,
+                                                   uint2* __restrict__ tile_of, uint32_t* __restrict__ keys, uint32_t* __restrict__ kbig,
                                                    uint32_t tile_of_n, const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ plast,
                                                    const uint32_t* __restrict__ counts, uint32_t n_paths, uint32_t* __restrict__ gate) {
     uint32_t n_lines = umin_(umin_(bump->lines, bases_n), ind->x * JL_WG);
@@ -391,7 +390,7 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
         }
         float last_z = floor_(s.a * ((float)s.imin - 1.0f) + s.b);
         uint32_t seg_base = seg_bases[gid];
-        if (big && s.imax > s.imin) atomicMax(gate, 0xffffffffu);
+        if (big && s.imax > s.imin) atomicMax(gate, bump->tile);  // the number of tiles the list-base scan has to cover
         for (uint32_t i = s.imin; i < s.imax; i++) {
             float zf = s.a * (float)i + s.b;
             float z = floor_(zf);
@@ -413,7 +412,7 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
                 seg_counts.p[seg_ix] = sc;
                 if (seg_ix < tile_of_n) {
                     keys[seg_ix] = tile.ok(t) ? t : 0xffffffffu;
-                    kpath[seg_ix] = P;
+                    kbig[seg_ix] = big ? 1u : 0u;
                     if (big) {
                         uint32_t arrival = 0u;  // order-dependent, only a unique slot inside the tile's temporary list
                         if (tile.ok(t)) arrival = atomicAdd(&tile.p[t].segment_count_or_ix, 1u);
@@ -439,7 +438,6 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restr
                                                          Buf<JlSegmentCount> seg_counts) {
     const uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
     const uint32_t lane = lane_id();
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t waves = (gridDim.x * JL_WG) >> 6;
     uint32_t P = (blockIdx.x * JL_WG + threadIdx.x) >> 6;
     uint32_t nps = 0u, npe = 0u;  // range of the path after this one (prefetched: the loop is a chain of dependent loads)
@@ -459,9 +457,11 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restr
             while (rem != 0ull) {
                 const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, (int)__builtin_ctzll(rem));
                 const uint64_t m = __builtin_amdgcn_ballot_w64(mine && my_t == t);
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                const uint32_t all = (uint32_t)__builtin_popcountll(m);  // scalar
                 if (mine && my_t == t) {
-                    before = (uint32_t)__builtin_popcountll(m & lt_mask);
-                    after = (uint32_t)__builtin_popcountll(m & ~lt_mask) - 1u;
+                    before = below;
+                    after = all - 1u - below;
                 }
                 rem &= ~m;
             }
@@ -486,19 +486,14 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restr
 // arrival number the count atomic returned in pass 2, so no further atomics are needed.
 __global__ __launch_bounds__(JL_WG) void k_pc_scatter(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
                                                       const uint2* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
-                                                      uint32_t tiles_cap, uint32_t* __restrict__ list, const uint32_t* __restrict__ kpath,
+                                                      uint32_t tiles_cap, uint32_t* __restrict__ list, const uint32_t* __restrict__ kbig,
                                                       const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ plast,
                                                       const uint32_t* __restrict__ counts, const uint32_t* __restrict__ seg_bases, uint32_t n_paths,
                                                       const uint32_t* __restrict__ gate) {
     if (*gate == 0u) return;  // no big path in this frame
     uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
     for (uint32_t k = blockIdx.x * JL_WG + threadIdx.x; k < n; k += gridDim.x * JL_WG) {
-        uint32_t P = kpath[k];
-        if (P < n_paths) {
-            uint32_t ps, pe;
-            path_range(P, pfirst, plast, counts, seg_bases, ps, pe);
-            if (pe - ps <= PC_BIG_PATH) continue;  // ranked by k_pc_rank_small
-        }
+        if (kbig[k] == 0u) continue;  // ranked by k_pc_rank_small
         uint2 ta = tile_of[k];
         if (ta.x >= tiles_cap || !tile.ok(ta.x)) continue;
         uint32_t pos = list_base[ta.x] + ta.y;
@@ -509,18 +504,13 @@ __global__ __launch_bounds__(JL_WG) void k_pc_scatter(const JlConfig* __restrict
 __global__ __launch_bounds__(JL_WG) void k_pc_rank(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
                                                    const uint2* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
                                                    uint32_t tiles_cap, const uint32_t* __restrict__ list, Buf<JlSegmentCount> seg_counts,
-                                                   const uint32_t* __restrict__ kpath, const uint32_t* __restrict__ pfirst,
+                                                   const uint32_t* __restrict__ kbig, const uint32_t* __restrict__ pfirst,
                                                    const uint32_t* __restrict__ plast, const uint32_t* __restrict__ counts,
                                                    const uint32_t* __restrict__ seg_bases, uint32_t n_paths, const uint32_t* __restrict__ gate) {
     if (*gate == 0u) return;  // no big path in this frame
     uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
     for (uint32_t k = blockIdx.x * JL_WG + threadIdx.x; k < n; k += gridDim.x * JL_WG) {
-        uint32_t P = kpath[k];
-        if (P < n_paths) {
-            uint32_t ps, pe;
-            path_range(P, pfirst, plast, counts, seg_bases, ps, pe);
-            if (pe - ps <= PC_BIG_PATH) continue;  // ranked by k_pc_rank_small
-        }
+        if (kbig[k] == 0u) continue;  // ranked by k_pc_rank_small
         uint32_t t = tile_of[k].x;
         if (t >= tiles_cap || !tile.ok(t) || !seg_counts.ok(k)) continue;
         uint32_t base = list_base[t];
@@ -537,8 +527,19 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank(const JlConfig* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // backdrop_dyn.wgsl:28-86
 // ------------------------------------------------------------------------------------------------
+//
+// The WGSL gives every row of a path to one thread, which walks the row tile by tile, and the rows of 256 paths to
+// one workgroup: fine for small paths, but a row of 100 tiles is a chain of 100 dependent memory round trips and the
+// 24 k rows of 300 large circles land on two workgroups (2.8 ms).  Paths wider than BD_WIDE tiles are therefore only
+// listed here -- (first global row number, first tile, width, rows), appended with one 64-bit atomic per wave that advances the
+// entry count and the row total together -- and k_backdrop_wide gives each of their rows to a wave (prefix sums are
+// integer sums: any association gives the WGSL's result).
+#define BD_WIDE 16u
+#define BD_UNIT 4u  // consecutive rows per wave step (one list search per unit)
+#define BD_ROWS_MASK ((1ull << 40) - 1ull)
 __global__ __launch_bounds__(JL_WG) void k_backdrop_dyn(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlPath> paths,
-                                                        Buf<JlTile> tiles) {
+                                                        Buf<JlTile> tiles, unsigned long long* __restrict__ wide_ctr, uint4* __restrict__ wide_list,
+                                                        uint32_t wide_cap) {
     __shared__ uint32_t sh_row_width[JL_WG];
     __shared__ uint32_t sh_row_count[JL_WG];
     __shared__ uint32_t sh_offset[JL_WG];
@@ -555,6 +556,27 @@ __global__ __launch_bounds__(JL_WG) void k_backdrop_dyn(const JlConfig* __restri
     } else {
         sh_row_width[lid] = 0u;
         sh_offset[lid] = 0u;
+    }
+    {
+        const bool wide = sh_row_width[lid] > BD_WIDE && row_count > 0u && drawobj_ix < wide_cap;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(wide);
+        if (m != 0ull) {  // uniform per wave
+            const uint32_t rows = wide ? row_count : 0u;
+            const uint32_t incl = wave_incl_scan_u32(rows);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t lane = lane_id();
+            unsigned long long old = 0ull;
+            if (lane == 0u) old = atomicAdd(wide_ctr, ((unsigned long long)__builtin_popcountll(m) << 40) | (unsigned long long)total);
+            const uint32_t old_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)old);
+            const uint32_t old_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(old >> 32));
+            const unsigned long long o = ((unsigned long long)old_hi << 32) | old_lo;
+            if (wide) {
+                const uint32_t slot = (uint32_t)(o >> 40) + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                if (slot < wide_cap)  // (first global row, first tile, tiles per row, rows)
+                    wide_list[slot] = make_uint4((uint32_t)(o & BD_ROWS_MASK) + incl - rows, sh_offset[lid], sh_row_width[lid], rows);
+                row_count = 0u;  // not dealt to this workgroup's threads
+            }
+        }
     }
     uint32_t total_rows;
     uint32_t excl = block_excl_scan_u32(row_count, sh_scan, &total_rows);
@@ -576,6 +598,47 @@ __global__ __launch_bounds__(JL_WG) void k_backdrop_dyn(const JlConfig* __restri
                 if (!tiles.ok(tile_ix)) break;
                 sum += tiles.p[tile_ix].backdrop;
                 tiles.p[tile_ix].backdrop = sum;
+            }
+        }
+    }
+}
+
+// One wave per row of a wide path: 64 tiles per step, inclusive scan by DPP, carry in a scalar.
+__global__ __launch_bounds__(JL_WG) void k_backdrop_wide(const JlBump* __restrict__ bump, Buf<JlTile> tiles,
+                                                         const unsigned long long* __restrict__ wide_ctr, const uint4* __restrict__ wide_list,
+                                                         uint32_t wide_cap) {
+    if (bump->failed != 0u) return;
+    const unsigned long long c = *wide_ctr;
+    const uint32_t n_wide = umin_((uint32_t)(c >> 40), wide_cap);
+    const uint32_t total_rows = (uint32_t)(c & BD_ROWS_MASK);
+    if (n_wide == 0u) return;
+    const uint32_t lane = lane_id();
+    const uint32_t waves = (gridDim.x * JL_WG) >> 6;
+    for (uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * JL_WG + threadIdx.x) >> 6)) * BD_UNIT; g0 < total_rows;
+         g0 += waves * BD_UNIT) {
+        uint32_t lo = 0u, hi = n_wide;  // the last entry whose first row is <= g0
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (wide_list[mid].x <= g0) lo = mid; else hi = mid;
+        }
+        uint4 e = wide_list[lo];
+        for (uint32_t g = g0; g < umin_(g0 + BD_UNIT, total_rows); g++) {
+            while (g - e.x >= e.w && lo + 1u < n_wide) {  // next entry (entries have at least one row)
+                lo += 1u;
+                e = wide_list[lo];
+            }
+            const uint32_t r = g - e.x;
+            if (r >= e.w) break;
+            const uint32_t width = e.z;
+            const uint32_t base = e.y + r * width;
+            uint32_t carry = 0u;
+            for (uint32_t x0 = 0u; x0 < width; x0 += 64u) {
+                const uint32_t x = x0 + lane;
+                const bool ok = x < width && tiles.ok(base + x);
+                const uint32_t v = ok ? (uint32_t)tiles.p[base + x].backdrop : 0u;
+                const uint32_t sum = wave_incl_scan_u32(v) + carry;
+                if (ok) tiles.p[base + x].backdrop = (int32_t)sum;
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)sum, 63);
             }
         }
     }
@@ -739,6 +802,7 @@ int jh_launch_tile_alloc(const JhLaunch& L) {
     if (rc) return rc;
     hipLaunchKernelGGL(k_tile_alloc_write, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, bump, paths, tiles, (const uint32_t*)counts,
                        (const uint32_t*)offsets, n);
+    hipLaunchKernelGGL(k_tile_zero, dim3(stride_grid(L, (uint64_t)tiles.n / 2u + 1u)), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tiles);
     return 0;
 }
 
@@ -789,7 +853,8 @@ int jh_launch_path_count(const JhLaunch& L) {
     const uint32_t *cpf = pfirst, *cpl = plast, *cc = counts, *cb = bases;
     hipLaunchKernelGGL(k_pc_emit, dim3(gl), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, ind, lines, paths, tile, segc, cb, lines_cap,
                        tile_of, keys, kpath, seg_cap, cpf, cpl, cc, n_paths, gate);
-    // Big paths only (none in most frames: `gate` stays 0, the scan then covers 0 elements and the kernels return at once):
+    // Big paths only (`gate` = number of tiles if there is one, else 0: the scan then covers 0 elements and the kernels
+    // return at once):
     // per-tile list bases = exclusive scan of Tile.segment_count_or_ix, scatter into the lists, rank inside the list.
     rc = jh_scan_u32(L, ((const uint32_t*)tile.p) + 1, 2, list_base, tiles_cap, gate, nullptr);
     if (rc) return rc;
@@ -808,8 +873,19 @@ int jh_launch_path_count(const JhLaunch& L) {
 int jh_launch_backdrop_dyn(const JhLaunch& L) {
     if (L.nb < 4) return -1;
     if (L.gx == 0) return 0;
-    hipLaunchKernelGGL(k_backdrop_dyn, dim3(L.gx), dim3(JL_WG), 0, L.stream, (const JlConfig*)L.b[0].ptr, (const JlBump*)L.b[1].ptr,
-                       mkbuf<JlPath>(L.b[2].ptr, L.b[2].size), mkbuf<JlTile>(L.b[3].ptr, L.b[3].size));
+    auto paths = mkbuf<JlPath>(L.b[2].ptr, L.b[2].size);
+    auto tiles = mkbuf<JlTile>(L.b[3].ptr, L.b[3].size);
+    const uint32_t wide_cap = paths.n;
+    // [counter (entries << 40 | rows) | list of (first global row, first tile, width, rows)]
+    uint8_t* w = (uint8_t*)jh_scratch_get(L.scratch, JH_SCR_A, 64 + (uint64_t)wide_cap * sizeof(uint4));
+    if (!w) return -5;
+    unsigned long long* wide_ctr = (unsigned long long*)w;
+    uint4* wide_list = (uint4*)(w + 64);
+    (void)hipMemsetAsync(wide_ctr, 0, 8, L.stream);
+    hipLaunchKernelGGL(k_backdrop_dyn, dim3(L.gx), dim3(JL_WG), 0, L.stream, (const JlConfig*)L.b[0].ptr, (const JlBump*)L.b[1].ptr, paths, tiles,
+                       wide_ctr, wide_list, wide_cap);
+    hipLaunchKernelGGL(k_backdrop_wide, dim3(stride_grid(L, (uint64_t)wide_cap * 64u)), dim3(JL_WG), 0, L.stream, (const JlBump*)L.b[1].ptr, tiles,
+                       (const unsigned long long*)wide_ctr, (const uint4*)wide_list, wide_cap);
     return 0;
 }
 

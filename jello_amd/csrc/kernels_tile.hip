@@ -356,13 +356,13 @@ JD void path_range(uint32_t P, const uint32_t* __restrict__ pstart, const uint32
 }
 
 // Paths with more crossings than this take the atomic route (per-tile arrival slots, lists, rank inside the list);
-// all others get their slice ranks from k_pc_rank_small without a single atomic.  k_pc_rank_small is one wave per path
-// and quadratic in the path's 64-crossing blocks (256 crossings: ~5 us, 2048: ~0.3 ms of one wave), the atomic route is
-// linear and spread over the whole device, but costs two passes over the crossings once a single path takes it.
-#ifndef PC_BIG_PATH
-#define PC_BIG_PATH 256u
-#endif
+// all others get their slice ranks from k_pc_rank_small without a single atomic.  k_pc_rank_small is one wave per path;
+// letting it walk a longer path in blocks of 64 is quadratic and, worse, a chain of memory round trips in ONE wave
+// (measured: 45 us for a 256-crossing path, 1.7 ms for 20 circles of 700 crossings), while the atomic route is linear
+// and spread over the whole device.  64 was the best threshold on every scene tried (tools/time_shapes.py, C3).
+#define PC_BIG_PATH 64u
 JD bool npe_big(uint32_t n) { return n > PC_BIG_PATH; }
+JD uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // pass 2: backdrops, SegmentCount records, the tile of every crossing (slice ranks are filled in later)
 __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump,
@@ -425,12 +425,11 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
     }
 }
 
-// Slice ranks without atomics.  One wave takes one path: its crossings are the contiguous range [pstart, pend) and
-// crossings in the same tile are crossings of the same path (tile_alloc gives every path its own tile range), hence
+// Slice ranks without atomics.  One wave takes one path of at most 64 crossings (lane = crossing): its crossings are
+// the contiguous range [pstart, pend) and crossings in the same tile are crossings of the same path (tile_alloc gives
+// every path its own tile range), hence
 //   seg_within_slice(k) = #{ j < k : key[j] == key[k] },   Tile.segment_count = that number + #{ j > k : ... } + 1,
-// the canonical (line, crossing) order by construction.  Inside a block of 64 crossings (lane = crossing) the counts
-// come from one ballot per DISTINCT tile of the block; a path with more than 64 crossings additionally streams its
-// other blocks through v_readlane (O(n^2/64) -- which is why paths above PC_BIG_PATH use the list-based kernels).
+// the canonical (line, crossing) order by construction, from one ballot per DISTINCT tile of the path.
 __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
                                                          const uint32_t* __restrict__ keys, uint32_t n_cap, const uint32_t* __restrict__ pfirst,
                                                          const uint32_t* __restrict__ plast, const uint32_t* __restrict__ counts,
@@ -443,18 +442,17 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restr
     uint32_t nps = 0u, npe = 0u;  // range of the path after this one (prefetched: the loop is a chain of dependent loads)
     if (P < n_paths) path_range(P, pfirst, plast, counts, seg_bases, nps, npe);
     for (; P < n_paths; P += waves) {
-        const uint32_t ps = nps, pe = umin_(npe, n);
+        const uint32_t ps = uni32(nps), pe_all = uni32(npe), pe = umin_(pe_all, n);  // uniform: scalar registers
         if (P + waves < n_paths) path_range(P + waves, pfirst, plast, counts, seg_bases, nps, npe);
-        if (pe <= ps || npe_big(pe - ps)) continue;  // uniform
-        for (uint32_t c0 = ps; c0 < pe; c0 += 64u) {       // own block [c0, c0 + 64)
-            const uint32_t k = c0 + lane;
+        if (pe <= ps || npe_big(pe_all - ps)) continue;  // (the same test as in k_pc_emit)
+        {
+            const uint32_t k = ps + lane;
             const bool valid = k < pe;
             uint32_t my_t = valid ? keys[k] : 0xffffffffu;
             const bool mine = valid && my_t != 0xffffffffu;  // 0xffffffff: crossing outside the tile buffer
             uint32_t before = 0u, after = 0u;
-            // inside the block: one ballot per distinct tile
             uint64_t rem = __builtin_amdgcn_ballot_w64(mine);
-            while (rem != 0ull) {
+            for (uint32_t it = 0u; it < 16u && rem != 0ull; it++) {
                 const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, (int)__builtin_ctzll(rem));
                 const uint64_t m = __builtin_amdgcn_ballot_w64(mine && my_t == t);
                 const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -465,14 +463,17 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restr
                 }
                 rem &= ~m;
             }
-            // the path's other blocks (none for a path of up to 64 crossings)
-            for (uint32_t b0 = ps; b0 < pe; b0 += 64u) {
-                if (b0 == c0) continue;
-                const uint32_t jn = umin_(pe - b0, 64u);
-                const uint32_t vec = (lane < jn) ? keys[b0 + lane] : 0xfffffffeu;
-                uint32_t cnt = 0u;
-                for (uint32_t jj = 0u; jj < jn; jj++) cnt += ((uint32_t)__builtin_amdgcn_readlane((int)vec, (int)jj) == my_t) ? 1u : 0u;
-                if (b0 < c0) before += cnt; else after += cnt;
+            // more than 16 distinct tiles (long lines: every crossing in another tile): the remaining lanes compare
+            // against all 64 keys instead (4 instructions per key, not 16 per distinct tile)
+            if (rem != 0ull) {
+                const bool todo = ((rem >> lane) & 1ull) != 0ull;
+                uint32_t b = 0u, a = 0u;
+                for (uint32_t jj = 0u; jj < 64u; jj++) {
+                    const bool eq = (uint32_t)__builtin_amdgcn_readlane((int)my_t, (int)jj) == my_t;
+                    b += (eq && jj < lane) ? 1u : 0u;
+                    a += (eq && jj > lane) ? 1u : 0u;
+                }
+                if (todo) { before = b; after = a; }
             }
             if (mine && seg_counts.ok(k)) {
                 seg_counts.p[k].counts |= before << 16;

@@ -162,6 +162,29 @@ def scene_images(size=256, seed=SEED + 7):
     return s, RenderParams(size, size, base_color=(0.2, 0.2, 0.2, 1.0))
 
 
+def scene_large_shapes(size=1536, n=60, seed=SEED + 11):
+    """Shapes of hundreds of tiles: a background rectangle over the whole target, filled and stroked circles of radius
+    100..700 (partly outside the target), under one clip layer.  Exercises what small random curves never reach: a
+    draw object in every bin, tile rows far wider than a wave handles in one step, paths with hundreds to thousands
+    of tile crossings, rows clipped by the target edge."""
+    r = SplitMix64(seed)
+    s = Scene()
+    s.fill(Fill.NonZero, None, Brush.solid((0.9, 0.9, 0.85, 1.0)), None, Path.rect(0, 0, size, size))
+    for i in range(n):
+        if i == n // 2:
+            s.push_layer(Mix.Multiply, Compose.SrcOver, 0.9, None, Path.circle(size * 0.5, size * 0.5, size * 0.45))
+        cx, cy, rad = r.uniform(-100, size + 100), r.uniform(-100, size + 100), r.uniform(100, 700)
+        col = (r.uniform(), r.uniform(), r.uniform(), r.uniform(0.3, 0.9))
+        if i % 3 == 0:
+            s.stroke(Stroke(width=r.uniform(1.0, 20.0)), None, Brush.solid(col), None, Path.circle(cx, cy, rad))
+        elif i % 3 == 1:
+            s.fill(Fill.NonZero, None, Brush.solid(col), None, Path.circle(cx, cy, rad))
+        else:
+            s.fill(Fill.EvenOdd, None, Brush.solid(col), None, Path.rect(cx - rad, cy - rad * 0.3, cx + rad, cy + rad * 0.3))
+    s.pop_layer()
+    return s, RenderParams(size, size, base_color=(0, 0, 0, 1))
+
+
 def scene_big_path(size=1024, n_zig=600, seed=SEED + 9):
     """One path with far more tile crossings than PC_BIG_PATH (a long zigzag polyline, filled even-odd and stroked)
     on top of a few small shapes: path_count's list-based route for big paths next to the atomics-free one."""

@@ -72,8 +72,19 @@ def test_msaa_matches_oracle(engine, aa, which):
     compare(engine, s, p)
 
 
+@pytest.mark.parametrize("aa", [jello_amd.Aa.Area, jello_amd.Aa.Msaa8])
+def test_large_shapes(engine, aa):
+    """A full-target background, circles and bars of hundreds of tiles, a large clip layer: the device-wide tile
+    clear, the wave-per-row backdrop route, bin lists with an element in every bin, the list route of path_count."""
+    s, p = scenes.scene_large_shapes()
+    p.bump = BumpSizes(ptcl=1 << 24)
+    p.aa = aa
+    r = compare(engine, s, p)
+    assert r["bump"]["tile"] > 90000
+
+
 def test_big_path_takes_the_list_route(engine):
-    """A single path with > 16384 tile crossings (PC_BIG_PATH) next to small ones: both rank routes of path_count."""
+    """A single path with far more tile crossings than PC_BIG_PATH next to small ones: both rank routes of path_count."""
     s, p = scenes.scene_big_path()
     p.bump = BumpSizes(ptcl=1 << 24)
     r = compare(engine, s, p)

@@ -531,7 +531,8 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank(const JlConfig* __restrict__ 
 //
 // The WGSL gives every row of a path to one thread, which walks the row tile by tile, and the rows of 256 paths to
 // one workgroup: fine for small paths, but a row of 100 tiles is a chain of 100 dependent memory round trips and the
-// 24 k rows of 300 large circles land on two workgroups (2.8 ms).  Paths wider than BD_WIDE tiles are therefore only
+// 24 k rows of 300 large circles land on two workgroups (2.8 ms).  Paths wider than `wide_min` tiles (BD_WIDE; less
+// when the scene has so few draw objects that this kernel cannot fill the device anyway) are therefore only
 // listed here -- (first global row number, first tile, width, rows), appended with one 64-bit atomic per wave that advances the
 // entry count and the row total together -- and k_backdrop_wide gives each of their rows to a wave (prefix sums are
 // integer sums: any association gives the WGSL's result).
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank(const JlConfig* __restrict__ 
 #define BD_ROWS_MASK ((1ull << 40) - 1ull)
 __global__ __launch_bounds__(JL_WG) void k_backdrop_dyn(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlPath> paths,
                                                         Buf<JlTile> tiles, unsigned long long* __restrict__ wide_ctr, uint4* __restrict__ wide_list,
-                                                        uint32_t wide_cap) {
+                                                        uint32_t wide_cap, uint32_t wide_min) {
     __shared__ uint32_t sh_row_width[JL_WG];
     __shared__ uint32_t sh_row_count[JL_WG];
     __shared__ uint32_t sh_offset[JL_WG];
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(JL_WG) void k_backdrop_dyn(const JlConfig* __restri
         sh_offset[lid] = 0u;
     }
     {
-        const bool wide = sh_row_width[lid] > BD_WIDE && row_count > 0u && drawobj_ix < wide_cap;
+        const bool wide = sh_row_width[lid] > wide_min && row_count > 0u && drawobj_ix < wide_cap;
         const uint64_t m = __builtin_amdgcn_ballot_w64(wide);
         if (m != 0ull) {  // uniform per wave
             const uint32_t rows = wide ? row_count : 0u;
@@ -633,13 +634,21 @@ __global__ __launch_bounds__(JL_WG) void k_backdrop_wide(const JlBump* __restric
             const uint32_t width = e.z;
             const uint32_t base = e.y + r * width;
             uint32_t carry = 0u;
-            for (uint32_t x0 = 0u; x0 < width; x0 += 64u) {
-                const uint32_t x = x0 + lane;
-                const bool ok = x < width && tiles.ok(base + x);
-                const uint32_t v = ok ? (uint32_t)tiles.p[base + x].backdrop : 0u;
-                const uint32_t sum = wave_incl_scan_u32(v) + carry;
-                if (ok) tiles.p[base + x].backdrop = (int32_t)sum;
-                carry = (uint32_t)__builtin_amdgcn_readlane((int)sum, 63);
+            for (uint32_t x0 = 0u; x0 < width; x0 += 256u) {  // four steps of 64 tiles per trip: their loads are in flight together
+                uint32_t v[4];
+                bool ok[4];
+#pragma unroll
+                for (uint32_t q = 0u; q < 4u; q++) {
+                    const uint32_t x = x0 + q * 64u + lane;
+                    ok[q] = x < width && tiles.ok(base + x);
+                    v[q] = ok[q] ? (uint32_t)tiles.p[base + x].backdrop : 0u;
+                }
+#pragma unroll
+                for (uint32_t q = 0u; q < 4u; q++) {
+                    const uint32_t sum = wave_incl_scan_u32(v[q]) + carry;
+                    if (ok[q]) tiles.p[base + x0 + q * 64u + lane].backdrop = (int32_t)sum;
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)sum, 63);
+                }
             }
         }
     }
@@ -883,8 +892,10 @@ int jh_launch_backdrop_dyn(const JhLaunch& L) {
     unsigned long long* wide_ctr = (unsigned long long*)w;
     uint4* wide_list = (uint4*)(w + 64);
     (void)hipMemsetAsync(wide_ctr, 0, 8, L.stream);
+    // one thread per row is the better deal only when there are enough paths to fill the device with such threads
+    const uint32_t wide_min = L.gx < 64u ? 2u : BD_WIDE;
     hipLaunchKernelGGL(k_backdrop_dyn, dim3(L.gx), dim3(JL_WG), 0, L.stream, (const JlConfig*)L.b[0].ptr, (const JlBump*)L.b[1].ptr, paths, tiles,
-                       wide_ctr, wide_list, wide_cap);
+                       wide_ctr, wide_list, wide_cap, wide_min);
     hipLaunchKernelGGL(k_backdrop_wide, dim3(stride_grid(L, (uint64_t)wide_cap * 64u)), dim3(JL_WG), 0, L.stream, (const JlBump*)L.b[1].ptr, tiles,
                        (const unsigned long long*)wide_ctr, (const uint4*)wide_list, wide_cap);
     return 0;

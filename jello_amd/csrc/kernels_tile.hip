@@ -364,63 +364,115 @@ JD void path_range(uint32_t P, const uint32_t* __restrict__ pstart, const uint32
 JD bool npe_big(uint32_t n) { return n > PC_BIG_PATH; }
 JD uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-// pass 2: backdrops, SegmentCount records, the tile of every crossing (slice ranks are filled in later)
+// pass 2: backdrops, SegmentCount records, the tile of every crossing (slice ranks are filled in later).
+// path_count.wgsl:168-199 is one thread per line walking the line's crossings; the walk only depends on the crossing
+// number i (last_z of the WGSL is floor(a * (i - 1) + b)), so a long line -- an edge of a large rectangle crosses 256
+// tiles, 1000 edge-to-edge strokes took 0.5 ms here -- is handed to the whole wave instead: lane = crossing.
+#define PC_LONG_LINE 32u
+struct EmitCtx {
+    const JlConfig* cfg;
+    const JlBump* bump;
+    Buf<JlTile> tile;
+    Buf<JlSegmentCount> seg_counts;
+    uint2* tile_of;
+    uint32_t* keys;
+    uint32_t* kbig;
+    uint32_t tile_of_n;
+};
+JD void emit_backdrop_row(const EmitCtx& c, const LineSetup& s, int32_t y) {
+    uint32_t base = (uint32_t)((int32_t)s.tiles + (y - s.bbox[1]) * s.stride);
+    if (c.tile.ok(base)) atomicAdd(&c.tile.p[base].backdrop, s.delta);
+}
+JD void emit_crossing(const EmitCtx& c, const LineSetup& s, uint32_t i, uint32_t gid, uint32_t seg_base, bool big) {
+    float last_z = floor_(s.a * ((float)i - 1.0f) + s.b);
+    float zf = s.a * (float)i + s.b;
+    float z = floor_(zf);
+    int32_t y = to_i32(s.y0 + (float)i - z);
+    int32_t x = to_i32(s.x0 + s.x_sign * z);
+    int32_t base = (int32_t)s.tiles + (y - s.bbox[1]) * s.stride - s.bbox[0];
+    bool top_edge = (i == 0u) ? (s.y0 == s.s0y) : (last_z == z);
+    if (top_edge && x + 1 < s.bbox[2]) {
+        int32_t x_bump = imax_(x + 1, s.bbox[0]);
+        uint32_t t = (uint32_t)(base + x_bump);
+        if (c.tile.ok(t)) atomicAdd(&c.tile.p[t].backdrop, s.delta);
+    }
+    uint32_t t = (uint32_t)(base + x);
+    uint32_t seg_ix = seg_base + i - s.imin;
+    if (seg_ix < c.cfg->seg_counts_size && c.seg_counts.ok(seg_ix)) {
+        JlSegmentCount sc;
+        sc.line_ix = gid;
+        sc.counts = i;  // low 16 bits; the slice rank is OR-ed in by k_pc_rank_small / k_pc_rank
+        c.seg_counts.p[seg_ix] = sc;
+        if (seg_ix < c.tile_of_n) {
+            c.keys[seg_ix] = c.tile.ok(t) ? t : 0xffffffffu;
+            c.kbig[seg_ix] = big ? 1u : 0u;
+            if (big) {
+                uint32_t arrival = 0u;  // order-dependent, only a unique slot inside the tile's temporary list
+                if (c.tile.ok(t)) arrival = atomicAdd(&c.tile.p[t].segment_count_or_ix, 1u);
+                c.tile_of[seg_ix] = make_uint2(t, arrival);
+            }
+        }
+    }
+}
+JD float rl_f(float v, uint32_t src) { return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(v), (int)src)); }
+JD int32_t rl_i(int32_t v, uint32_t src) { return __builtin_amdgcn_readlane(v, (int)src); }
+JD uint32_t rl_u(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
+
 __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump,
                                                    const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines, Buf<JlPath> paths, Buf<JlTile> tile,
                                                    Buf<JlSegmentCount> seg_counts, const uint32_t* __restrict__ seg_bases, uint32_t bases_n,
                                                    uint2* __restrict__ tile_of, uint32_t* __restrict__ keys, uint32_t* __restrict__ kbig,
                                                    uint32_t tile_of_n, const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ plast,
                                                    const uint32_t* __restrict__ counts, uint32_t n_paths, uint32_t* __restrict__ gate) {
-    uint32_t n_lines = umin_(umin_(bump->lines, bases_n), ind->x * JL_WG);
-    for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
-        if (!lines.ok(gid)) continue;
-        const uint32_t P = lines.p[gid].path_ix;
-        LineSetup s = line_setup(lines.p[gid], paths);
-        if (!s.valid) continue;
+    EmitCtx c;
+    c.cfg = cfg; c.bump = bump; c.tile = tile; c.seg_counts = seg_counts; c.tile_of = tile_of; c.keys = keys; c.kbig = kbig;
+    c.tile_of_n = tile_of_n;
+    const uint32_t n_lines = umin_(umin_(bump->lines, bases_n), ind->x * JL_WG);
+    const uint32_t lane = lane_id();
+    for (uint32_t g0 = blockIdx.x * JL_WG + (threadIdx.x & ~63u); g0 < n_lines; g0 += gridDim.x * JL_WG) {  // uniform per wave
+        const uint32_t gid = g0 + lane;
+        LineSetup s;
+        s.valid = false;
+        uint32_t P = 0u;
+        if (gid < n_lines && lines.ok(gid)) {
+            P = lines.p[gid].path_ix;
+            s = line_setup(lines.p[gid], paths);
+        }
         // big path (or a path index outside the table): arrival slots by atomics, as k_pc_scatter / k_pc_rank expect
         bool big = true;
-        if (P < n_paths) {
-            uint32_t ps, pe;
-            path_range(P, pfirst, plast, counts, seg_bases, ps, pe);
-            big = pe - ps > PC_BIG_PATH;
-        }
-        for (int32_t y = s.ymin; y < s.ymax; y++) {
-            uint32_t base = (uint32_t)((int32_t)s.tiles + (y - s.bbox[1]) * s.stride);
-            if (tile.ok(base)) atomicAdd(&tile.p[base].backdrop, s.delta);
-        }
-        float last_z = floor_(s.a * ((float)s.imin - 1.0f) + s.b);
-        uint32_t seg_base = seg_bases[gid];
-        if (big && s.imax > s.imin) atomicMax(gate, bump->tile);  // the number of tiles the list-base scan has to cover
-        for (uint32_t i = s.imin; i < s.imax; i++) {
-            float zf = s.a * (float)i + s.b;
-            float z = floor_(zf);
-            int32_t y = to_i32(s.y0 + (float)i - z);
-            int32_t x = to_i32(s.x0 + s.x_sign * z);
-            int32_t base = (int32_t)s.tiles + (y - s.bbox[1]) * s.stride - s.bbox[0];
-            bool top_edge = (i == 0u) ? (s.y0 == s.s0y) : (last_z == z);
-            if (top_edge && x + 1 < s.bbox[2]) {
-                int32_t x_bump = imax_(x + 1, s.bbox[0]);
-                uint32_t t = (uint32_t)(base + x_bump);
-                if (tile.ok(t)) atomicAdd(&tile.p[t].backdrop, s.delta);
+        uint32_t seg_base = 0u;
+        if (s.valid) {
+            if (P < n_paths) {
+                uint32_t ps, pe;
+                path_range(P, pfirst, plast, counts, seg_bases, ps, pe);
+                big = pe - ps > PC_BIG_PATH;
             }
-            uint32_t t = (uint32_t)(base + x);
-            uint32_t seg_ix = seg_base + i - s.imin;
-            if (seg_ix < cfg->seg_counts_size && seg_counts.ok(seg_ix)) {
-                JlSegmentCount sc;
-                sc.line_ix = gid;
-                sc.counts = i;  // low 16 bits; the slice rank is OR-ed in by k_pc_rank_small / k_pc_rank
-                seg_counts.p[seg_ix] = sc;
-                if (seg_ix < tile_of_n) {
-                    keys[seg_ix] = tile.ok(t) ? t : 0xffffffffu;
-                    kbig[seg_ix] = big ? 1u : 0u;
-                    if (big) {
-                        uint32_t arrival = 0u;  // order-dependent, only a unique slot inside the tile's temporary list
-                        if (tile.ok(t)) arrival = atomicAdd(&tile.p[t].segment_count_or_ix, 1u);
-                        tile_of[seg_ix] = make_uint2(t, arrival);
-                    }
-                }
-            }
-            last_z = z;
+            seg_base = seg_bases[gid];
+            if (big && s.imax > s.imin) atomicMax(gate, bump->tile);  // the number of tiles the list-base scan has to cover
+        } else {
+            s.imin = 0u; s.imax = 0u; s.ymin = 0; s.ymax = 0;
+        }
+        const bool is_long = s.valid && (s.imax - s.imin > PC_LONG_LINE || s.ymax - s.ymin > (int32_t)PC_LONG_LINE);
+        if (s.valid && !is_long) {
+            for (int32_t y = s.ymin; y < s.ymax; y++) emit_backdrop_row(c, s, y);
+            for (uint32_t i = s.imin; i < s.imax; i++) emit_crossing(c, s, i, gid, seg_base, big);
+        }
+        uint64_t m = __builtin_amdgcn_ballot_w64(is_long);
+        while (m != 0ull) {  // uniform
+            const uint32_t src = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            LineSetup t;
+            t.valid = true; t.is_down = false; t.is_positive_slope = false;
+            t.a = rl_f(s.a, src); t.b = rl_f(s.b, src); t.x0 = rl_f(s.x0, src); t.y0 = rl_f(s.y0, src);
+            t.x_sign = rl_f(s.x_sign, src); t.s0y = rl_f(s.s0y, src);
+            t.imin = rl_u(s.imin, src); t.imax = rl_u(s.imax, src);
+            t.ymin = rl_i(s.ymin, src); t.ymax = rl_i(s.ymax, src); t.delta = rl_i(s.delta, src);
+            t.bbox[0] = rl_i(s.bbox[0], src); t.bbox[1] = rl_i(s.bbox[1], src); t.bbox[2] = rl_i(s.bbox[2], src); t.bbox[3] = rl_i(s.bbox[3], src);
+            t.stride = rl_i(s.stride, src); t.tiles = rl_u(s.tiles, src);
+            const uint32_t t_gid = g0 + src, t_seg_base = rl_u(seg_base, src);
+            const bool t_big = rl_u(big ? 1u : 0u, src) != 0u;
+            for (int32_t y = t.ymin + (int32_t)lane; y < t.ymax; y += 64) emit_backdrop_row(c, t, y);
+            for (uint32_t i = t.imin + lane; i < t.imax; i += 64u) emit_crossing(c, t, i, t_gid, t_seg_base, t_big);
         }
     }
 }
@@ -483,6 +535,8 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restr
     }
 }
 
+#define PC_DENSE_TILE 16u   // tiles with longer lists are ranked by a wave each (k_pc_rank, phase B)
+#define PC_DENSE_LDS 1024u  // entries of a tile's list staged per pass and wave
 // pass 3: scatter crossing indices into per-tile lists; the slot inside a list is the (arbitrary but unique)
 // arrival number the count atomic returned in pass 2, so no further atomics are needed.
 __global__ __launch_bounds__(JL_WG) void k_pc_scatter(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
@@ -490,38 +544,88 @@ __global__ __launch_bounds__(JL_WG) void k_pc_scatter(const JlConfig* __restrict
                                                       uint32_t tiles_cap, uint32_t* __restrict__ list, const uint32_t* __restrict__ kbig,
                                                       const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ plast,
                                                       const uint32_t* __restrict__ counts, const uint32_t* __restrict__ seg_bases, uint32_t n_paths,
-                                                      const uint32_t* __restrict__ gate) {
+                                                      uint32_t* __restrict__ gate, uint32_t* __restrict__ dense, uint32_t dense_cap) {
     if (*gate == 0u) return;  // no big path in this frame
     uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
-    for (uint32_t k = blockIdx.x * JL_WG + threadIdx.x; k < n; k += gridDim.x * JL_WG) {
-        if (kbig[k] == 0u) continue;  // ranked by k_pc_rank_small
-        uint2 ta = tile_of[k];
-        if (ta.x >= tiles_cap || !tile.ok(ta.x)) continue;
-        uint32_t pos = list_base[ta.x] + ta.y;
-        if (pos < n_cap) list[pos] = k;
+    const uint32_t lane = lane_id();
+    for (uint32_t k0 = blockIdx.x * JL_WG + (threadIdx.x & ~63u); k0 < n; k0 += gridDim.x * JL_WG) {  // uniform per wave
+        const uint32_t k = k0 + lane;
+        bool first_of_dense = false;  // the crossing that arrived first in a tile with a long list announces the tile
+        uint32_t t = 0u;
+        if (k < n && kbig[k] != 0u) {  // (others are ranked by k_pc_rank_small)
+            uint2 ta = tile_of[k];
+            if (ta.x < tiles_cap && tile.ok(ta.x)) {
+                uint32_t pos = list_base[ta.x] + ta.y;
+                if (pos < n_cap) list[pos] = k;
+                t = ta.x;
+                first_of_dense = ta.y == 0u && tile.p[t].segment_count_or_ix > PC_DENSE_TILE;
+            }
+        }
+        const uint64_t m = __builtin_amdgcn_ballot_w64(first_of_dense);
+        if (m != 0ull) {  // one atomic per wave
+            uint32_t at = 0u;
+            if (lane == 0u) at = atomicAdd(&gate[1], (uint32_t)__builtin_popcountll(m));
+            at = uni32(at) + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (first_of_dense && at < dense_cap) dense[at] = t;
+        }
     }
 }
-// pass 4: seg_within_slice = rank of k among the crossings of its tile
+// pass 4: seg_within_slice = rank of k among the crossings of its tile.
+// Phase A, thread = crossing: counts the smaller entries of its tile's list -- fine for the usual handful of crossings
+// per tile.  A dense polyline (a 200 k-vertex outline: 240 crossings in each tile of its ring) makes that
+// 240 uncoalesced loads per crossing (1.1 ms); tiles with more than PC_DENSE_TILE entries are therefore left to
+// phase B, wave = tile: the list goes to LDS once, every lane ranks its entries against broadcast reads.
 __global__ __launch_bounds__(JL_WG) void k_pc_rank(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
                                                    const uint2* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
                                                    uint32_t tiles_cap, const uint32_t* __restrict__ list, Buf<JlSegmentCount> seg_counts,
                                                    const uint32_t* __restrict__ kbig, const uint32_t* __restrict__ pfirst,
                                                    const uint32_t* __restrict__ plast, const uint32_t* __restrict__ counts,
-                                                   const uint32_t* __restrict__ seg_bases, uint32_t n_paths, const uint32_t* __restrict__ gate) {
+                                                   const uint32_t* __restrict__ seg_bases, uint32_t n_paths, const uint32_t* __restrict__ gate,
+                                                   const uint32_t* __restrict__ dense, uint32_t dense_cap) {
+    __shared__ uint32_t sh_list[JL_WG / 64][PC_DENSE_LDS];
     if (*gate == 0u) return;  // no big path in this frame
     uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
     for (uint32_t k = blockIdx.x * JL_WG + threadIdx.x; k < n; k += gridDim.x * JL_WG) {
         if (kbig[k] == 0u) continue;  // ranked by k_pc_rank_small
         uint32_t t = tile_of[k].x;
         if (t >= tiles_cap || !tile.ok(t) || !seg_counts.ok(k)) continue;
-        uint32_t base = list_base[t];
         uint32_t cnt = tile.p[t].segment_count_or_ix;
+        if (cnt > PC_DENSE_TILE) continue;  // phase B
+        uint32_t base = list_base[t];
         uint32_t rank = 0u;
         for (uint32_t j = 0; j < cnt; j++) {
             uint32_t pos = base + j;
             if (pos < n_cap && list[pos] < k) rank++;
         }
         seg_counts.p[k].counts |= rank << 16;
+    }
+    // phase B: one wave per announced tile
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    uint32_t* my_list = sh_list[wv];
+    const uint32_t n_dense = umin_(gate[1], dense_cap);
+    const uint32_t waves = (gridDim.x * JL_WG) >> 6;
+    for (uint32_t d = uni32((blockIdx.x * JL_WG + threadIdx.x) >> 6); d < n_dense; d += waves) {
+        const uint32_t t = uni32(dense[d]);
+        if (t >= tiles_cap || !tile.ok(t)) continue;
+        const uint32_t base = uni32(list_base[t]);
+        uint32_t m = uni32(tile.p[t].segment_count_or_ix);
+        if (base >= n_cap) continue;
+        m = umin_(m, n_cap - base);
+        for (uint32_t o0 = 0u; o0 < m; o0 += PC_DENSE_LDS) {  // the "other" entries, PC_DENSE_LDS at a time
+            const uint32_t on = umin_(m - o0, PC_DENSE_LDS);
+            wave_sync();
+            for (uint32_t i = lane; i < ((on + 3u) & ~3u); i += 64u) my_list[i] = i < on ? list[base + o0 + i] : 0xffffffffu;
+            wave_sync();
+            for (uint32_t j = lane; j < m; j += 64u) {  // own entries
+                const uint32_t e = list[base + j];
+                uint32_t r = 0u;
+                for (uint32_t i = 0u; i < on; i += 4u) {
+                    const uint4 q = *(const uint4*)&my_list[i];  // broadcast read
+                    r += (q.x < e ? 1u : 0u) + (q.y < e ? 1u : 0u) + (q.z < e ? 1u : 0u) + (q.w < e ? 1u : 0u);
+                }
+                if (seg_counts.ok(e)) seg_counts.p[e].counts += r << 16;  // (this lane owns entry e; passes add up)
+            }
+        }
     }
 }
 
@@ -849,7 +953,10 @@ int jh_launch_path_count(const JhLaunch& L) {
     uint32_t* keys = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_F, (uint64_t)seg_cap * 4);
     uint32_t* kpath = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_H, (uint64_t)seg_cap * 4);
     uint32_t n_paths = paths.n;
-    // [pstart | pend | gate]: zeroed every frame (the variables below keep the names of the path_range parameters)
+    const uint32_t dense_cap = seg_cap / PC_DENSE_TILE + 1u;  // tiles with more than PC_DENSE_TILE crossings of a big path
+    uint32_t* dense = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, (uint64_t)dense_cap * 4);
+    if (!dense) return -5;
+    // [pstart | pend | gate, number of dense tiles]: zeroed every frame (the variables below keep the names of the path_range parameters)
     uint32_t* prange = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_I, ((uint64_t)n_paths * 2 + 64) * 4);
     if (!counts || !bases || !tile_of || !list || !list_base || !keys || !kpath || !prange) return -5;
     uint32_t *pfirst = prange, *plast = prange + n_paths, *gate = prange + 2 * (size_t)n_paths;
@@ -869,10 +976,10 @@ int jh_launch_path_count(const JhLaunch& L) {
     rc = jh_scan_u32(L, ((const uint32_t*)tile.p) + 1, 2, list_base, tiles_cap, gate, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pc_scatter, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint2*)tile_of, seg_cap,
-                       (const uint32_t*)list_base, tiles_cap, list, (const uint32_t*)kpath, cpf, cpl, cc, cb, n_paths, (const uint32_t*)gate);
+                       (const uint32_t*)list_base, tiles_cap, list, (const uint32_t*)kpath, cpf, cpl, cc, cb, n_paths, gate, dense, dense_cap);
     hipLaunchKernelGGL(k_pc_rank, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint2*)tile_of, seg_cap,
                        (const uint32_t*)list_base, tiles_cap, (const uint32_t*)list, segc, (const uint32_t*)kpath, cpf, cpl, cc, cb, n_paths,
-                       (const uint32_t*)gate);
+                       (const uint32_t*)gate, (const uint32_t*)dense, dense_cap);
     // everything else: atomics-free ranks
     hipLaunchKernelGGL(k_pc_rank_small, dim3(stride_grid(L, (uint64_t)n_paths * 64u)), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile,
                        (const uint32_t*)keys, seg_cap, cpf, cpl, cc, cb, n_paths, segc);

@@ -185,6 +185,28 @@ def scene_large_shapes(size=1536, n=60, seed=SEED + 11):
     return s, RenderParams(size, size, base_color=(0, 0, 0, 1))
 
 
+def scene_dense_polygon(n_pts=40000, size=256, seed=SEED + 12):
+    """One even-odd polygon whose n_pts vertices zigzag radially (a dense outline zoomed far out): thousands of tile
+    crossings of ONE path in every tile of a ring -- per-tile lists far longer than a wave, under a few long thin
+    strokes from edge to edge (every line crosses dozens of tiles)."""
+    r = SplitMix64(seed)
+    s = Scene()
+    p = Path()
+    c = size * 0.5
+    for i in range(n_pts):
+        a = 2.0 * math.pi * i / n_pts
+        rad = size * (0.25 + 0.2 * r.uniform())
+        x, y = c + rad * math.cos(a), c + rad * math.sin(a)
+        p = p.move_to(x, y) if i == 0 else p.line_to(x, y)
+    p.close()
+    s.fill(Fill.EvenOdd, None, Brush.solid((0.2, 0.5, 0.3, 1.0)), None, p)
+    for i in range(24):
+        q = Path().move_to(0.0, r.uniform(0, size)).line_to(float(size), r.uniform(0, size)) if i % 2 == 0 else \
+            Path().move_to(r.uniform(0, size), 0.0).line_to(r.uniform(0, size), float(size))
+        s.stroke(Stroke(width=r.uniform(0.5, 3.0)), None, Brush.solid((r.uniform(), r.uniform(), r.uniform(), 0.8)), None, q)
+    return s, RenderParams(size, size, base_color=(1, 1, 1, 1))
+
+
 def scene_big_path(size=1024, n_zig=600, seed=SEED + 9):
     """One path with far more tile crossings than PC_BIG_PATH (a long zigzag polyline, filled even-odd and stroked)
     on top of a few small shapes: path_count's list-based route for big paths next to the atomics-free one."""

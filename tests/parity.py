@@ -84,6 +84,8 @@ def compare(engine, scene, params, check_image=True, names=None):
         check("binHeaderBuf", np.uint32, ((nd + 255) // 256) * 256, 2)
         check("pathBuf", np.uint32, nd * 8 // 8 * 8 // 8, 8, mask=np.tile(np.array([1, 1, 1, 1, 1, 0, 0, 0], bool), nd))
         check("segCountsBuf", np.uint32, n_segc, 2)
+        if n_segc:  # SegmentCount.counts = seg_within_slice << 16 | seg_within_line
+            out["max_tile_segments"] = int(both("segCountsBuf", np.uint32, n_segc, 2)[0][1::2].max() >> 16) + 1
         check("tileBuf", np.uint32, n_tile, 2)
         # segments: 5 live words of 6 per record
         check("segmentsBuf", np.uint32, n_seg, 6, mask=np.tile(np.array([1, 1, 1, 1, 1, 0], bool), n_seg))

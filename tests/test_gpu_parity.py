@@ -83,6 +83,16 @@ def test_large_shapes(engine, aa):
     assert r["bump"]["tile"] > 90000
 
 
+def test_dense_polygon_and_long_lines(engine):
+    """40 k radial zigzag edges of one path (more than 1024 crossings in a single tile: the wave-per-tile ranking of
+    path_count in several LDS passes) and edge-to-edge strokes (lines handed to a whole wave in k_pc_emit)."""
+    s, p = scenes.scene_dense_polygon()
+    p.bump = BumpSizes(lines=1 << 17, seg_counts=1 << 20, segments=1 << 20, ptcl=1 << 22)
+    r = compare(engine, s, p)
+    assert r["bump"]["seg_counts"] > 90000
+    assert r["max_tile_segments"] > 1024
+
+
 def test_big_path_takes_the_list_route(engine):
     """A single path with far more tile crossings than PC_BIG_PATH next to small ones: both rank routes of path_count."""
     s, p = scenes.scene_big_path()

@@ -1,0 +1,81 @@
+"""Synthetic scenes outside the BASELINE configs, used to look for scaling cliffs: large shapes, long lines, very many tiny
+paths, one path with a very long tag stream (tools/time_shapes.py times them, tools/prof_scene.py profiles one)."""
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from jello_amd import scenes, BumpSizes
+from jello_amd.scene import Scene, Path, Brush, Fill, Stroke, RenderParams
+from jello_amd.scenes import SplitMix64
+
+
+def scene_shapes(n, rmin, rmax, size, seed=77):
+    r = SplitMix64(seed)
+    s = Scene()
+    for i in range(n):
+        cx, cy, rad = r.uniform(0, size), r.uniform(0, size), r.uniform(rmin, rmax)
+        col = (r.uniform(), r.uniform(), r.uniform(), 0.5)
+        if i % 2 == 0:
+            s.fill(Fill.NonZero, None, Brush.solid(col), None, Path.circle(cx, cy, rad))
+        else:
+            s.stroke(Stroke(width=3.0), None, Brush.solid(col), None, Path.circle(cx, cy, rad))
+    return s, RenderParams(size, size, base_color=(0, 0, 0, 1))
+
+def scene_long_lines(n, size, seed=78):
+    """n thin strokes from edge to edge (a chart / grid): every line crosses hundreds of tiles."""
+    r = SplitMix64(seed)
+    s = Scene()
+    for i in range(n):
+        p = Path().move_to(0.0, r.uniform(0, size)).line_to(float(size), r.uniform(0, size)) if i % 2 == 0 else \
+            Path().move_to(r.uniform(0, size), 0.0).line_to(r.uniform(0, size), float(size))
+        s.stroke(Stroke(width=1.5), None, Brush.solid((r.uniform(), r.uniform(), r.uniform(), 0.8)), None, p)
+    return s, RenderParams(size, size, base_color=(1, 1, 1, 1))
+
+def scene_tiny_rects(n, size, seed=79):
+    """n rectangles of 2..6 px (particles / a scatter plot): draw-object-bound stages."""
+    r = SplitMix64(seed)
+    s = Scene()
+    for i in range(n):
+        x, y, w, h = r.uniform(0, size - 8), r.uniform(0, size - 8), r.uniform(2, 6), r.uniform(2, 6)
+        s.fill(Fill.NonZero, None, Brush.solid((r.uniform(), r.uniform(), r.uniform(), 0.9)), None, Path.rect(x, y, x + w, y + h))
+    return s, RenderParams(size, size, base_color=(0, 0, 0, 1))
+
+def scene_polygon(n_pts, size, seed=80):
+    """One polygon with n_pts vertices (a coastline): a single path with a very long tag stream."""
+    r = SplitMix64(seed)
+    s = Scene()
+    p = Path()
+    c = size * 0.5
+    for i in range(n_pts):
+        a = 2.0 * math.pi * i / n_pts
+        rad = size * (0.25 + 0.2 * r.uniform())
+        x, y = c + rad * math.cos(a), c + rad * math.sin(a)
+        p = p.move_to(x, y) if i == 0 else p.line_to(x, y)
+    p = p.close()
+    s.fill(Fill.EvenOdd, None, Brush.solid((0.2, 0.5, 0.3, 1.0)), None, p)
+    return s, RenderParams(size, size, base_color=(0, 0, 0, 1))
+
+
+def big_buffers():
+    return BumpSizes(lines=1 << 23, seg_counts=1 << 24, segments=1 << 24, tiles=1 << 24, ptcl=1 << 27, bin_data=1 << 22, blend_spill=1 << 20)
+
+
+def _hd(mk):
+    s, p = mk()
+    p.height = 1088
+    return s, p
+
+
+CASES = [("C1", scenes.scene_c1),
+         ("2000 circles r 20..150, 1920x1088", lambda: _hd(lambda: scene_shapes(2000, 20, 150, 1920))),
+         ("300 circles r 200..1000, 4096^2", lambda: scene_shapes(300, 200, 1000, 4096)),
+         ("20 circles r 1000..2000, 4096^2", lambda: scene_shapes(20, 1000, 2000, 4096)),
+         ("C3 20k paths, 4096^2", lambda: scenes.scene_c3(20000, 4096)),
+         ("1000 edge-to-edge strokes, 4096^2", lambda: scene_long_lines(1000, 4096)),
+         ("200k rects of 2..6 px, 1920x1088", lambda: _hd(lambda: scene_tiny_rects(200000, 1920))),
+         ("one polygon, 200k vertices, 2048^2", lambda: scene_polygon(200000, 2048))]
+
+
+def select(keys):
+    return [c for c in CASES if not keys or any(k in c[0] for k in keys)]

@@ -1117,7 +1117,12 @@ __global__ __launch_bounds__(JL_WG) void k_flatten_bbox(const JlConfig* __restri
                     out->x0 = imin_(out->x0, fx0); out->y0 = imin_(out->y0, fy0);
                     out->x1 = imax_(out->x1, fx1); out->y1 = imax_(out->y1, fy1);
                 } else {
-                    atomicMin(&out->x0, fx0); atomicMin(&out->y0, fy0); atomicMax(&out->x1, fx1); atomicMax(&out->y1, fy1);
+                    // a path spread over many waves (one outline of 200 k segments): the box only grows, so a wave whose
+                    // box is already inside what it reads (possibly stale, i.e. smaller) has nothing to add
+                    if (fx0 < __hip_atomic_load(&out->x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&out->x0, fx0);
+                    if (fy0 < __hip_atomic_load(&out->y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&out->y0, fy0);
+                    if (fx1 > __hip_atomic_load(&out->x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&out->x1, fx1);
+                    if (fy1 > __hip_atomic_load(&out->y1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&out->y1, fy1);
                 }
             }
         }

@@ -448,9 +448,14 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
                 big = pe - ps > PC_BIG_PATH;
             }
             seg_base = seg_bases[gid];
-            if (big && s.imax > s.imin) atomicMax(gate, bump->tile);  // the number of tiles the list-base scan has to cover
         } else {
             s.imin = 0u; s.imax = 0u; s.ymin = 0; s.ymax = 0;
+        }
+        // open the gate of the list route: the number of tiles its list-base scan has to cover (one lane per wave, and
+        // only while the word does not hold the value yet -- 200 k lines of one big path would queue on that word)
+        if (__builtin_amdgcn_ballot_w64(s.valid && big && s.imax > s.imin) != 0ull && lane == 0u) {
+            const uint32_t want = bump->tile;
+            if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) atomicMax(gate, want);
         }
         const bool is_long = s.valid && (s.imax - s.imin > PC_LONG_LINE || s.ymax - s.ymin > (int32_t)PC_LONG_LINE);
         if (s.valid && !is_long) {

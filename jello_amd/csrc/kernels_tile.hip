@@ -1008,7 +1008,8 @@ int jh_launch_backdrop_dyn(const JhLaunch& L) {
     const uint32_t wide_min = L.gx < 64u ? 2u : BD_WIDE;
     hipLaunchKernelGGL(k_backdrop_dyn, dim3(L.gx), dim3(JL_WG), 0, L.stream, (const JlConfig*)L.b[0].ptr, (const JlBump*)L.b[1].ptr, paths, tiles,
                        wide_ctr, wide_list, wide_cap, wide_min);
-    hipLaunchKernelGGL(k_backdrop_wide, dim3(stride_grid(L, (uint64_t)wide_cap * 64u)), dim3(JL_WG), 0, L.stream, (const JlBump*)L.b[1].ptr, tiles,
+    // (a wave per BD_UNIT rows; a wide path has tens to hundreds of rows)
+    hipLaunchKernelGGL(k_backdrop_wide, dim3(stride_grid(L, (uint64_t)wide_cap * 64u * 64u)), dim3(JL_WG), 0, L.stream, (const JlBump*)L.b[1].ptr, tiles,
                        (const unsigned long long*)wide_ctr, (const uint4*)wide_list, wide_cap);
     return 0;
 }

@@ -5,8 +5,10 @@
 A step = one full pass of the hot path (pathtag scan -> flatten -> draw/clip scans -> binning ->
 tile_alloc -> path_count -> backdrop -> coarse -> path_tiling -> fine) over one synthetic scene that is
 already resident in HBM (scene bytes + config uploaded before the timed region).  At N > 1 every rank
-renders its own independent scene (weak scaling, no data-path collective) and the finished RGBA16F
-images are gathered to rank 0 over RCCL, overlapped with the next frame.
+renders its own independent scene (weak scaling, no data-path collective); the finished RGBA16F image
+stays in that rank's HBM, as the reference leaves it in a texture of the device that rendered it.
+`--gather` additionally collects the images on rank 0 over RCCL, overlapped with the next frame (a
+compositor on one GPU; 7 x 128 MiB per frame into one device is then the bound, not the renderer).
 
 Prints ONE JSON line on rank 0.
 """
@@ -34,7 +36,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--aa", choices=["area", "msaa8", "msaa16"], default="area", help="coverage mode of the fine stage (the headline is area)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="N > 1: also gather every rank's image to rank 0 (RCCL, asynchronous)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     args = ap.parse_args()
 
@@ -82,7 +84,7 @@ def main():
     # output images: torch owns the device memory (double-buffered for the overlapped gather)
     outs = [torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(2)]
     gathered = None
-    if world > 1 and rank == 0 and not args.no_gather:
+    if world > 1 and rank == 0 and args.gather:
         gathered = [[torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(world)] for _ in range(2)]
 
     eng.run(rec, RUN_UPLOADS | RUN_DISPATCHES, outs[0].data_ptr())  # uploads scene/config; allocates every buffer
@@ -94,7 +96,7 @@ def main():
     graphs = [None, None]
     use_graph = not args.no_graph
     if use_graph:
-        for k in range(2 if world > 1 and not args.no_gather else 1):
+        for k in range(2 if world > 1 and args.gather else 1):
             graphs[k] = eng.capture(rec, outs[k].data_ptr())
         if graphs[1] is None:
             graphs[1] = graphs[0]
@@ -109,7 +111,7 @@ def main():
             eng.replay(graphs[k])
         else:
             eng.run(rec, RUN_DISPATCHES, outs[k].data_ptr())
-        if world > 1 and not args.no_gather:
+        if world > 1 and args.gather:
             pending[k] = dist.gather(outs[k], gathered[k] if rank == 0 else None, dst=0, async_op=True)
 
     def drain():
@@ -209,7 +211,7 @@ def main():
             "config": {"workload": "C3: %d random stroked+filled cubic Beziers, %dx%d RGBA16F target, %s AA, one independent scene per GPU"
                                    % (args.paths, W, H, args.aa),
                        "paths": args.paths, "draw_objects": cfg["n_drawobj"], "width": W, "height": H,
-                       "parallelism": "scene-per-gpu x%d%s" % (world, "" if world == 1 or args.no_gather else " + RCCL image gather")},
+                       "parallelism": "scene-per-gpu x%d%s" % (world, "" if world == 1 or not args.gather else " + RCCL image gather")},
             "paths_per_s": round(args.paths * world / (elapsed / args.steps), 1),
             "fine_mpixels_per_s": round(W * H / (fine_ms * 1e-3) / 1e6, 2),
             "launch": "hipGraph replay" if use_graph else "eager",

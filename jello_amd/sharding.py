@@ -5,7 +5,7 @@ Two modes, neither needs a collective on the data path:
   * bands:  disjoint bin-row bands of ONE target -- every rank runs the cheap element stages on the
             whole scene (replicated, so allocation scans and hence PTCL addresses are identical on
             every rank) and coarse+fine only for its band -- `band_for_rank`.
-The only exchange is the final image gather to rank 0 (`gather_images`): RCCL on GPUs ("nccl"
+The only (optional: `bench.py --gather`) exchange is the final image gather to rank 0 (`gather_images`): RCCL on GPUs ("nccl"
 backend), gloo in the CPU tests.
 """
 from . import scenes

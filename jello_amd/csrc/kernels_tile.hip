@@ -318,7 +318,11 @@ JD LineSetup line_setup(const JlLineSoup& line, const Buf<JlPath>& paths) {
 
 // pass 1: crossings per line
 __global__ __launch_bounds__(JL_WG) void k_pc_count(const JlBump* __restrict__ bump, const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines,
-                                                    Buf<JlPath> paths, uint32_t* __restrict__ counts, uint32_t counts_n) {
+                                                    Buf<JlPath> paths, uint32_t* __restrict__ counts, uint32_t counts_n,
+                                                    uint32_t* __restrict__ zero, uint32_t zero_n) {
+    // (the path ranges, the gate and the dense-tile counter of the later passes start from zero: cleared here, this
+    // kernel does not use them, instead of by a separate fill launch)
+    for (uint32_t i = blockIdx.x * JL_WG + threadIdx.x; i < zero_n; i += gridDim.x * JL_WG) zero[i] = 0u;
     uint32_t n_lines = umin_(bump->lines, counts_n);
     uint32_t n_threads = umin_(ind->x * JL_WG, counts_n);
     for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
@@ -961,13 +965,13 @@ int jh_launch_path_count(const JhLaunch& L) {
     const uint32_t dense_cap = seg_cap / PC_DENSE_TILE + 1u;  // tiles with more than PC_DENSE_TILE crossings of a big path
     uint32_t* dense = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, (uint64_t)dense_cap * 4);
     if (!dense) return -5;
-    // [pstart | pend | gate, number of dense tiles]: zeroed every frame (the variables below keep the names of the path_range parameters)
+    // [pstart | pend | gate, number of dense tiles]: zeroed every frame (by k_pc_count) (the variables below keep the names of the path_range parameters)
     uint32_t* prange = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_I, ((uint64_t)n_paths * 2 + 64) * 4);
     if (!counts || !bases || !tile_of || !list || !list_base || !keys || !kpath || !prange) return -5;
     uint32_t *pfirst = prange, *plast = prange + n_paths, *gate = prange + 2 * (size_t)n_paths;
-    (void)hipMemsetAsync(prange, 0, ((size_t)n_paths * 2 + 64) * 4, L.stream);
     uint32_t gl = stride_grid(L, lines_cap), gs = stride_grid(L, seg_cap);
-    hipLaunchKernelGGL(k_pc_count, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, paths, counts, lines_cap);
+    hipLaunchKernelGGL(k_pc_count, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, paths, counts, lines_cap, prange,
+                       n_paths * 2u + 64u);
     int rc = jh_scan_u32(L, counts, 1, bases, lines_cap, &bump->lines, &bump->seg_counts);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pc_paths, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, (const uint32_t*)counts,

@@ -57,6 +57,33 @@ def scene_polygon(n_pts, size, seed=80):
     return s, RenderParams(size, size, base_color=(0, 0, 0, 1))
 
 
+def scene_gradients(n, size, kind, seed=81):
+    """C3-like filled cubics whose brushes are all gradients of one kind ("linear", "radial", "sweep") or a 64x64 image."""
+    import numpy as np
+    from jello_amd.scene import ColorStop, Extend
+    r = SplitMix64(seed)
+    s = Scene()
+    img = (np.arange(64 * 64 * 4, dtype=np.uint32) * 2654435761 >> 24).astype(np.uint8).reshape(64, 64, 4)
+    for i in range(n):
+        ax, ay = r.uniform(0, size), r.uniform(0, size)
+        p = Path().move_to(ax, ay)
+        p.cubic_to(ax + r.uniform(-32, 32), ay + r.uniform(-32, 32), ax + r.uniform(-32, 32), ay + r.uniform(-32, 32),
+                   ax + r.uniform(-32, 32), ay + r.uniform(-32, 32))
+        stops = [ColorStop(0.0, (r.uniform(), r.uniform(), r.uniform(), 1.0)), ColorStop(1.0, (r.uniform(), r.uniform(), r.uniform(), 0.5))]
+        bt = None
+        if kind == "linear":
+            b = Brush.linear((ax - 20, ay), (ax + 20, ay + 10), stops, Extend.Pad)
+        elif kind == "radial":
+            b = Brush.radial((ax, ay), 2.0, (ax + 5, ay + 3), 40.0, stops, Extend.Pad)
+        elif kind == "sweep":
+            b = Brush.sweep((ax, ay), 0.0, 1.0, stops, Extend.Pad)
+        else:
+            b = Brush.image(img, key=7)
+            bt = (1, 0, 0, 1, ax - 32, ay - 32)
+        s.fill(Fill.NonZero, None, b, bt, p)
+    return s, RenderParams(size, size, base_color=(0, 0, 0, 1))
+
+
 def big_buffers():
     return BumpSizes(lines=1 << 23, seg_counts=1 << 24, segments=1 << 24, tiles=1 << 24, ptcl=1 << 27, bin_data=1 << 22, blend_spill=1 << 20)
 
@@ -74,7 +101,12 @@ CASES = [("C1", scenes.scene_c1),
          ("C3 20k paths, 4096^2", lambda: scenes.scene_c3(20000, 4096)),
          ("1000 edge-to-edge strokes, 4096^2", lambda: scene_long_lines(1000, 4096)),
          ("200k rects of 2..6 px, 1920x1088", lambda: _hd(lambda: scene_tiny_rects(200000, 1920))),
-         ("one polygon, 200k vertices, 2048^2", lambda: scene_polygon(200000, 2048))]
+         ("one polygon, 200k vertices, 2048^2", lambda: scene_polygon(200000, 2048)),
+         ("40k solid fills (C3 without strokes), 4096^2", lambda: scenes.scene_c3(40000, 4096)),
+         ("40k linear-gradient fills, 4096^2", lambda: scene_gradients(40000, 4096, "linear")),
+         ("40k radial-gradient fills, 4096^2", lambda: scene_gradients(40000, 4096, "radial")),
+         ("40k sweep-gradient fills, 4096^2", lambda: scene_gradients(40000, 4096, "sweep")),
+         ("40k image fills, 4096^2", lambda: scene_gradients(40000, 4096, "image"))]
 
 
 def select(keys):

@@ -226,11 +226,17 @@ def scene_big_path(size=1024, n_zig=600, seed=SEED + 9):
     return s, RenderParams(size, size, base_color=(1, 1, 1, 1))
 
 
-def scene_fuzz(seed, size=256, n=40):
+def scene_fuzz(seed, size=256, n=40, extreme=False):
     """Random mixture of everything the pipeline handles: fills (both rules) and strokes (all joins / caps / widths,
     closed and open, lines / quads / cubics, degenerate segments), per-draw affine transforms, solid / linear / radial /
-    sweep / image brushes with all extend modes, nested clip layers with every mix mode.  Drives the parity fuzz test."""
-    r = SplitMix64(SEED + 1000 + seed)
+    sweep / image brushes with all extend modes, nested clip layers with every mix mode.  Drives the parity fuzz test.
+    extreme: coordinates far outside the target, scales from 0.02 to 40, stroke widths up to 300, up to 9 nested
+    layers (more than the 4 blend-stack entries fine keeps in registers: the spill buffer), twice the draws."""
+    r = SplitMix64(SEED + (5000 if extreme else 1000) + seed)
+    span_lo, span_hi = (-2.0 * size, 3.0 * size) if extreme else (0.0, float(size))
+    max_layers = 9 if extreme else 5
+    if extreme:
+        n *= 2
     s = Scene()
     img = (splitmix64_array(16 * 16 * 4, SEED + 2000 + seed) * 256.0).astype(np.uint8).reshape(16, 16, 4)
     open_layers = 0
@@ -240,16 +246,20 @@ def scene_fuzz(seed, size=256, n=40):
         if k == 0:
             return None
         a, sc = r.uniform(0, 2 * math.pi), r.uniform(0.4, 2.0)
+        if extreme and r.uniform() < 0.3:
+            sc = 10.0 ** r.uniform(-1.7, 1.6)
         c, sn = math.cos(a) * sc, math.sin(a) * sc
         return (c, sn, -sn, c * r.uniform(0.5, 1.5), r.uniform(0, size * 0.5), r.uniform(0, size * 0.5))
 
     def rnd_path(closed):
         p = Path()
-        x, y = r.uniform(0, size), r.uniform(0, size)
+        x, y = r.uniform(span_lo, span_hi), r.uniform(span_lo, span_hi)
+        if extreme and r.uniform() < 0.6:
+            x, y = r.uniform(0, size), r.uniform(0, size)
         p.move_to(x, y)
         for _ in range(1 + int(r.uniform(0, 5))):
             k = int(r.uniform(0, 4))
-            ext = r.uniform(2, size * 0.4)
+            ext = r.uniform(2, size * 0.4) if not extreme else 10.0 ** r.uniform(-2.0, math.log10(size * 2.0))
             nx, ny = x + r.uniform(-ext, ext), y + r.uniform(-ext, ext)
             if k == 0:
                 p.line_to(nx, ny)
@@ -283,7 +293,7 @@ def scene_fuzz(seed, size=256, n=40):
 
     for i in range(n):
         act = int(r.uniform(0, 10))
-        if act == 0 and open_layers < 5:
+        if (act == 0 or (extreme and act == 2)) and open_layers < max_layers:
             s.push_layer(Mix(int(r.uniform(0, 16))) if r.uniform() < 0.7 else Mix.Clip, Compose.SrcOver, r.uniform(0.3, 1.0), rnd_affine(),
                          Path.circle(r.uniform(0.2 * size, 0.8 * size), r.uniform(0.2 * size, 0.8 * size), r.uniform(0.3 * size, 0.8 * size)))
             open_layers += 1
@@ -294,7 +304,8 @@ def scene_fuzz(seed, size=256, n=40):
             s.fill(Fill.EvenOdd if r.uniform() < 0.3 else Fill.NonZero, rnd_affine(), rnd_brush(), rnd_affine() if r.uniform() < 0.3 else None,
                    rnd_path(True))
         else:
-            st = Stroke(r.uniform(0.3, 12.0), Join(int(r.uniform(0, 3))), r.uniform(1.0, 8.0), Cap(int(r.uniform(0, 3))), Cap(int(r.uniform(0, 3))))
+            wd = r.uniform(0.3, 12.0) if not extreme else 10.0 ** r.uniform(-1.5, 2.5)
+            st = Stroke(wd, Join(int(r.uniform(0, 3))), r.uniform(1.0, 8.0), Cap(int(r.uniform(0, 3))), Cap(int(r.uniform(0, 3))))
             s.stroke(st, rnd_affine(), rnd_brush(), None, rnd_path(r.uniform() < 0.4))
     while open_layers > 0:
         s.pop_layer()

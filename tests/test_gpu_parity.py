@@ -114,6 +114,18 @@ def test_fuzz_mixed_scenes(engine, seed):
     compare(engine, s, p)
 
 
+@pytest.mark.parametrize("seed", [1, 7, 8, 13, 20, 24])
+def test_fuzz_extreme_scenes(engine, seed):
+    """scene_fuzz(extreme=True): coordinates far outside the target, scales 0.02..40, stroke widths up to 300, up to nine
+    nested layers (seeds 1 and 7 reach the blend spill buffer of fine)."""
+    s, p = scenes.scene_fuzz(seed, extreme=True)
+    p.bump = BumpSizes(ptcl=1 << 22, blend_spill=1 << 18)
+    p.aa = [jello_amd.Aa.Area, jello_amd.Aa.Msaa8, jello_amd.Aa.Msaa16][seed % 3]
+    r = compare(engine, s, p)
+    if seed in (1, 7):
+        assert r["bump"]["blend"] > 0
+
+
 def test_non_multiple_of_16_target(engine):
     s, p = scenes.scene_c3(400, 256)
     p.width, p.height = 250, 199

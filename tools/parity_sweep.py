@@ -14,6 +14,8 @@ big = lambda: BumpSizes(lines=1 << 21, seg_counts=1 << 22, segments=1 << 22, til
 cases = []
 for seed in range(16, 64):
     cases.append(("fuzz %d" % seed, (lambda sd: lambda: scenes.scene_fuzz(sd))(seed), [Aa.Area, Aa.Msaa8, Aa.Msaa16][seed % 3]))
+for seed in range(32):
+    cases.append(("extreme fuzz %d" % seed, (lambda sd: lambda: scenes.scene_fuzz(sd, extreme=True))(seed), [Aa.Area, Aa.Msaa8, Aa.Msaa16][seed % 3]))
 cases += [("circles r 20..150 @1024", lambda: sh.scene_shapes(400, 20, 150, 1024), Aa.Area),
           ("circles r 200..1000 @2048", lambda: sh.scene_shapes(120, 200, 1000, 2048), Aa.Area),
           ("circles r 1000..2000 @2048", lambda: sh.scene_shapes(12, 1000, 2000, 2048), Aa.Msaa8),

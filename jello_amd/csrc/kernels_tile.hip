@@ -960,14 +960,14 @@ int jh_launch_path_count(const JhLaunch& L) {
     uint32_t* list = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)seg_cap * 4);
     uint32_t* list_base = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_E, (uint64_t)tiles_cap * 4);
     uint32_t* keys = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_F, (uint64_t)seg_cap * 4);
-    uint32_t* kpath = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_H, (uint64_t)seg_cap * 4);
+    uint32_t* kbig = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_H, (uint64_t)seg_cap * 4);
     uint32_t n_paths = paths.n;
     const uint32_t dense_cap = seg_cap / PC_DENSE_TILE + 1u;  // tiles with more than PC_DENSE_TILE crossings of a big path
     uint32_t* dense = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, (uint64_t)dense_cap * 4);
     if (!dense) return -5;
     // [pstart | pend | gate, number of dense tiles]: zeroed every frame (by k_pc_count) (the variables below keep the names of the path_range parameters)
     uint32_t* prange = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_I, ((uint64_t)n_paths * 2 + 64) * 4);
-    if (!counts || !bases || !tile_of || !list || !list_base || !keys || !kpath || !prange) return -5;
+    if (!counts || !bases || !tile_of || !list || !list_base || !keys || !kbig || !prange) return -5;
     uint32_t *pfirst = prange, *plast = prange + n_paths, *gate = prange + 2 * (size_t)n_paths;
     uint32_t gl = stride_grid(L, lines_cap), gs = stride_grid(L, seg_cap);
     hipLaunchKernelGGL(k_pc_count, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, paths, counts, lines_cap, prange,
@@ -978,16 +978,16 @@ int jh_launch_path_count(const JhLaunch& L) {
                        (const uint32_t*)bases, lines_cap, pfirst, plast, n_paths);
     const uint32_t *cpf = pfirst, *cpl = plast, *cc = counts, *cb = bases;
     hipLaunchKernelGGL(k_pc_emit, dim3(gl), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, ind, lines, paths, tile, segc, cb, lines_cap,
-                       tile_of, keys, kpath, seg_cap, cpf, cpl, cc, n_paths, gate);
+                       tile_of, keys, kbig, seg_cap, cpf, cpl, cc, n_paths, gate);
     // Big paths only (`gate` = number of tiles if there is one, else 0: the scan then covers 0 elements and the kernels
     // return at once):
     // per-tile list bases = exclusive scan of Tile.segment_count_or_ix, scatter into the lists, rank inside the list.
     rc = jh_scan_u32(L, ((const uint32_t*)tile.p) + 1, 2, list_base, tiles_cap, gate, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pc_scatter, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint2*)tile_of, seg_cap,
-                       (const uint32_t*)list_base, tiles_cap, list, (const uint32_t*)kpath, cpf, cpl, cc, cb, n_paths, gate, dense, dense_cap);
+                       (const uint32_t*)list_base, tiles_cap, list, (const uint32_t*)kbig, cpf, cpl, cc, cb, n_paths, gate, dense, dense_cap);
     hipLaunchKernelGGL(k_pc_rank, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint2*)tile_of, seg_cap,
-                       (const uint32_t*)list_base, tiles_cap, (const uint32_t*)list, segc, (const uint32_t*)kpath, cpf, cpl, cc, cb, n_paths,
+                       (const uint32_t*)list_base, tiles_cap, (const uint32_t*)list, segc, (const uint32_t*)kbig, cpf, cpl, cc, cb, n_paths,
                        (const uint32_t*)gate, (const uint32_t*)dense, dense_cap);
     // everything else: atomics-free ranks
     hipLaunchKernelGGL(k_pc_rank_small, dim3(stride_grid(L, (uint64_t)n_paths * 64u)), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile,

@@ -199,6 +199,12 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #ifndef FINE_LEAN_WAVES_PER_EU
 #define FINE_LEAN_WAVES_PER_EU 5  // 88 VGPRs; 6 (80 VGPRs, 7 spills) measured the same
 #endif
+#ifndef FINE_CLIP_WAVES_PER_EU
+#define FINE_CLIP_WAVES_PER_EU 2  // instantiations with the clip/blend stack in registers (219 VGPRs)
+#endif
+#ifndef FINE_CLIP_MS_WAVES_PER_EU
+#define FINE_CLIP_MS_WAVES_PER_EU 3  // the multisampled ones need fewer registers (C4 msaa16: 6.5 -> 5.6 ms; area AA at 3: 11 ms, spills)
+#endif
 #ifndef FINE_WAVES
 #define FINE_WAVES 2
 #endif
@@ -459,7 +465,7 @@ template <> struct FineLdsSel<0> { typedef FillLds type; };
 // Pixel ownership = the WGSL's: lane = ly*4 + lx (workgroup (4,16)), pixel i = 0..3 at column 4*lx + i.
 // AA = 0: analytic area coverage (fine_area); 8 / 16: fine_msaa8 / fine_msaa16.
 template <int AA, bool CLIPS, bool PAINTS>
-__global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu(CLIPS ? 2 : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU), CLIPS ? 2 : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU)))) void k_fine_area(const JlConfig* __restrict__ cfg, const float* __restrict__ segments, uint32_t segments_n,
+__global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu(CLIPS ? (AA != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU), CLIPS ? (AA != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU)))) void k_fine_area(const JlConfig* __restrict__ cfg, const float* __restrict__ segments, uint32_t segments_n,
                                                   const uint32_t* __restrict__ ptcl, uint32_t ptcl_n, const uint32_t* __restrict__ info,
                                                   uint32_t info_n, Buf<V4> blend_spill, uint16_t* __restrict__ output, uint32_t out_w,
                                                   uint32_t out_h, const uint16_t* __restrict__ gradients, uint32_t grad_h, FineImages images,

@@ -1040,20 +1040,23 @@ JD float fkey_inv(uint32_t k) { return u2f((k & 0x80000000u) ? (k & 0x7fffffffu)
 // box in LDS; finally lane g tests the extent and merges (integer min/max on the path boxes are order-free).
 __global__ __launch_bounds__(JL_WG) void k_flatten_bbox(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump,
                                                         const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines,
-                                                        Buf<JlPathBbox> path_bboxes) {
+                                                        Buf<JlPathBbox> path_bboxes, uint32_t tags_per_wave) {
+    // tags_per_wave (a power of two <= 64): 64 for large scenes; fewer when the scene has so few tags that 64 per wave
+    // would leave most of the device idle while a handful of waves stream all the lines (20 large circles: 37 us)
     __shared__ uint32_t sh_box[JL_WG / 64][64][4];
     const uint32_t n_tags = n_slots / 3u;
     const uint32_t total = umin_(umin_(bump->lines, cfg->lines_size), lines.n);
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t waves = (gridDim.x * JL_WG) >> 6;
-    for (uint32_t g0 = ((blockIdx.x * JL_WG + threadIdx.x) >> 6) * 64u; g0 < n_tags; g0 += waves * 64u) {
-        const uint32_t g = g0 + lane;
+    for (uint32_t g0 = ((blockIdx.x * JL_WG + threadIdx.x) >> 6) * tags_per_wave; g0 < n_tags; g0 += waves * tags_per_wave) {
+        const uint32_t g = g0 + umin_(lane, tags_per_wave - 1u);  // lanes behind the wave's tags repeat its last tag ...
         uint32_t lo = total, hi = total;
         if (g < n_tags) {
             lo = umin_(bases[3u * g], total);
             hi = (3u * g + 3u < n_slots) ? umin_(bases[3u * g + 3u], total) : total;
             if (hi < lo) hi = lo;
         }
+        if (lane >= tags_per_wave) lo = hi;  // ... with an empty range of their own
         const uint32_t LO = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
         const uint32_t HI = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
         sh_box[wv][lane][0] = fkey(1e31f); sh_box[wv][lane][1] = fkey(1e31f);
@@ -1184,8 +1187,11 @@ int jh_launch_flatten(const JhLaunch& L) {
     hipLaunchKernelGGL(k_flatten_lines, dim3(gp), dim3(JL_WG), 0, L.stream, cfg, scene, (const uint32_t*)counters, (const uint32_t*)tinfo,
                        (const uint4*)pieces, (const uint4*)ends, tcap, (const JlLineSoup*)tlines, (const uint2*)tkeys, (const uint32_t*)chunk_used,
                        g, FL_CHUNK, (const uint32_t*)bases, n_slots, lines);
-    uint32_t gb = (n_tags + JL_WG - 1) / JL_WG;  // one wave per 64 tags
-    if (gb > gp_cap) gb = gp_cap;
-    hipLaunchKernelGGL(k_flatten_bbox, dim3(gb), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, (const uint32_t*)bases, n_slots, lines, pb);
+    uint32_t tags_per_wave = 64u;  // fewer when that would give the device less than one wave per SIMD
+    while (tags_per_wave > 1u && n_tags / tags_per_wave < gp_cap / 2u) tags_per_wave >>= 1;
+    uint64_t gb64 = ((uint64_t)(n_tags + tags_per_wave - 1u) / tags_per_wave + 3u) / 4u;  // four waves per workgroup
+    uint32_t gb = gb64 > gp_cap ? gp_cap : (uint32_t)gb64;
+    hipLaunchKernelGGL(k_flatten_bbox, dim3(gb), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, (const uint32_t*)bases, n_slots, lines, pb,
+                       tags_per_wave);
     return 0;
 }

@@ -93,6 +93,12 @@ const char* jh_stage_name(int stage);
 /* Run on a caller-owned HIP stream (e.g. torch's current stream); NULL = the context's own. */
 int jh_set_stream(jh_ctx* ctx, void* hip_stream);
 int jh_sync(jh_ctx* ctx);
+/* Band mode (sharding ONE target over several GPUs): this context writes the PTCL and rasterises only the
+ * bin rows [bin_row0, bin_row1) (a bin row = 16 tile rows = 256 pixel rows).  Every other stage, and the counting pass
+ * of coarse, still covers the whole scene, so all allocation offsets -- hence every PTCL word and segment index of the
+ * band -- are those of the unsharded run; the target image is written in the band's rows only.  (0, UINT32_MAX) = whole
+ * target (default).  The reference has no counterpart: one wgpu device renders the whole target (render.go:399-434). */
+int jh_set_band(jh_ctx* ctx, uint32_t bin_row0, uint32_t bin_row1);
 
 /* ---- buffers (ids are the recording's ResourceIDs; sizes in bytes) ---- */
 int jh_buffer_create(jh_ctx* ctx, uint64_t id, uint64_t size);

@@ -174,6 +174,7 @@ def _declare(L):
     hip.jh_image_device_ptr.argtypes = [vp, ctypes.c_uint64]
     hip.jh_sync.argtypes = [vp]
     hip.jh_set_stream.argtypes = [vp, vp]
+    hip.jh_set_band.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32]
     hip.jh_profile_enable.argtypes = [vp, ci]
     hip.jh_profile_collect.argtypes = [vp, vp, ci]
     hip.jh_graph_begin.argtypes = [vp]

@@ -56,6 +56,7 @@ struct jh_ctx {
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> free_events;
     std::string last_error;
+    uint32_t band_row0 = 0u, band_row1 = 0xffffffffu;  // jh_set_band
 };
 
 static int fail(jh_ctx* ctx, int code, const std::string& msg) {
@@ -178,6 +179,13 @@ const char* jh_last_error(jh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : 
 int jh_set_stream(jh_ctx* ctx, void* hip_stream) {
     if (!ctx) return JH_ERR_INVALID;
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return JH_OK;
+}
+
+int jh_set_band(jh_ctx* ctx, uint32_t bin_row0, uint32_t bin_row1) {
+    if (!ctx || bin_row1 < bin_row0) return JH_ERR_INVALID;
+    ctx->band_row0 = bin_row0;
+    ctx->band_row1 = bin_row1;
     return JH_OK;
 }
 
@@ -427,6 +435,8 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
     L.indirect = indirect;
     L.num_cus = ctx->num_cus;
     L.cfg_host = nullptr;
+    L.band_row0 = ctx->band_row0;
+    L.band_row1 = ctx->band_row1;
     if (n_bindings > 0 && bindings[0].kind == JH_BIND_BUFFER) {
         auto sh = ctx->config_shadow.find(bindings[0].id);
         if (sh != ctx->config_shadow.end()) L.cfg_host = &sh->second;

@@ -200,6 +200,7 @@ struct JhLaunch {
     const uint32_t* indirect;  // device pointer to IndirectCount (indirect dispatch) or nullptr
     int num_cus;
     const JlConfig* cfg_host;  // host shadow of the uploaded ConfigUniform bound at index 0, or nullptr
+    uint32_t band_row0, band_row1;  // jh_set_band: bin rows [row0, row1) this context writes PTCL for and rasterises (0, ~0u = all)
 };
 
 enum {  // scratch slots

@@ -96,7 +96,10 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                                                   JlBump* __restrict__ bump, Buf<uint32_t> ptcl, uint32_t* __restrict__ cnt_seg,
                                                   uint32_t* __restrict__ cnt_chunk, uint32_t* __restrict__ cnt_blend,
                                                   const uint32_t* __restrict__ base_seg, const uint32_t* __restrict__ base_chunk,
-                                                  const uint32_t* __restrict__ base_blend) {
+                                                  const uint32_t* __restrict__ base_blend, uint32_t bin_row0) {
+    // bin_row0: first bin row of the launch (band mode writes the PTCL of its band only; the counting pass always
+    // covers the whole target, so that every allocation base is the one of the unsharded run)
+    const uint32_t bin_y = blockIdx.y + bin_row0;
     __shared__ uint32_t sh_bitmaps[8][JL_N_TILE];
     __shared__ uint32_t sh_part_count[JL_WG];
     __shared__ uint32_t sh_part_offsets[JL_WG];
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
 
     const uint32_t lid = threadIdx.x;
     const uint32_t width_in_bins = (cfg->width_in_tiles + JL_N_TILE_X - 1u) / JL_N_TILE_X;
-    const uint32_t bin_ix = width_in_bins * blockIdx.y + blockIdx.x;
+    const uint32_t bin_ix = width_in_bins * bin_y + blockIdx.x;
     const uint32_t slot = bin_ix * JL_N_TILE + lid;  // position in the canonical (bin, tile) order
 
     {  // coarse.wgsl:161-176
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     }
     const uint32_t n_partitions = (cfg->layout.n_drawobj + JL_N_TILE - 1u) / JL_N_TILE;
     const uint32_t bin_tile_x = JL_N_TILE_X * blockIdx.x;
-    const uint32_t bin_tile_y = JL_N_TILE_Y * blockIdx.y;
+    const uint32_t bin_tile_y = JL_N_TILE_Y * bin_y;
     const uint32_t tile_x = lid % JL_N_TILE_X;
     const uint32_t tile_y = lid / JL_N_TILE_X;
     const uint32_t this_tile_ix = (bin_tile_y + tile_y) * cfg->width_in_tiles + bin_tile_x + tile_x;
@@ -418,14 +421,17 @@ int jh_launch_coarse(const JhLaunch& L) {
     JlBump* bump = (JlBump*)L.b[7].ptr;
     auto ptcl = mkbuf<uint32_t>(L.b[8].ptr, L.b[8].size);
     dim3 grid(L.gx, L.gy), blk(JL_WG);
+    const uint32_t row0 = L.band_row0 < L.gy ? L.band_row0 : L.gy, row1 = L.band_row1 < L.gy ? L.band_row1 : L.gy;
+    dim3 grid_w(L.gx, row1 > row0 ? row1 - row0 : 0u);
     const bool clips = !(L.cfg_host && L.cfg_host->layout.n_clip == 0u);  // host shadow of the uploaded ConfigUniform
-#define JH_COARSE(W, C, ...) hipLaunchKernelGGL((k_coarse<W, C>), grid, blk, 0, L.stream, cfg, scene, dm, bh, ibd, paths, tiles, bump, ptcl, __VA_ARGS__)
-    if (clips) JH_COARSE(false, true, cnt_seg, cnt_chunk, cnt_blend, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-    else JH_COARSE(false, false, cnt_seg, cnt_chunk, cnt_blend, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+#define JH_COARSE(W, C, G, ...) hipLaunchKernelGGL((k_coarse<W, C>), G, blk, 0, L.stream, cfg, scene, dm, bh, ibd, paths, tiles, bump, ptcl, __VA_ARGS__)
+    if (clips) JH_COARSE(false, true, grid, cnt_seg, cnt_chunk, cnt_blend, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
+    else JH_COARSE(false, false, grid, cnt_seg, cnt_chunk, cnt_blend, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
     int rc = jh_scan3_u32(L, cnt_seg, base_seg, n, &bump->segments, &bump->ptcl, &bump->blend);
     if (rc) return rc;
-    if (clips) JH_COARSE(true, true, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend);
-    else JH_COARSE(true, false, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend);
+    if (grid_w.y == 0u) return 0;
+    if (clips) JH_COARSE(true, true, grid_w, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend, row0);
+    else JH_COARSE(true, false, grid_w, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend, row0);
 #undef JH_COARSE
     return 0;
 }

@@ -469,7 +469,9 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
                                                   const uint32_t* __restrict__ ptcl, uint32_t ptcl_n, const uint32_t* __restrict__ info,
                                                   uint32_t info_n, Buf<V4> blend_spill, uint16_t* __restrict__ output, uint32_t out_w,
                                                   uint32_t out_h, const uint16_t* __restrict__ gradients, uint32_t grad_h, FineImages images,
-                                                  uint32_t tiles_x, const uint32_t* __restrict__ mask_lut, uint32_t mask_lut_n) {
+                                                  uint32_t tiles_x, const uint32_t* __restrict__ mask_lut, uint32_t mask_lut_n,
+                                                  uint32_t tile_row0) {  // first tile row of the launch (band mode)
+    const uint32_t tile_y = blockIdx.y + tile_row0;
     // FINE_WAVES independent waves (= tiles, side by side in x) per workgroup: the CU runs at most 16 workgroups, so
     // single-wave workgroups would cap the occupancy at 4 waves per SIMD.  The waves never synchronise with each other.
     __shared__ uint32_t win_all[FINE_WAVES][JL_PTCL_INCREMENT];  // wave-private PTCL windows
@@ -482,9 +484,9 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
     if (ptcl_n == 0u || ptcl[0] == ~0u) return;  // fine.wgsl:889-893
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t ly = lane >> 2, lx = lane & 3u;
-    const uint32_t tile_ix = blockIdx.y * cfg->width_in_tiles + tile_x;
+    const uint32_t tile_ix = tile_y * cfg->width_in_tiles + tile_x;
     const float xyx = (float)((tile_x * 4u + lx) * 4u);  // WGSL xy.x = f32(global_id.x * 4)
-    const float xyy = (float)(blockIdx.y * 16u + ly);         // WGSL xy.y
+    const float xyy = (float)(tile_y * 16u + ly);         // WGSL xy.y
     V4 rgba[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) rgba[k] = v4(cfg->base_color[0], cfg->base_color[1], cfg->base_color[2], cfg->base_color[3]);
@@ -983,7 +985,7 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
     }
     // fine.wgsl:1092-1102: un-premultiply, store RGBA16F (four adjacent pixels = 32 bytes per lane; 4 lanes = one 128-B row)
     const uint32_t cx0 = tile_x * 16u + lx * 4u;
-    const uint32_t cy = blockIdx.y * 16u + ly;
+    const uint32_t cy = tile_y * 16u + ly;
     if (cy < out_h) {
         uint32_t packed[8];
 #pragma unroll
@@ -1043,12 +1045,16 @@ static int launch_fine(const JhLaunch& L, int aa) {
     // instead of 109 VGPRs (6 instead of 4 waves per SIMD; the kernel is latency-bound).
     bool paints = grad_h != 0u;
     for (int i = 0; i < imgs.n; i++) paints = paints || imgs.px[i] != nullptr;
+    // band mode: tile rows of the context's bin rows (a bin row = JL_N_TILE_Y tile rows)
+    const uint64_t tr0 = (uint64_t)L.band_row0 * JL_N_TILE_Y, tr1 = (uint64_t)L.band_row1 * JL_N_TILE_Y;
+    const uint32_t trow0 = tr0 < L.gy ? (uint32_t)tr0 : L.gy, trow1 = tr1 < L.gy ? (uint32_t)tr1 : L.gy;
+    if (trow1 <= trow0) return 0;
     const float* seg_ptr = (segments_n != 0u && L.b[1].ptr) ? (const float*)L.b[1].ptr : (const float*)cfg;  // see load_segraw_clamped
     if (seg_ptr == (const float*)cfg) segments_n = 0u;
 #define JH_FINE_LAUNCH(A, C, P)                                                                                                          \
-    hipLaunchKernelGGL((k_fine_area<A, C, P>), dim3((L.gx + FINE_WAVES - 1) / FINE_WAVES, L.gy), dim3(64 * FINE_WAVES), 0, L.stream, cfg, seg_ptr, \
+    hipLaunchKernelGGL((k_fine_area<A, C, P>), dim3((L.gx + FINE_WAVES - 1) / FINE_WAVES, trow1 - trow0), dim3(64 * FINE_WAVES), 0, L.stream, cfg, seg_ptr, \
                        segments_n, (const uint32_t*)L.b[2].ptr, ptcl_n, (const uint32_t*)L.b[3].ptr, info_n, spill, (uint16_t*)out.ptr,         \
-                       out.width, out.height, (const uint16_t*)grad.ptr, grad_h, imgs, L.gx, mask_lut, mask_lut_n)
+                       out.width, out.height, (const uint16_t*)grad.ptr, grad_h, imgs, L.gx, mask_lut, mask_lut_n, trow0)
 #define JH_FINE_PICK(A)                                  \
     do {                                                 \
         if (clips && paints) JH_FINE_LAUNCH(A, true, true);   \

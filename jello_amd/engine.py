@@ -176,6 +176,14 @@ class Engine:
     def set_stream(self, stream_ptr):
         self._check(self.hip.jh_set_stream(self.ctx, stream_ptr), "set_stream")
 
+    def clear(self, buf_id, offset=0, size=-1):
+        self._check(self.hip.jh_clear(self.ctx, buf_id, offset, size), "clear")
+
+    def set_band(self, bin_row0=0, bin_row1=0xffffffff):
+        """Band mode (sharding.band_for_rank): write the PTCL and rasterise only the bin rows [bin_row0, bin_row1);
+        no arguments = the whole target."""
+        self._check(self.hip.jh_set_band(self.ctx, int(bin_row0), int(bin_row1)), "set_band")
+
     def download(self, buf_id, nbytes=None, offset=0, dtype=np.uint8):
         size = self.hip.jh_buffer_size(self.ctx, buf_id)
         if nbytes is None:

@@ -126,6 +126,59 @@ def test_fuzz_extreme_scenes(engine, seed):
         assert r["bump"]["blend"] > 0
 
 
+@pytest.mark.parametrize("which,world", [("c3", 3), ("c4", 2), ("fuzz", 4)])
+def test_band_mode_reassembles_the_unsharded_frame(engine, which, world):
+    """SURVEY 8e, second way: every "rank" runs the element stages on the whole scene and coarse(write)+fine only for its
+    band of bin rows (Engine.set_band); bump allocators and the PTCL words of the band are those of the unsharded run
+    and the bands stitched together are the unsharded image, bit for bit.  (The ranks run one after the other here.)"""
+    from jello_amd import sharding
+    from jello_amd.engine import RUN_DISPATCHES, RUN_UPLOADS
+    if which == "c3":
+        s, p = scenes.scene_c3(3000, 1024)
+    elif which == "c4":
+        s, p = scenes.scene_c4(600, 768)
+    else:
+        s, p = scenes.scene_fuzz(5, size=1100, n=120)
+    p.bump = BumpSizes(ptcl=1 << 23, blend_spill=1 << 20)
+    host = jello_amd.Host()
+    rec = host.record(s, p)
+    t = rec.target
+    engine.run(rec, RUN_UPLOADS | RUN_DISPATCHES)
+    engine.sync()
+    full = engine.download_image(t["id"], t["width"], t["height"]).copy()
+    full_bump = engine.download(rec.buffer("bumpBuf")[0], dtype=np.uint32)[:8].copy()
+    full_ptcl = engine.download(rec.buffer("ptclBuf")[0], dtype=np.uint32).copy()
+    assert full_bump[0] == 0
+    from parity import ptcl_walk
+    hb = (rec.config["height_in_tiles"] + 15) // 16
+    live_full = ptcl_walk(full_ptcl, rec.config)
+    live_union = np.zeros_like(live_full)
+    stitched = np.zeros_like(full)
+    try:
+        for rank in range(world):
+            y0, y1 = sharding.band_for_rank(hb, world, rank)
+            engine.set_band(y0, y1)
+            engine.clear(rec.buffer("ptclBuf")[0])  # whatever is live afterwards was written by this run
+            engine.run(rec, RUN_UPLOADS | RUN_DISPATCHES)
+            engine.sync()
+            img = engine.download_image(t["id"], t["width"], t["height"])
+            stitched[y0 * 256:y1 * 256] = img[y0 * 256:y1 * 256]
+            assert np.array_equal(engine.download(rec.buffer("bumpBuf")[0], dtype=np.uint32)[:8], full_bump)
+            ptcl = engine.download(rec.buffer("ptclBuf")[0], dtype=np.uint32)
+            live = ptcl_walk(ptcl, rec.config)  # tiles outside the band: an all-zero head, i.e. CMD_END at once
+            wt, ht = rec.config["width_in_tiles"], rec.config["height_in_tiles"]
+            live[:y0 * 16 * wt * 64] = False                       # ... whose two head words are not this band's business
+            live[min(y1 * 16, ht) * wt * 64:wt * ht * 64] = False
+            assert live.any() and not (live & ~live_full).any()
+            assert np.array_equal(ptcl[live], full_ptcl[live])
+            live_union |= live
+    finally:
+        engine.set_band()
+    assert np.array_equal(live_union & live_full, live_full)  # every live word of the unsharded PTCL was written by some band
+    assert np.array_equal(stitched.view(np.uint16), full.view(np.uint16))
+    engine.release(rec)
+
+
 def test_non_multiple_of_16_target(engine):
     s, p = scenes.scene_c3(400, 256)
     p.width, p.height = 250, 199

@@ -37,6 +37,11 @@ def main():
     ap.add_argument("--aa", choices=["area", "msaa8", "msaa16"], default="area", help="coverage mode of the fine stage (the headline is area)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="N > 1: also gather every rank's image to rank 0 (RCCL, asynchronous)")
+    ap.add_argument("--bands", action="store_true",
+                    help="N > 1: ONE scene, every rank runs the element stages on it and coarse+fine for its band of bin rows "
+                         "(strong scaling of one frame; SURVEY 8e) instead of one independent scene per rank")
+    ap.add_argument("--emulate-band-of", type=int, default=0, metavar="N",
+                    help="with --bands on ONE GPU: time what rank N/2 of an N-GPU band job would do (its band of the frame)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     args = ap.parse_args()
 
@@ -59,7 +64,7 @@ def main():
 
     W = H = args.size
     # independent scene per rank (same generator, different seed)
-    scene, params = scenes.scene_c3(args.paths, args.size, seed=scenes.SEED + rank)
+    scene, params = scenes.scene_c3(args.paths, args.size, seed=scenes.SEED + (0 if args.bands else rank))
     params.aa = {"area": jello_amd.Aa.Area, "msaa8": jello_amd.Aa.Msaa8, "msaa16": jello_amd.Aa.Msaa16}[args.aa]
     fine_stage = {"area": "fine_area", "msaa8": "fine_msaa8", "msaa16": "fine_msaa16"}[args.aa]
     eng = jello_amd.Engine(dev.index)
@@ -87,6 +92,12 @@ def main():
     if world > 1 and rank == 0 and args.gather:
         gathered = [[torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(world)] for _ in range(2)]
 
+    if args.bands:  # (buffers were sized by the unsharded render above; from here on this rank owns its band only)
+        from jello_amd import sharding
+        if world == 1 and args.emulate_band_of > 1:
+            eng.set_band(*sharding.band_for_rank((cfg["height_in_tiles"] + 15) // 16, args.emulate_band_of, args.emulate_band_of // 2))
+        else:
+            eng.set_band(*sharding.band_for_rank((cfg["height_in_tiles"] + 15) // 16, world, rank))
     eng.run(rec, RUN_UPLOADS | RUN_DISPATCHES, outs[0].data_ptr())  # uploads scene/config; allocates every buffer
     torch.cuda.synchronize(dev)
 
@@ -200,19 +211,23 @@ def main():
                 roofline["traffic"] = json.load(open(pm)).get("hbm_bytes_per_launch")
             except Exception:
                 pass
+        if args.bands and (world > 1 or args.emulate_band_of > 1):  # one band only: the whole-target byte count does not apply
+            roofline = None
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(host)
-        mpix = W * H * world / (elapsed / args.steps) / 1e6
+        units = 1 if args.bands else world  # frames finished per step by the whole job
+        mpix = W * H * units / (elapsed / args.steps) / 1e6
         result = {
             "metric": "Mpixels/sec fine-raster + paths/sec, 100k-path 4096^2 scene", "value": round(mpix, 2), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if args.bands else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C3: %d random stroked+filled cubic Beziers, %dx%d RGBA16F target, %s AA, one independent scene per GPU"
                                    % (args.paths, W, H, args.aa),
                        "paths": args.paths, "draw_objects": cfg["n_drawobj"], "width": W, "height": H,
-                       "parallelism": "scene-per-gpu x%d%s" % (world, "" if world == 1 or not args.gather else " + RCCL image gather")},
-            "paths_per_s": round(args.paths * world / (elapsed / args.steps), 1),
+                       "parallelism": ("bin-row bands of one scene x%d" % world) if args.bands else
+                                      "scene-per-gpu x%d%s" % (world, "" if world == 1 or not args.gather else " + RCCL image gather")},
+            "paths_per_s": round(args.paths * units / (elapsed / args.steps), 1),
             "fine_mpixels_per_s": round(W * H / (fine_ms * 1e-3) / 1e6, 2),
             "launch": "hipGraph replay" if use_graph else "eager",
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},

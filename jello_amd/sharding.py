@@ -4,7 +4,7 @@ Two modes, neither needs a collective on the data path:
   * scenes: independent scenes, one per rank (weak scaling) -- `scene_seed_for_rank`;
   * bands:  disjoint bin-row bands of ONE target -- every rank runs the cheap element stages on the
             whole scene (replicated, so allocation scans and hence PTCL addresses are identical on
-            every rank) and coarse+fine only for its band -- `band_for_rank`.
+            every rank) and coarse's write pass + fine only for its band -- `band_for_rank` + `Engine.set_band`.
 The only (optional: `bench.py --gather`) exchange is the final image gather to rank 0 (`gather_images`): RCCL on GPUs ("nccl"
 backend), gloo in the CPU tests.
 """

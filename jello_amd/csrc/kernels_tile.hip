@@ -551,8 +551,6 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restr
 __global__ __launch_bounds__(JL_WG) void k_pc_scatter(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
                                                       const uint2* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
                                                       uint32_t tiles_cap, uint32_t* __restrict__ list, const uint32_t* __restrict__ kbig,
-                                                      const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ plast,
-                                                      const uint32_t* __restrict__ counts, const uint32_t* __restrict__ seg_bases, uint32_t n_paths,
                                                       uint32_t* __restrict__ gate, uint32_t* __restrict__ dense, uint32_t dense_cap) {
     if (*gate == 0u) return;  // no big path in this frame
     uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
@@ -587,9 +585,7 @@ __global__ __launch_bounds__(JL_WG) void k_pc_scatter(const JlConfig* __restrict
 __global__ __launch_bounds__(JL_WG) void k_pc_rank(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
                                                    const uint2* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
                                                    uint32_t tiles_cap, const uint32_t* __restrict__ list, Buf<JlSegmentCount> seg_counts,
-                                                   const uint32_t* __restrict__ kbig, const uint32_t* __restrict__ pfirst,
-                                                   const uint32_t* __restrict__ plast, const uint32_t* __restrict__ counts,
-                                                   const uint32_t* __restrict__ seg_bases, uint32_t n_paths, const uint32_t* __restrict__ gate,
+                                                   const uint32_t* __restrict__ kbig, const uint32_t* __restrict__ gate,
                                                    const uint32_t* __restrict__ dense, uint32_t dense_cap) {
     __shared__ uint32_t sh_list[JL_WG / 64][PC_DENSE_LDS];
     if (*gate == 0u) return;  // no big path in this frame
@@ -985,10 +981,10 @@ int jh_launch_path_count(const JhLaunch& L) {
     rc = jh_scan_u32(L, ((const uint32_t*)tile.p) + 1, 2, list_base, tiles_cap, gate, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pc_scatter, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint2*)tile_of, seg_cap,
-                       (const uint32_t*)list_base, tiles_cap, list, (const uint32_t*)kbig, cpf, cpl, cc, cb, n_paths, gate, dense, dense_cap);
+                       (const uint32_t*)list_base, tiles_cap, list, (const uint32_t*)kbig, gate, dense, dense_cap);
     hipLaunchKernelGGL(k_pc_rank, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint2*)tile_of, seg_cap,
-                       (const uint32_t*)list_base, tiles_cap, (const uint32_t*)list, segc, (const uint32_t*)kbig, cpf, cpl, cc, cb, n_paths,
-                       (const uint32_t*)gate, (const uint32_t*)dense, dense_cap);
+                       (const uint32_t*)list_base, tiles_cap, (const uint32_t*)list, segc, (const uint32_t*)kbig, (const uint32_t*)gate,
+                       (const uint32_t*)dense, dense_cap);
     // everything else: atomics-free ranks
     hipLaunchKernelGGL(k_pc_rank_small, dim3(stride_grid(L, (uint64_t)n_paths * 64u)), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile,
                        (const uint32_t*)keys, seg_cap, cpf, cpl, cc, cb, n_paths, segc);

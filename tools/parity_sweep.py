@@ -25,7 +25,10 @@ cases += [("circles r 20..150 @1024", lambda: sh.scene_shapes(400, 20, 150, 1024
           ("gradients linear @1024", lambda: sh.scene_gradients(3000, 1024, "linear"), Aa.Area),
           ("gradients radial @1024", lambda: sh.scene_gradients(3000, 1024, "radial"), Aa.Msaa16),
           ("gradients sweep @1024", lambda: sh.scene_gradients(3000, 1024, "sweep"), Aa.Area),
-          ("images @1024", lambda: sh.scene_gradients(3000, 1024, "image"), Aa.Area)]
+          ("images @1024", lambda: sh.scene_gradients(3000, 1024, "image"), Aa.Area),
+          ("glyphs @1280x720", lambda: sh.scene_glyphs(4000, 1280, 720), Aa.Area),
+          ("glyphs msaa16 @1280x720", lambda: sh.scene_glyphs(4000, 1280, 720), Aa.Msaa16),
+          ("wide 16384x1024", lambda: sh._wide(), Aa.Area)]
 sel = sys.argv[1:]
 bad = 0
 for name, mk, aa in cases:

@@ -84,6 +84,36 @@ def scene_gradients(n, size, kind, seed=81):
     return s, RenderParams(size, size, base_color=(0, 0, 0, 1))
 
 
+def scene_glyphs(n, w, h, seed=82):
+    """n glyph-like outlines: closed paths of 6..14 quadratic segments inside 8..28 px boxes (two contours for every third
+    one, filled even-odd), laid out on text lines."""
+    r = SplitMix64(seed)
+    s = Scene()
+    x, y = 8.0, 30.0
+    for i in range(n):
+        size = r.uniform(8, 28)
+        p = Path()
+        for contour in range(2 if i % 3 == 0 else 1):
+            k = 6 + int(r.uniform(0, 9))
+            rad = size * (0.5 if contour == 0 else 0.22)
+            cx, cy = x + size * 0.5, y - size * 0.5
+            pts = [(cx + rad * math.cos(2 * math.pi * j / k) * r.uniform(0.6, 1.0), cy + rad * math.sin(2 * math.pi * j / k) * r.uniform(0.6, 1.0))
+                   for j in range(k)]
+            p.move_to(*pts[0])
+            for j in range(k):
+                a, b = pts[j], pts[(j + 1) % k]
+                p.quad_to((a[0] + b[0]) * 0.5 + r.uniform(-2, 2), (a[1] + b[1]) * 0.5 + r.uniform(-2, 2), b[0], b[1])
+            p.close()
+        s.fill(Fill.EvenOdd, None, Brush.solid((0.05, 0.05, 0.1, 1.0)), None, p)
+        x += size * 0.9
+        if x > w - 40:
+            x = 8.0
+            y += 34.0
+            if y > h - 8:
+                y = 30.0
+    return s, RenderParams(w, h, base_color=(1, 1, 1, 1))
+
+
 def big_buffers():
     return BumpSizes(lines=1 << 23, seg_counts=1 << 24, segments=1 << 24, tiles=1 << 24, ptcl=1 << 27, bin_data=1 << 22, blend_spill=1 << 20)
 
@@ -106,7 +136,21 @@ CASES = [("C1", scenes.scene_c1),
          ("40k linear-gradient fills, 4096^2", lambda: scene_gradients(40000, 4096, "linear")),
          ("40k radial-gradient fills, 4096^2", lambda: scene_gradients(40000, 4096, "radial")),
          ("40k sweep-gradient fills, 4096^2", lambda: scene_gradients(40000, 4096, "sweep")),
-         ("40k image fills, 4096^2", lambda: scene_gradients(40000, 4096, "image"))]
+         ("40k image fills, 4096^2", lambda: scene_gradients(40000, 4096, "image")),
+         ("50k glyph outlines, 3840x2160", lambda: scene_glyphs(50000, 3840, 2160)),
+         ("C3-like 30k paths, 16384x1024", lambda: _wide())]
+
+
+def _wide():
+    r = SplitMix64(83)
+    s = Scene()
+    for i in range(30000):
+        ax, ay = r.uniform(0, 16384), r.uniform(0, 1024)
+        p = Path().move_to(ax, ay)
+        p.cubic_to(ax + r.uniform(-32, 32), ay + r.uniform(-32, 32), ax + r.uniform(-32, 32), ay + r.uniform(-32, 32),
+                   ax + r.uniform(-32, 32), ay + r.uniform(-32, 32))
+        s.fill(Fill.NonZero, None, Brush.solid((r.uniform(), r.uniform(), r.uniform(), 0.8)), None, p)
+    return s, RenderParams(16384, 1024, base_color=(0, 0, 0, 1))
 
 
 def select(keys):

@@ -154,8 +154,11 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     const uint32_t blend_offset = c.cmd_offset;
     c.cmd_offset += 1u;
 
-    for (;;) {
-        for (uint32_t i = 0; i < 8u; i++) sh_bitmaps[i][lid] = 0u;
+    // The batch loop is software-pipelined: an element's record needs three dependent memory round trips (bin_data ->
+    // tag / draw monoid -> info, draw data, path), which used to sit in front of every batch.  Now the next batch is
+    // gathered and its first-level loads are issued before this batch's include test, its second-level loads before
+    // this batch's command walk, and the record is complete when the walk is.
+    auto gather = [&]() -> uint32_t {  // coarse.wgsl:201-241: this thread's element of the next batch (~0u: none)
         for (;;) {
             if (ready_ix == wr_ix && partition_ix < n_partitions) {
                 part_start_ix = ready_ix;
@@ -188,25 +191,38 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             if (wr_ix - rd_ix >= JL_N_TILE || (wr_ix >= ready_ix && partition_ix >= n_partitions)) break;
             __syncthreads();
         }
-        // sh_drawobj_ix[0 .. wr_ix - rd_ix) holds the merged binning results of this batch.
-        uint32_t tag = JL_DRAWTAG_NOP;
-        uint32_t drawobj_ix = 0u;
-        if (lid + rd_ix < wr_ix) {
-            drawobj_ix = sh_drawobj_ix[lid];
-            tag = scene.rd(cfg->layout.drawtag_base + drawobj_ix);
+        // sh_drawobj_ix[0 .. wr_ix - rd_ix) holds the merged binning results of the batch (every thread its own slot).
+        return (lid + rd_ix < wr_ix) ? sh_drawobj_ix[lid] : 0xffffffffu;
+    };
+    // first-level loads of an element: tag and draw monoid
+    uint32_t n_obj = 0xffffffffu, n_tag = JL_DRAWTAG_NOP;
+    JlDrawMonoid n_dm;
+    n_dm.path_ix = 0u; n_dm.clip_ix = 0u; n_dm.scene_offset = 0u; n_dm.info_offset = 0u;
+    auto stage1 = [&](uint32_t obj) {
+        n_obj = obj;
+        n_tag = JL_DRAWTAG_NOP;
+        if (obj != 0xffffffffu) {
+            n_tag = scene.rd(cfg->layout.drawtag_base + obj);
+            n_dm = draw_monoids.rd(obj);
         }
-        uint32_t tile_count = 0u;
-        uint4 r0 = make_uint4(tag, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0u, 0u), r2 = make_uint4(0u, 0u, 0u, 0u);
+    };
+    // second-level loads and the record (r1.z is filled in after the batch's tile-count scan)
+    uint4 n_r0 = make_uint4(JL_DRAWTAG_NOP, 0u, 0u, 0u), n_r1 = make_uint4(0u, 0u, 0u, 0u), n_r2 = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t n_tile_count = 0u;
+    auto stage2 = [&]() {
+        const uint32_t tag = n_tag;
+        n_tile_count = 0u;
+        n_r0 = make_uint4(tag, 0u, 0u, 0u); n_r1 = make_uint4(0u, 0u, 0u, 0u); n_r2 = make_uint4(0u, 0u, 0u, 0u);
         if (tag != JL_DRAWTAG_NOP && !(COARSE_EXP & 4)) {
-            JlDrawMonoid dm0 = draw_monoids.rd(drawobj_ix);
+            const JlDrawMonoid dm0 = n_dm;
             uint32_t path_ix = dm0.path_ix;
             uint32_t dd0 = cfg->layout.drawdata_base + dm0.scene_offset;
-            r1.w = dm0.info_offset;
-            r0.y = info_bin_data.rd(dm0.info_offset);
-            r2 = make_uint4(scene.rd(dd0), scene.rd(dd0 + 1u), scene.rd(dd0 + 2u), scene.rd(dd0 + 3u));
+            n_r1.w = dm0.info_offset;
+            n_r0.y = info_bin_data.rd(dm0.info_offset);
+            n_r2 = make_uint4(scene.rd(dd0), scene.rd(dd0 + 1u), scene.rd(dd0 + 2u), scene.rd(dd0 + 3u));
             JlPath path = paths.rd(path_ix);
             uint32_t stride = path.bbox[2] - path.bbox[0];
-            r0.w = stride;
+            n_r0.w = stride;
             int32_t dx = (int32_t)path.bbox[0] - (int32_t)bin_tile_x;
             int32_t dy = (int32_t)path.bbox[1] - (int32_t)bin_tile_y;
             int32_t x0 = iclamp_(dx, 0, JL_N_TILE_X);
@@ -215,18 +231,28 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             int32_t y1 = iclamp_((int32_t)path.bbox[3] - (int32_t)bin_tile_y, 0, JL_N_TILE_Y);
             {   // width (<= 16) and ceil(2^16 / width): the include test divides pair indices (< 4096) by the width
                 const uint32_t wdt = (uint32_t)(x1 - x0);
-                r1.y = wdt | ((wdt ? (65536u + wdt - 1u) / wdt : 0u) << 5);
+                n_r1.y = wdt | ((wdt ? (65536u + wdt - 1u) / wdt : 0u) << 5);
             }
-            r1.x = (uint32_t)x0 | ((uint32_t)y0 << 16);
-            tile_count = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
-            r0.z = path.tiles - (uint32_t)(dy * (int32_t)stride + dx);
+            n_r1.x = (uint32_t)x0 | ((uint32_t)y0 << 16);
+            n_tile_count = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
+            n_r0.z = path.tiles - (uint32_t)(dy * (int32_t)stride + dx);
         }
+    };
+    stage1(gather());
+    stage2();
+    for (;;) {
+        for (uint32_t i = 0; i < 8u; i++) sh_bitmaps[i][lid] = 0u;
+        const uint32_t tile_count = n_tile_count;
+        uint4 r0 = n_r0, r1 = n_r1, r2 = n_r2;
         uint32_t total_tile_count;
         uint32_t excl_tc = block_excl_scan_u32(tile_count, sh_scan, &total_tile_count);
         sh_tile_count[lid] = excl_tc + tile_count;
         r1.z = excl_tc;
         sh_r0[lid] = r0; sh_r1[lid] = r1; sh_r2[lid] = r2;
         __syncthreads();
+        rd_ix += JL_N_TILE;
+        const bool has_next = !(rd_ix >= ready_ix && partition_ix >= n_partitions);  // uniform
+        if (has_next) stage1(gather());
         // (draw, tile) include test, coarse.wgsl:318-341.  The workgroup is alone on its CU (one workgroup per bin), so
         // the Tile loads are issued four at a time per thread instead of one dependent load per iteration, and what
         // they return is kept in LDS for the command walk below.
@@ -284,6 +310,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                 if (include_tile) atomicOr(&sh_bitmaps[el_ix / 32u][p_xy[u]], 1u << (el_ix & 31u));
             }
         }
+        if (has_next) stage2();
         __syncthreads();
         // Write the per-tile command list for this tile (coarse.wgsl:344-444)
         uint32_t slice_ix = 0u;
@@ -376,8 +403,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                 }
             }
         }
-        rd_ix += JL_N_TILE;
-        if (rd_ix >= ready_ix && partition_ix >= n_partitions) break;
+        if (!has_next) break;
         __syncthreads();
     }
     uint32_t scratch_size = 0u;

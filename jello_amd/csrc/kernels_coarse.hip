@@ -313,35 +313,49 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         if (has_next) stage2();
         __syncthreads();
         // Write the per-tile command list for this tile (coarse.wgsl:344-444)
+        // The walk is one wave per SIMD chasing LDS round trips (bitmap -> record -> cached Tile), so it is pipelined by
+        // hand: the reads of the NEXT element are issued before the commands of the current one are written.
         uint32_t slice_ix = 0u;
         uint32_t bitmap = sh_bitmaps[0][lid];
-        for (; !(COARSE_EXP & 2);) {
-            if (bitmap == 0u) {
+        auto next_el = [&]() -> uint32_t {  // next set bit of this tile's bitmaps, ~0u at the end
+            while (bitmap == 0u) {
                 slice_ix += 1u;
-                if (slice_ix == 8u) break;
+                if (slice_ix == 8u) return 0xffffffffu;
                 bitmap = sh_bitmaps[slice_ix][lid];
-                if (bitmap == 0u) continue;
             }
-            uint32_t el_ix = slice_ix * 32u + (uint32_t)__builtin_ctz(bitmap);
+            const uint32_t e = slice_ix * 32u + (uint32_t)__builtin_ctz(bitmap);
             bitmap &= bitmap - 1u;
-            const uint4 q0 = sh_r0[el_ix], q1 = sh_r1[el_ix], q2 = sh_r2[el_ix];
+            return e;
+        };
+        uint4 w_q0 = make_uint4(0u, 0u, 0u, 0u), w_q1 = w_q0, w_q2 = w_q0;
+        JlTile w_tile;
+        w_tile.backdrop = 0; w_tile.segment_count_or_ix = 0u;
+        auto fetch = [&](uint32_t e) {  // record and Tile of element e for this tile (the bit is only set for tiles inside its box)
+            if (e == 0xffffffffu) return;
+            w_q0 = sh_r0[e]; w_q1 = sh_r1[e]; w_q2 = sh_r2[e];
+            // the pair's slot in the include-test order: what that pass loaded is still in LDS
+            const uint32_t pair = w_q1.z + (tile_y - (w_q1.x >> 16)) * (w_q1.y & 31u) + (tile_x - (w_q1.x & 0xffffu));
+            if (pair < COARSE_TILE_CACHE) {
+                const uint2 tc = sh_tile_cache[pair];
+                w_tile.backdrop = (int32_t)tc.x;
+                w_tile.segment_count_or_ix = tc.y;
+            } else {
+                w_tile = tiles.rd(w_q0.z + w_q0.w * tile_y + tile_x);
+            }
+        };
+        uint32_t el_next = (COARSE_EXP & 2) ? 0xffffffffu : next_el();
+        fetch(el_next);
+        while (el_next != 0xffffffffu) {
+            const uint4 q0 = w_q0, q1 = w_q1, q2 = w_q2;
+            const JlTile tile = w_tile;
+            el_next = next_el();
+            fetch(el_next);
             uint32_t drawtag = q0.x;
             uint32_t di = q1.w;
             uint32_t draw_flags = q0.y;
             if (COARSE_EXP & 8) { c.seg_used += q0.x + q1.y + q2.x; continue; }  // timing experiment: iteration + record reads only
             if (!CLIPS || clip_zero_depth == 0u) {
                 uint32_t tile_ix = q0.z + q0.w * tile_y + tile_x;
-                JlTile tile;
-                {   // the pair's slot in the include-test order: what that pass loaded is still in LDS
-                    const uint32_t pair = q1.z + (tile_y - (q1.x >> 16)) * (q1.y & 31u) + (tile_x - (q1.x & 0xffffu));
-                    if (pair < COARSE_TILE_CACHE) {
-                        const uint2 tc = sh_tile_cache[pair];
-                        tile.backdrop = (int32_t)tc.x;
-                        tile.segment_count_or_ix = tc.y;
-                    } else {
-                        tile = tiles.rd(tile_ix);
-                    }
-                }
                 if (COARSE_EXP & 16) { c.seg_used += tile.segment_count_or_ix; continue; }  // ... + tile cache read
                 if (drawtag == JL_DRAWTAG_FILL_COLOR) {  // by far the most frequent draw object: tested first
                     write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);

@@ -905,7 +905,11 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
     };
     flatten_euler_wave(o, e, pieces, ends, refill);
     // how much of the reserved chunk is in use (k_flatten_lines skips the unused tail); every wave reports, the last wins
-    if (lane == 0u) atomicMax(&chunk_used[chunk / FL_CHUNK], umin_(sh_next, chunk + FL_CHUNK) - chunk);
+    if (lane == 0u) {
+        const uint32_t used = umin_(sh_next, chunk + FL_CHUNK) - chunk;
+        atomicMax(&chunk_used[chunk / FL_CHUNK], used);
+        atomicMax(&counters[3], used);  // the longest used chunk prefix: k_flatten_lines visits no batch behind it
+    }
 }
 
 // One thread per temporary slot: the Euler line (or the directly emitted line) that lives there, moved to
@@ -921,7 +925,22 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
     const uint32_t n_t = umin_(counters[2], tcap);
     const uint32_t lines_lim = umin_(cfg->lines_size, lines.n);
     const uint32_t lane = lane_id();
-    for (uint32_t t0 = blockIdx.x * JL_WG; t0 < n_t; t0 += gridDim.x * JL_WG) {  // uniform per workgroup
+    // Work units = batches of JL_WG slots: batch bi of chunk c for bi below the longest used chunk prefix (interleaved
+    // over the chunks), then the overflow area.  (Walking the whole slot space cost a memory round trip for every batch
+    // in the unused tail of a chunk -- about half of them.)
+    const uint32_t chunk_batches = (umin_(counters[3], FL_CHUNK) + JL_WG - 1u) / JL_WG;
+    const uint32_t units_chunks = n_chunks * chunk_batches;
+    const uint32_t ov_start = n_chunks * FL_CHUNK;
+    const uint32_t units = units_chunks + (n_t > ov_start ? (n_t - ov_start + JL_WG - 1u) / JL_WG : 0u);
+    for (uint32_t u = blockIdx.x; u < units; u += gridDim.x) {  // uniform per workgroup
+        uint32_t t0;
+        if (u < units_chunks) {
+            const uint32_t uc = u % n_chunks, bi = u / n_chunks;
+            if (bi * JL_WG >= chunk_used[uc]) continue;
+            t0 = uc * FL_CHUNK + bi * JL_WG;
+        } else {
+            t0 = ov_start + (u - units_chunks) * JL_WG;
+        }
         const uint32_t t = t0 + threadIdx.x;
         // which piece covers slot t?  Its first slot carries the marker (pieces have at most 100 lines).  The wave looks
         // at its 64 markers together: the nearest marker at or before a lane (DPP running maximum); only lanes before

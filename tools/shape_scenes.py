@@ -114,6 +114,24 @@ def scene_glyphs(n, w, h, seed=82):
     return s, RenderParams(w, h, base_color=(1, 1, 1, 1))
 
 
+def scene_roads(n, size, seed=84):
+    """n stroked random-walk polylines of 40..200 vertices, steps of 5..25 px (a road network): mid-size paths with hundreds
+    of tile crossings each, all of them on the list route of path_count."""
+    r = SplitMix64(seed)
+    s = Scene()
+    for i in range(n):
+        x, y = r.uniform(0, size), r.uniform(0, size)
+        a = r.uniform(0, 2 * math.pi)
+        p = Path().move_to(x, y)
+        for _ in range(40 + int(r.uniform(0, 160))):
+            a += r.uniform(-0.5, 0.5)
+            st = r.uniform(5, 25)
+            x, y = x + st * math.cos(a), y + st * math.sin(a)
+            p.line_to(x, y)
+        s.stroke(Stroke(width=r.uniform(1.0, 4.0)), None, Brush.solid((r.uniform(), r.uniform(), r.uniform(), 1.0)), None, p)
+    return s, RenderParams(size, size, base_color=(0.95, 0.95, 0.9, 1))
+
+
 def big_buffers():
     return BumpSizes(lines=1 << 23, seg_counts=1 << 24, segments=1 << 24, tiles=1 << 24, ptcl=1 << 27, bin_data=1 << 22, blend_spill=1 << 20)
 
@@ -138,7 +156,8 @@ CASES = [("C1", scenes.scene_c1),
          ("40k sweep-gradient fills, 4096^2", lambda: scene_gradients(40000, 4096, "sweep")),
          ("40k image fills, 4096^2", lambda: scene_gradients(40000, 4096, "image")),
          ("50k glyph outlines, 3840x2160", lambda: scene_glyphs(50000, 3840, 2160)),
-         ("C3-like 30k paths, 16384x1024", lambda: _wide())]
+         ("C3-like 30k paths, 16384x1024", lambda: _wide()),
+         ("10k road polylines (40..200 vertices), 4096^2", lambda: scene_roads(10000, 4096))]
 
 
 def _wide():

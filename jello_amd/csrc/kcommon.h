@@ -214,7 +214,8 @@ enum {  // scratch slots
     JH_SCR_G = 7,
     JH_SCR_H = 8,
     JH_SCR_I = 9,
-    JH_SCR_COUNT = 10
+    JH_SCR_J = 10,
+    JH_SCR_COUNT = 11
 };
 
 // Generic device-side exclusive scan of u32 (stride in words between consecutive inputs).

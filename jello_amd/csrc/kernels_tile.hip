@@ -319,35 +319,37 @@ JD LineSetup line_setup(const JlLineSoup& line, const Buf<JlPath>& paths) {
 // pass 1: crossings per line
 __global__ __launch_bounds__(JL_WG) void k_pc_count(const JlBump* __restrict__ bump, const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines,
                                                     Buf<JlPath> paths, uint32_t* __restrict__ counts, uint32_t counts_n,
-                                                    uint32_t* __restrict__ zero, uint32_t zero_n) {
+                                                    uint32_t* __restrict__ zero, uint32_t zero_n, uint32_t* __restrict__ line_path) {
     // (the path ranges, the gate and the dense-tile counter of the later passes start from zero: cleared here, this
     // kernel does not use them, instead of by a separate fill launch)
     for (uint32_t i = blockIdx.x * JL_WG + threadIdx.x; i < zero_n; i += gridDim.x * JL_WG) zero[i] = 0u;
     uint32_t n_lines = umin_(bump->lines, counts_n);
     uint32_t n_threads = umin_(ind->x * JL_WG, counts_n);
     for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
-        uint32_t c = 0u;
+        uint32_t c = 0u, pix = 0xffffffffu;
         if (gid < n_threads && lines.ok(gid)) {
+            pix = lines.p[gid].path_ix;
             LineSetup s = line_setup(lines.p[gid], paths);
             if (s.valid) c = s.imax - s.imin;
         }
         counts[gid] = c;
+        line_path[gid] = pix;  // k_pc_paths needs nothing else of the line (4 instead of 24 bytes per line there)
     }
 }
 // Crossing ranges of the paths: lines are in path order (canonical LineSoup order), so the crossings of path P are
 // the contiguous range [pstart[P], pend[P]) of seg_counts.  Both arrays are zeroed before (paths without lines).
 // (Deriving the range from first/last line indices inside the consumers instead measured slower: five dependent
 // loads per line.)
-__global__ __launch_bounds__(JL_WG) void k_pc_paths(const JlBump* __restrict__ bump, const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines,
-                                                    const uint32_t* __restrict__ counts, const uint32_t* __restrict__ seg_bases, uint32_t bases_n,
-                                                    uint32_t* __restrict__ pstart, uint32_t* __restrict__ pend, uint32_t n_paths) {
+__global__ __launch_bounds__(JL_WG) void k_pc_paths(const JlBump* __restrict__ bump, const JlIndirectCount* __restrict__ ind,
+                                                    const uint32_t* __restrict__ line_path, const uint32_t* __restrict__ counts,
+                                                    const uint32_t* __restrict__ seg_bases, uint32_t bases_n, uint32_t* __restrict__ pstart,
+                                                    uint32_t* __restrict__ pend, uint32_t n_paths) {
     uint32_t n_lines = umin_(umin_(bump->lines, bases_n), ind->x * JL_WG);
     for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
-        if (!lines.ok(gid)) continue;
-        uint32_t P = lines.p[gid].path_ix;
+        uint32_t P = line_path[gid];  // (0xffffffff for a line outside the buffer)
         if (P >= n_paths) continue;
-        uint32_t prevP = (gid > 0u && lines.ok(gid - 1u)) ? lines.p[gid - 1u].path_ix : 0xffffffffu;
-        uint32_t nextP = (gid + 1u < n_lines && lines.ok(gid + 1u)) ? lines.p[gid + 1u].path_ix : 0xffffffffu;
+        uint32_t prevP = gid > 0u ? line_path[gid - 1u] : 0xffffffffu;
+        uint32_t nextP = gid + 1u < n_lines ? line_path[gid + 1u] : 0xffffffffu;
         if (P != prevP) pstart[P] = seg_bases[gid];
         if (P != nextP) pend[P] = seg_bases[gid] + counts[gid];
     }
@@ -998,17 +1000,18 @@ int jh_launch_path_count(const JhLaunch& L) {
     uint32_t n_paths = paths.n;
     const uint32_t dense_cap = seg_cap / PC_DENSE_TILE + 1u;  // tiles with more than PC_DENSE_TILE crossings of a big path
     uint32_t* dense = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, (uint64_t)dense_cap * 4);
-    if (!dense) return -5;
+    uint32_t* line_path = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_J, (uint64_t)lines_cap * 4);
+    if (!dense || !line_path) return -5;
     // [pstart | pend | gate, number of dense tiles]: zeroed every frame (by k_pc_count) (the variables below keep the names of the path_range parameters)
     uint32_t* prange = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_I, ((uint64_t)n_paths * 2 + 64) * 4);
     if (!counts || !bases || !tile_of || !list || !list_base || !keys || !kbig || !prange) return -5;
     uint32_t *pfirst = prange, *plast = prange + n_paths, *gate = prange + 2 * (size_t)n_paths;
     uint32_t gl = stride_grid(L, lines_cap), gs = stride_grid(L, seg_cap);
     hipLaunchKernelGGL(k_pc_count, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, paths, counts, lines_cap, prange,
-                       n_paths * 2u + 64u);
+                       n_paths * 2u + 64u, line_path);
     int rc = jh_scan_u32(L, counts, 1, bases, lines_cap, &bump->lines, &bump->seg_counts);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_pc_paths, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, (const uint32_t*)counts,
+    hipLaunchKernelGGL(k_pc_paths, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, (const uint32_t*)line_path, (const uint32_t*)counts,
                        (const uint32_t*)bases, lines_cap, pfirst, plast, n_paths);
     const uint32_t *cpf = pfirst, *cpl = plast, *cc = counts, *cb = bases;
     hipLaunchKernelGGL(k_pc_emit, dim3(gl), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, ind, lines, paths, tile, segc, cb, lines_cap,

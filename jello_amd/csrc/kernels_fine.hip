@@ -243,10 +243,14 @@ JD void load_segraw_clamped(const float* __restrict__ segments, uint32_t segment
 // out-of-range workgroup indices drop the write, float->int conversions saturate (dmath.h).
 // ------------------------------------------------------------------------------------------------
 struct MsLds {
-    uint32_t sh_count[64];
+    // rolling window over the tile's segment stream (its slices are contiguous, in command order): 64 segments' end
+    // points, so that a fill of a few segments does not start with a global round trip of its own
+    alignas(16) float sh_seg[64][4];
+    alignas(16) uint32_t sh_samples[1024];  // (16-byte aligned: the 16-sample variant moves four words per pixel at a time)
+    alignas(16) uint32_t sh_count[64];
+    alignas(16) uint32_t sh_winding[64];
     uint32_t sh_winding_y[4], sh_winding_y_prefix[4];
-    uint32_t sh_winding[64];
-    uint32_t sh_samples[1024];
+    uint32_t seg_win_base, seg_win_valid;
 };
 JD uint32_t shl32(uint32_t v, uint32_t s) { return v << (s & 31u); }
 JD uint32_t shr32(uint32_t v, uint32_t s) { return v >> (s & 31u); }
@@ -274,17 +278,29 @@ JD void fill_path_ms(MsLds& T, uint32_t lane, uint32_t size_and_rule, uint32_t s
     }
     for (uint32_t i = 0u; i < 4u * WORDS; i++) T.sh_samples[th_ix * 4u * WORDS + i] = init;
     wave_sync();
-    auto load_seg = [&](uint32_t so, float& p0x, float& p0y, float& p1x, float& p1y) {
-        p0x = 0.0f; p0y = 0.0f; p1x = 0.0f; p1y = 0.0f;
-        if (so < segments_n) {
-            const float2* sp = (const float2*)(segments + (size_t)so * 6);
-            float2 a = sp[0], b = sp[1];
-            p0x = a.x; p0y = a.y; p1x = b.x; p1y = b.y;
-        }
+    auto load_seg = [&](uint32_t so, float& p0x, float& p0y, float& p1x, float& p1y) {  // (so inside the window)
+        const uint32_t w = so - T.seg_win_base;
+        p0x = T.sh_seg[w][0]; p0y = T.sh_seg[w][1]; p1x = T.sh_seg[w][2]; p1y = T.sh_seg[w][3];
     };
     const uint32_t n_batch = (n_segs + 63u) / 64u;
     for (uint32_t batch = 0u; batch < n_batch; batch++) {
         const uint32_t slice_size = umin_(n_segs - batch * 64u, 64u);
+        {   // make the window cover [first, first + slice_size)
+            const uint32_t first = seg_data + batch * 64u;
+            const bool inside = T.seg_win_valid != 0u && first >= T.seg_win_base && first - T.seg_win_base + slice_size <= 64u;  // uniform
+            if (!inside) {
+                wave_sync();  // (everybody has read the flags above)
+                const uint32_t so = first + th_ix;
+                float2 a = make_float2(0.0f, 0.0f), b = a;  // segments behind the buffer read as zeros (robust access)
+                if (so < segments_n) {
+                    const float2* sp = (const float2*)(segments + (size_t)so * 6);
+                    a = sp[0]; b = sp[1];
+                }
+                T.sh_seg[th_ix][0] = a.x; T.sh_seg[th_ix][1] = a.y; T.sh_seg[th_ix][2] = b.x; T.sh_seg[th_ix][3] = b.y;
+                if (th_ix == 0u) { T.seg_win_base = first; T.seg_win_valid = 1u; }
+                wave_sync();
+            }
+        }
         uint32_t count = 0u;
         if (th_ix < slice_size) {  // fine.wgsl:176-203 / :532-555
             float x0, y0, x1, y1;
@@ -503,6 +519,8 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
     }
     if constexpr (AA == 0) {
         if (lane < 16u) F.contrib[lane][64] = 0.0f;  // the "no pair" slot
+    } else {
+        if (lane == 0u) F.seg_win_valid = 0u;  // fill_path_ms: no segment window yet
     }
     wave_sync();
     uint32_t cmd_ix = 0u;  // relative to win_base

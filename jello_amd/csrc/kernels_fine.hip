@@ -205,6 +205,9 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #ifndef FINE_CLIP_MS_WAVES_PER_EU
 #define FINE_CLIP_MS_WAVES_PER_EU 3  // the multisampled ones need fewer registers (C4 msaa16: 6.5 -> 5.6 ms; area AA at 3: 11 ms, spills)
 #endif
+#ifndef FINE_MS_EXP
+#define FINE_MS_EXP 0  // timing experiments for fill_path_ms (results wrong unless 0)
+#endif
 #ifndef FINE_WAVES
 #define FINE_WAVES 2
 #endif
@@ -276,7 +279,8 @@ JD void fill_path_ms(MsLds& T, uint32_t lane, uint32_t size_and_rule, uint32_t s
         if (th_ix < 4u) T.sh_winding_y[th_ix] = init;
         T.sh_winding[th_ix] = init;
     }
-    for (uint32_t i = 0u; i < 4u * WORDS; i++) T.sh_samples[th_ix * 4u * WORDS + i] = init;
+    if (!(FINE_MS_EXP & 4))
+        for (uint32_t i = 0u; i < 4u * WORDS; i++) T.sh_samples[th_ix * 4u * WORDS + i] = init;
     wave_sync();
     auto load_seg = [&](uint32_t so, float& p0x, float& p0y, float& p1x, float& p1y) {  // (so inside the window)
         const uint32_t w = so - T.seg_win_base;
@@ -320,7 +324,7 @@ JD void fill_path_ms(MsLds& T, uint32_t lane, uint32_t size_and_rule, uint32_t s
         T.sh_count[th_ix] = incl;
         wave_sync();
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(slice_size - 1u));
-        for (uint32_t i = th_ix; i < total; i += 64u) {  // :217-383 / :566-675
+        for (uint32_t i = th_ix; i < total && !(FINE_MS_EXP & 1); i += 64u) {  // :217-383 / :566-675
             uint32_t lo = 0u, hi = slice_size;
             while (hi > lo + 1u) {
                 uint32_t mid = (lo + hi) >> 1;
@@ -410,6 +414,7 @@ JD void fill_path_ms(MsLds& T, uint32_t lane, uint32_t size_and_rule, uint32_t s
         wave_sync();
     }
     // resolve (:386-501 / :677-710)
+    if (FINE_MS_EXP & 2) { wave_sync(); return; }
     if (even_odd) {
         uint32_t scan_x = T.sh_winding[ly];
         scan_x ^= scan_x << 1; scan_x ^= scan_x << 2; scan_x ^= scan_x << 4; scan_x ^= scan_x << 8;

@@ -366,7 +366,9 @@ JD void path_range(uint32_t P, const uint32_t* __restrict__ pstart, const uint32
 // letting it walk a longer path in blocks of 64 is quadratic and, worse, a chain of memory round trips in ONE wave
 // (measured: 45 us for a 256-crossing path, 1.7 ms for 20 circles of 700 crossings), while the atomic route is linear
 // and spread over the whole device.  64 was the best threshold on every scene tried (tools/time_shapes.py, C3).
-#define PC_BIG_PATH 64u
+#ifndef PC_BIG_PATH
+#define PC_BIG_PATH 64u  // (tools/sweep_pc.sh builds other values)
+#endif
 JD bool npe_big(uint32_t n) { return n > PC_BIG_PATH; }
 JD uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 

@@ -4,11 +4,17 @@
 
 A step = one full pass of the hot path (pathtag scan -> flatten -> draw/clip scans -> binning ->
 tile_alloc -> path_count -> backdrop -> coarse -> path_tiling -> fine) over one synthetic scene that is
-already resident in HBM (scene bytes + config uploaded before the timed region).  At N > 1 every rank
-renders its own independent scene (weak scaling, no data-path collective); the finished RGBA16F image
-stays in that rank's HBM, as the reference leaves it in a texture of the device that rendered it.
-`--gather` additionally collects the images on rank 0 over RCCL, overlapped with the next frame (a
-compositor on one GPU; 7 x 128 MiB per frame into one device is then the bound, not the renderer).
+already resident in HBM (scene bytes + config uploaded before the timed region).
+
+`--gpus N` with N > 1 (and no torchrun environment) STARTS the N ranks itself, as child processes and
+before this process has imported torch or touched the GPU (`jello_amd.sharding.launch_ranks` = the
+driver's own `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`),
+and exits with the launcher's code.  Under torchrun it is one rank: every rank renders its own
+independent scene (C5: weak scaling, no data-path collective) and, as C5 is written, the finished
+RGBA16F images are gathered on rank 0 over RCCL, double-buffered so that the transfer of frame i
+overlaps the render of frame i+1.  For N > 1 both figures are timed (K steps each, each bracketed by
+barrier + synchronize): `value` is the one WITH the gather, `value_no_gather` the renderer alone
+(`--no-gather` makes that one the `value`).
 
 Prints ONE JSON line on rank 0.
 """
@@ -19,43 +25,70 @@ import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~4.8 TB/s is what a device copy reaches
+BUMP_NAMES = ["failed", "binning", "ptcl", "tile", "seg_counts", "segments", "blend", "lines"]
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--paths", type=int, default=100_000)
-    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--scene", choices=["c3", "c4"], default="c3",
+                    help="c3 = the headline scene (BASELINE.json configs[2]); c4 = configs[3]: nested clips + radial gradients + blends")
+    ap.add_argument("--paths", type=int, default=0, help="default: 100000 (c3) / 30000 (c4)")
+    ap.add_argument("--size", type=int, default=0, help="default: 4096 (c3) / 2048 (c4)")
     ap.add_argument("--aa", choices=["area", "msaa8", "msaa16"], default="area", help="coverage mode of the fine stage (the headline is area)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", action="store_true", help="N > 1: also gather every rank's image to rank 0 (RCCL, asynchronous)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: time only the independent renders, no image gather")
     ap.add_argument("--bands", action="store_true",
                     help="N > 1: ONE scene, every rank runs the element stages on it and coarse+fine for its band of bin rows "
                          "(strong scaling of one frame; SURVEY 8e) instead of one independent scene per rank")
     ap.add_argument("--emulate-band-of", type=int, default=0, metavar="N",
                     help="with --bands on ONE GPU: time what rank N/2 of an N-GPU band job would do (its band of the frame)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.paths <= 0:
+        args.paths = 100_000 if args.scene == "c3" else 30_000
+    if args.size <= 0:
+        args.size = 4096 if args.scene == "c3" else 2048
+    return args
 
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # Not under torchrun: become the launcher.  Nothing above imported torch or opened the device.
+        from jello_amd import sharding
+        rc = sharding.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus)
+        if rc != 0:
+            sys.stderr.write("bench.py: the %d-rank job failed (launcher exit code %d)\n" % (args.gpus, rc))
+        sys.exit(rc)
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+        sys.exit(2)
+    run_rank(args, world)
+
+
+def run_rank(args, world):
+    import numpy as np
     import torch
     import jello_amd
-    from jello_amd import BumpSizes, scenes
+    from jello_amd import BumpSizes, scenes, sharding
     from jello_amd.engine import RUN_DISPATCHES, RUN_UPLOADS
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
         import torch.distributed as dist
+        if local_rank >= torch.cuda.device_count():
+            raise RuntimeError("rank %d: this node has %d GPU(s), --gpus %d needs one per rank" % (rank, torch.cuda.device_count(), world))
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
@@ -64,7 +97,13 @@ def main():
 
     W = H = args.size
     # independent scene per rank (same generator, different seed)
-    scene, params = scenes.scene_c3(args.paths, args.size, seed=scenes.SEED + (0 if args.bands else rank))
+    seed_off = 0 if args.bands else rank
+    if args.scene == "c3":
+        scene, params = scenes.scene_c3(args.paths, args.size, seed=sharding.scene_seed_for_rank(seed_off))
+        what = "C3: %d random stroked+filled cubic Beziers" % args.paths
+    else:
+        scene, params = scenes.scene_c4(args.paths, args.size, seed=scenes.SEED + 4 + seed_off)
+        what = "C4: %d paths in groups of 10 under 3-deep clip layers (16 mix modes), every 3rd brush a radial gradient" % args.paths
     params.aa = {"area": jello_amd.Aa.Area, "msaa8": jello_amd.Aa.Msaa8, "msaa16": jello_amd.Aa.Msaa16}[args.aa]
     fine_stage = {"area": "fine_area", "msaa8": "fine_msaa8", "msaa16": "fine_msaa16"}[args.aa]
     eng = jello_amd.Engine(dev.index)
@@ -72,8 +111,7 @@ def main():
     stream = torch.cuda.current_stream(dev)
     eng.set_stream(stream.cuda_stream)
 
-    # ---- size the bump buffers once (regrow loop), outside the timed region ----
-    params.bump = BumpSizes(lines=1 << 22, seg_counts=1 << 23, segments=1 << 23, tiles=1 << 22, ptcl=1 << 26, bin_data=1 << 21)
+    # ---- size the bump buffers once, outside the timed region: estimator first, regrow loop as the safety net ----
     rec0, bump, attempts = eng.render(scene, params, robust=True)
     if bump["failed"]:
         raise RuntimeError("bump allocation still failing after regrow: %s" % bump)
@@ -86,44 +124,27 @@ def main():
     rec = host.record(scene, params)
     cfg = rec.config
 
+    gather = world > 1 and not args.no_gather and not args.bands
     # output images: torch owns the device memory (double-buffered for the overlapped gather)
-    outs = [torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(2)]
+    outs = [torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(2 if gather else 1)]
     gathered = None
-    if world > 1 and rank == 0 and args.gather:
+    if gather and rank == 0:
         gathered = [[torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(world)] for _ in range(2)]
 
     if args.bands:  # (buffers were sized by the unsharded render above; from here on this rank owns its band only)
-        from jello_amd import sharding
+        hb = (cfg["height_in_tiles"] + 15) // 16
         if world == 1 and args.emulate_band_of > 1:
-            eng.set_band(*sharding.band_for_rank((cfg["height_in_tiles"] + 15) // 16, args.emulate_band_of, args.emulate_band_of // 2))
+            eng.set_band(*sharding.band_for_rank(hb, args.emulate_band_of, args.emulate_band_of // 2))
         else:
-            eng.set_band(*sharding.band_for_rank((cfg["height_in_tiles"] + 15) // 16, world, rank))
+            eng.set_band(*sharding.band_for_rank(hb, world, rank))
     eng.run(rec, RUN_UPLOADS | RUN_DISPATCHES, outs[0].data_ptr())  # uploads scene/config; allocates every buffer
     torch.cuda.synchronize(dev)
 
-    pending = [None, None]
-    # One frame is ~60 short launches (launch-bound on the host), so the dispatch-only replay of the
-    # recording is captured once into a hipGraph per output buffer and the timed steps replay it.
-    graphs = [None, None]
+    # One frame is ~45 short launches, so the dispatch-only replay of the recording is captured once into a hipGraph
+    # per output buffer and the timed steps replay it.
     use_graph = not args.no_graph
-    if use_graph:
-        for k in range(2 if world > 1 and args.gather else 1):
-            graphs[k] = eng.capture(rec, outs[k].data_ptr())
-        if graphs[1] is None:
-            graphs[1] = graphs[0]
-            outs[1] = outs[0]
-
-    def step(i):
-        k = i & 1
-        if pending[k] is not None:
-            pending[k].wait()
-            pending[k] = None
-        if use_graph:
-            eng.replay(graphs[k])
-        else:
-            eng.run(rec, RUN_DISPATCHES, outs[k].data_ptr())
-        if world > 1 and args.gather:
-            pending[k] = dist.gather(outs[k], gathered[k] if rank == 0 else None, dst=0, async_op=True)
+    graphs = [eng.capture(rec, o.data_ptr()) for o in outs] if use_graph else []
+    pending = [None, None]
 
     def drain():
         for j in range(2):
@@ -131,41 +152,53 @@ def main():
                 pending[j].wait()
                 pending[j] = None
 
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
+    def timed(with_gather):
+        """W warmup steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        def step(i):
+            k = (i & 1) if with_gather else 0
+            if pending[k] is not None:
+                pending[k].wait()  # the gather that last read outs[k] (stream-ordered: the host does not block)
+                pending[k] = None
+            if use_graph:
+                eng.replay(graphs[k])
+            else:
+                eng.run(rec, RUN_DISPATCHES, outs[k].data_ptr())
+            if with_gather:
+                _, pending[k] = sharding.gather_images(dist, outs[k], rank, world, dst=0, async_op=True, out=gathered[k] if rank == 0 else None)
+        for i in range(args.warmup):
+            step(i)
+        drain()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        drain()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
 
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
+    elapsed_plain = timed(False)
+    elapsed_gather = timed(True) if gather else None
+    elapsed = elapsed_gather if gather else elapsed_plain
 
-    # Per-stage device times: the same K steps once more, eagerly, with a hipEvent pair around every
-    # stage on the launch stream (events cannot be read back from inside a replayed graph).
+    # Per-stage device times: the same K steps once more, eagerly, with a hipEvent pair around every stage on the
+    # launch stream (events cannot be read back from inside a replayed graph).
     eng.profile(True)
     for i in range(args.steps):
         eng.run(rec, RUN_DISPATCHES, outs[0].data_ptr())
     torch.cuda.synchronize(dev)
     prof = eng.profile_collect(1 << 16)
     eng.profile(False)
-
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    ms_per_step = elapsed * 1e3 / args.steps
-
-    # ---- per-stage device times (hipEvent pairs recorded on the launch stream during the timed region) ----
     stage_ms = {}
     for name, ms in prof:
         stage_ms[name] = stage_ms.get(name, 0.0) + ms
@@ -175,82 +208,110 @@ def main():
     result = None
     if rank == 0:
         # ---- algorithmic bytes of the fine stage, from the PTCL this run produced ----
-        ptcl_id, ptcl_size = rec.buffer("ptclBuf")
+        ptcl_id, _ = rec.buffer("ptclBuf")
         ptcl = eng.download(ptcl_id, dtype=np.uint32)
         st = (ctypes.c_uint64 * 8)()
-        rc = eng._L.jl_ptcl_stats(ptcl.ctypes.data, ptcl.size, cfg["width_in_tiles"], cfg["height_in_tiles"], st)
-        if rc != 0:
+        if eng._L.jl_ptcl_stats(ptcl.ctypes.data, ptcl.size, cfg["width_in_tiles"], cfg["height_in_tiles"], st) != 0:
             raise RuntimeError("malformed PTCL")
         words, segs, info_words, texels, spill_px = st[0], st[1], st[2], st[3], st[4]
         b_fine = 4 * words + 24 * segs + 4 * info_words + 8 * texels + 32 * spill_px + 8 * W * H
         achieved = b_fine / (fine_ms * 1e-3) / 1e9
-        bump_now = eng.download(rec.buffer("bumpBuf")[0], dtype=np.uint32)[:8]
-        # achievable HBM bandwidth on this device: a 1 GiB device-to-device copy (read + write bytes), reported
-        # next to the 8 TB/s vendor figure that `peak` uses (SURVEY 8d asks for both)
-        try:
-            ca = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
-            cb = torch.empty_like(ca)
-            cb.copy_(ca)
-            ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ce0.record()
-            for _ in range(5):
-                cb.copy_(ca)
-            ce1.record()
-            torch.cuda.synchronize(dev)
-            copy_gbs = 5 * 2 * (1 << 30) / (ce0.elapsed_time(ce1) * 1e-3) / 1e9
-            del ca, cb
-        except Exception:  # noqa: BLE001 - the measurement is optional
-            copy_gbs = None
-        roofline = {"kernel": "k_fine_area" if args.aa == "area" else "k_fine_area<%s>" % args.aa, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        bump_now = dict(zip(BUMP_NAMES, [int(v) for v in eng.download(rec.buffer("bumpBuf")[0], dtype=np.uint32)[:8]]))
+        copy_gbs = measured_copy_gbs(torch, dev)
+        kname = "k_fine_area" if args.aa == "area" else "k_fine_area<%s>" % args.aa
+        roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes": int(b_fine), "avg_ms": round(fine_ms, 4),
                     "segment_pixel_evals": int(segs) * 256,
                     "peak_measured_copy": None if copy_gbs is None else round(copy_gbs, 1)}
-        pm = os.path.join(ROOT, "profiles", "fine_traffic.json")
-        if os.path.exists(pm):
-            try:
-                roofline["traffic"] = json.load(open(pm)).get("hbm_bytes_per_launch")
-            except Exception:
-                pass
+        roofline.update(committed_counters(args, fine_ms))
         if args.bands and (world > 1 or args.emulate_band_of > 1):  # one band only: the whole-target byte count does not apply
             roofline = None
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(host)
+            cpu = cpu_baseline(host, args)
         units = 1 if args.bands else world  # frames finished per step by the whole job
-        mpix = W * H * units / (elapsed / args.steps) / 1e6
+        per = elapsed / args.steps
+        mode = ("bin-row bands of one scene x%d" % world) if args.bands else \
+            "scene-per-gpu x%d%s" % (world, " + RCCL image gather to rank 0 (overlapped, double-buffered)" if gather else "")
         result = {
-            "metric": "Mpixels/sec fine-raster + paths/sec, 100k-path 4096^2 scene", "value": round(mpix, 2), "unit": "Mpixels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "metric": "Mpixels/sec fine-raster + paths/sec, 100k-path 4096^2 scene", "value": round(W * H * units / per / 1e6, 2), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if args.bands else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3: %d random stroked+filled cubic Beziers, %dx%d RGBA16F target, %s AA, one independent scene per GPU"
-                                   % (args.paths, W, H, args.aa),
-                       "paths": args.paths, "draw_objects": cfg["n_drawobj"], "width": W, "height": H,
-                       "parallelism": ("bin-row bands of one scene x%d" % world) if args.bands else
-                                      "scene-per-gpu x%d%s" % (world, "" if world == 1 or not args.gather else " + RCCL image gather")},
-            "paths_per_s": round(args.paths * units / (elapsed / args.steps), 1),
+            "config": {"workload": "%s, %dx%d RGBA16F target, %s AA, %s" % (what, W, H, args.aa,
+                                   "one scene split into bin-row bands" if args.bands else "one independent scene per GPU"),
+                       "paths": args.paths, "draw_objects": cfg["n_drawobj"], "width": W, "height": H, "parallelism": mode},
+            "paths_per_s": round(args.paths * units / per, 1),
             "fine_mpixels_per_s": round(W * H / (fine_ms * 1e-3) / 1e6, 2),
             "launch": "hipGraph replay" if use_graph else "eager",
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_source": "eager replay of the same %d steps with a hipEvent pair per stage" % args.steps,
-            "bump": {k: int(v) for k, v in zip(["failed", "binning", "ptcl", "tile", "seg_counts", "segments", "blend", "lines"], bump_now)},
-            "stage_roofline": stage_roofline(cfg, dict(zip(["failed", "binning", "ptcl", "tile", "seg_counts", "segments", "blend", "lines"],
-                                                           [int(v) for v in bump_now])), stage_ms, rec),
+            "bump": bump_now, "sizing_attempts": attempts,
+            "stage_roofline": stage_roofline(cfg, bump_now, stage_ms, rec),
             "roofline": roofline,
             "cpu_baseline": cpu,
             "device": eng.device_info()["name"],
         }
-    for g in set(id(x) for x in graphs if x is not None):
-        pass
-    if graphs[0] is not None:
-        eng.graph_destroy(graphs[0])
-        if graphs[1] is not graphs[0]:
-            eng.graph_destroy(graphs[1])
+        if world > 1 and not args.bands:
+            pp = elapsed_plain / args.steps
+            result["value_no_gather"] = round(W * H * world / pp / 1e6, 2)
+            result["ms_per_step_no_gather"] = round(pp * 1e3, 4)
+            if gather:
+                result["value_with_gather"] = result["value"]
+                result["gather"] = {"bytes_per_rank_and_frame": W * H * 8, "into": "rank 0",
+                                    "link_bound_ms": round(W * H * 8 / 76.8e9 * 1e3, 3),
+                                    "note": "each source GPU reaches rank 0 over its own xGMI link (153.6 GB/s bidirectional = 76.8 GB/s one way)"}
+    for g in graphs:
+        eng.graph_destroy(g)
     eng.release(rec)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def measured_copy_gbs(torch, dev):
+    """Achievable HBM bandwidth on this device: a 1 GiB device-to-device copy (read + write bytes), reported next to
+    the 8 TB/s vendor figure that `peak` uses (SURVEY 8d asks for both)."""
+    try:
+        ca = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        cb = torch.empty_like(ca)
+        cb.copy_(ca)
+        ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ce0.record()
+        for _ in range(5):
+            cb.copy_(ca)
+        ce1.record()
+        torch.cuda.synchronize(dev)
+        return 5 * 2 * (1 << 30) / (ce0.elapsed_time(ce1) * 1e-3) / 1e9
+    except Exception:  # noqa: BLE001 - the measurement is optional
+        return None
+
+
+def committed_counters(args, fine_ms):
+    """Counter-derived figures of the fine kernel.  Hardware counters cannot be read from inside this process, so they
+    come from the committed rocprofv3 --pmc summary of THIS command (profiles/fine_counters.json, regenerated with
+    tools/pmc_fine.sh) and carry the commit and workload they were measured on; null when that file does not describe
+    this workload."""
+    out = {"traffic": None, "traffic_source": None, "issue_bound_ms": None}
+    pm = os.path.join(ROOT, "profiles", "fine_counters.json")
+    if not os.path.exists(pm):
+        return out
+    try:
+        c = json.load(open(pm))
+    except Exception:  # noqa: BLE001
+        return out
+    if c.get("scene") != args.scene or c.get("paths") != args.paths or c.get("size") != args.size or c.get("aa") != args.aa:
+        return out
+    out["traffic"] = c.get("hbm_bytes_per_launch")
+    out["traffic_source"] = "profiles/fine_counters.json: rocprofv3 --pmc passes at commit %s (not re-measured in this run)" % c.get("commit", "?")
+    # VALU issue bound: a wave64 VALU instruction occupies its SIMD for 4 cycles (16 lanes per SIMD)
+    if c.get("valu_insts_per_launch") and c.get("simds") and c.get("clock_ghz"):
+        ib = c["valu_insts_per_launch"] * 4.0 / (c["simds"] * c["clock_ghz"] * 1e9) * 1e3
+        out["issue_bound_ms"] = round(ib, 4)
+        out["issue_bound_note"] = ("%.3g VALU wave-instructions per launch x 4 cycles / (%d SIMDs x %.2f GHz); measured kernel time / bound = %.2f"
+                                   % (c["valu_insts_per_launch"], c["simds"], c["clock_ghz"], fine_ms / ib if ib > 0 else float("nan")))
+    return out
 
 
 def stage_roofline(cfg, bump, stage_ms, rec):
@@ -279,37 +340,53 @@ def stage_roofline(cfg, bump, stage_ms, rec):
     return out
 
 
-def cpu_baseline(host):
-    """The CPU restatement of the Jello/Vello pipeline (oracle/, single thread) timed on a bounded
-    sample of the same workload: one frame of the full headline scene (about 5-10 s of CPU work)."""
+def cpu_baseline(host, args):
+    """The CPU restatement of the Jello/Vello pipeline (oracle/) timed on the host cores of this box on a bounded
+    sample of the same workload: whole frames of the scene the GPU just rendered, on every core the process may use
+    (the stages that parallelise over independent units do; the sequential-allocation stages stay serial), median of
+    up to 5 frames within ~25 s; plus one single-thread frame."""
+    import numpy as np
     from jello_amd import BumpSizes, scenes
-    from oracle.oracle_engine import OracleEngine
-    n, size = 100_000, 4096
-    scene, params = scenes.scene_c3(n, size)
-    params.bump = BumpSizes(lines=1 << 22, seg_counts=1 << 23, segments=1 << 23, tiles=1 << 21, ptcl=1 << 25, bin_data=1 << 20)
-    rec = host.record(scene, params)
     from oracle import oracle_engine
-    # fine (79 % of the single-thread time) runs tile rows on `threads` host threads; the element stages stay serial
-    threads = max(1, min(16, len(os.sched_getaffinity(0))))
-    res = {}
-    for nt in ([1, threads] if threads > 1 else [1]):
+    from oracle.oracle_engine import OracleEngine
+    n, size = args.paths, args.size
+    if args.scene == "c3":
+        scene, params = scenes.scene_c3(n, size)
+    else:
+        scene, params = scenes.scene_c4(n, size)
+    import jello_amd
+    params.aa = {"area": jello_amd.Aa.Area, "msaa8": jello_amd.Aa.Msaa8, "msaa16": jello_amd.Aa.Msaa16}[args.aa]
+    params.bump = BumpSizes(lines=1 << 23, seg_counts=1 << 24, segments=1 << 24, tiles=1 << 23, ptcl=1 << 27, bin_data=1 << 22, blend_spill=1 << 22)
+    rec = host.record(scene, params)
+    threads = max(1, len(os.sched_getaffinity(0)))
+
+    def one(nt):
         oracle_engine.lib().oracle_set_threads(nt)
         orc = OracleEngine()
         t0 = time.perf_counter()
         orc.run(rec)
         dt = time.perf_counter() - t0
-        bump = orc.get(rec, "bumpBuf", np.uint32)[:8]
-        if bump[0] != 0:
+        if orc.get(rec, "bumpBuf", np.uint32)[0] != 0:
             raise RuntimeError("oracle bump failure in cpu_baseline")
-        res[nt] = (dt, {k: round(v, 4) for k, v in orc.stage_seconds.items()})
+        return dt, {k: round(v, 4) for k, v in orc.stage_seconds.items()}
+
+    runs = []
+    budget = time.perf_counter() + 25.0
+    while len(runs) < 5 and (not runs or time.perf_counter() + runs[-1][0] < budget):
+        runs.append(one(threads))
+    runs.sort(key=lambda r: r[0])
+    dt, stages = runs[len(runs) // 2]
+    one_thread = one(1)[0] if threads > 1 and dt * 12 < 60 else None
     oracle_engine.lib().oracle_set_threads(1)
-    dt, stages = res[threads]
     return {"value": round(size * size / dt / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-            "sample": "CPU restatement of the Jello/Vello pipeline (oracle/; fine on %d threads over tile rows, element stages serial), "
-                      "C3 generator with %d paths at %dx%d = the full headline workload, one frame, all stages incl. fine" % (threads, n, size, size),
-            "seconds": round(dt, 3), "paths_per_s": round(n / dt, 1),
+            "sample": "CPU restatement of the Jello/Vello pipeline (oracle/; OpenMP over independent units where the stage has them: fine over "
+                      "tile rows, path_tiling over crossings; the stages that allocate in canonical order -- flatten, path_count, coarse -- "
+                      "and the small scans stay serial), %s scene with %d paths at %dx%d = the "
+                      "workload of this line, whole frames incl. fine, median of %d" % (args.scene.upper(), n, size, size, len(runs)),
+            "seconds": round(dt, 3), "paths_per_s": round(n / dt, 1), "runs": len(runs),
             "stage_seconds": stages,
-            "value_1thread": round(size * size / res[1][0] / 1e6, 3), "seconds_1thread": round(res[1][0], 3),
+            "value_1thread": None if one_thread is None else round(size * size / one_thread / 1e6, 3),
+            "seconds_1thread": None if one_thread is None else round(one_thread, 3),
             "host_cpus": os.cpu_count()}
 
 

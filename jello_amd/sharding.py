@@ -8,6 +8,11 @@ Two modes, neither needs a collective on the data path:
 The only (optional: `bench.py --gather`) exchange is the final image gather to rank 0 (`gather_images`): RCCL on GPUs ("nccl"
 backend), gloo in the CPU tests.
 """
+import os
+import socket
+import subprocess
+import sys
+
 from . import scenes
 
 
@@ -42,3 +47,25 @@ def assemble_bands(images, height_in_bins, world):
         y0, y1 = band_for_rank(height_in_bins, world, r)
         out[y0 * 256:y1 * 256] = im[y0 * 256:y1 * 256]
     return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(script, script_args, n, env=None, timeout=None):
+    """Start `n` ranks of `script` on this node (one process per GPU, the driver's own recipe:
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 ...`) as CHILD processes
+    and return the launcher's exit code (non-zero when any rank failed).  Must be called before the calling process has
+    touched the GPU (nothing here imports torch): a process that has initialised HIP must never exec or fork GPU work."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n)),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(script_args)
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes needs it on this image)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    return subprocess.run(cmd, env=e, timeout=timeout).returncode

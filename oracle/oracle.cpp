@@ -1619,6 +1619,10 @@ static void path_tiling_setup(OBuf* b) {
     ind->y = 1u; ind->z = 1u;
 }
 
+// Host threads for the stages whose invocations are independent (path_tiling: one segment record per crossing;
+// fine: disjoint pixels per tile).  Default 1; bench.py's cpu_baseline raises it.  Results do not depend on it.
+static int g_oracle_threads = 1;
+
 // path_tiling.wgsl:39-173 -- [bump, seg_counts, lines, paths, tiles, segments]
 static void path_tiling(uint32_t n_wg, OBuf* b) {
     Bump* bump = (Bump*)b[0].p;
@@ -1628,6 +1632,7 @@ static void path_tiling(uint32_t n_wg, OBuf* b) {
     View<Tile> tiles(b[4]);
     View<Segment> segments(b[5]);
     uint32_t n_segments = bump->seg_counts;
+#pragma omp parallel for schedule(static) num_threads(g_oracle_threads)
     for (uint32_t gid = 0; gid < n_wg * WG; gid++) {
         if (!(gid < n_segments)) continue;
         SegmentCount sc = seg_counts.rd(gid);
@@ -2078,7 +2083,6 @@ static void fill_path_ms_tile(int SAMPLES, uint32_t size_and_rule, uint32_t seg_
     }
 }
 
-static int g_oracle_threads = 1;
 extern "C" void oracle_set_threads(int n) { g_oracle_threads = n < 1 ? 1 : n; }
 
 // aa = 0: analytic area (fine_area); 8 / 16: fine_msaa8 / fine_msaa16 with the mask LUT as last binding

@@ -75,3 +75,47 @@ def test_band_assignment_covers_all_bin_rows():
                 rows += list(range(y0, y1))
             assert rows == list(range(h))
     assert sharding.band_for_rank(16, 8, 3) == (6, 8)
+
+
+_RANK_SCRIPT = '''
+import os, sys
+import torch.distributed as dist
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == int(sys.argv[1]) and os.environ["MASTER_ADDR"] == "127.0.0.1"
+open(os.path.join(sys.argv[2], "rank%d" % rank), "w").write("ok")
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(int(sys.argv[3]) if rank == world - 1 else 0)
+'''
+
+
+def test_launcher_starts_one_process_per_rank_and_propagates_failure(tmp_path):
+    """`bench.py --gpus N` outside torchrun goes through sharding.launch_ranks: N child ranks, exit code of the job."""
+    sys.path.insert(0, ROOT)
+    from jello_amd import sharding
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    assert sharding.launch_ranks(str(script), ["2", str(tmp_path), "0"], 2, timeout=300) == 0
+    assert (tmp_path / "rank0").exists() and (tmp_path / "rank1").exists()
+    assert sharding.launch_ranks(str(script), ["2", str(tmp_path), "3"], 2, timeout=300) != 0
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_gpus_2_without_gpus_fails_loudly():
+    """No GPU here (and one on the GPU box): the 2-rank job must exit non-zero, not print a 1-GPU line."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:  # (counting devices does not initialise the GPU)
+        pytest.skip("this node could really run two ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert '"n_gpus"' not in r.stdout

@@ -12,7 +12,10 @@
  *   jh_download                   Download command + map               wgpu.go:554-563, 645-657
  *   jh_free / jh_image_free       FreeBuffer / FreeImage (pool return) wgpu.go:587-616, 772-808
  *   jh_image_import/buffer_import ExternalResource{ExternalImage,..}   wgpu.go:81-93, lib.go:257-262
- *   jh_profile_*                  ProfilerGroup.Compute timestamps     engine/wgpu_engine/profiler.go:160-177
+ *   jh_image_write                WriteImage command                   wgpu.go:422-452 (queue.WriteTexture)
+ *   jh_profile_enable/collect     ProfilerGroup.Compute timestamps     engine/wgpu_engine/profiler.go:160-177
+ *   jh_profile_group_begin/end    Profiler.Start / Nest / End          profiler.go:49-65, 113-158
+ *   jh_profile_collect_tree       Profiler.Collect (nested results)    profiler.go:304-385
  *   jh_stage                      renderer.FullShaders field order     renderer/render.go:17-43
  * Binding order for every stage is the WGSL @binding order = renderer/render.go dispatch order.
  *
@@ -20,7 +23,9 @@
  * jh_status (never aborts -- the reference panics, wgpu.go:77,213,282,544,558,594,955);
  * one jh_ctx = one device + one stream, not thread-safe; several contexts (one per GPU) may be
  * used concurrently from different threads/processes.  Work is enqueued asynchronously; only
- * jh_download, jh_image_download, jh_sync and jh_profile_collect wait for the device.
+ * jh_download, jh_image_download, jh_sync and jh_profile_collect[_tree] wait for the device.
+ * Uploads copy the caller's bytes into a pinned staging arena before returning (the slice may be
+ * reused at once, as with queue.WriteBuffer) and leave the DMA in flight.
  */
 #ifndef JELLO_HIP_H
 #define JELLO_HIP_H
@@ -85,6 +90,20 @@ typedef struct jh_profile_record {
     float ms; /* device time of the whole stage (all of its kernels), hipEvent pair */
 } jh_profile_record;
 
+/* One node of the nested profile (ProfilerResult, profiler.go:289-302): a group (label, CPU interval, children) or a GPU
+ * query (one per dispatch, label = the stage's name as in wgpu.go:486).  Nodes come in creation order, so a node's
+ * parent always precedes it; times are milliseconds relative to the first node (CPU clock) / the first query (GPU). */
+typedef enum jh_profile_kind { JH_PROF_GROUP = 0, JH_PROF_QUERY = 1 } jh_profile_kind;
+typedef struct jh_profile_node {
+    int32_t kind;   /* jh_profile_kind */
+    int32_t parent; /* index of the enclosing group in the same array, -1 at top level */
+    int32_t stage;  /* query: jh_stage; group: -1 */
+    uint32_t pad;
+    char label[48];
+    double cpu_start_ms, cpu_end_ms; /* group: Start/Nest .. End; query: the enqueue call */
+    float gpu_start_ms, gpu_end_ms;  /* query: its hipEvent pair; group: hull of the queries below it (0,0 if none) */
+} jh_profile_node;
+
 /* ---- context ---- */
 int jh_create(jh_ctx** out, int device);
 void jh_destroy(jh_ctx* ctx);
@@ -117,6 +136,8 @@ uint64_t jh_buffer_size(jh_ctx* ctx, uint64_t id);
 int jh_image_create(jh_ctx* ctx, uint64_t id, uint32_t width, uint32_t height, int format);
 int jh_image_import(jh_ctx* ctx, uint64_t id, void* device_ptr, uint32_t width, uint32_t height, int format);
 int jh_image_upload(jh_ctx* ctx, uint64_t id, uint32_t width, uint32_t height, int format, const void* data, uint64_t size);
+/* WriteImage: `data` holds height rows of width texels, tightly packed; written to the rectangle at (x, y). */
+int jh_image_write(jh_ctx* ctx, uint64_t id, uint32_t x, uint32_t y, uint32_t width, uint32_t height, const void* data, uint64_t size);
 int jh_image_download(jh_ctx* ctx, uint64_t id, void* dst, uint64_t size);
 int jh_image_free(jh_ctx* ctx, uint64_t id);
 void* jh_image_device_ptr(jh_ctx* ctx, uint64_t id);
@@ -135,7 +156,9 @@ int jh_dispatch_indirect(jh_ctx* ctx, int stage, uint64_t indirect_buffer_id, ui
  * jh_graph_begin starts capturing everything enqueued on the context's stream (dispatches, clears);
  * jh_graph_end returns an executable graph; jh_graph_launch replays it.  Uploads/downloads/frees and
  * profiling must not be issued while capturing, and every buffer and scratch array must already exist
- * (run the recording once eagerly first). */
+ * (run the recording once eagerly first).  A graph bakes in device pointers and the kernel instantiations chosen at
+ * capture time: it stays valid only until a buffer or image it uses is freed, regrown or re-imported, or an eager run
+ * makes a scratch array grow.  jh_graph_launch detects this (a generation counter) and returns JH_ERR_INVALID. */
 int jh_graph_begin(jh_ctx* ctx);
 int jh_graph_end(jh_ctx* ctx, void** graph_exec);
 int jh_graph_launch(jh_ctx* ctx, void* graph_exec);
@@ -145,6 +168,13 @@ int jh_graph_destroy(jh_ctx* ctx, void* graph_exec);
 int jh_profile_enable(jh_ctx* ctx, int on);
 /* Waits for the device, writes up to max records (one per dispatch since the last collect), returns the count. */
 int jh_profile_collect(jh_ctx* ctx, jh_profile_record* out, int max);
+/* Nested spans as in the reference's profiler: group_begin opens a group under the innermost open one (Profiler.Start at
+ * top level, ProfilerGroup.Nest below), group_end closes it; every dispatch issued in between becomes a query of that
+ * group.  No-ops while profiling is disabled (the reference's nil profiler).  collect_tree = Profiler.Collect: waits for
+ * the device and returns everything since the last collect as a flattened tree (and clears it, like jh_profile_collect). */
+int jh_profile_group_begin(jh_ctx* ctx, const char* label);
+int jh_profile_group_end(jh_ctx* ctx);
+int jh_profile_collect_tree(jh_ctx* ctx, jh_profile_node* out, int max);
 
 /* ---- diagnostics (not used by the render path) ----
  * Evaluates one of the kernels' scalar math routines on n host floats: op 0 sin, 1 cos, 2 atan2(a,b),

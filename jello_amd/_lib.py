@@ -100,7 +100,8 @@ class CCommand(ctypes.Structure):
                 ("img_id", ctypes.c_uint64), ("img_w", ctypes.c_uint32), ("img_h", ctypes.c_uint32),
                 ("img_format", ctypes.c_int32), ("n_bindings", ctypes.c_int32),
                 ("data", ctypes.POINTER(ctypes.c_uint8)), ("data_len", ctypes.c_uint64),
-                ("offset", ctypes.c_uint64), ("size", ctypes.c_int64), ("bindings", ctypes.POINTER(CBinding))]
+                ("offset", ctypes.c_uint64), ("size", ctypes.c_int64), ("bindings", ctypes.POINTER(CBinding)),
+                ("coords", ctypes.c_uint32 * 4)]
 
 
 class CConfig(ctypes.Structure):
@@ -131,6 +132,8 @@ def _declare(L):
     L.jl_scene_stream.restype = ctypes.c_uint64
     L.jl_scene_stream.argtypes = [vp, ci, ctypes.POINTER(vp)]
     L.jl_scene_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
+    L.jl_scene_bump_sizes.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp]
+    L.jl_scene_bump_estimate.argtypes = [vp, dp, ctypes.POINTER(ctypes.c_uint32)]
     L.jl_scene_fill_stroke_cubics.argtypes = [vp, ci, dp, dp, dp, dp, ci, ci, ci]
     L.jl_ptcl_stats.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
     L.jl_host_new.restype = vp
@@ -177,6 +180,12 @@ def _declare(L):
     hip.jh_set_band.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32]
     hip.jh_profile_enable.argtypes = [vp, ci]
     hip.jh_profile_collect.argtypes = [vp, vp, ci]
+    hip.jh_profile_group_begin.argtypes = [vp, ctypes.c_char_p]
+    hip.jh_profile_group_end.argtypes = [vp]
+    hip.jh_profile_collect_tree.argtypes = [vp, vp, ci]
+    hip.jh_image_create.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ci]
+    hip.jh_image_write.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64]
+    hip.jh_buffer_import.argtypes = [vp, ctypes.c_uint64, vp, ctypes.c_uint64]
     hip.jh_graph_begin.argtypes = [vp]
     hip.jh_graph_end.argtypes = [vp, ctypes.POINTER(vp)]
     hip.jh_graph_launch.argtypes = [vp, vp]

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -34,9 +35,25 @@ struct Alloc {
     bool written = false;   // images: has content (uploaded / imported); a created-only image reads as zero like a new wgpu texture
 };
 
+// One node of the profile tree (engine/wgpu_engine/profiler.go:96-158): a group (Start/Nest ... End: CPU interval and
+// children) or a GPU query (ProfilerGroup.Compute: one hipEvent pair around a dispatch).
 struct ProfEntry {
-    int stage;
-    hipEvent_t start, stop;
+    int kind;    // JH_PROF_GROUP / JH_PROF_QUERY
+    int parent;  // index of the enclosing group, -1 at top level
+    int stage;   // query: jh_stage
+    std::string label;
+    double cpu_start_ms = 0.0, cpu_end_ms = 0.0;
+    hipEvent_t start = nullptr, stop = nullptr;  // query only
+};
+
+struct JhGraph {  // a captured frame plus the resource generation it was captured against
+    hipGraphExec_t exec;
+    uint64_t generation;
+};
+
+struct Staging {  // pinned host arena for uploads: the caller's slice is copied once, the DMA runs asynchronously
+    char* base = nullptr;
+    uint64_t cap = 0, used = 0;
 };
 
 struct jh_ctx {
@@ -55,8 +72,18 @@ struct jh_ctx {
     bool profiling = false;
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> free_events;
+    std::vector<int> prof_stack;  // open groups (indices into prof)
     std::string last_error;
     uint32_t band_row0 = 0u, band_row1 = 0xffffffffu;  // jh_set_band
+    // Bumped whenever a device pointer a captured graph may have baked in goes away or moves: buffer / image free,
+    // regrow or import, scratch regrow.  jh_graph_launch refuses a graph captured against an older generation.
+    uint64_t generation = 0;
+    bool capturing = false;
+    Staging staging;
+    // fine: descriptor table of the bound image array when it has more entries than fit in the kernel arguments
+    void* image_table = nullptr;
+    uint64_t image_table_cap = 0;
+    std::vector<JhImageDesc> image_table_host;
 };
 
 static int fail(jh_ctx* ctx, int code, const std::string& msg) {
@@ -108,7 +135,10 @@ void* jh_scratch_get(JhScratch* s, int slot, uint64_t bytes) {
     uint64_t cap = pool_size_class(bytes);
     void* p = nullptr;
     if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
-    if (s->ptr[slot]) s->retired.push_back(s->ptr[slot]);
+    if (s->ptr[slot]) {
+        s->retired.push_back(s->ptr[slot]);
+        s->ctx->generation++;  // a captured graph may hold the old pointer
+    }
     s->ptr[slot] = p;
     s->cap[slot] = cap;
     return p;
@@ -118,6 +148,49 @@ static void scratch_release_retired(JhScratch* s) {
     for (void* p : s->retired) (void)hipFree(p);
     s->retired.clear();
 }
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Copies `size` host bytes into the pinned arena and returns the pinned address (valid until the arena wraps, which
+// first waits for the stream).  nullptr on allocation failure.
+static void* stage_copy(jh_ctx* ctx, const void* data, uint64_t size) {
+    Staging& st = ctx->staging;
+    uint64_t need = (size + 255u) & ~255ull;
+    if (st.used + need > st.cap) {
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;  // every earlier copy out of the arena is done
+        st.used = 0;
+        if (need > st.cap) {
+            uint64_t cap = st.cap ? st.cap : (8ull << 20);
+            while (cap < need) cap *= 2;
+            if (st.base) (void)hipHostFree(st.base);
+            st.base = nullptr;
+            st.cap = 0;
+            void* p = nullptr;
+            if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+            st.base = (char*)p;
+            st.cap = cap;
+        }
+    }
+    void* dst = st.base + st.used;
+    std::memcpy(dst, data, size);
+    st.used += need;
+    return dst;
+}
+
+// Per-stage binding contract (SURVEY Appendix C = renderer/render.go dispatch order): minimum binding count and the
+// slots whose contents the launchers dereference as fixed structs -- checked before every launch so that a buffer that
+// is too small yields JH_ERR_INVALID instead of an out-of-bounds read.
+struct StageContract { int n_min, cfg, bump, indirect; };
+static const StageContract kContract[JH_STAGE_COUNT] = {
+    /* pathtag_reduce */ {3, 0, -1, -1}, /* pathtag_reduce2 */ {2, -1, -1, -1}, /* pathtag_scan1 */ {3, -1, -1, -1},
+    /* pathtag_scan_small */ {4, 0, -1, -1}, /* pathtag_scan_large */ {4, 0, -1, -1}, /* bbox_clear */ {2, 0, -1, -1},
+    /* flatten */ {6, 0, 4, -1}, /* draw_reduce */ {3, 0, -1, -1}, /* draw_leaf */ {7, 0, -1, -1}, /* clip_reduce */ {4, -1, -1, -1},
+    /* clip_leaf */ {7, 0, -1, -1}, /* binning */ {8, 0, 5, -1}, /* tile_alloc */ {6, 0, 3, -1}, /* backdrop_dyn */ {4, 0, 1, -1},
+    /* path_count_setup */ {2, -1, 0, 1}, /* path_count */ {6, 0, 1, -1}, /* coarse */ {9, 0, 7, -1},
+    /* path_tiling_setup */ {3, -1, 0, 1}, /* path_tiling */ {6, -1, 0, -1}, /* fine_area */ {7, 0, -1, -1},
+    /* fine_msaa8 */ {9, 0, -1, -1}, /* fine_msaa16 */ {9, 0, -1, -1}};
 
 extern "C" {
 
@@ -168,7 +241,10 @@ void jh_destroy(jh_ctx* ctx) {
     for (int i = 0; i < JH_SCR_COUNT; i++)
         if (ctx->scratch.ptr[i]) (void)hipFree(ctx->scratch.ptr[i]);
     scratch_release_retired(&ctx->scratch);
-    for (auto& p : ctx->prof) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
+    if (ctx->staging.base) (void)hipHostFree(ctx->staging.base);
+    if (ctx->image_table) (void)hipFree(ctx->image_table);
+    for (auto& p : ctx->prof)
+        if (p.kind == JH_PROF_QUERY) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (auto& e : ctx->free_events) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -178,7 +254,12 @@ const char* jh_last_error(jh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : 
 
 int jh_set_stream(jh_ctx* ctx, void* hip_stream) {
     if (!ctx) return JH_ERR_INVALID;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (next != ctx->stream && ctx->staging.used) {  // uploads still in flight on the old stream read the pinned arena
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->staging.used = 0;
+    }
+    ctx->stream = next;
     return JH_OK;
 }
 
@@ -194,6 +275,7 @@ int jh_sync(jh_ctx* ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     scratch_release_retired(&ctx->scratch);
+    ctx->staging.used = 0;
     return JH_OK;
 }
 
@@ -201,13 +283,15 @@ int jh_sync(jh_ctx* ctx) {
 static int buffer_get_or_create(jh_ctx* ctx, uint64_t id, uint64_t size, Alloc** out) {
     auto it = ctx->buffers.find(id);
     if (it != ctx->buffers.end()) {
-        if (it->second.size >= size || !it->second.owned) {
+        if (it->second.size >= size) {
             *out = &it->second;
             return 0;
         }
+        if (!it->second.owned) return fail(ctx, JH_ERR_INVALID, "imported buffer is smaller than the requested size (the caller owns it: cannot grow)");
         // grow: return the old allocation to the pool
         ctx->pool.insert({it->second.capacity, it->second.ptr});
         ctx->buffers.erase(it);
+        ctx->generation++;
     }
     Alloc a;
     int rc = pool_get(ctx, size, &a.ptr, &a.capacity);
@@ -229,13 +313,19 @@ int jh_buffer_create(jh_ctx* ctx, uint64_t id, uint64_t size) {
 int jh_buffer_import(jh_ctx* ctx, uint64_t id, void* device_ptr, uint64_t size) {
     if (!ctx || !device_ptr) return JH_ERR_INVALID;
     auto it = ctx->buffers.find(id);
-    if (it != ctx->buffers.end() && it->second.owned) ctx->pool.insert({it->second.capacity, it->second.ptr});
+    if (it != ctx->buffers.end() && it->second.owned) {
+        ctx->pool.insert({it->second.capacity, it->second.ptr});
+        ctx->generation++;  // pool memory a graph may point to goes back into circulation
+    }
+    // (Re-importing caller-owned memory does not invalidate graphs: a graph captured while another pointer was bound keeps
+    // using that pointer, which stays valid for as long as its owner keeps it -- e.g. double-buffered output images.)
     Alloc a;
     a.ptr = device_ptr;
     a.size = size;
     a.capacity = size;
     a.owned = false;
     ctx->buffers[id] = a;
+    ctx->config_shadow.erase(id);  // whatever was uploaded under this id is not what the new memory holds
     return JH_OK;
 }
 
@@ -246,9 +336,14 @@ int jh_upload(jh_ctx* ctx, uint64_t id, const void* data, uint64_t size) {
     int rc = buffer_get_or_create(ctx, id, size, &a);
     if (rc) return rc;
     if (size == sizeof(JlConfig)) std::memcpy(&ctx->config_shadow[id], data, sizeof(JlConfig));
-    if (size) HIP_TRY(ctx, hipMemcpyAsync(a->ptr, data, size, hipMemcpyHostToDevice, ctx->stream));
-    // The host slice is only valid for the duration of the call (reference: queue.WriteBuffer copies).
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    else ctx->config_shadow.erase(id);
+    if (size) {
+        // The host slice is only valid for the duration of the call (reference: queue.WriteBuffer copies, wgpu.go:360):
+        // it is copied into the pinned arena here and the DMA is left in flight -- no stream synchronisation per upload.
+        void* src = stage_copy(ctx, data, size);
+        if (!src) return fail(ctx, JH_ERR_OOM, "jh_upload: pinned staging allocation failed");
+        HIP_TRY(ctx, hipMemcpyAsync(a->ptr, src, size, hipMemcpyHostToDevice, ctx->stream));
+    }
     return JH_OK;
 }
 
@@ -262,6 +357,7 @@ int jh_clear(jh_ctx* ctx, uint64_t id, uint64_t offset, int64_t size) {
     uint64_t n = size < 0 ? a.size - offset : (uint64_t)size;
     if (offset + n > a.size) n = a.size - offset;
     if (n) HIP_TRY(ctx, hipMemsetAsync((char*)a.ptr + offset, 0, n, ctx->stream));
+    if (n && offset < sizeof(JlConfig)) ctx->config_shadow.erase(id);  // the shadow no longer describes the device copy
     return JH_OK;
 }
 
@@ -280,7 +376,10 @@ int jh_free(jh_ctx* ctx, uint64_t id) {
     if (!ctx) return JH_ERR_INVALID;
     auto it = ctx->buffers.find(id);
     if (it == ctx->buffers.end()) return JH_OK;  // the reference ignores frees of unknown ids (wgpu.go:601-603)
-    if (it->second.owned) ctx->pool.insert({it->second.capacity, it->second.ptr});
+    if (it->second.owned) {
+        ctx->pool.insert({it->second.capacity, it->second.ptr});
+        ctx->generation++;
+    }
     ctx->buffers.erase(it);
     ctx->config_shadow.erase(id);
     return JH_OK;
@@ -317,6 +416,7 @@ int jh_image_create(jh_ctx* ctx, uint64_t id, uint32_t width, uint32_t height, i
         if (it->second.width == width && it->second.height == height && it->second.format == format) return JH_OK;
         if (it->second.owned) ctx->pool.insert({it->second.capacity, it->second.ptr});
         ctx->images.erase(it);
+        ctx->generation++;
     }
     Alloc a;
     int rc = pool_get(ctx, size ? size : 8, &a.ptr, &a.capacity);
@@ -331,7 +431,10 @@ int jh_image_import(jh_ctx* ctx, uint64_t id, void* device_ptr, uint32_t width, 
     uint64_t bpp = format_bpp(format);
     if (!bpp) return fail(ctx, JH_ERR_INVALID, "jh_image_import: bad format");
     auto it = ctx->images.find(id);
-    if (it != ctx->images.end() && it->second.owned) ctx->pool.insert({it->second.capacity, it->second.ptr});
+    if (it != ctx->images.end() && it->second.owned) {
+        ctx->pool.insert({it->second.capacity, it->second.ptr});
+        ctx->generation++;
+    }
     Alloc a;
     a.ptr = device_ptr; a.size = (uint64_t)width * height * bpp; a.capacity = a.size; a.owned = false;
     a.width = width; a.height = height; a.format = format; a.written = true;
@@ -342,15 +445,41 @@ int jh_image_import(jh_ctx* ctx, uint64_t id, void* device_ptr, uint32_t width, 
 int jh_image_upload(jh_ctx* ctx, uint64_t id, uint32_t width, uint32_t height, int format, const void* data, uint64_t size) {
     int rc = jh_image_create(ctx, id, width, height, format);
     if (rc) return rc;
+    if (!data && size) return JH_ERR_INVALID;
     Alloc& a = ctx->images[id];
     if (size > a.size) size = a.size;
-    if (size) HIP_TRY(ctx, hipMemcpyAsync(a.ptr, data, size, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (size) {
+        void* src = stage_copy(ctx, data, size);
+        if (!src) return fail(ctx, JH_ERR_OOM, "jh_image_upload: pinned staging allocation failed");
+        HIP_TRY(ctx, hipMemcpyAsync(a.ptr, src, size, hipMemcpyHostToDevice, ctx->stream));
+    }
     // an all-zero image (the 1x1 placeholder of render.go:115-124) contributes zero texels: bind it as absent
     bool nonzero = false;
     const uint8_t* bytes = (const uint8_t*)data;
     for (uint64_t i = 0; i < size && !nonzero; i++) nonzero = bytes[i] != 0;
+    if (a.written != nonzero) ctx->generation++;  // fine binds a never-written image as absent: the choice is baked into a graph
     a.written = nonzero;
+    return JH_OK;
+}
+
+// WriteImage (renderer/recording.go:204-208; wgpu.go:422-452 queue.WriteTexture): rows of `width` texels, tightly
+// packed in `data`, into the rectangle (x, y, width, height) of the image.
+int jh_image_write(jh_ctx* ctx, uint64_t id, uint32_t x, uint32_t y, uint32_t width, uint32_t height, const void* data, uint64_t size) {
+    if (!ctx || (!data && size)) return JH_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    auto it = ctx->images.find(id);
+    if (it == ctx->images.end()) return fail(ctx, JH_ERR_INVALID, "jh_image_write: unknown image id (create it first)");
+    Alloc& a = it->second;
+    const uint64_t bpp = format_bpp(a.format);
+    if ((uint64_t)x + width > a.width || (uint64_t)y + height > a.height) return fail(ctx, JH_ERR_INVALID, "jh_image_write: rectangle outside the image");
+    const uint64_t row = (uint64_t)width * bpp;
+    if (size < row * height) return fail(ctx, JH_ERR_INVALID, "jh_image_write: data smaller than the rectangle");
+    if (row == 0 || height == 0) return JH_OK;
+    void* src = stage_copy(ctx, data, row * height);
+    if (!src) return fail(ctx, JH_ERR_OOM, "jh_image_write: pinned staging allocation failed");
+    HIP_TRY(ctx, hipMemcpy2DAsync((char*)a.ptr + ((uint64_t)y * a.width + x) * bpp, (uint64_t)a.width * bpp, src, row, row, height,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    if (!a.written) { a.written = true; ctx->generation++; }
     return JH_OK;
 }
 
@@ -369,7 +498,10 @@ int jh_image_free(jh_ctx* ctx, uint64_t id) {
     if (!ctx) return JH_ERR_INVALID;
     auto it = ctx->images.find(id);
     if (it == ctx->images.end()) return JH_OK;
-    if (it->second.owned) ctx->pool.insert({it->second.capacity, it->second.ptr});
+    if (it->second.owned) {
+        ctx->pool.insert({it->second.capacity, it->second.ptr});
+        ctx->generation++;
+    }
     ctx->images.erase(it);
     return JH_OK;
 }
@@ -424,6 +556,13 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
     std::vector<JhBound> b, images;
     int rc = resolve_bindings(ctx, bindings, n_bindings, b, images);
     if (rc) return rc;
+    {   // the launchers read these slots as fixed structs: refuse buffers that cannot hold them
+        const StageContract& sc = kContract[stage];
+        if ((int)b.size() < sc.n_min) return fail(ctx, JH_ERR_INVALID, std::string("bad bindings for stage ") + jh_stage_name(stage) + ": too few");
+        auto too_small = [&](int slot, uint64_t need) { return slot >= 0 && (b[slot].ptr == nullptr || b[slot].size < need); };
+        if (too_small(sc.cfg, sizeof(JlConfig)) || too_small(sc.bump, sizeof(JlBump)) || too_small(sc.indirect, 12))
+            return fail(ctx, JH_ERR_INVALID, std::string("bad bindings for stage ") + jh_stage_name(stage) + ": config / bump / indirect buffer too small");
+    }
     JhLaunch L;
     L.stream = ctx->stream;
     L.scratch = &ctx->scratch;
@@ -437,6 +576,35 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
     L.cfg_host = nullptr;
     L.band_row0 = ctx->band_row0;
     L.band_row1 = ctx->band_row1;
+    L.image_table = nullptr;
+    if ((int)images.size() > JH_FINE_INLINE_IMAGES && stage >= JH_FINE_AREA) {
+        // More images than fit in the kernel arguments: fine indexes a device table of descriptors (the reference binds
+        // an array of up to 2048 textures, wgpu.go:278).  The table is re-uploaded only when the bound set changes.
+        std::vector<JhImageDesc> t(images.size());
+        for (size_t i = 0; i < images.size(); i++) {
+            t[i].ptr = images[i].ptr; t[i].width = images[i].width; t[i].height = images[i].height;
+            t[i].srgb = images[i].format == JL_RGBA8_SRGB ? 1u : 0u; t[i].pad = 0u;
+        }
+        const bool same = t.size() == ctx->image_table_host.size() &&
+                          std::memcmp(t.data(), ctx->image_table_host.data(), t.size() * sizeof(JhImageDesc)) == 0;
+        if (!same) {
+            if (ctx->capturing) return fail(ctx, JH_ERR_INVALID, "fine: the image table changed during graph capture (run the recording once eagerly first)");
+            const uint64_t bytes = t.size() * sizeof(JhImageDesc);
+            if (bytes > ctx->image_table_cap) {
+                void* np = nullptr;
+                if (hipMalloc(&np, pool_size_class(bytes)) != hipSuccess) return fail(ctx, JH_ERR_OOM, "fine: image table allocation failed");
+                if (ctx->image_table) ctx->scratch.retired.push_back(ctx->image_table);
+                ctx->image_table = np;
+                ctx->image_table_cap = pool_size_class(bytes);
+                ctx->generation++;
+            }
+            void* src = stage_copy(ctx, t.data(), bytes);
+            if (!src) return fail(ctx, JH_ERR_OOM, "fine: pinned staging allocation failed");
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->image_table, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+            ctx->image_table_host = t;
+        }
+        L.image_table = (const JhImageDesc*)ctx->image_table;
+    }
     if (n_bindings > 0 && bindings[0].kind == JH_BIND_BUFFER) {
         auto sh = ctx->config_shadow.find(bindings[0].id);
         if (sh != ctx->config_shadow.end()) L.cfg_host = &sh->second;
@@ -449,7 +617,11 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
         };
         HIP_TRY(ctx, get_event(&pe.start));
         HIP_TRY(ctx, get_event(&pe.stop));
+        pe.kind = JH_PROF_QUERY;
+        pe.parent = ctx->prof_stack.empty() ? -1 : ctx->prof_stack.back();
         pe.stage = stage;
+        pe.label = jh_stage_name(stage);  // ProfilerGroup.Compute(arena, shader.Label), wgpu.go:486,537
+        pe.cpu_start_ms = now_ms();
         HIP_TRY(ctx, hipEventRecord(pe.start, ctx->stream));
     }
     switch (stage) {
@@ -479,6 +651,7 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
     }
     if (ctx->profiling) {
         HIP_TRY(ctx, hipEventRecord(pe.stop, ctx->stream));
+        pe.cpu_end_ms = now_ms();
         ctx->prof.push_back(pe);
     }
     if (rc == -5) return fail(ctx, JH_ERR_OOM, "scratch allocation failed");
@@ -506,27 +679,41 @@ int jh_graph_begin(jh_ctx* ctx) {
     if (ctx->profiling) return fail(ctx, JH_ERR_INVALID, "jh_graph_begin: disable profiling first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
     return JH_OK;
 }
 int jh_graph_end(jh_ctx* ctx, void** graph_exec) {
     if (!ctx || !graph_exec) return JH_ERR_INVALID;
+    *graph_exec = nullptr;
     hipGraph_t graph = nullptr;
+    ctx->capturing = false;
     HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &graph));
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (e != hipSuccess) return hip_fail(ctx, e, "hipGraphInstantiate");
-    *graph_exec = (void*)exec;
+    *graph_exec = (void*)new JhGraph{exec, ctx->generation};
     return JH_OK;
 }
 int jh_graph_launch(jh_ctx* ctx, void* graph_exec) {
     if (!ctx || !graph_exec) return JH_ERR_INVALID;
-    HIP_TRY(ctx, hipGraphLaunch((hipGraphExec_t)graph_exec, ctx->stream));
+    JhGraph* g = (JhGraph*)graph_exec;
+    // The graph holds raw device pointers (buffers, scratch, image table) and the kernel instantiations picked at capture
+    // time: it is only valid while none of them has been freed, regrown or re-imported since.
+    if (g->generation != ctx->generation)
+        return fail(ctx, JH_ERR_INVALID, "jh_graph_launch: stale graph (a buffer, image or scratch array it refers to was freed, regrown or "
+                                         "re-imported after the capture) -- capture again");
+    HIP_TRY(ctx, hipGraphLaunch(g->exec, ctx->stream));
     return JH_OK;
 }
 int jh_graph_destroy(jh_ctx* ctx, void* graph_exec) {
     if (!ctx) return JH_ERR_INVALID;
-    if (graph_exec) HIP_TRY(ctx, hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    if (graph_exec) {
+        JhGraph* g = (JhGraph*)graph_exec;
+        hipError_t e = hipGraphExecDestroy(g->exec);
+        delete g;
+        if (e != hipSuccess) return hip_fail(ctx, e, "hipGraphExecDestroy");
+    }
     return JH_OK;
 }
 
@@ -537,12 +724,44 @@ int jh_profile_enable(jh_ctx* ctx, int on) {
     return JH_OK;
 }
 
+// Profiler.Start / ProfilerGroup.Nest (profiler.go:49-65, 138-158): opens a group under the innermost open one.
+int jh_profile_group_begin(jh_ctx* ctx, const char* label) {
+    if (!ctx) return JH_ERR_INVALID;
+    if (!ctx->profiling) return JH_OK;  // a nil profiler accepts every call (profiler.go:45-52)
+    ProfEntry g;
+    g.kind = JH_PROF_GROUP;
+    g.parent = ctx->prof_stack.empty() ? -1 : ctx->prof_stack.back();
+    g.stage = -1;
+    g.label = label ? label : "";
+    g.cpu_start_ms = now_ms();
+    ctx->prof_stack.push_back((int)ctx->prof.size());
+    ctx->prof.push_back(g);
+    return JH_OK;
+}
+// ProfilerGroup.End (profiler.go:113-125); ending a group that was never begun is an error (the reference panics).
+int jh_profile_group_end(jh_ctx* ctx) {
+    if (!ctx) return JH_ERR_INVALID;
+    if (!ctx->profiling && ctx->prof_stack.empty()) return JH_OK;
+    if (ctx->prof_stack.empty()) return fail(ctx, JH_ERR_INVALID, "jh_profile_group_end: no open group");
+    ctx->prof[ctx->prof_stack.back()].cpu_end_ms = now_ms();
+    ctx->prof_stack.pop_back();
+    return JH_OK;
+}
+
+static void prof_recycle(jh_ctx* ctx) {
+    for (auto& p : ctx->prof)
+        if (p.kind == JH_PROF_QUERY) { ctx->free_events.push_back(p.start); ctx->free_events.push_back(p.stop); }
+    ctx->prof.clear();
+    ctx->prof_stack.clear();
+}
+
 int jh_profile_collect(jh_ctx* ctx, jh_profile_record* out, int max) {
     if (!ctx) return JH_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     int n = 0;
     for (auto& p : ctx->prof) {
+        if (p.kind != JH_PROF_QUERY) continue;
         float ms = 0.0f;
         (void)hipEventElapsedTime(&ms, p.start, p.stop);
         if (out && n < max) {
@@ -551,10 +770,57 @@ int jh_profile_collect(jh_ctx* ctx, jh_profile_record* out, int max) {
             out[n].ms = ms;
             n++;
         }
-        ctx->free_events.push_back(p.start);
-        ctx->free_events.push_back(p.stop);
     }
-    ctx->prof.clear();
+    prof_recycle(ctx);
+    return n;
+}
+
+// Profiler.Collect (profiler.go:337-385): the tree, flattened in creation order (a node's parent always precedes it).
+int jh_profile_collect_tree(jh_ctx* ctx, jh_profile_node* out, int max) {
+    if (!ctx) return JH_ERR_INVALID;
+    if (!ctx->prof_stack.empty()) return fail(ctx, JH_ERR_INVALID, "jh_profile_collect_tree: a group is still open");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipEvent_t base = nullptr;
+    double cpu0 = 0.0;
+    bool have_cpu0 = false;
+    for (auto& p : ctx->prof) {
+        if (!have_cpu0) { cpu0 = p.cpu_start_ms; have_cpu0 = true; }
+        if (p.kind == JH_PROF_QUERY && !base) base = p.start;
+    }
+    int n = 0;
+    for (auto& p : ctx->prof) {
+        if (!out || n >= max) break;
+        jh_profile_node& o = out[n++];
+        std::memset(&o, 0, sizeof o);
+        o.kind = p.kind;
+        o.parent = p.parent;
+        o.stage = p.stage;
+        std::strncpy(o.label, p.label.c_str(), sizeof(o.label) - 1);
+        o.cpu_start_ms = p.cpu_start_ms - cpu0;
+        o.cpu_end_ms = p.cpu_end_ms - cpu0;
+        if (p.kind == JH_PROF_QUERY) {
+            float a = 0.0f, d = 0.0f;
+            (void)hipEventElapsedTime(&a, base, p.start);
+            (void)hipEventElapsedTime(&d, p.start, p.stop);
+            o.gpu_start_ms = a;
+            o.gpu_end_ms = a + d;
+        }
+    }
+    // a group's GPU interval = the hull of the queries below it (filled bottom-up: children follow their parents)
+    for (int i = n - 1; i >= 0; i--) {
+        if (out[i].kind == JH_PROF_QUERY || (out[i].kind == JH_PROF_GROUP && out[i].gpu_end_ms > out[i].gpu_start_ms)) {
+            int par = out[i].parent;
+            if (par >= 0 && par < n) {
+                if (out[par].gpu_end_ms <= out[par].gpu_start_ms) { out[par].gpu_start_ms = out[i].gpu_start_ms; out[par].gpu_end_ms = out[i].gpu_end_ms; }
+                else {
+                    if (out[i].gpu_start_ms < out[par].gpu_start_ms) out[par].gpu_start_ms = out[i].gpu_start_ms;
+                    if (out[i].gpu_end_ms > out[par].gpu_end_ms) out[par].gpu_end_ms = out[i].gpu_end_ms;
+                }
+            }
+        }
+    }
+    prof_recycle(ctx);
     return n;
 }
 

@@ -186,6 +186,15 @@ struct JhBound {
     int format;
 };
 
+// fine's image array: up to JH_FINE_INLINE_IMAGES descriptors travel in the kernel arguments, larger arrays as a device table
+#define JH_FINE_INLINE_IMAGES 8
+struct JhImageDesc {
+    const void* ptr;  // RGBA8 texels, row-major; nullptr = never written (samples as transparent black)
+    uint32_t width, height;
+    uint32_t srgb;    // 1: JL_RGBA8_SRGB (decode to linear when sampled)
+    uint32_t pad;
+};
+
 struct JhScratch;  // per-context scratch allocator, defined in jello_hip.cpp
 void* jh_scratch_get(JhScratch* s, int slot, uint64_t bytes);  // grows on demand, returns device pointer (nullptr on OOM)
 
@@ -201,6 +210,7 @@ struct JhLaunch {
     int num_cus;
     const JlConfig* cfg_host;  // host shadow of the uploaded ConfigUniform bound at index 0, or nullptr
     uint32_t band_row0, band_row1;  // jh_set_band: bin rows [row0, row1) this context writes PTCL for and rasterises (0, ~0u = all)
+    const JhImageDesc* image_table;  // device table of all n_images descriptors when n_images > JH_FINE_INLINE_IMAGES, else nullptr
 };
 
 enum {  // scratch slots

@@ -83,9 +83,6 @@ JD void write_path(Cmd& c, const Buf<JlTile>& tiles, JlTile tile, uint32_t tile_
 }
 
 #define COARSE_UNROLL 4u
-#ifndef COARSE_EXP
-#define COARSE_EXP 0
-#endif
 #define COARSE_TILE_CACHE 4096u
 
 // CLIPS = false: instantiation for scenes without clip layers (ConfigUniform.n_clip == 0): no BEGIN/END_CLIP draw
@@ -213,7 +210,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         const uint32_t tag = n_tag;
         n_tile_count = 0u;
         n_r0 = make_uint4(tag, 0u, 0u, 0u); n_r1 = make_uint4(0u, 0u, 0u, 0u); n_r2 = make_uint4(0u, 0u, 0u, 0u);
-        if (tag != JL_DRAWTAG_NOP && !(COARSE_EXP & 4)) {
+        if (tag != JL_DRAWTAG_NOP) {
             const JlDrawMonoid dm0 = n_dm;
             uint32_t path_ix = dm0.path_ix;
             uint32_t dd0 = cfg->layout.drawdata_base + dm0.scene_offset;
@@ -256,7 +253,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         // (draw, tile) include test, coarse.wgsl:318-341.  The workgroup is alone on its CU (one workgroup per bin), so
         // the Tile loads are issued four at a time per thread instead of one dependent load per iteration, and what
         // they return is kept in LDS for the command walk below.
-        for (uint32_t base = 0u; base < total_tile_count && !(COARSE_EXP & 1); base += COARSE_UNROLL * JL_N_TILE) {
+        for (uint32_t base = 0u; base < total_tile_count; base += COARSE_UNROLL * JL_N_TILE) {
             uint32_t p_el[COARSE_UNROLL], p_xy[COARSE_UNROLL], p_tile[COARSE_UNROLL];
             JlTile p_t[COARSE_UNROLL];
 #pragma unroll
@@ -343,7 +340,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                 w_tile = tiles.rd(w_q0.z + w_q0.w * tile_y + tile_x);
             }
         };
-        uint32_t el_next = (COARSE_EXP & 2) ? 0xffffffffu : next_el();
+        uint32_t el_next = next_el();
         fetch(el_next);
         while (el_next != 0xffffffffu) {
             const uint4 q0 = w_q0, q1 = w_q1, q2 = w_q2;
@@ -353,10 +350,8 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             uint32_t drawtag = q0.x;
             uint32_t di = q1.w;
             uint32_t draw_flags = q0.y;
-            if (COARSE_EXP & 8) { c.seg_used += q0.x + q1.y + q2.x; continue; }  // timing experiment: iteration + record reads only
             if (!CLIPS || clip_zero_depth == 0u) {
                 uint32_t tile_ix = q0.z + q0.w * tile_y + tile_x;
-                if (COARSE_EXP & 16) { c.seg_used += tile.segment_count_or_ix; continue; }  // ... + tile cache read
                 if (drawtag == JL_DRAWTAG_FILL_COLOR) {  // by far the most frequent draw object: tested first
                     write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);
                     alloc_cmd<WRITE>(c, 5u);

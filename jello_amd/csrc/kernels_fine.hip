@@ -157,12 +157,16 @@ JD float extend_mode(float t, uint32_t mode) {  // fine.wgsl:800-812
     }
 }
 
-#define FINE_MAX_IMAGES 8
+// The image array of the binding (the reference binds up to 2048 textures, wgpu.go:278).  Up to FINE_MAX_IMAGES
+// descriptors travel in the kernel arguments (scalar registers: no load on the IMAGE path); a larger array is indexed
+// through a device table of JhImageDesc built by the dispatcher (jello_hip.cpp), `table` != nullptr then.
+#define FINE_MAX_IMAGES JH_FINE_INLINE_IMAGES
 struct FineImages {
     const uint8_t* px[FINE_MAX_IMAGES];
     uint32_t w[FINE_MAX_IMAGES], h[FINE_MAX_IMAGES];
     uint32_t srgb_mask;  // bit q: image q is JL_RGBA8_SRGB (texels decode to linear like an rgba8unorm-srgb texture)
     int n;
+    const JhImageDesc* table;  // all n descriptors when n > FINE_MAX_IMAGES
 };
 
 JD uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -205,16 +209,10 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #ifndef FINE_CLIP_MS_WAVES_PER_EU
 #define FINE_CLIP_MS_WAVES_PER_EU 3  // the multisampled ones need fewer registers (C4 msaa16: 6.5 -> 5.6 ms; area AA at 3: 11 ms, spills)
 #endif
-#ifndef FINE_MS_EXP
-#define FINE_MS_EXP 0  // timing experiments for fill_path_ms (results wrong unless 0)
-#endif
 #ifndef FINE_WAVES
 #define FINE_WAVES 2
 #endif
 #define FB_STRIDE 65  // 64 pairs + the all-zero slot 64 (odd stride: conflict-free)
-#ifndef FINE_EXP
-#define FINE_EXP 0
-#endif
 struct SegRaw { float p0x, p0y, p1x, p1y, ye; };
 struct FillLds {
     float seg[4][64];            // window segments (lane-indexed): p0x p0y dx dy
@@ -279,8 +277,7 @@ JD void fill_path_ms(MsLds& T, uint32_t lane, uint32_t size_and_rule, uint32_t s
         if (th_ix < 4u) T.sh_winding_y[th_ix] = init;
         T.sh_winding[th_ix] = init;
     }
-    if (!(FINE_MS_EXP & 4))
-        for (uint32_t i = 0u; i < 4u * WORDS; i++) T.sh_samples[th_ix * 4u * WORDS + i] = init;
+    for (uint32_t i = 0u; i < 4u * WORDS; i++) T.sh_samples[th_ix * 4u * WORDS + i] = init;
     wave_sync();
     auto load_seg = [&](uint32_t so, float& p0x, float& p0y, float& p1x, float& p1y) {  // (so inside the window)
         const uint32_t w = so - T.seg_win_base;
@@ -324,7 +321,7 @@ JD void fill_path_ms(MsLds& T, uint32_t lane, uint32_t size_and_rule, uint32_t s
         T.sh_count[th_ix] = incl;
         wave_sync();
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(slice_size - 1u));
-        for (uint32_t i = th_ix; i < total && !(FINE_MS_EXP & 1); i += 64u) {  // :217-383 / :566-675
+        for (uint32_t i = th_ix; i < total; i += 64u) {  // :217-383 / :566-675
             uint32_t lo = 0u, hi = slice_size;
             while (hi > lo + 1u) {
                 uint32_t mid = (lo + hi) >> 1;
@@ -414,7 +411,6 @@ JD void fill_path_ms(MsLds& T, uint32_t lane, uint32_t size_and_rule, uint32_t s
         wave_sync();
     }
     // resolve (:386-501 / :677-710)
-    if (FINE_MS_EXP & 2) { wave_sync(); return; }
     if (even_odd) {
         uint32_t scan_x = T.sh_winding[ly];
         scan_x ^= scan_x << 1; scan_x ^= scan_x << 2; scan_x ^= scan_x << 4; scan_x ^= scan_x << 8;
@@ -611,7 +607,7 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
         // stage 2
         uint32_t ms = 0u, spos = 0u;
         float s2_dy = 0.0f, s2_tx0 = 0.0f, s2_tx1 = 0.0f, s2_p0x = 0.0f;  // read by stage 3 lanes with ds_bpermute
-        if (lane < npairs && !(FINE_EXP & 1)) {
+        if (lane < npairs) {
             const uint32_t j = lane;
             const uint32_t row = ((pmeta >> 17) & 31u) + (j - (pmeta & 0xfffu));
             const float rowf = (float)row;
@@ -658,7 +654,7 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
         wave_sync();
         const uint32_t nspec = (uint32_t)__builtin_amdgcn_readfirstlane((int)F.nspec);
         // stage 3, in passes of FB_SPEC crossing pixels (one pass unless the batch is full of long flat segments)
-        for (uint32_t pass = 0u; pass < nspec && !(FINE_EXP & 4); pass += FB_SPEC) {
+        for (uint32_t pass = 0u; pass < nspec; pass += FB_SPEC) {
             if (pass != 0u) wave_sync();
             {
                 uint32_t bits = ms, k = spos - pass;
@@ -712,7 +708,7 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
         auto W = [&](int k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)wv[k]); };
         const uint32_t tag = W(0);
         const uint32_t W1 = W(1), W2 = W(2);
-        if (tag == JL_CMD_END || (FINE_EXP & 32)) break;  // 32: timing experiment, prologue + epilogue only
+        if (tag == JL_CMD_END) break;
         if (tag == JL_CMD_FILL) {  // fill_path, fine.wgsl:824-878
             uint32_t size_and_rule = W1;
             uint32_t seg_data = W2;
@@ -729,7 +725,7 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
             for (int k = 0; k < 4; k++) area[k] = backdrop_f;
             uint32_t sa = seg_data, remaining = n_segs;
             while (remaining != 0u) {  // uniform
-                if (sa - batch_lo >= batch_hi - batch_lo) { if (FINE_EXP & 16) { batch_lo = sa; batch_hi = sa + 16u; cur_base = sa; } else build_batch(sa); }
+                if (sa - batch_lo >= batch_hi - batch_lo) build_batch(sa);
                 uint32_t take = umin_(remaining, batch_hi - sa);
                 uint32_t r0 = sa - cur_base;  // window-relative segments [r0, r0 + take)
                 // two segments per trip: both LDS reads are in flight before the (ordered) adds (four measured the same)
@@ -754,7 +750,7 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
                     }
                 };
                 uint32_t q = 0u;
-                if (!(FINE_EXP & 2)) {
+                {
                     for (; q + 1u < take; q += 2u) {
                         float ca[4], cb[4];
                         uint32_t ya, yb;
@@ -790,7 +786,7 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
             if (cmd_ix + 4u < JL_PTCL_INCREMENT && W(4) == JL_CMD_COLOR) {  // the usual pair: no second trip through the decoder
                 V4 fg = v4(u2f(W(5)), u2f(W(6)), u2f(W(7)), u2f(W(8)));
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (!(FINE_EXP & 8)) rgba[k] = over(rgba[k], fg, area[k]);
+                for (int k = 0; k < 4; k++) rgba[k] = over(rgba[k], fg, area[k]);
                 cmd_ix += 5u;
             }
         } else if (tag == JL_CMD_SOLID) {
@@ -800,7 +796,7 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
         } else if (tag == JL_CMD_COLOR) {
             V4 fg = v4(u2f(W1), u2f(W2), u2f(W(3)), u2f(W(4)));
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (!(FINE_EXP & 8)) rgba[k] = over(rgba[k], fg, area[k]);
+            for (int k = 0; k < 4; k++) rgba[k] = over(rgba[k], fg, area[k]);
             cmd_ix += 5u;
         } else if (CLIPS && tag == JL_CMD_BEGIN_CLIP) {
             if (clip_depth < JL_BLEND_STACK_SPLIT) {
@@ -969,9 +965,16 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
             const uint8_t* ipx = nullptr;
             uint32_t iw = 0, ih = 0;
             bool is_srgb = false;
+            if (images.table != nullptr) {
+                if (index < (uint32_t)images.n) {  // index comes from a uniform info word: scalar loads
+                    const JhImageDesc d = images.table[index];
+                    ipx = (const uint8_t*)d.ptr; iw = d.width; ih = d.height; is_srgb = d.srgb != 0u;
+                }
+            } else {
 #pragma unroll
-            for (int q = 0; q < FINE_MAX_IMAGES; q++)
-                if ((uint32_t)q == index && q < images.n) { ipx = images.px[q]; iw = images.w[q]; ih = images.h[q]; is_srgb = ((images.srgb_mask >> q) & 1u) != 0u; }
+                for (int q = 0; q < FINE_MAX_IMAGES; q++)
+                    if ((uint32_t)q == index && q < images.n) { ipx = images.px[q]; iw = images.w[q]; ih = images.h[q]; is_srgb = ((images.srgb_mask >> q) & 1u) != 0u; }
+            }
             auto texel = [&](int32_t tx, int32_t ty) -> V4 {
                 if (!ipx || tx < 0 || ty < 0 || (uint32_t)tx >= iw || (uint32_t)ty >= ih) return v4(0, 0, 0, 0);
                 uint32_t raw = *(const uint32_t*)(ipx + ((size_t)ty * iw + (size_t)tx) * 4);
@@ -1052,13 +1055,20 @@ static int launch_fine(const JhLaunch& L, int aa) {
     FineImages imgs;
     imgs.n = 0;
     imgs.srgb_mask = 0u;
+    imgs.table = nullptr;
     for (int i = 0; i < FINE_MAX_IMAGES; i++) { imgs.px[i] = nullptr; imgs.w[i] = 0; imgs.h[i] = 0; }
-    for (int i = 0; i < L.n_images && i < FINE_MAX_IMAGES; i++) {
-        imgs.px[i] = (const uint8_t*)L.images[i].ptr;
-        imgs.w[i] = L.images[i].width;
-        if (L.images[i].format == JL_RGBA8_SRGB) imgs.srgb_mask |= 1u << i;
-        imgs.h[i] = L.images[i].height;
-        imgs.n = i + 1;
+    if (L.n_images > FINE_MAX_IMAGES) {
+        if (!L.image_table) return -1;  // the dispatcher builds the table for arrays that do not fit in the arguments
+        imgs.table = L.image_table;
+        imgs.n = L.n_images;
+    } else {
+        for (int i = 0; i < L.n_images; i++) {
+            imgs.px[i] = (const uint8_t*)L.images[i].ptr;
+            imgs.w[i] = L.images[i].width;
+            if (L.images[i].format == JL_RGBA8_SRGB) imgs.srgb_mask |= 1u << i;
+            imgs.h[i] = L.images[i].height;
+            imgs.n = i + 1;
+        }
     }
     uint32_t grad_h = (grad.ptr && grad.width == JL_GRADIENT_WIDTH) ? grad.height : 0u;
     // Scenes without clip layers (ConfigUniform.n_clip == 0, read from the host shadow of the uploaded uniform)
@@ -1067,7 +1077,7 @@ static int launch_fine(const JhLaunch& L, int aa) {
     // Without ramps and images every gradient/image texel is 0; the instantiation without that code needs 78
     // instead of 109 VGPRs (6 instead of 4 waves per SIMD; the kernel is latency-bound).
     bool paints = grad_h != 0u;
-    for (int i = 0; i < imgs.n; i++) paints = paints || imgs.px[i] != nullptr;
+    for (int i = 0; i < L.n_images; i++) paints = paints || L.images[i].ptr != nullptr;
     // band mode: tile rows of the context's bin rows (a bin row = JL_N_TILE_Y tile rows)
     const uint64_t tr0 = (uint64_t)L.band_row0 * JL_N_TILE_Y, tr1 = (uint64_t)L.band_row1 * JL_N_TILE_Y;
     const uint32_t trow0 = tr0 < L.gy ? (uint32_t)tr0 : L.gy, trow1 = tr1 < L.gy ? (uint32_t)tr1 : L.gy;

@@ -54,7 +54,8 @@ class Recording:
             data = ctypes.string_at(c.data, c.data_len) if c.data_len else b""
             out.append({"kind": c.kind, "shader": c.shader, "wg": tuple(c.wg), "buf_id": c.buf_id, "buf_size": c.buf_size,
                         "buf_name": (c.buf_name or b"").decode(), "img_id": c.img_id, "img_w": c.img_w, "img_h": c.img_h,
-                        "img_format": c.img_format, "data": data, "offset": c.offset, "size": c.size, "bindings": binds})
+                        "img_format": c.img_format, "data": data, "offset": c.offset, "size": c.size, "bindings": binds,
+                        "coords": tuple(c.coords)})
         return out
 
     @property
@@ -208,6 +209,33 @@ class Engine:
         if n < 0:
             self._check(n, "profile_collect")
         return [(STAGE_NAMES[arr[i].stage], arr[i].ms) for i in range(n)]
+
+    def profile_collect_tree(self, max_nodes=1 << 16):
+        """Profiler.Collect (profiler.go:337-385): list of dicts {kind, parent, stage, label, cpu_start_ms, cpu_end_ms,
+        gpu_start_ms, gpu_end_ms}; a node's parent precedes it."""
+        class Node(ctypes.Structure):
+            _fields_ = [("kind", ctypes.c_int32), ("parent", ctypes.c_int32), ("stage", ctypes.c_int32), ("pad", ctypes.c_uint32),
+                        ("label", ctypes.c_char * 48), ("cpu_start_ms", ctypes.c_double), ("cpu_end_ms", ctypes.c_double),
+                        ("gpu_start_ms", ctypes.c_float), ("gpu_end_ms", ctypes.c_float)]
+        arr = (Node * max_nodes)()
+        n = self.hip.jh_profile_collect_tree(self.ctx, arr, max_nodes)
+        if n < 0:
+            self._check(n, "profile_collect_tree")
+        return [{"kind": "group" if arr[i].kind == 0 else "query", "parent": arr[i].parent, "stage": arr[i].stage,
+                 "label": arr[i].label.decode(), "cpu_start_ms": arr[i].cpu_start_ms, "cpu_end_ms": arr[i].cpu_end_ms,
+                 "gpu_start_ms": arr[i].gpu_start_ms, "gpu_end_ms": arr[i].gpu_end_ms} for i in range(n)]
+
+    def profile_group(self, label):
+        """Context manager: ProfilerGroup.Nest(label) ... End()."""
+        eng = self
+
+        class _G:
+            def __enter__(self_inner):
+                eng._check(eng.hip.jh_profile_group_begin(eng.ctx, label.encode()), "profile_group_begin")
+
+            def __exit__(self_inner, *a):
+                eng._check(eng.hip.jh_profile_group_end(eng.ctx), "profile_group_end")
+        return _G()
 
     def device_info(self):
         name = ctypes.create_string_buffer(256)

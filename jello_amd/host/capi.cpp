@@ -53,6 +53,7 @@ struct jl_command_c {
     uint64_t offset;
     int64_t size;
     const jl_binding_c* bindings;
+    uint32_t coords[4];  // WriteImage: x, y, width, height
 };
 
 static thread_local std::string g_err;
@@ -142,6 +143,19 @@ void jl_scene_counts(void* s, uint32_t out[4]) {
     out[0] = e.num_paths; out[1] = e.num_path_segments; out[2] = e.num_clips; out[3] = e.num_open_clips;
 }
 
+// Scene.bumpEstimate (scene.go:36-43) turned into buffer sizes for a width x height render (Scene::bump_sizes)
+void jl_scene_bump_sizes(void* s, uint32_t width, uint32_t height, jl_bump_sizes* out) {
+    BumpSizes b = ((Scene*)s)->bump_sizes(width, height);
+    out->bin_data = b.bin_data; out->tiles = b.tiles; out->lines = b.lines; out->seg_counts = b.seg_counts; out->segments = b.segments;
+    out->blend_spill = b.blend_spill; out->ptcl = b.ptcl;
+}
+// the raw tally of the BumpEstimator: out = {binning, ptcl, tile, blend, seg_counts, segments, lines}
+void jl_scene_bump_estimate(void* s, const double* transform, uint32_t* out) {
+    Affine a = to_affine(transform);
+    BumpEstimate e = ((Scene*)s)->bump_estimate(transform ? &a : nullptr);
+    out[0] = e.binning; out[1] = e.ptcl; out[2] = e.tile; out[3] = e.blend; out[4] = e.seg_counts; out[5] = e.segments; out[6] = e.lines;
+}
+
 // Bulk helper for the synthetic benchmark scenes: for each i, Fill(NonZero, identity, solid fill_rgba[i])
 // of the closed cubic pts[i] and, if widths[i] > 0, Stroke(width, join, caps, solid stroke_rgba[i]) of the
 // open cubic.  Exactly equivalent to calling jl_scene_fill / jl_scene_stroke in a loop.
@@ -207,6 +221,7 @@ static void flatten_recording(RecHandle* h) {
         f.img_id = c.image.id; f.img_w = c.image.width; f.img_h = c.image.height; f.img_format = (int)c.image.format;
         f.data = c.data.data(); f.data_len = c.data.size();
         f.offset = c.offset; f.size = c.size;
+        std::memcpy(f.coords, c.coords, sizeof f.coords);
         h->flat_bindings.emplace_back();
         std::vector<jl_binding_c>& fb = h->flat_bindings.back();
         for (const ResourceProxy& r : c.bindings) {

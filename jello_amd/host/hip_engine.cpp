@@ -19,6 +19,9 @@ void Engine::check(int rc, const char* what) {
 
 void Engine::run_recording(const Recording& rec, const std::vector<ExternalImage>& ext_images, const std::vector<ExternalBuffer>& ext_buffers,
                            unsigned flags) {
+    // pgroup = pgroup.Nest("RunRecording"); defer pgroup.End()  (wgpu.go:330-331) -- a no-op unless profiling is on
+    check(jh_profile_group_begin(ctx_, "RunRecording"), "profile_group_begin");
+    struct GroupEnd { jh_ctx* c; ~GroupEnd() { (void)jh_profile_group_end(c); } } group_end{ctx_};
     for (const ExternalImage& e : ext_images)
         check(jh_image_import(ctx_, e.proxy.id, e.device_ptr, e.proxy.width, e.proxy.height, (int)e.proxy.format), "image_import");
     for (const ExternalBuffer& e : ext_buffers) check(jh_buffer_import(ctx_, e.proxy.id, e.device_ptr, e.proxy.size), "buffer_import");
@@ -78,7 +81,15 @@ void Engine::run_recording(const Recording& rec, const std::vector<ExternalImage
                                           cmd.data.size()),
                           "image_upload");
                 break;
-            case Command::WriteImage: throw EngineError(JH_ERR_UNSUPPORTED, "WriteImage is never recorded by RenderFull");
+            case Command::WriteImage:  // wgpu.go:422-452 (RenderFull never records one; Recording::write_image does)
+                if (flags & kRunUploads) {
+                    if (jh_image_device_ptr(ctx_, cmd.image.id) == nullptr)
+                        check(jh_image_create(ctx_, cmd.image.id, cmd.image.width, cmd.image.height, (int)cmd.image.format), "image_create");
+                    check(jh_image_write(ctx_, cmd.image.id, cmd.coords[0], cmd.coords[1], cmd.coords[2], cmd.coords[3], cmd.data.data(),
+                                         cmd.data.size()),
+                          "image_write");
+                }
+                break;
             case Command::Dispatch:
                 if (flags & kRunDispatches) {
                     bind(cmd.bindings);
@@ -156,7 +167,6 @@ Engine::Frame Engine::render_to_texture(const Encoding& enc, RenderParams params
         if (retain) release(f);
         if (std::memcmp(&before, &bsz, sizeof bsz) == 0) break;  // nothing left to grow: give up
     }
-    f.config.gpu.lines_size = f.config.gpu.lines_size;  // (kept for clarity: config reflects the final attempt)
     return f;
 }
 

@@ -46,6 +46,14 @@ ImageProxy Recording::upload_image(uint32_t w, uint32_t h, JlImageFormat format,
     commands.push_back(std::move(c));
     return commands.back().image;
 }
+void Recording::write_image(const ImageProxy& img, uint32_t x, uint32_t y, uint32_t w, uint32_t h, const void* data, size_t n) {
+    Command c;
+    c.kind = Command::WriteImage;
+    c.image = img;
+    c.coords[0] = x; c.coords[1] = y; c.coords[2] = w; c.coords[3] = h;
+    c.data.assign((const uint8_t*)data, (const uint8_t*)data + n);
+    commands.push_back(std::move(c));
+}
 void Recording::dispatch(ShaderID shader, const uint32_t wg[3], std::vector<ResourceProxy> resources) {
     Command c;
     c.kind = Command::Dispatch;

@@ -46,6 +46,7 @@ struct Command {  // recording.go:158-239
     std::vector<ResourceProxy> bindings;
     uint64_t offset = 0;             // DispatchIndirect / Clear
     int64_t size = -1;               // Clear (-1 = whole buffer)
+    uint32_t coords[4] = {0, 0, 0, 0};  // WriteImage: x, y, width, height (recording.go:204-208); texels in `data`
 };
 
 class Recording {  // recording.go:38-103
@@ -54,6 +55,7 @@ class Recording {  // recording.go:38-103
     BufferProxy upload(const std::string& name, const void* data, size_t n);
     BufferProxy upload_uniform(const std::string& name, const void* data, size_t n);
     ImageProxy upload_image(uint32_t w, uint32_t h, JlImageFormat format, const void* data, size_t n);
+    void write_image(const ImageProxy& img, uint32_t x, uint32_t y, uint32_t w, uint32_t h, const void* data, size_t n);  // recording.go:66-72
     void dispatch(ShaderID shader, const uint32_t wg[3], std::vector<ResourceProxy> resources);
     void dispatch_indirect(ShaderID shader, const BufferProxy& buf, uint64_t offset, std::vector<ResourceProxy> resources);
     void download(const BufferProxy& buf);

@@ -2,6 +2,8 @@
 // style de-duplication produces the same streams.
 #include "scene.h"
 
+#include "renderer.h"
+
 #include <algorithm>
 #include <stdexcept>
 
@@ -25,17 +27,56 @@ void Scene::push_layer(BlendMode blend, float alpha, const Affine& clip_transfor
         // Invalid layer shape: encode a valid empty path, which suppresses drawing until the pop.
         encoding_.encode_path(zero_rect_path(), true);
         encoding_.encode_empty_shape();
+        BezPath degenerate;  // scene.go:69-73
+        degenerate.push_back(PathEl{PathElKind::MoveTo, {0, 0}, {0, 0}, {0, 0}});
+        degenerate.push_back(PathEl{PathElKind::LineTo, {0, 0}, {0, 0}, {0, 0}});
+        estimator_.count_path(degenerate, t, nullptr);
+        footprint_.add(zero_rect_path(), t, nullptr);
+    } else {
+        estimator_.count_path(clip, t, nullptr);
+        footprint_.add(clip, t, nullptr);
     }
+    footprint_.push_layer();
     encoding_.encode_begin_clip(blend, std::min(std::max(alpha, 0.0f), 1.0f));
 }
 
-void Scene::pop_layer() { encoding_.encode_end_clip(); }  // scene.go:73-79
+void Scene::pop_layer() {  // scene.go:73-79
+    encoding_.encode_end_clip();
+    footprint_.pop_layer();
+}
+
+BumpEstimate Scene::bump_estimate(const Affine* transform) const {
+    if (!transform) return estimator_.tally(nullptr);
+    Transform t = transform->to_transform();
+    return estimator_.tally(&t);
+}
+
+BumpSizes Scene::bump_sizes(uint32_t width, uint32_t height) const {
+    BumpEstimate e = estimator_.tally(nullptr);
+    uint64_t tiles = 0, bins = 0, ptcl = 0, blend = 0;
+    footprint_.tally(width, height, &tiles, &bins, &ptcl, &blend);
+    uint64_t info = 0;  // info words precede the bin data in the same buffer (resolve.go:271-276)
+    for (uint32_t tag : encoding_.draw_tags) info += (tag >> 6) & 0xf;
+    const uint64_t wt = (width + 15) / 16, ht = (height + 15) / 16;
+    auto cap = [](uint64_t v) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(v + v / 8 + 1024, 4096), 0xfffffff0ull); };
+    BumpSizes b;
+    b.lines = cap(e.lines);
+    b.seg_counts = cap(e.seg_counts);
+    b.segments = cap(e.segments);
+    b.tiles = cap(tiles);
+    b.bin_data = cap(info + bins);
+    b.ptcl = cap(ptcl + wt * ht * JL_PTCL_INITIAL_ALLOC);
+    b.blend_spill = cap(blend);
+    return b;
+}
 
 void Scene::fill(Fill style, const Affine& transform, const Brush& brush, const Affine& brush_transform, const BezPath& path) {  // scene.go:81-110
     Transform t = transform.to_transform();
     encoding_.encode_transform(t);
     encoding_.encode_fill_style(style);
     if (encoding_.encode_path(path, true)) {
+        estimator_.count_path(path, t, nullptr);
+        footprint_.add(path, t, nullptr);
         if (!brush_transform.is_identity()) {
             if (encoding_.encode_transform(transform.mul(brush_transform).to_transform())) encoding_.swap_last_path_tags();
         }
@@ -49,8 +90,10 @@ void Scene::stroke(const Stroke& style, const Affine& transform, const Brush& br
     Transform t = transform.to_transform();
     encoding_.encode_transform(t);
     encoding_.encode_stroke_style(style);
+    estimator_.count_path(shape, t, &style);  // scene.go:161 (counted whether or not the path encodes)
     bool encode_result = encoding_.encode_path(shape, false);
     if (encode_result) {
+        footprint_.add(shape, t, &style);
         if (!brush_transform.is_identity()) {
             if (encoding_.encode_transform(transform.mul(brush_transform).to_transform())) encoding_.swap_last_path_tags();
         }

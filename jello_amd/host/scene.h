@@ -1,15 +1,18 @@
 // scene.h -- the user-facing drawing API.  Mirrors scene.go:20-214 (Scene.Fill / Stroke /
-// PushLayer / PopLayer / Append / ApplyTransform / Encoding).  The BumpEstimator side channel
-// of the reference (scene.go:22,64-69) is not used to size buffers there either
-// (renderer/config.go:141-151); sizing here is done by the engine's regrow loop.
+// PushLayer / PopLayer / Append / ApplyTransform / Encoding), including the BumpEstimator side
+// channel (scene.go:22,36-43,73,75,115,161,203).  The reference computes that estimate and never
+// reads it (renderer/config.go:141-151 hard-codes the sizes); here `bump_sizes` turns it into the
+// element counts the renderer allocates, so that the first attempt normally fits
+// and the engine's regrow loop is only the safety net.
 #pragma once
 #include "encoding.h"
+#include "estimate.h"
 
 namespace jello {
 
 class Scene {
    public:
-    void reset() { encoding_.reset(); }
+    void reset() { encoding_.reset(); estimator_.reset(); footprint_.reset(); }
     Encoding& encoding() { return encoding_; }
     const Encoding& encoding() const { return encoding_; }
 
@@ -17,11 +20,31 @@ class Scene {
     void pop_layer();
     void fill(Fill style, const Affine& transform, const Brush& brush, const Affine& brush_transform, const BezPath& path);
     void stroke(const Stroke& style, const Affine& transform, const Brush& brush, const Affine& brush_transform, const BezPath& shape);
-    void append(const Scene& other, const Affine& transform) { encoding_.append(other.encoding_, transform.to_transform()); }
-    void apply_transform(const Affine& transform) { encoding_.apply_transform(transform.to_transform()); }
+    void append(const Scene& other, const Affine& transform) {  // scene.go:200-204
+        Transform t = transform.to_transform();
+        encoding_.append(other.encoding_, t);
+        estimator_.append(other.estimator_, &t);
+        footprint_.append(other.footprint_, t);
+    }
+    void apply_transform(const Affine& transform) {
+        Transform t = transform.to_transform();
+        encoding_.apply_transform(t);
+        BumpEstimator scaled;
+        scaled.append(estimator_, &t);
+        estimator_ = scaled;
+        footprint_.apply_transform(t);
+    }
+
+    // scene.go:36-43 bumpEstimate
+    BumpEstimate bump_estimate(const Affine* transform = nullptr) const;
+    // Element counts for the bump-allocated buffers of a width x height render: lines / seg_counts / segments from the
+    // BumpEstimator, tiles / bin_data / ptcl / blend_spill from the draw objects' bounding boxes; never below `floor`.
+    BumpSizes bump_sizes(uint32_t width, uint32_t height) const;
 
    private:
     Encoding encoding_;
+    BumpEstimator estimator_;
+    FootprintEstimator footprint_;
 };
 
 }  // namespace jello

@@ -245,6 +245,20 @@ class Scene:
             return b""
         return ctypes.string_at(p.value, n)
 
+    def bump_sizes(self, width, height):
+        """Buffer sizes for a width x height render from the scene's BumpEstimator (scene.go:36-43, renderer/estimate.go)
+        plus the bounding-box bounds for tiles / bin data / PTCL: the first attempt normally fits."""
+        from ._lib import CBumpSizes
+        out = CBumpSizes()
+        self._L.jl_scene_bump_sizes(self._h, int(width), int(height), ctypes.byref(out))
+        return BumpSizes(**{f: getattr(out, f) for f in BumpSizes.FIELDS})
+
+    def bump_estimate(self, transform=None):
+        """The raw BumpEstimator tally (renderer/estimate.go:173-197)."""
+        out = (ctypes.c_uint32 * 7)()
+        self._L.jl_scene_bump_estimate(self._h, None if transform is None else _aff(transform), out)
+        return dict(zip(["binning", "ptcl", "tile", "blend", "seg_counts", "segments", "lines"], out))
+
     def counts(self):
         out = (ctypes.c_uint32 * 4)()
         self._L.jl_scene_counts(self._h, out)

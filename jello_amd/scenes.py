@@ -162,6 +162,20 @@ def scene_images(size=256, seed=SEED + 7):
     return s, RenderParams(size, size, base_color=(0.2, 0.2, 0.2, 1.0))
 
 
+def scene_many_images(n=13, seed=SEED + 13):
+    """n small opaque sRGB images, each filling its own 32x32 square (5 per row): more than the 8 image descriptors
+    that fit in fine's kernel arguments, so the device descriptor table is used."""
+    s = Scene()
+    u = splitmix64_array(n * 8 * 8 * 4, seed)
+    for k in range(n):
+        px = (u[k * 256:(k + 1) * 256] * 256.0).astype(np.uint8).reshape(8, 8, 4)
+        px[:, :, 3] = 255
+        x, y = 36 * (k % 5), 36 * (k // 5)
+        s.fill(Fill.NonZero, None, Brush.image(px, key=100 + k), (4, 0, 0, 4, x, y), Path.rect(x, y, x + 32, y + 32))
+    rows = (n + 4) // 5
+    return s, RenderParams(192, max(16, 36 * rows), base_color=(0, 0, 0, 0))
+
+
 def scene_large_shapes(size=1536, n=60, seed=SEED + 11):
     """Shapes of hundreds of tiles: a background rectangle over the whole target, filled and stroked circles of radius
     100..700 (partly outside the target), under one clip layer.  Exercises what small random curves never reach: a

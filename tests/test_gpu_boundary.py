@@ -1,0 +1,153 @@
+"""-m gpu: the pieces of the drop-in boundary beyond plain dispatch: estimator-sized first attempt,
+WriteImage, image arrays larger than the inline descriptor set, nested profile groups, stale-graph detection, and the
+size checks that keep a too-small buffer from being read out of bounds."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import jello_amd
+from jello_amd import BumpSizes, scenes
+from jello_amd.engine import RUN_DISPATCHES, RUN_UPLOADS
+
+from parity import compare
+
+pytestmark = pytest.mark.gpu
+
+
+class Binding(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_uint32), ("count", ctypes.c_uint32), ("id", ctypes.c_uint64), ("ids", ctypes.POINTER(ctypes.c_uint64))]
+
+
+def test_c3_headline_is_sized_by_the_estimator_in_one_attempt(engine):
+    """renderer/estimate.go feeds the buffer sizes; the regrow loop must not be needed for C3."""
+    s, p = scenes.scene_c3(100_000, 4096)
+    p.bump = s.bump_sizes(p.width, p.height)
+    rec, bump, attempts = engine.render(s, p, robust=True, retain=False)
+    assert bump["failed"] == 0 and attempts == 1
+    assert bump["lines"] > 3_000_000 and p.bump.lines < 4 * bump["lines"]
+
+
+def test_c4_full_size_is_sized_by_the_estimator_in_one_attempt(engine):
+    s, p = scenes.scene_c4(30_000, 2048)
+    p.bump = s.bump_sizes(p.width, p.height)
+    rec, bump, attempts = engine.render(s, p, robust=True, retain=False)
+    assert bump["failed"] == 0 and attempts == 1
+
+
+def test_write_image_updates_a_sub_rectangle(engine):
+    """WriteImage (recording.go:204-208, wgpu.go:422-452): rows of the rectangle land at (x, y), nothing else changes."""
+    hip, ctx = engine.hip, engine.ctx
+    iid = 0x77110001
+    w, h = 37, 21
+    base = (np.arange(w * h * 4, dtype=np.uint32) % 251).astype(np.uint8).reshape(h, w, 4)
+    hip.jh_image_upload.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64]
+    hip.jh_image_free.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+    assert hip.jh_image_upload(ctx, iid, w, h, 0, base.ctypes.data, base.nbytes) == 0
+    patch = np.full((5, 9, 4), 200, np.uint8)
+    patch[..., 1] = np.arange(9, dtype=np.uint8)[None, :]
+    assert hip.jh_image_write(ctx, iid, 11, 3, 9, 5, patch.ctypes.data, patch.nbytes) == 0
+    out = np.zeros_like(base)
+    assert hip.jh_image_download(ctx, iid, out.ctypes.data, out.nbytes) == 0
+    want = base.copy()
+    want[3:8, 11:20] = patch
+    assert np.array_equal(out, want)
+    # outside the image, or too little data: error codes, image untouched
+    assert hip.jh_image_write(ctx, iid, 30, 3, 9, 5, patch.ctypes.data, patch.nbytes) < 0
+    assert hip.jh_image_write(ctx, iid, 0, 0, 9, 5, patch.ctypes.data, 10) < 0
+    assert hip.jh_image_write(ctx, 0xdead, 0, 0, 1, 1, patch.ctypes.data, 4) < 0
+    assert hip.jh_image_download(ctx, iid, out.ctypes.data, out.nbytes) == 0
+    assert np.array_equal(out, want)
+    assert hip.jh_image_free(ctx, iid) == 0
+
+
+def test_more_images_than_the_inline_descriptor_set(engine):
+    """The reference binds an array of up to 2048 textures (wgpu.go:278); past the 8 descriptors that travel in the
+    kernel arguments fine indexes a device table.  Every one of the 13 images must really be sampled."""
+    s, p = scenes.scene_many_images(13)
+    r = compare(engine, s, p)
+    img = r["image"].view(np.float16).astype(np.float32)
+    for k in range(13):
+        cx, cy = 16 + 36 * (k % 5), 16 + 36 * (k // 5)
+        assert img[cy, cx, 3] > 0.9, k  # opaque texels of image k reached the target
+
+
+def test_nested_profile_groups(engine):
+    """Profiler.Start / Nest / Compute / Collect (profiler.go): the tree has the caller's group, RunRecording below it,
+    one query per dispatch below that, GPU intervals ordered and nested."""
+    s, p = scenes.scene_c1()
+    rec = jello_amd.Host().record(s, p)
+    engine.run(rec, RUN_UPLOADS | RUN_DISPATCHES)
+    engine.profile(True)
+    try:
+        with engine.profile_group("frame 1"):
+            engine.run(rec, RUN_DISPATCHES)
+        with engine.profile_group("frame 2"):
+            engine.run(rec, RUN_DISPATCHES)
+        nodes = engine.profile_collect_tree()
+    finally:
+        engine.profile(False)
+        engine.release(rec)
+    tops = [i for i, n in enumerate(nodes) if n["parent"] == -1]
+    assert [nodes[i]["label"] for i in tops] == ["frame 1", "frame 2"]
+    n_dispatch = sum(1 for c in rec.commands() if c["kind"] in (jello_amd.CMD.DISPATCH, jello_amd.CMD.DISPATCH_INDIRECT))
+    for t in tops:
+        kids = [i for i, n in enumerate(nodes) if n["parent"] == t]
+        assert len(kids) == 1 and nodes[kids[0]]["label"] == "RunRecording" and nodes[kids[0]]["kind"] == "group"
+        qs = [n for n in nodes if n["parent"] == kids[0]]
+        assert len(qs) == n_dispatch and all(q["kind"] == "query" for q in qs)
+        assert qs[0]["label"] == "pathtag_reduce" and qs[-1]["label"] == "fine_area"
+        for a, b in zip(qs, qs[1:]):
+            assert a["gpu_start_ms"] <= a["gpu_end_ms"] <= b["gpu_start_ms"] + 1e-3
+        g = nodes[t]
+        assert g["gpu_start_ms"] <= qs[0]["gpu_start_ms"] and g["gpu_end_ms"] >= qs[-1]["gpu_end_ms"]
+        assert g["cpu_end_ms"] >= g["cpu_start_ms"]
+    assert nodes[tops[1]]["gpu_start_ms"] >= nodes[tops[0]]["gpu_end_ms"] - 1e-3
+    assert engine.profile_collect_tree() == []  # collected once
+
+
+def test_stale_graph_is_refused(engine):
+    """A captured frame holds raw device pointers: after one of its buffers went back to the pool the replay must be
+    refused (JH_ERR_INVALID), not run into freed memory."""
+    s, p = scenes.scene_c1()
+    rec = jello_amd.Host().record(s, p)
+    engine.run(rec, RUN_UPLOADS | RUN_DISPATCHES)
+    g = engine.capture(rec)
+    engine.replay(g)
+    engine.sync()
+    t = rec.target
+    a = engine.download_image(t["id"], t["width"], t["height"]).copy()
+    engine.replay(g)  # still valid: nothing was freed
+    engine.sync()
+    assert np.array_equal(a, engine.download_image(t["id"], t["width"], t["height"]))
+    engine.release(rec)  # frees every buffer of the frame
+    assert engine.hip.jh_graph_launch(engine.ctx, g) < 0
+    assert b"stale" in engine.hip.jh_last_error(engine.ctx)
+    engine.graph_destroy(g)
+
+
+def test_too_small_buffers_are_refused_not_read(engine):
+    hip, ctx = engine.hip, engine.ctx
+    hip.jh_dispatch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(Binding), ctypes.c_int]
+    small, big = 0x5511, 0x5512
+    z = np.zeros(4096, np.uint8)
+    assert hip.jh_upload(ctx, small, z.ctypes.data, 16) == 0      # 16 bytes: cannot hold a ConfigUniform or BumpAllocators
+    assert hip.jh_upload(ctx, big, z.ctypes.data, 4096) == 0
+    # bbox_clear: [config, path_bboxes] with a 16-byte "config"
+    b = (Binding * 2)(Binding(1, 0, small, None), Binding(1, 0, big, None))
+    assert hip.jh_dispatch(ctx, 5, 1, 1, 1, b, 2) < 0
+    # path_count_setup: [bump, indirect] with a 16-byte bump buffer
+    b = (Binding * 2)(Binding(1, 0, small, None), Binding(1, 0, big, None))
+    assert hip.jh_dispatch(ctx, 14, 1, 1, 1, b, 2) < 0
+    # an imported (caller-owned) buffer cannot be grown by an upload
+    import torch
+    mem = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    assert hip.jh_buffer_import(ctx, 0x5513, mem.data_ptr(), 64) == 0
+    assert hip.jh_upload(ctx, 0x5513, z.ctypes.data, 4096) < 0
+    assert hip.jh_upload(ctx, 0x5513, z.ctypes.data, 64) == 0
+    engine.sync()
+    for i in (small, big, 0x5513):
+        assert hip.jh_free(ctx, i) == 0
+    s, p = scenes.scene_c1()
+    rec, bump, attempts = engine.render(s, p, retain=False)  # the context is still usable
+    assert bump["failed"] == 0

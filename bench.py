@@ -112,6 +112,7 @@ def run_rank(args, world):
     eng.set_stream(stream.cuda_stream)
 
     # ---- size the bump buffers once, outside the timed region: estimator first, regrow loop as the safety net ----
+    params.bump = scene.bump_sizes(W, H)
     rec0, bump, attempts = eng.render(scene, params, robust=True)
     if bump["failed"]:
         raise RuntimeError("bump allocation still failing after regrow: %s" % bump)
@@ -358,7 +359,8 @@ def cpu_baseline(host, args):
     params.aa = {"area": jello_amd.Aa.Area, "msaa8": jello_amd.Aa.Msaa8, "msaa16": jello_amd.Aa.Msaa16}[args.aa]
     params.bump = BumpSizes(lines=1 << 23, seg_counts=1 << 24, segments=1 << 24, tiles=1 << 23, ptcl=1 << 27, bin_data=1 << 22, blend_spill=1 << 22)
     rec = host.record(scene, params)
-    threads = max(1, len(os.sched_getaffinity(0)))
+    # a one-GPU box shares its host: 16 cores are this job's share (more threads than that measured slower)
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
 
     def one(nt):
         oracle_engine.lib().oracle_set_threads(nt)

@@ -54,37 +54,40 @@ JD int32_t to_i32(float f) {
 }
 
 // ---- binary64 kernels ----
+// Every polynomial is evaluated with explicit fused multiply-adds in Estrin form (a fixed tree, written out below):
+// half the operations of mul+add Horner and a dependency chain of 4-5 instead of 14-18 -- the flatten kernels that
+// use these are bound by exactly that latency.  The CPU oracle executes the identical sequence (oracle/omath.h).
+JD double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 JD double reduce_pio2(double x, int* q) {
     const double TWO_OVER_PI = 0.6366197723675814;
     const double PIO2_1 = 1.57079632673412561417e+00;
     const double PIO2_1T = 6.07710050650619224932e-11;
     double k = rint(x * TWO_OVER_PI);
-    double r = (x - k * PIO2_1) - k * PIO2_1T;
+    double r = dfma(-k, PIO2_1T, dfma(-k, PIO2_1, x));
     *q = (int)((long long)k & 3);
     return r;
 }
-JD double sin_poly(double r) {
+JD double sin_poly(double r) {  // r + r z (S1 + S2 z + ... + S7 z^6), z = r^2
+    const double S1 = -1.0 / 6.0, S2 = 1.0 / 120.0, S3 = -1.0 / 5040.0, S4 = 1.0 / 362880.0, S5 = -1.0 / 39916800.0,
+                 S6 = 1.0 / 6227020800.0, S7 = -1.0 / 1307674368000.0;
     double z = r * r;
-    double p = -1.0 / 1307674368000.0;
-    p = 1.0 / 6227020800.0 + z * p;
-    p = -1.0 / 39916800.0 + z * p;
-    p = 1.0 / 362880.0 + z * p;
-    p = -1.0 / 5040.0 + z * p;
-    p = 1.0 / 120.0 + z * p;
-    p = -1.0 / 6.0 + z * p;
-    return r + r * (z * p);
+    double z2 = z * z;
+    double z4 = z2 * z2;
+    double a = dfma(z, S2, S1), b = dfma(z, S4, S3), c = dfma(z, S6, S5);
+    double ab = dfma(z2, b, a), cd = dfma(z2, S7, c);
+    double p = dfma(z4, cd, ab);
+    return dfma(r * z, p, r);
 }
-JD double cos_poly(double r) {
+JD double cos_poly(double r) {  // 1 + z (C1 + C2 z + ... + C8 z^7)
+    const double C1 = -0.5, C2 = 1.0 / 24.0, C3 = -1.0 / 720.0, C4 = 1.0 / 40320.0, C5 = -1.0 / 3628800.0,
+                 C6 = 1.0 / 479001600.0, C7 = -1.0 / 87178291200.0, C8 = 1.0 / 20922789888000.0;
     double z = r * r;
-    double p = 1.0 / 20922789888000.0;
-    p = -1.0 / 87178291200.0 + z * p;
-    p = 1.0 / 479001600.0 + z * p;
-    p = -1.0 / 3628800.0 + z * p;
-    p = 1.0 / 40320.0 + z * p;
-    p = -1.0 / 720.0 + z * p;
-    p = 1.0 / 24.0 + z * p;
-    p = -0.5 + z * p;
-    return 1.0 + z * p;
+    double z2 = z * z;
+    double z4 = z2 * z2;
+    double a = dfma(z, C2, C1), b = dfma(z, C4, C3), c = dfma(z, C6, C5), d = dfma(z, C8, C7);
+    double ab = dfma(z2, b, a), cd = dfma(z2, d, c);
+    double p = dfma(z4, cd, ab);
+    return dfma(z, p, 1.0);
 }
 JD double dsin(double x) {
     int q;
@@ -112,22 +115,27 @@ JD double atan_tab(int k) {
         default: return 0.7853981633974483;
     }
 }
-JD double datan01(double a) {
-    if (!(a >= 0.0 && a <= 1.0)) return a;
-    double kf = rint(a * 8.0);
+// atan(n/d) for 0 <= n <= d, d > 0: split at k/8, atan(n/d) = atan(k/8) + atan(t), t = (n - c d) / (d + c n), c = k/8.
+// k is picked from the binary32 quotient (any k with |n/d - k/8| <= 1/16 + 2^-24 keeps |t| < 0.07), so the only
+// binary64 division is the one of t.
+JD double datan_frac(double n, double d) {
+    float af = (float)n / (float)d;  // IEEE binary32 division of the operands rounded to binary32 (exact for atan2_'s)
+    if (!(af >= 0.0f && af <= 1.0f)) return (double)af;  // NaN passes through
+    float kf = rintf(af * 8.0f);
     int k = (int)kf;
-    double c = kf * 0.125;
-    double t = (a - c) / (1.0 + a * c);
+    double c = (double)kf * 0.125;
+    double t = dfma(-c, d, n) / dfma(c, n, d);
+    const double A1 = -1.0 / 3.0, A2 = 1.0 / 5.0, A3 = -1.0 / 7.0, A4 = 1.0 / 9.0, A5 = -1.0 / 11.0, A6 = 1.0 / 13.0;
     double z = t * t;
-    double p = 1.0 / 13.0;
-    p = -1.0 / 11.0 + z * p;
-    p = 1.0 / 9.0 + z * p;
-    p = -1.0 / 7.0 + z * p;
-    p = 1.0 / 5.0 + z * p;
-    p = -1.0 / 3.0 + z * p;
-    return atan_tab(k) + (t + t * (z * p));
+    double z2 = z * z;
+    double z4 = z2 * z2;
+    double a = dfma(z, A2, A1), b = dfma(z, A4, A3), cc = dfma(z, A6, A5);
+    double ab = dfma(z2, b, a);
+    double p = dfma(z4, cc, ab);
+    return atan_tab(k) + dfma(t * z, p, t);
 }
 JD bool dsignbit(double x) { return (__double_as_longlong(x) >> 63) != 0; }
+// (operands: binary32 values widened to binary64, or sqrt(1 - x^2) next to such an x -- all well inside binary32's range)
 JD double datan2(double y, double x) {
     const double PI = 3.141592653589793;
     const double PIO2 = 1.5707963267948966;
@@ -136,36 +144,35 @@ JD double datan2(double y, double x) {
     if (ax == 0.0 && ay == 0.0) {
         r = 0.0;
     } else if (ay <= ax) {
-        r = datan01(ay / ax);
+        r = datan_frac(ay, ax);
     } else {
-        r = PIO2 - datan01(ax / ay);
+        r = PIO2 - datan_frac(ax, ay);
     }
     if (dsignbit(x)) r = PI - r;
     return dsignbit(y) ? -r : r;
 }
-JD double dacos(double x) { return datan2(sqrt((1.0 - x) * (1.0 + x)), x); }
-JD double dasin(double x) { return datan2(x, sqrt((1.0 - x) * (1.0 + x))); }
-JD double dcbrt_pos(double x) {
-    uint64_t hx = (uint64_t)__double_as_longlong(x) >> 32;
-    double t = __longlong_as_double((long long)((uint64_t)(hx / 3u + 715094163u) << 32));
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        double t3 = t * t * t;
-        t = t * ((t3 + (x + x)) / ((t3 + t3) + x));
-    }
-    return t;
-}
+JD double dsqrt1mx2(double x) { return sqrt(dfma(-x, x, 1.0)); }  // sqrt(1 - x^2), the product not rounded
+// |x|^(2/3) = x * x^(-1/3): bit-trick seed for the inverse cube root (relative error < 6 %), four division-free Newton
+// steps r <- r (4 - x r^3) / 3 (error -> 2 e^2: 6e-2, 7e-3, 1e-4, 2e-8, 1e-15), then one more for the rounding.
 JD double dpow23(double ax) {
     if (ax == 0.0) return 0.0;
-    double c = dcbrt_pos(ax);
-    return c * c;
+    uint64_t hx = (uint64_t)__double_as_longlong(ax) >> 32;
+    double r = __longlong_as_double((long long)((uint64_t)(0x553EF0FFu - (uint32_t)(hx / 3u)) << 32));
+    const double THIRD = 1.0 / 3.0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        double r3 = (r * r) * r;
+        double h = dfma(-ax, r3, 4.0);
+        r = (r * h) * THIRD;
+    }
+    return ax * r;
 }
 
 JD float sin_(float x) { return (float)dsin((double)x); }
 JD float cos_(float x) { return (float)dcos((double)x); }
 JD float atan2_(float y, float x) { return (float)datan2((double)y, (double)x); }
-JD float acos_(float x) { return (float)dacos((double)x); }
-JD float asin_(float x) { return (float)dasin((double)x); }
+JD float acos_(float x) { return (float)datan2(dsqrt1mx2((double)x), (double)x); }
+JD float asin_(float x) { return (float)datan2((double)x, dsqrt1mx2((double)x)); }
 JD float pow23_abs_(float x) { return (float)dpow23((double)abs_(x)); }
 
 // binary16 <-> binary32 (hardware v_cvt, RTNE)

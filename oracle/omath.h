@@ -71,38 +71,40 @@ static inline int32_t to_i32(float f) {
 }
 
 // ---------------------------------------------------------------- binary64 kernels
+// Every polynomial uses explicit fused multiply-adds (std::fma is exact whether it compiles to vfmadd or calls libm) in
+// Estrin form, a fixed tree of operations written out below; jello_amd/csrc/dmath.h executes the identical sequence.
+static inline double dfma(double a, double b, double c) { return std::fma(a, b, c); }
 // sin/cos: Cody-Waite reduction by pi/2 (fdlibm split), Taylor polynomials on [-pi/4, pi/4].
 static inline double reduce_pio2(double x, int* q) {
     const double TWO_OVER_PI = 0.6366197723675814;
     const double PIO2_1 = 1.57079632673412561417e+00;   // first 33 bits of pi/2
     const double PIO2_1T = 6.07710050650619224932e-11;  // pi/2 - PIO2_1
     double k = std::nearbyint(x * TWO_OVER_PI);
-    double r = (x - k * PIO2_1) - k * PIO2_1T;
+    double r = dfma(-k, PIO2_1T, dfma(-k, PIO2_1, x));
     *q = (int)((long long)k & 3);
     return r;
 }
-static inline double sin_poly(double r) {
+static inline double sin_poly(double r) {  // r + r z (S1 + S2 z + ... + S7 z^6), z = r^2
+    const double S1 = -1.0 / 6.0, S2 = 1.0 / 120.0, S3 = -1.0 / 5040.0, S4 = 1.0 / 362880.0, S5 = -1.0 / 39916800.0,
+                 S6 = 1.0 / 6227020800.0, S7 = -1.0 / 1307674368000.0;
     double z = r * r;
-    double p = -1.0 / 1307674368000.0;
-    p = 1.0 / 6227020800.0 + z * p;
-    p = -1.0 / 39916800.0 + z * p;
-    p = 1.0 / 362880.0 + z * p;
-    p = -1.0 / 5040.0 + z * p;
-    p = 1.0 / 120.0 + z * p;
-    p = -1.0 / 6.0 + z * p;
-    return r + r * (z * p);
+    double z2 = z * z;
+    double z4 = z2 * z2;
+    double a = dfma(z, S2, S1), b = dfma(z, S4, S3), c = dfma(z, S6, S5);
+    double ab = dfma(z2, b, a), cd = dfma(z2, S7, c);
+    double p = dfma(z4, cd, ab);
+    return dfma(r * z, p, r);
 }
-static inline double cos_poly(double r) {
+static inline double cos_poly(double r) {  // 1 + z (C1 + C2 z + ... + C8 z^7)
+    const double C1 = -0.5, C2 = 1.0 / 24.0, C3 = -1.0 / 720.0, C4 = 1.0 / 40320.0, C5 = -1.0 / 3628800.0,
+                 C6 = 1.0 / 479001600.0, C7 = -1.0 / 87178291200.0, C8 = 1.0 / 20922789888000.0;
     double z = r * r;
-    double p = 1.0 / 20922789888000.0;
-    p = -1.0 / 87178291200.0 + z * p;
-    p = 1.0 / 479001600.0 + z * p;
-    p = -1.0 / 3628800.0 + z * p;
-    p = 1.0 / 40320.0 + z * p;
-    p = -1.0 / 720.0 + z * p;
-    p = 1.0 / 24.0 + z * p;
-    p = -0.5 + z * p;
-    return 1.0 + z * p;
+    double z2 = z * z;
+    double z4 = z2 * z2;
+    double a = dfma(z, C2, C1), b = dfma(z, C4, C3), c = dfma(z, C6, C5), d = dfma(z, C8, C7);
+    double ab = dfma(z2, b, a), cd = dfma(z2, d, c);
+    double p = dfma(z4, cd, ab);
+    return dfma(z, p, 1.0);
 }
 static inline double dsin(double x) {
     int q;
@@ -117,8 +119,10 @@ static inline double dcos(double x) {
     return ((q + 1) & 2) ? -c : c;
 }
 
-// atan on [0,1]: split at k/8, atan(a) = atan(k/8) + atan((a - k/8) / (1 + a k/8)).
-static inline double datan01(double a) {
+// atan(n/d) for 0 <= n <= d, d > 0: split at k/8, atan(n/d) = atan(k/8) + atan(t), t = (n - c d) / (d + c n), c = k/8.
+// k is picked from the binary32 quotient of the operands rounded to binary32 (any k with |n/d - k/8| <= 1/16 + 2^-22 keeps
+// |t| < 0.07), so the only binary64 division is the one of t.
+static inline double datan_frac(double n, double d) {
     static const double T[9] = {0.0,
                                 0.12435499454676144,
                                 0.24497866312686414,
@@ -128,20 +132,22 @@ static inline double datan01(double a) {
                                 0.6435011087932844,
                                 0.7188299996216245,
                                 0.7853981633974483};
-    if (!(a >= 0.0 && a <= 1.0)) return a;  // NaN passes through
-    double kf = std::nearbyint(a * 8.0);
+    float af = (float)n / (float)d;
+    if (!(af >= 0.0f && af <= 1.0f)) return (double)af;  // NaN passes through
+    float kf = std::nearbyintf(af * 8.0f);
     int k = (int)kf;
-    double c = kf * 0.125;
-    double t = (a - c) / (1.0 + a * c);
+    double c = (double)kf * 0.125;
+    double t = dfma(-c, d, n) / dfma(c, n, d);
+    const double A1 = -1.0 / 3.0, A2 = 1.0 / 5.0, A3 = -1.0 / 7.0, A4 = 1.0 / 9.0, A5 = -1.0 / 11.0, A6 = 1.0 / 13.0;
     double z = t * t;
-    double p = 1.0 / 13.0;
-    p = -1.0 / 11.0 + z * p;
-    p = 1.0 / 9.0 + z * p;
-    p = -1.0 / 7.0 + z * p;
-    p = 1.0 / 5.0 + z * p;
-    p = -1.0 / 3.0 + z * p;
-    return T[k] + (t + t * (z * p));
+    double z2 = z * z;
+    double z4 = z2 * z2;
+    double a = dfma(z, A2, A1), b = dfma(z, A4, A3), cc = dfma(z, A6, A5);
+    double ab = dfma(z2, b, a);
+    double p = dfma(z4, cc, ab);
+    return T[k] + dfma(t * z, p, t);
 }
+// (operands: binary32 values widened to binary64, or sqrt(1 - x^2) next to such an x -- all well inside binary32's range)
 static inline double datan2(double y, double x) {
     const double PI = 3.141592653589793;
     const double PIO2 = 1.5707963267948966;
@@ -150,31 +156,30 @@ static inline double datan2(double y, double x) {
     if (ax == 0.0 && ay == 0.0) {
         r = 0.0;
     } else if (ay <= ax) {
-        r = datan01(ay / ax);
+        r = datan_frac(ay, ax);
     } else {
-        r = PIO2 - datan01(ax / ay);
+        r = PIO2 - datan_frac(ax, ay);
     }
     if (std::signbit(x)) r = PI - r;
     return std::signbit(y) ? -r : r;
 }
-static inline double dacos(double x) { return datan2(std::sqrt((1.0 - x) * (1.0 + x)), x); }
-static inline double dasin(double x) { return datan2(x, std::sqrt((1.0 - x) * (1.0 + x))); }
+static inline double dsqrt1mx2(double x) { return std::sqrt(dfma(-x, x, 1.0)); }  // sqrt(1 - x^2), the product not rounded
+static inline double dacos(double x) { return datan2(dsqrt1mx2(x), x); }
+static inline double dasin(double x) { return datan2(x, dsqrt1mx2(x)); }
 
-// cbrt for x > 0 (normal): exponent/3 seed (fdlibm B1) + 4 Halley steps.
-static inline double dcbrt_pos(double x) {
-    uint64_t hx = d2u(x) >> 32;
-    double t = u2d((uint64_t)(hx / 3u + 715094163u) << 32);
-    for (int i = 0; i < 4; i++) {
-        double t3 = t * t * t;
-        t = t * ((t3 + (x + x)) / ((t3 + t3) + x));
-    }
-    return t;
-}
-// |x|^(2/3)
+// |x|^(2/3) = x * x^(-1/3): bit-trick seed for the inverse cube root (relative error < 6 %), division-free Newton steps
+// r <- r (4 - x r^3) / 3 (error -> 2 e^2: 6e-2, 7e-3, 1e-4, 2e-8, 1e-15), the fifth for the rounding.
 static inline double dpow23(double ax) {
     if (ax == 0.0) return 0.0;
-    double c = dcbrt_pos(ax);
-    return c * c;
+    uint64_t hx = d2u(ax) >> 32;
+    double r = u2d((uint64_t)(0x553EF0FFu - (uint32_t)(hx / 3u)) << 32);
+    const double THIRD = 1.0 / 3.0;
+    for (int i = 0; i < 5; i++) {
+        double r3 = (r * r) * r;
+        double h = dfma(-ax, r3, 4.0);
+        r = (r * h) * THIRD;
+    }
+    return ax * r;
 }
 
 // ---------------------------------------------------------------- f32 entry points

@@ -322,11 +322,12 @@ JD void wave_fence() {
 }
 
 // piece record: one 64-byte sector, 4 x uint4 at pieces[4 * tpos] (the lines kernel fetches one sector per piece):
-//   0: es_p0.x es_p0.y es_p1.x es_p1.y   1: th0 k0 k1 ch   2: noff n slot first   3: path_ix trans_ix flags -
+//   0: es_p0.x es_p0.y es_p1.x es_p1.y   1: th0 k0 k1 ch   2: noff n slot first   3: path_ix trans_ix<<6|flags int0 integral
 // plus ends[tpos] = (t_start.x, t_start.y, t_end.x, t_end.y), read only for the first / last line of an item.
 // flags: bits 0-1 robust case, 4 = ends at t == 1 (last line ends in t_end), 8 = offset >= 0, 16 = offset == 0,
-//        32 = first piece of its item.  The subdivision constants a, b, integral, int0 of flatten.wgsl:404-433 are
-//        recomputed from (k0, k1, ch, noff) by the same operations instead of being stored.
+//        32 = first piece of its item.  Of the subdivision constants of flatten.wgsl:404-433, int0 and integral (two
+//        espc_int_approx evaluations) travel in the record; a and b are recomputed from (k0, k1, ch, noff) by the same
+//        two products.
 
 struct EulerJob {
     bool valid;
@@ -412,7 +413,7 @@ JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ piece
 
         bool accept = false;
         uint32_t n_u = 0u;
-        float pc_n = 0.0f, pc_noff = 0.0f;
+        float pc_n = 0.0f, pc_noff = 0.0f, pc_int0 = 0.0f, pc_integral = 0.0f;
         EulerParams ep;
         ep.th0 = ep.th1 = ep.k0 = ep.k1 = ep.ch = 0.0f;
         V2 es_p0 = v2(0, 0), es_p1 = v2(0, 0);
@@ -470,7 +471,7 @@ JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ piece
                     float n = clamp_(ceil_(n_frac * scale_multiplier), 1.0f, 100.0f);
                     n_u = to_u32(n);
                     accept = true;
-                    pc_n = n; pc_noff = normalized_offset;  // a, b, integral, int0 are recomputed by k_flatten_lines
+                    pc_n = n; pc_noff = normalized_offset; pc_int0 = int0; pc_integral = integral;  // (a, b: two products, recomputed)
                     es_p0 = this_p0; es_p1 = this_pq1.point;
                     pc_flags = robust | ((t1 == 1.0f) ? 4u : 0u) | ((offset >= 0.0f) ? 8u : 0u) | ((offset == 0.0f) ? 16u : 0u);
                     last_p = this_pq1.point;
@@ -495,7 +496,7 @@ JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ piece
                 rec[0] = make_uint4(f2u(es_p0.x), f2u(es_p0.y), f2u(es_p1.x), f2u(es_p1.y));
                 rec[1] = make_uint4(f2u(ep.th0), f2u(ep.k0), f2u(ep.k1), f2u(ep.ch));
                 rec[2] = make_uint4(f2u(pc_noff), f2u(pc_n), o.slot, first);
-                rec[3] = make_uint4(e.path_ix, e.trans_ix, fl, 0u);
+                rec[3] = make_uint4(e.path_ix, (e.trans_ix << 6) | fl, f2u(pc_int0), f2u(pc_integral));
                 if ((fl & (32u | 4u)) != 0u) ends[tpos] = make_uint4(f2u(e.t_start.x), f2u(e.t_start.y), f2u(t_end.x), f2u(t_end.y));
                 o.tinfo[tpos] = FL_INFO_PIECE | n_u;
                 if (tpos >= o.overflow_start)  // only the chunk area is zeroed up front (rare path)
@@ -822,11 +823,147 @@ JD void run_item(const JlConfig* cfg, const Scene& s, Out<EMIT>& o, uint32_t slo
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-cooperative subdivision (the Euler jobs of k_flatten_items).
+//
+// flatten_euler (flatten.wgsl:328-477) walks the dyadic intervals of [0,1] depth first: try [t0, t0+dt]; accept it as
+// one Euler piece, or halve dt.  Whether an interval is accepted depends only on the cubic and the interval: the state
+// carried from piece to piece (last_p, last_q, last_t) is the cubic evaluated at the interval's start (with the WGSL's
+// own fix-up where the derivative vanishes), which every node can recompute with the same operations on the same
+// values.  So the nodes of the subdivision trees of a whole batch of jobs are independent work items: the wave keeps
+// them on a stack in LDS and evaluates 64 of them per step, whichever jobs they belong to, instead of one job per
+// lane (1...27 dependent attempts per job: a third of the lanes busy).  A rejected node pushes its two halves, an
+// accepted one becomes a piece: it reserves its temp slots and leaves its record exactly like the sequential walk.
+// What the sequential walk gets for free -- the index of a piece's first line inside its item = the lines of the
+// pieces before it -- is filled in when the batch has drained: every piece adds up the line counts of its job's
+// pieces with a smaller t0 (a linked list per job in LDS; a job has ~5 pieces).
+// Bounds: the stack is LIFO, so it holds at most 64 nodes per tree level (+128); if it or the piece list of a batch
+// overflows, or a tree goes deeper than FLQ_MAX_LEVEL (dt < 2^-9; none of the test scenes goes below 2^-6), the
+// unfinished jobs of the batch fall back to the sequential walk.
+// ------------------------------------------------------------------------------------------------
+#define FLQ_STACK 448u
+#define FLQ_LEAVES 640u
+#define FLQ_MAX_LEVEL 9u  // deeper trees (t0 no longer fits the 9 key bits) take the sequential walk
+struct FlBatch {
+    uint32_t jhead[64];                // newest piece of the job + 1 (0 = none), lane = job
+    uint32_t jpend[64];                // nodes of the job that are still unresolved
+    uint32_t stack[FLQ_STACK];         // job | level << 6 | t0_u << 11
+    uint32_t l_tpos[FLQ_LEAVES];
+    uint16_t l_key[FLQ_LEAVES];        // t0 in units of 2^-9 << 7 | n
+    uint16_t l_link[FLQ_LEAVES];       // job << 10 | next piece of the job + 1
+    uint32_t n_stack, n_leaves, bail;
+};
+// The job state (control points, scale, offset, ids) stays in the registers of the lane that set the job up; the lane
+// that evaluates one of its nodes fetches it with ds_bpermute (no LDS storage: occupancy is bound by registers only).
+JD float lanef(float v, uint32_t src) { return u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)f2u(v))); }
+JD uint32_t laneu(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v); }
+
+struct NodeResult {
+    bool accept;
+    CubicParams cp;
+    V2 es_p0, es_p1;
+    bool ends_at_one;
+};
+// One attempt of flatten.wgsl:362-403 for the interval [t0_u, t0_u + 1] * 2^-level of the cubic (p0..p3).
+JD NodeResult node_test(V2 p0, V2 p1, V2 p2, V2 p3, float scale, uint32_t level, uint32_t t0_u) {
+    const float tol = 0.25f;
+    const float dt = u2f((127u - level) << 23);  // 2^-level
+    const float t0 = (float)t0_u * dt;
+    // the state the sequential walk carries into this interval: the end of the piece that ended at t0
+    V2 last_p, last_q;
+    float last_t;
+    if (t0_u == 0u) {
+        last_p = p0;
+        last_q = p1 - p0;
+        if (dot(last_q, last_q) < DERIV_THRESH_SQUARED) last_q = eval_cubic_and_deriv(p0, p1, p2, p3, DERIV_EPS).deriv;
+        last_t = 0.0f;
+    } else {
+        PointDeriv pq0 = eval_cubic_and_deriv(p0, p1, p2, p3, t0);
+        last_t = t0;
+        if (dot(pq0.deriv, pq0.deriv) < DERIV_THRESH_SQUARED) {  // (t0 < 1 here: the piece before took the adjusted end)
+            PointDeriv n0 = eval_cubic_and_deriv(p0, p1, p2, p3, t0 - DERIV_EPS);
+            pq0.deriv = n0.deriv;
+            pq0.point = n0.point;
+            last_t = t0 - DERIV_EPS;
+        }
+        last_p = pq0.point;
+        last_q = pq0.deriv;
+    }
+    float t1 = t0 + dt;
+    PointDeriv this_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1);
+    if (dot(this_pq1.deriv, this_pq1.deriv) < DERIV_THRESH_SQUARED) {
+        PointDeriv new_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1 - DERIV_EPS);
+        this_pq1.deriv = new_pq1.deriv;
+        if (t1 < 1.0f) {
+            this_pq1.point = new_pq1.point;
+            t1 = t1 - DERIV_EPS;
+        }
+    }
+    const float actual_dt = t1 - last_t;
+    NodeResult r;
+    r.cp = cubic_from_points_derivs(last_p, this_pq1.point, last_q, this_pq1.deriv, actual_dt);
+    r.accept = r.cp.err * scale <= tol || dt <= SUBDIV_LIMIT;
+    r.es_p0 = last_p;
+    r.es_p1 = this_pq1.point;
+    r.ends_at_one = t1 == 1.0f;
+    return r;
+}
+
+// What flatten.wgsl:404-447 computes for an accepted interval besides the lines themselves: the Euler parameters and
+// the number of lines.
+struct PieceParams {
+    EulerParams ep;
+    float n, noff, int0, integral;
+    uint32_t n_u, robust;
+};
+JD PieceParams piece_params(const CubicParams& cp, float scale, float offset) {
+    const float tol = 0.25f;
+    PieceParams r;
+    r.ep = es_params_from_angles(cp.th0, cp.th1);
+    const EulerParams& ep = r.ep;
+    float k0 = ep.k0 - 0.5f * ep.k1;
+    float k1 = ep.k1;
+    float normalized_offset = offset / cp.chord_len;
+    float dist_scaled = normalized_offset * ep.ch;
+    float scale_multiplier = sqrt_(0.125f * scale * cp.chord_len / (ep.ch * tol));
+    float a = 0.0f, b = 0.0f, integral = 0.0f, int0 = 0.0f, n_frac;
+    uint32_t robust = 0u;
+    if (abs_(k1) < K1_THRESH) {
+        float k = ep.k0;
+        n_frac = sqrt_(abs_(k * (k * dist_scaled + 1.0f)));
+        robust = 1u;
+    } else if (abs_(dist_scaled) < DIST_THRESH) {
+        a = k1;
+        b = k0;
+        int0 = pow_1_5_signed(b);
+        float int1 = pow_1_5_signed(a + b);
+        integral = int1 - int0;
+        n_frac = (float)(2.0 / 3.0) * integral / a;
+        robust = 2u;
+    } else {
+        a = -2.0f * dist_scaled * k1;
+        b = -1.0f - 2.0f * dist_scaled * k0;
+        int0 = espc_int_approx(b);
+        float int1 = espc_int_approx(a + b);
+        integral = int1 - int0;
+        float k_peak = k0 - k1 * b / a;
+        float integrand_peak = sqrt_(abs_(k_peak * (k_peak * dist_scaled + 1.0f)));
+        n_frac = integral * integrand_peak / a;
+    }
+    r.n = clamp_(ceil_(n_frac * scale_multiplier), 1.0f, 100.0f);
+    r.n_u = to_u32(r.n);
+    r.noff = normalized_offset;
+    r.int0 = int0;
+    r.integral = integral;
+    r.robust = robust;
+    return r;
+}
+
 #ifndef FL_WAVES_PER_EU
-#define FL_WAVES_PER_EU 4
+#define FL_WAVES_PER_EU 3  // 149 VGPRs, no spills (4: 128 VGPRs with spills measured slower)
 #endif
 #ifndef FL_BLOCKS_PER_CU
-#define FL_BLOCKS_PER_CU 4
+#define FL_BLOCKS_PER_CU 5  // more workgroups than fit at once: the dynamic batch queue evens out the tail
 #endif
 __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_PER_EU, FL_WAVES_PER_EU))) void k_flatten_items(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
                                                          Buf<JlPathBbox> path_bboxes, const uint32_t* __restrict__ list,
@@ -837,6 +974,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
     __shared__ uint32_t sh_next;
     __shared__ uint32_t sh_chunk;
     __shared__ uint32_t sh_item;  // next position of this workgroup's share of the item list
+    __shared__ FlBatch sh_batch[JL_WG / 64];
     Scene s;
     s.cfg = cfg; s.scene = scene; s.tag_monoids = tag_monoids;
     uint32_t n_heavy = umin_(counters[0], cap), n_light = umin_(counters[1], cap - n_heavy);
@@ -854,56 +992,150 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
         if (chunk + i < tcap) tinfo[chunk + i] = 0u;
     __syncthreads();  // before any wave of the workgroup marks a slot
     const uint32_t lane = lane_id();
-    // Work distribution: the item list (heavy items first) is dealt to the workgroups in chunks of 64, round robin;
-    // the waves of a workgroup draw their items from its share through one LDS counter.
+    FlBatch& B = sh_batch[threadIdx.x >> 6];
     Out<true> o;
     o.cfg = cfg; o.tlines = tlines; o.tkeys = tkeys; o.tinfo = tinfo; o.overflow_start = gridDim.x * FL_CHUNK; o.tcap = tcap; o.slot = 0u;
     o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
     o.lds_next = &sh_next; o.lds_limit = chunk + FL_CHUNK; o.g_next = &counters[2];
     o.bx0 = 1e31f; o.by0 = 1e31f; o.bx1 = -1e31f; o.by1 = -1e31f;
-    EulerLane e;
-    e.p0 = e.p1 = e.p2 = e.p3 = v2(0, 0);
-    e.scale = 1.0f; e.offset = 0.0f; e.t_end = v2(0, 0); e.t0_u = 0u; e.dt = 1.0f; e.last_p = e.last_q = v2(0, 0); e.last_t = 0.0f;
-    e.t_start = v2(0, 0); e.first_piece = true; e.path_ix = 0u; e.trans_ix = 0u; e.done = true;
-    bool have = false;       // this lane holds an item that is not finalised yet
-    uint32_t path_ix = 0u;
-    auto refill = [&]() -> bool {
-        for (;;) {
-            if (e.done && have) {  // the lane's item is complete (path bounding boxes: k_flatten_bbox)
-                counts[o.slot] = o.cursor;
-                have = false;
-            }
-            const bool want = e.done;
-            const uint64_t wm = __builtin_amdgcn_ballot_w64(want);
-            const uint32_t nwant = (uint32_t)__builtin_popcountll(wm);
-            const uint32_t rank = (uint32_t)__builtin_popcountll(wm & ((1ull << lane) - 1ull));
-            uint32_t base = 0u;
-            if (want && rank == 0u) base = atomicAdd(&sh_item, nwant);
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(wm | (1ull << 63)));
-            // position q of the workgroup's share -> list position t
-            const uint32_t q = base + rank;
-            const uint32_t t = ((q >> 6) * gridDim.x + blockIdx.x) * 64u + (q & 63u);
-            const uint32_t t_first = ((base >> 6) * gridDim.x + blockIdx.x) * 64u + (base & 63u);
-            if (want && t < n) {
-                const uint32_t slot = t < n_heavy ? list[t] : list[cap - 1u - (t - n_heavy)];
-                o.slot = slot; o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
-                o.bx0 = 1e31f; o.by0 = 1e31f; o.bx1 = -1e31f; o.by1 = -1e31f;
-                EulerJob job;
-                job.valid = false; job.path_ix = 0u; job.trans_ix = 0u; job.offset = 0.0f;
-                job.start_p = v2(0, 0); job.end_p = v2(0, 0);
-                job.cubic.p0 = job.cubic.p1 = job.cubic.p2 = job.cubic.p3 = v2(0, 0);
-                job.local_to_device = xf_identity();
-                run_item<true>(cfg, s, o, slot, job, path_ix);
-                euler_begin(e, job);
-                have = true;
-            }
-            wave_fence();
-            if (__builtin_amdgcn_ballot_w64(!e.done) != 0ull) return true;   // somebody has Euler work
-            if (__builtin_amdgcn_ballot_w64(have) == 0ull && t_first >= n) return false;  // nothing held, queue empty
-            // only direct items (lines, caps, joins) were drawn, or finished ones wait to be finalised: go round again
+    // Work distribution: the item list (heavy items first) is dealt to the workgroups in chunks of 64, round robin; a
+    // wave takes one chunk (= one batch) at a time through the workgroup's LDS counter.
+    for (;;) {
+        uint32_t base = 0u;
+        if (lane == 0u) base = atomicAdd(&sh_item, 64u);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t t_first = ((base >> 6) * gridDim.x + blockIdx.x) * 64u;
+        if (t_first >= n) break;
+        const uint32_t t = t_first + lane;
+        // ---- set up the batch: direct items are emitted at once, Euler jobs go to LDS ----
+        EulerJob job;
+        job.valid = false; job.path_ix = 0u; job.trans_ix = 0u; job.offset = 0.0f;
+        job.start_p = v2(0, 0); job.end_p = v2(0, 0);
+        job.cubic.p0 = job.cubic.p1 = job.cubic.p2 = job.cubic.p3 = v2(0, 0);
+        job.local_to_device = xf_identity();
+        uint32_t slot = FL_INVALID;
+        if (t < n) {
+            slot = t < n_heavy ? list[t] : list[cap - 1u - (t - n_heavy)];
+            o.slot = slot; o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
+            uint32_t path_ix;
+            run_item<true>(cfg, s, o, slot, job, path_ix);
+            if (!job.valid) counts[slot] = o.cursor;  // a direct item is complete
         }
-    };
-    flatten_euler_wave(o, e, pieces, ends, refill);
+        EulerLane e;
+        euler_begin(e, job);  // (transforms the control points of a fill, scale of an offset curve, degenerate test)
+        const bool active = job.valid && !e.done;
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;  // uniform: nothing to subdivide in this batch
+        B.jhead[lane] = 0u;
+        B.jpend[lane] = active ? 1u : 0u;
+        {
+            const uint64_t am = __builtin_amdgcn_ballot_w64(active);
+            if (active) B.stack[(uint32_t)__builtin_popcountll(am & ((1ull << lane) - 1ull))] = lane;  // root: level 0, t0_u 0
+            if (lane == 0u) { B.n_stack = (uint32_t)__builtin_popcountll(am); B.n_leaves = 0u; B.bail = 0u; }
+        }
+        wave_fence();
+        // ---- drain the stack ----
+        for (;;) {
+            const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.n_stack);
+            if (ns == 0u) break;
+            const uint32_t take = umin_(ns, 64u);
+            const bool has = lane < take;
+            const uint32_t node = has ? B.stack[ns - 1u - lane] : 0u;
+            wave_fence();
+            const uint32_t j = node & 63u, level = (node >> 6) & 31u, t0_u = node >> 11;
+            // the job's state from its owner lane (every lane takes part in the permutes)
+            const V2 jp0 = v2(lanef(e.p0.x, j), lanef(e.p0.y, j)), jp1 = v2(lanef(e.p1.x, j), lanef(e.p1.y, j));
+            const V2 jp2 = v2(lanef(e.p2.x, j), lanef(e.p2.y, j)), jp3 = v2(lanef(e.p3.x, j), lanef(e.p3.y, j));
+            const float scale = lanef(e.scale, j), offset = lanef(e.offset, j);
+            NodeResult r;
+            r.accept = false;
+            if (has) r = node_test(jp0, jp1, jp2, jp3, scale, level, t0_u);
+            // a piece needs the ids of its job and, if it is the item's first or last, the item's end points
+            const uint32_t j_slot = laneu(slot, j), j_path = laneu(e.path_ix, j), j_trans = laneu(e.trans_ix, j);
+            const float j_tsx = lanef(e.t_start.x, j), j_tsy = lanef(e.t_start.y, j), j_tex = lanef(e.t_end.x, j), j_tey = lanef(e.t_end.y, j);
+            const bool acc = has && r.accept, rej = has && !r.accept;
+            const uint64_t accm = __builtin_amdgcn_ballot_w64(acc), rejm = __builtin_amdgcn_ballot_w64(rej);
+            const uint32_t n_acc = (uint32_t)__builtin_popcountll(accm), n_rej = (uint32_t)__builtin_popcountll(rejm);
+            const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.n_leaves);
+            const bool too_deep = __builtin_amdgcn_ballot_w64(rej && level + 1u > FLQ_MAX_LEVEL) != 0ull;
+            if (too_deep || ns - take + 2u * n_rej > FLQ_STACK || nl + n_acc > FLQ_LEAVES) {  // uniform: give up on the unfinished jobs
+                if (lane == 0u) B.bail = 1u;
+                wave_fence();
+                break;
+            }
+            const uint64_t below = (1ull << lane) - 1ull;
+            if (rej) {
+                const uint32_t pos = ns - take + 2u * (uint32_t)__builtin_popcountll(rejm & below);
+                B.stack[pos] = j | ((level + 1u) << 6) | ((2u * t0_u + 1u) << 11);
+                B.stack[pos + 1u] = j | ((level + 1u) << 6) | ((2u * t0_u) << 11);  // the left half on top: popped first
+                atomicAdd(&B.jpend[j], 1u);
+            }
+            if (acc) {
+                const PieceParams pp = piece_params(r.cp, scale, offset);
+                const uint32_t n_u = pp.n_u;
+                uint32_t tpos = atomicAdd(o.lds_next, n_u);
+                if (tpos + n_u > o.lds_limit) tpos = atomicAdd(o.g_next, n_u);
+                const uint32_t fl = pp.robust | (r.ends_at_one ? 4u : 0u) | ((offset >= 0.0f) ? 8u : 0u) | ((offset == 0.0f) ? 16u : 0u) |
+                                    ((t0_u == 0u) ? 32u : 0u);
+                if (tpos < tcap && tpos + n_u <= tcap) {
+                    uint4* rec = pieces + (size_t)tpos * 4u;
+                    rec[0] = make_uint4(f2u(r.es_p0.x), f2u(r.es_p0.y), f2u(r.es_p1.x), f2u(r.es_p1.y));
+                    rec[1] = make_uint4(f2u(pp.ep.th0), f2u(pp.ep.k0), f2u(pp.ep.k1), f2u(pp.ep.ch));
+                    ((uint2*)rec)[4] = make_uint2(f2u(pp.noff), f2u(pp.n));  // rec[2] = noff, n, slot, first line of the piece --
+                    ((uint32_t*)rec)[10] = j_slot;                            // the last word is written once, below
+                    rec[3] = make_uint4(j_path, (j_trans << 6) | fl, f2u(pp.int0), f2u(pp.integral));
+                    if ((fl & (32u | 4u)) != 0u) ends[tpos] = make_uint4(f2u(j_tsx), f2u(j_tsy), f2u(j_tex), f2u(j_tey));
+                    tinfo[tpos] = FL_INFO_PIECE | n_u;
+                    if (tpos >= o.overflow_start)  // only the chunk area is zeroed up front (rare path)
+                        for (uint32_t i = 1u; i < n_u; i++) tinfo[tpos + i] = 0u;
+                }
+                const uint32_t li = nl + (uint32_t)__builtin_popcountll(accm & below);
+                B.l_tpos[li] = tpos;
+                B.l_key[li] = (uint16_t)(((t0_u << (FLQ_MAX_LEVEL - level)) << 7) | n_u);
+                const uint32_t prev = atomicExch(&B.jhead[j], li + 1u);
+                B.l_link[li] = (uint16_t)((j << 10) | prev);
+                atomicSub(&B.jpend[j], 1u);
+            }
+            if (lane == 0u) { B.n_stack = ns - take + 2u * n_rej; B.n_leaves = nl + n_acc; }
+            wave_fence();
+        }
+        // ---- a piece's first line = the lines of its job's pieces before it; a job's line count ----
+        const bool bail = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.bail) != 0u;
+        const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.n_leaves);
+        for (uint32_t li = lane; li < nl; li += 64u) {
+            const uint32_t j = B.l_link[li] >> 10, tpos = B.l_tpos[li], key = B.l_key[li];
+            const bool ok = tpos < tcap && tpos + (key & 127u) <= tcap;
+            if (B.jpend[j] != 0u) {  // unfinished (bail): the job is redone below, its pieces so far are withdrawn
+                if (ok) tinfo[tpos] = 0u;
+                continue;
+            }
+            uint32_t first = 0u;
+            for (uint32_t q = B.jhead[j]; q != 0u; q = B.l_link[q - 1u] & 1023u) {
+                const uint32_t k2 = B.l_key[q - 1u];
+                if ((k2 >> 7) < (key >> 7)) first += k2 & 127u;
+            }
+            if (ok) ((uint32_t*)pieces)[(size_t)tpos * 16u + 11u] = first;
+        }
+        const bool redo = active && B.jpend[lane] != 0u;
+        if (active && !redo) {
+            uint32_t total = 0u;
+            for (uint32_t q = B.jhead[lane]; q != 0u; q = B.l_link[q - 1u] & 1023u) total += B.l_key[q - 1u] & 127u;
+            counts[slot] = total;
+        }
+        wave_fence();
+        if (bail) {  // uniform, rare: the sequential walk for the jobs that did not finish
+            o.slot = slot; o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
+            if (!redo) e.done = true;
+            bool have = redo;
+            auto finish = [&]() -> bool {
+                if (e.done && have) {
+                    counts[o.slot] = o.cursor;
+                    have = false;
+                }
+                return __builtin_amdgcn_ballot_w64(!e.done) != 0ull;
+            };
+            flatten_euler_wave(o, e, pieces, ends, finish);
+        }
+    }
     // how much of the reserved chunk is in use (k_flatten_lines skips the unused tail); every wave reports, the last wins
     if (lane == 0u) {
         const uint32_t used = umin_(sh_next, chunk + FL_CHUNK) - chunk;
@@ -975,7 +1207,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
         if (i >= n_u) continue;
         const uint4* rec = pieces + (size_t)tp * 4u;
         const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-        const uint32_t flags = r3.z;
+        const uint32_t flags = r3.y & 63u;
         const bool last_of_item = i + 1u == n_u && (flags & 4u) != 0u;
         const uint32_t slot = r2.z, k = r2.w + i;
         uint4 en = make_uint4(0u, 0u, 0u, 0u);
@@ -993,17 +1225,14 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
             if (robust != 1u) {
                 const float k0 = ep.k0 - 0.5f * ep.k1, k1 = ep.k1;
                 const float dist_scaled = noff * ep.ch;
-                float a, b, int0, integral;
+                const float int0 = u2f(r3.z), integral = u2f(r3.w);  // as k_flatten_items computed them
+                float a, b;
                 if (robust == 2u) {
                     a = k1;
                     b = k0;
-                    int0 = pow_1_5_signed(b);
-                    integral = pow_1_5_signed(a + b) - int0;
                 } else {
                     a = -2.0f * dist_scaled * k1;
                     b = -1.0f - 2.0f * dist_scaled * k0;
-                    int0 = espc_int_approx(b);
-                    integral = espc_int_approx(a + b) - int0;
                 }
                 float u = integral * tt + int0;
                 float inv;
@@ -1016,7 +1245,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
         if ((flags & 16u) != 0u) {
             tr = xf_identity();
         } else {
-            uint32_t tb = cfg->layout.transform_base + r3.y * 6u;
+            uint32_t tb = cfg->layout.transform_base + (r3.y >> 6) * 6u;
             tr.m0 = u2f(scene.rd(tb)); tr.m1 = u2f(scene.rd(tb + 1u)); tr.m2 = u2f(scene.rd(tb + 2u));
             tr.m3 = u2f(scene.rd(tb + 3u)); tr.t0 = u2f(scene.rd(tb + 4u)); tr.t1 = u2f(scene.rd(tb + 5u));
         }

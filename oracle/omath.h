@@ -152,14 +152,11 @@ static inline double datan2(double y, double x) {
     const double PI = 3.141592653589793;
     const double PIO2 = 1.5707963267948966;
     double ax = std::fabs(x), ay = std::fabs(y);
-    double r;
-    if (ax == 0.0 && ay == 0.0) {
-        r = 0.0;
-    } else if (ay <= ax) {
-        r = datan_frac(ay, ax);
-    } else {
-        r = PIO2 - datan_frac(ax, ay);
-    }
+    // one evaluation on (smaller, larger) instead of one per branch (on the GPU both branches of a divergent wave run)
+    const bool swap = !(ay <= ax);
+    double f = datan_frac(swap ? ax : ay, swap ? ay : ax);
+    double r = swap ? PIO2 - f : f;
+    if (ax == 0.0 && ay == 0.0) r = 0.0;
     if (std::signbit(x)) r = PI - r;
     return std::signbit(y) ? -r : r;
 }

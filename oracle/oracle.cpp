@@ -460,6 +460,10 @@ enum { ESPC_ROBUST_NORMAL = 0, ESPC_ROBUST_LOW_K1 = 1, ESPC_ROBUST_LOW_DIST = 2 
 // flatten.wgsl:328-477
 // instrumentation only (tools/flatten_stats.py): [jobs, attempts, lines, pieces, histogram of attempts per job (28 bins)]
 static uint64_t g_flatten_stats[32];
+static uint64_t g_flatten_depth[20];  // histogram over jobs of the deepest accepted piece (dt = 2^-depth), bin 19 = deeper
+extern "C" void oracle_flatten_depth(uint64_t* out, int reset) {
+    for (int i = 0; i < 20; i++) { out[i] = g_flatten_depth[i]; if (reset) g_flatten_depth[i] = 0; }
+}
 static float* g_flatten_pairs = nullptr;  // optional (root error * scale, attempts) log for tools/flatten_stats.py
 static size_t g_flatten_pairs_n = 0, g_flatten_pairs_cap = 0;
 extern "C" void oracle_flatten_pairs(float* buf, size_t cap) { g_flatten_pairs = buf; g_flatten_pairs_cap = cap; g_flatten_pairs_n = 0; }
@@ -499,7 +503,7 @@ static void flatten_euler(Ctx& c, const CubicPoints& cubic, uint32_t path_ix, co
     if (dot(last_q, last_q) < DERIV_THRESH_SQUARED) last_q = eval_cubic_and_deriv(p0, p1, p2, p3, DERIV_EPS).deriv;
     float last_t = 0.0f;
     V2 lp0 = t_start;
-    uint32_t st_attempts = 0u, st_pieces = 0u;
+    uint32_t st_attempts = 0u, st_pieces = 0u, st_depth = 0u;
     float st_root_err = 0.0f;
     for (;;) {
         float t0 = (float)t0_u * dt;
@@ -579,6 +583,7 @@ static void flatten_euler(Ctx& c, const CubicPoints& cubic, uint32_t path_ix, co
                 lp0 = lp1;
             }
             st_pieces++;
+            { uint32_t d = 0u; float q = dt; while (q < 1.0f && d < 19u) { q *= 2.0f; d++; } if (d > st_depth) st_depth = d; }
             g_flatten_stats[2] += n_u;
             last_p = this_pq1.point;
             last_q = this_pq1.deriv;
@@ -593,6 +598,7 @@ static void flatten_euler(Ctx& c, const CubicPoints& cubic, uint32_t path_ix, co
         }
     }
     g_flatten_stats[0] += 1u;
+    g_flatten_depth[st_depth] += 1u;
     g_flatten_stats[1] += st_attempts;
     g_flatten_stats[3] += st_pieces;
     g_flatten_stats[4 + (st_attempts < 27u ? st_attempts : 27u)] += 1u;

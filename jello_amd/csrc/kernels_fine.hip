@@ -201,7 +201,7 @@ JD V4 over(V4 bg, V4 fg, float area) {
 // ------------------------------------------------------------------------------------------------
 #define FB_SPEC 128u
 #ifndef FINE_LEAN_WAVES_PER_EU
-#define FINE_LEAN_WAVES_PER_EU 5  // 88 VGPRs; 6 (80 VGPRs, 7 spills) measured the same
+#define FINE_LEAN_WAVES_PER_EU 6
 #endif
 #ifndef FINE_CLIP_WAVES_PER_EU
 #define FINE_CLIP_WAVES_PER_EU 2  // instantiations with the clip/blend stack in registers (219 VGPRs)
@@ -491,10 +491,8 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
     const uint32_t tile_y = blockIdx.y + tile_row0;
     // FINE_WAVES independent waves (= tiles, side by side in x) per workgroup: the CU runs at most 16 workgroups, so
     // single-wave workgroups would cap the occupancy at 4 waves per SIMD.  The waves never synchronise with each other.
-    __shared__ uint32_t win_all[FINE_WAVES][JL_PTCL_INCREMENT];  // wave-private PTCL windows
     __shared__ typename FineLdsSel<AA>::type F_all[FINE_WAVES];
     const uint32_t wave_in_wg = threadIdx.x >> 6;
-    uint32_t* const win = win_all[wave_in_wg];
     auto& F = F_all[wave_in_wg];
     const uint32_t tile_x = blockIdx.x * FINE_WAVES + wave_in_wg;
     if (tile_x >= tiles_x) return;  // tiles_x = the dispatch's x size
@@ -512,23 +510,19 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
     for (int k = 0; k < 4; k++) { bs0[k] = v4(0, 0, 0, 0); bs1[k] = bs0[k]; bs2[k] = bs0[k]; bs3[k] = bs0[k]; }
     uint32_t clip_depth = 0u;
     float area[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    // PTCL window: words [win_base, win_base + 256) of the global stream live in `win`
-    uint32_t win_base = tile_ix * JL_PTCL_INITIAL_ALLOC;
-    {
-        uint32_t gi = win_base + lane;
-        win[lane] = gi < ptcl_n ? ptcl[gi] : 0u;
-    }
+    // The command stream is the same for all 64 lanes: it is read with SCALAR loads (uniform index, read-only buffer ->
+    // s_load_dword*, served by the scalar cache), so a command's tag and arguments arrive in SGPRs -- no LDS staging, no
+    // per-word address arithmetic or v_readfirstlane on the vector unit (18 VALU instructions per command before).
+    uint32_t pc = uni(tile_ix * JL_PTCL_INITIAL_ALLOC);  // absolute word index of the next command
     if constexpr (AA == 0) {
         if (lane < 16u) F.contrib[lane][64] = 0.0f;  // the "no pair" slot
     } else {
         if (lane == 0u) F.seg_win_valid = 0u;  // fill_path_ms: no segment window yet
     }
     wave_sync();
-    uint32_t cmd_ix = 0u;  // relative to win_base
-    auto P = [&](uint32_t rel) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)win[rel & (JL_PTCL_INCREMENT - 1u)]); };
     auto I = [&](uint32_t i) -> uint32_t { return i < info_n ? info[i] : 0u; };
-    const uint32_t blend_offset = P(cmd_ix);
-    cmd_ix += 1u;
+    const uint32_t blend_offset = pc < ptcl_n ? ptcl[pc] : 0u;
+    pc += 1u;
     auto load_grad = [&](int32_t x, uint32_t y) -> V4 {
         if (x < 0 || x >= JL_GRADIENT_WIDTH || y >= grad_h) return v4(0, 0, 0, 0);
         const uint16_t* t = gradients + ((size_t)y * JL_GRADIENT_WIDTH + (size_t)x) * 4;
@@ -699,15 +693,37 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
       }
     };
 
-    for (uint32_t guard = 0; guard < (1u << 24); guard++) {
-        // one LDS round trip per command: tag and arguments together (CMD_FILL is nearly always followed by
-        // CMD_COLOR: both are decoded from the same nine words)
-        uint32_t wv[9];
+    // nine words at word index `at` (uniform); words behind the end of the buffer read as zero (robust access)
+    auto load_cmd = [&](uint32_t at, uint32_t (&w)[9]) {
+        if (at + 9u <= ptcl_n && at + 9u > at) {  // uniform
 #pragma unroll
-        for (int k = 0; k < 9; k++) wv[k] = win[(cmd_ix + (uint32_t)k) & (JL_PTCL_INCREMENT - 1u)];
-        auto W = [&](int k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)wv[k]); };
+            for (int k = 0; k < 9; k++) w[k] = ptcl[at + (uint32_t)k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; k++) w[k] = (at + (uint32_t)k < ptcl_n && at + (uint32_t)k >= at) ? ptcl[at + (uint32_t)k] : 0u;
+        }
+    };
+    uint32_t wv[9];
+    load_cmd(pc, wv);
+    for (uint32_t guard = 0; guard < (1u << 24); guard++) {
+        // tag and arguments together (CMD_FILL is nearly always followed by CMD_COLOR: both are decoded from the same nine
+        // words).  The words of the NEXT command are requested right away -- its position follows from this command's tag --
+        // so that their scalar-load latency passes under this command's work.
+        auto W = [&](int k) -> uint32_t { return wv[k]; };
         const uint32_t tag = W(0);
         const uint32_t W1 = W(1), W2 = W(2);
+        uint32_t npc = pc;
+        switch (tag) {
+            case JL_CMD_FILL: npc = pc + ((W(4) == JL_CMD_COLOR) ? 9u : 4u); break;
+            case JL_CMD_SOLID: case JL_CMD_BEGIN_CLIP: npc = pc + 1u; break;
+            case JL_CMD_COLOR: npc = pc + 5u; break;
+            case JL_CMD_END_CLIP: case JL_CMD_LIN_GRAD: case JL_CMD_RAD_GRAD: case JL_CMD_SWEEP_GRAD: npc = pc + 3u; break;
+            case JL_CMD_IMAGE: npc = pc + 2u; break;
+            case JL_CMD_JUMP: npc = W1; break;
+            default: break;  // END, or an unknown tag (stops below)
+        }
+        uint32_t nx[9];
+        load_cmd(npc, nx);
         if (tag == JL_CMD_END) break;
         if (tag == JL_CMD_FILL) {  // fill_path, fine.wgsl:824-878
             uint32_t size_and_rule = W1;
@@ -782,22 +798,18 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
             (void)n_segs; (void)even_odd;
             fill_path_ms<AA>(F, lane, size_and_rule, seg_data, backdrop, segments, segments_n, mask_lut, mask_lut_n, area);
           }
-            cmd_ix += 4u;
-            if (cmd_ix + 4u < JL_PTCL_INCREMENT && W(4) == JL_CMD_COLOR) {  // the usual pair: no second trip through the decoder
+            if (W(4) == JL_CMD_COLOR) {  // the usual pair: no second trip through the decoder
                 V4 fg = v4(u2f(W(5)), u2f(W(6)), u2f(W(7)), u2f(W(8)));
 #pragma unroll
                 for (int k = 0; k < 4; k++) rgba[k] = over(rgba[k], fg, area[k]);
-                cmd_ix += 5u;
             }
         } else if (tag == JL_CMD_SOLID) {
 #pragma unroll
             for (int k = 0; k < 4; k++) area[k] = 1.0f;
-            cmd_ix += 1u;
         } else if (tag == JL_CMD_COLOR) {
             V4 fg = v4(u2f(W1), u2f(W2), u2f(W(3)), u2f(W(4)));
 #pragma unroll
             for (int k = 0; k < 4; k++) rgba[k] = over(rgba[k], fg, area[k]);
-            cmd_ix += 5u;
         } else if (CLIPS && tag == JL_CMD_BEGIN_CLIP) {
             if (clip_depth < JL_BLEND_STACK_SPLIT) {
 #pragma unroll
@@ -820,7 +832,6 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
                 }
             }
             clip_depth += 1u;
-            cmd_ix += 1u;
         } else if (CLIPS && tag == JL_CMD_END_CLIP) {
             uint32_t blend = W1;
             float alpha = u2f(W2);
@@ -843,31 +854,12 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
                 V4 fg = v4(rgba[k].x * area[k] * alpha, rgba[k].y * area[k] * alpha, rgba[k].z * area[k] * alpha, rgba[k].w * area[k] * alpha);
                 rgba[k] = blend_mix_compose(bg, fg, blend);
             }
-            cmd_ix += 3u;
         } else if (tag == JL_CMD_JUMP) {
-            win_base = W1;
-            cmd_ix = 0u;
-            wave_sync();  // everyone is done reading the old window
-            {
-                uint32_t gi = win_base + lane * 4u;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (gi + 3u < ptcl_n && (win_base & 3u) == 0u) {
-                    v = *(const uint4*)(ptcl + gi);
-                } else {
-                    if (gi < ptcl_n) v.x = ptcl[gi];
-                    if (gi + 1u < ptcl_n) v.y = ptcl[gi + 1u];
-                    if (gi + 2u < ptcl_n) v.z = ptcl[gi + 2u];
-                    if (gi + 3u < ptcl_n) v.w = ptcl[gi + 3u];
-                }
-                *(uint4*)(&win[lane * 4u]) = v;
-            }
-            wave_sync();
         } else if (!PAINTS && (tag == JL_CMD_LIN_GRAD || tag == JL_CMD_RAD_GRAD || tag == JL_CMD_SWEEP_GRAD || tag == JL_CMD_IMAGE)) {
             // This instantiation is only launched when no ramp and no image is bound: every texel fetch of the
             // WGSL returns 0 then, i.e. the command composites a transparent colour.
 #pragma unroll
             for (int k = 0; k < 4; k++) rgba[k] = over(rgba[k], v4(0, 0, 0, 0), area[k]);
-            cmd_ix += (tag == JL_CMD_IMAGE) ? 2u : 3u;
         } else if (PAINTS && tag == JL_CMD_LIN_GRAD) {
             uint32_t index_mode = W1;
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
@@ -880,7 +872,6 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
                 int32_t x = to_i32(round_(extend_mode(my_d, ext) * 511.0f));
                 rgba[k] = over(rgba[k], load_grad(x, index), area[k]);
             }
-            cmd_ix += 3u;
         } else if (PAINTS && tag == JL_CMD_RAD_GRAD) {
             uint32_t index_mode = W1;
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
@@ -926,7 +917,6 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
                     rgba[k] = over(rgba[k], load_grad(gxi, index), area[k]);
                 }
             }
-            cmd_ix += 3u;
         } else if (PAINTS && tag == JL_CMD_SWEEP_GRAD) {
             uint32_t index_mode = W1;
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
@@ -954,7 +944,6 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
                 int32_t ramp_x = to_i32(round_(t * 511.0f));
                 rgba[k] = over(rgba[k], load_grad(ramp_x, index), area[k]);
             }
-            cmd_ix += 3u;
         } else if (PAINTS && tag == JL_CMD_IMAGE) {
             uint32_t io = W1;
             float m0 = u2f(I(io)), m1 = u2f(I(io + 1u)), m2 = u2f(I(io + 2u)), m3 = u2f(I(io + 3u));
@@ -1004,10 +993,12 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
                     rgba[k] = over(rgba[k], fg, area[k]);
                 }
             }
-            cmd_ix += 2u;
         } else {
             break;  // unknown tag: the WGSL would never advance; stop instead of hanging the GPU
         }
+        pc = npc;
+#pragma unroll
+        for (int k = 0; k < 9; k++) wv[k] = nx[k];
     }
     // fine.wgsl:1092-1102: un-premultiply, store RGBA16F (four adjacent pixels = 32 bytes per lane; 4 lanes = one 128-B row)
     const uint32_t cx0 = tile_x * 16u + lx * 4u;

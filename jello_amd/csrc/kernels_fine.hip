@@ -725,6 +725,11 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
         uint32_t nx[9];
         load_cmd(npc, nx);
         if (tag == JL_CMD_END) break;
+        // A solid colour (uniform: it sits in scalar registers) is composited at ONE place below, whichever command brought
+        // it -- one definition of rgba per trip keeps the sixteen colour registers where they are (three composite sites
+        // cost ~35 register moves per command).
+        bool have_fg = false;
+        V4 fg = v4(0, 0, 0, 0);
         if (tag == JL_CMD_FILL) {  // fill_path, fine.wgsl:824-878
             uint32_t size_and_rule = W1;
             uint32_t seg_data = W2;
@@ -799,17 +804,15 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
             fill_path_ms<AA>(F, lane, size_and_rule, seg_data, backdrop, segments, segments_n, mask_lut, mask_lut_n, area);
           }
             if (W(4) == JL_CMD_COLOR) {  // the usual pair: no second trip through the decoder
-                V4 fg = v4(u2f(W(5)), u2f(W(6)), u2f(W(7)), u2f(W(8)));
-#pragma unroll
-                for (int k = 0; k < 4; k++) rgba[k] = over(rgba[k], fg, area[k]);
+                fg = v4(u2f(W(5)), u2f(W(6)), u2f(W(7)), u2f(W(8)));
+                have_fg = true;
             }
         } else if (tag == JL_CMD_SOLID) {
 #pragma unroll
             for (int k = 0; k < 4; k++) area[k] = 1.0f;
         } else if (tag == JL_CMD_COLOR) {
-            V4 fg = v4(u2f(W1), u2f(W2), u2f(W(3)), u2f(W(4)));
-#pragma unroll
-            for (int k = 0; k < 4; k++) rgba[k] = over(rgba[k], fg, area[k]);
+            fg = v4(u2f(W1), u2f(W2), u2f(W(3)), u2f(W(4)));
+            have_fg = true;
         } else if (CLIPS && tag == JL_CMD_BEGIN_CLIP) {
             if (clip_depth < JL_BLEND_STACK_SPLIT) {
 #pragma unroll
@@ -858,8 +861,7 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
         } else if (!PAINTS && (tag == JL_CMD_LIN_GRAD || tag == JL_CMD_RAD_GRAD || tag == JL_CMD_SWEEP_GRAD || tag == JL_CMD_IMAGE)) {
             // This instantiation is only launched when no ramp and no image is bound: every texel fetch of the
             // WGSL returns 0 then, i.e. the command composites a transparent colour.
-#pragma unroll
-            for (int k = 0; k < 4; k++) rgba[k] = over(rgba[k], v4(0, 0, 0, 0), area[k]);
+            have_fg = true;
         } else if (PAINTS && tag == JL_CMD_LIN_GRAD) {
             uint32_t index_mode = W1;
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
@@ -995,6 +997,10 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
             }
         } else {
             break;  // unknown tag: the WGSL would never advance; stop instead of hanging the GPU
+        }
+        if (have_fg) {  // uniform
+#pragma unroll
+            for (int k = 0; k < 4; k++) rgba[k] = over(rgba[k], fg, area[k]);
         }
         pc = npc;
 #pragma unroll

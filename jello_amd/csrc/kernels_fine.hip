@@ -204,10 +204,10 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #define FINE_LEAN_WAVES_PER_EU 6
 #endif
 #ifndef FINE_CLIP_WAVES_PER_EU
-#define FINE_CLIP_WAVES_PER_EU 2  // instantiations with the clip/blend stack in registers (219 VGPRs)
+#define FINE_CLIP_WAVES_PER_EU 2  // the clip / blend stack lives in LDS (16 KiB per tile-wave): LDS, not registers, bounds the occupancy
 #endif
 #ifndef FINE_CLIP_MS_WAVES_PER_EU
-#define FINE_CLIP_MS_WAVES_PER_EU 3  // the multisampled ones need fewer registers (C4 msaa16: 6.5 -> 5.6 ms; area AA at 3: 11 ms, spills)
+#define FINE_CLIP_MS_WAVES_PER_EU 2
 #endif
 #ifndef FINE_WAVES
 #define FINE_WAVES 2
@@ -478,11 +478,20 @@ JD void fill_path_ms(MsLds& T, uint32_t lane, uint32_t size_and_rule, uint32_t s
 
 template <int AA> struct FineLdsSel { typedef MsLds type; };
 template <> struct FineLdsSel<0> { typedef FillLds type; };
+// The first JL_BLEND_STACK_SPLIT levels of the clip / blend stack (fine.wgsl:938-973 keeps them in registers; deeper
+// levels go to blend_spill): wave-private LDS, one float4 per pixel, lane-contiguous (conflict-free 16-byte accesses),
+// addressed by the (uniform) level.  In registers the four levels needed a four-way switch with sixteen moves per case
+// and 64 VGPRs: 219 VGPRs and ~290 VALU instructions per command for the clip instantiations.
+template <bool CLIPS> struct FineStackSel { struct type { float4 lvl[JL_BLEND_STACK_SPLIT][4][64]; }; };
+template <> struct FineStackSel<false> { struct type { float4 lvl[1][1][1]; }; };
 
 // Pixel ownership = the WGSL's: lane = ly*4 + lx (workgroup (4,16)), pixel i = 0..3 at column 4*lx + i.
 // AA = 0: analytic area coverage (fine_area); 8 / 16: fine_msaa8 / fine_msaa16.
+// Tile-waves per workgroup: two where LDS is small (the CU runs at most 16 workgroups, so single-wave workgroups would cap
+// the occupancy at 4 waves per SIMD); one for the clip instantiations, whose 22 KB per wave then pack 7 to a CU instead of 6.
+#define FINE_WG_WAVES(CLIPS) ((CLIPS) ? 1 : FINE_WAVES)
 template <int AA, bool CLIPS, bool PAINTS>
-__global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu(CLIPS ? (AA != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU), CLIPS ? (AA != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU)))) void k_fine_area(const JlConfig* __restrict__ cfg, const float* __restrict__ segments, uint32_t segments_n,
+__global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_waves_per_eu(CLIPS ? (AA != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU), CLIPS ? (AA != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU)))) void k_fine_area(const JlConfig* __restrict__ cfg, const float* __restrict__ segments, uint32_t segments_n,
                                                   const uint32_t* __restrict__ ptcl, uint32_t ptcl_n, const uint32_t* __restrict__ info,
                                                   uint32_t info_n, Buf<V4> blend_spill, uint16_t* __restrict__ output, uint32_t out_w,
                                                   uint32_t out_h, const uint16_t* __restrict__ gradients, uint32_t grad_h, FineImages images,
@@ -491,10 +500,13 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
     const uint32_t tile_y = blockIdx.y + tile_row0;
     // FINE_WAVES independent waves (= tiles, side by side in x) per workgroup: the CU runs at most 16 workgroups, so
     // single-wave workgroups would cap the occupancy at 4 waves per SIMD.  The waves never synchronise with each other.
-    __shared__ typename FineLdsSel<AA>::type F_all[FINE_WAVES];
+    constexpr uint32_t WV = FINE_WG_WAVES(CLIPS);
+    __shared__ typename FineLdsSel<AA>::type F_all[WV];
+    __shared__ typename FineStackSel<CLIPS>::type S_all[WV];
     const uint32_t wave_in_wg = threadIdx.x >> 6;
     auto& F = F_all[wave_in_wg];
-    const uint32_t tile_x = blockIdx.x * FINE_WAVES + wave_in_wg;
+    auto& S = S_all[CLIPS ? wave_in_wg : 0u];  // (one dummy element per wave when !CLIPS: 16 bytes)
+    const uint32_t tile_x = blockIdx.x * WV + wave_in_wg;
     if (tile_x >= tiles_x) return;  // tiles_x = the dispatch's x size
     if (ptcl_n == 0u || ptcl[0] == ~0u) return;  // fine.wgsl:889-893
     const uint32_t lane = threadIdx.x & 63u;
@@ -505,14 +517,22 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
     V4 rgba[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) rgba[k] = v4(cfg->base_color[0], cfg->base_color[1], cfg->base_color[2], cfg->base_color[3]);
-    V4 bs0[4], bs1[4], bs2[4], bs3[4];  // blend_stack[0..3]
-#pragma unroll
-    for (int k = 0; k < 4; k++) { bs0[k] = v4(0, 0, 0, 0); bs1[k] = bs0[k]; bs2[k] = bs0[k]; bs3[k] = bs0[k]; }
     uint32_t clip_depth = 0u;
+    // Lazy layers.  BEGIN_CLIP saves the colour so far and starts the layer from zero; content such as the C4 scene opens
+    // hundreds of layers over a tile of which only a few draw anything there.  So the save is DEFERRED: levels
+    // [pushed_depth, clip_depth) are open but not yet on the stack -- rgba still holds the colour from before the
+    // outermost of them.  The first composite inside them performs the pending saves (`materialize`: the outermost
+    // pending level gets rgba, the ones inside it the zeros they would have started from).  A layer that is closed while
+    // still pending is empty: END_CLIP then blends an all-zero source into rgba, which for the common blend modes leaves
+    // it bit for bit as it is (shown at END_CLIP below) -- no stack traffic and no blend arithmetic for empty layers.
+    uint32_t pushed_depth = 0u;
     float area[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    // The command stream is the same for all 64 lanes: it is read with SCALAR loads (uniform index, read-only buffer ->
-    // s_load_dword*, served by the scalar cache), so a command's tag and arguments arrive in SGPRs -- no LDS staging, no
-    // per-word address arithmetic or v_readfirstlane on the vector unit (18 VALU instructions per command before).
+    // The command stream is the same for all 64 lanes.  It is kept in a REGISTER window: lane k of `wcur` holds word
+    // wbase + k of the stream (one coalesced 256-byte load per 64 words, bounds-checked per lane: robust access), `wnext`
+    // the 64 words after that -- requested one window ahead, so its latency passes under the commands in between.  A
+    // command's words are read off the lanes with v_readlane (uniform lane index) into scalar registers: no LDS staging,
+    // no per-word address arithmetic, and no memory latency between short commands (a scalar load per command had
+    // ~1 us of it: fatal for streams of hundreds of one-word clip commands).
     uint32_t pc = uni(tile_ix * JL_PTCL_INITIAL_ALLOC);  // absolute word index of the next command
     if constexpr (AA == 0) {
         if (lane < 16u) F.contrib[lane][64] = 0.0f;  // the "no pair" slot
@@ -693,37 +713,44 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
       }
     };
 
-    // nine words at word index `at` (uniform); words behind the end of the buffer read as zero (robust access)
-    auto load_cmd = [&](uint32_t at, uint32_t (&w)[9]) {
-        if (at + 9u <= ptcl_n && at + 9u > at) {  // uniform
+    auto load_win = [&](uint32_t b) -> uint32_t {
+        const uint32_t i = b + lane;
+        return (i < ptcl_n && i >= b) ? ptcl[i] : 0u;
+    };
+    uint32_t wbase = pc;
+    uint32_t wcur = load_win(wbase), wnext = load_win(wbase + 64u);
+    auto materialize = [&]() {  // perform the pending saves of BEGIN_CLIP (fine.wgsl:938-950), outermost first
+        if constexpr (CLIPS) {
+            while (pushed_depth < clip_depth) {  // uniform
+                if (pushed_depth < JL_BLEND_STACK_SPLIT) {
 #pragma unroll
-            for (int k = 0; k < 9; k++) w[k] = ptcl[at + (uint32_t)k];
-        } else {
+                    for (int k = 0; k < 4; k++) S.lvl[pushed_depth][k][lane] = make_float4(rgba[k].x, rgba[k].y, rgba[k].z, rgba[k].w);
+                } else {
+                    const uint32_t spill_base = blend_offset + (pushed_depth - JL_BLEND_STACK_SPLIT) * JL_TILE_WIDTH * JL_TILE_HEIGHT;
 #pragma unroll
-            for (int k = 0; k < 9; k++) w[k] = (at + (uint32_t)k < ptcl_n && at + (uint32_t)k >= at) ? ptcl[at + (uint32_t)k] : 0u;
+                    for (int k = 0; k < 4; k++) blend_spill.wr(spill_base + pix_spill(k), rgba[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) rgba[k] = v4(0, 0, 0, 0);
+                pushed_depth += 1u;
+            }
         }
     };
-    uint32_t wv[9];
-    load_cmd(pc, wv);
     for (uint32_t guard = 0; guard < (1u << 24); guard++) {
-        // tag and arguments together (CMD_FILL is nearly always followed by CMD_COLOR: both are decoded from the same nine
-        // words).  The words of the NEXT command are requested right away -- its position follows from this command's tag --
-        // so that their scalar-load latency passes under this command's work.
-        auto W = [&](int k) -> uint32_t { return wv[k]; };
-        const uint32_t tag = W(0);
-        const uint32_t W1 = W(1), W2 = W(2);
-        uint32_t npc = pc;
-        switch (tag) {
-            case JL_CMD_FILL: npc = pc + ((W(4) == JL_CMD_COLOR) ? 9u : 4u); break;
-            case JL_CMD_SOLID: case JL_CMD_BEGIN_CLIP: npc = pc + 1u; break;
-            case JL_CMD_COLOR: npc = pc + 5u; break;
-            case JL_CMD_END_CLIP: case JL_CMD_LIN_GRAD: case JL_CMD_RAD_GRAD: case JL_CMD_SWEEP_GRAD: npc = pc + 3u; break;
-            case JL_CMD_IMAGE: npc = pc + 2u; break;
-            case JL_CMD_JUMP: npc = W1; break;
-            default: break;  // END, or an unknown tag (stops below)
+        if (pc - wbase > 64u - 9u) {  // uniform: fewer than nine words of the command are in `wcur`
+            // Re-base the window at pc: lane k takes word pc + k from the two windows (ds_bpermute: a lane shuffle through
+            // the LDS crossbar, no LDS storage), and the window behind the new one is requested.
+            const uint32_t sh = pc - wbase;  // 56 .. 64: a command advances pc by at most nine words (jumps reload)
+            const uint32_t src = lane + sh;
+            const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src & 63u) << 2), (int)wcur);
+            const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src & 63u) << 2), (int)wnext);
+            wcur = src < 64u ? a : b;      // src <= 127
+            wbase = pc;
+            wnext = load_win(wbase + 64u);
         }
-        uint32_t nx[9];
-        load_cmd(npc, nx);
+        const uint32_t woff = pc - wbase;  // <= 55: the nine words a command may have are all in wcur
+        auto W = [&](uint32_t k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)wcur, (int)(woff + k)); };
+        const uint32_t tag = W(0);
         if (tag == JL_CMD_END) break;
         // A solid colour (uniform: it sits in scalar registers) is composited at ONE place below, whichever command brought
         // it -- one definition of rgba per trip keeps the sixteen colour registers where they are (three composite sites
@@ -731,8 +758,8 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
         bool have_fg = false;
         V4 fg = v4(0, 0, 0, 0);
         if (tag == JL_CMD_FILL) {  // fill_path, fine.wgsl:824-878
-            uint32_t size_and_rule = W1;
-            uint32_t seg_data = W2;
+            uint32_t size_and_rule = W(1);
+            uint32_t seg_data = W(2);
             int32_t backdrop = (int32_t)W(3);
             uint32_t n_segs = size_and_rule >> 1;
             // segments behind the end of the buffer read as zero and contribute nothing (robust access), so a corrupt
@@ -803,69 +830,110 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
             (void)n_segs; (void)even_odd;
             fill_path_ms<AA>(F, lane, size_and_rule, seg_data, backdrop, segments, segments_n, mask_lut, mask_lut_n, area);
           }
+            pc += 4u;
             if (W(4) == JL_CMD_COLOR) {  // the usual pair: no second trip through the decoder
                 fg = v4(u2f(W(5)), u2f(W(6)), u2f(W(7)), u2f(W(8)));
                 have_fg = true;
+                pc += 5u;
             }
         } else if (tag == JL_CMD_SOLID) {
 #pragma unroll
             for (int k = 0; k < 4; k++) area[k] = 1.0f;
+            pc += 1u;
         } else if (tag == JL_CMD_COLOR) {
-            fg = v4(u2f(W1), u2f(W2), u2f(W(3)), u2f(W(4)));
+            fg = v4(u2f(W(1)), u2f(W(2)), u2f(W(3)), u2f(W(4)));
             have_fg = true;
+            pc += 5u;
         } else if (CLIPS && tag == JL_CMD_BEGIN_CLIP) {
-            if (clip_depth < JL_BLEND_STACK_SPLIT) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    switch (clip_depth) {
-                        case 0: bs0[k] = rgba[k]; break;
-                        case 1: bs1[k] = rgba[k]; break;
-                        case 2: bs2[k] = rgba[k]; break;
-                        default: bs3[k] = rgba[k]; break;
-                    }
-                    rgba[k] = v4(0, 0, 0, 0);
-                }
-            } else {
-                uint32_t blend_in_scratch = clip_depth - JL_BLEND_STACK_SPLIT;
-                uint32_t spill_base = blend_offset + blend_in_scratch * JL_TILE_WIDTH * JL_TILE_HEIGHT;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    blend_spill.wr(spill_base + pix_spill(k), rgba[k]);
-                    rgba[k] = v4(0, 0, 0, 0);
-                }
-            }
-            clip_depth += 1u;
+            clip_depth += 1u;  // (the save is deferred, see pushed_depth)
+            pc += 1u;
         } else if (CLIPS && tag == JL_CMD_END_CLIP) {
-            uint32_t blend = W1;
-            float alpha = u2f(W2);
-            clip_depth -= 1u;
+            pc += 3u;
+            const uint32_t blend = W(1);
+            const float alpha = u2f(W(2));
+            const uint32_t level = clip_depth - 1u;
+            // A layer that is still pending is empty: the blend's source rgba_layer * area * alpha is +0 in every lane (given
+            // 0 <= area <= 1 and 0 <= alpha < inf), its backdrop is rgba itself, and blend_mix_compose(bg, +0, mode) reduces
+            // EXACTLY to
+            //   (mode & 0x7fff) == 0 (normal / clip, src-over):  bg * (1 - 0) + 0 = bg + 0 per channel (x * 1 is the identity;
+            //                      the addition of +0 is kept: it turns a -0 of the backdrop into +0 like the full formula);
+            //   src-over with a separable mix mode (1..11):       (bg.c * 1 + cs'.c * 0, 0 + bg.a * 1), where cs' is a FINITE
+            //                      value for 0 <= bg <= 16 (every operation of blend_mix on cb = bg.c / max(bg.a, 1e-15) and
+            //                      cs = 0 stays far below overflow), so cs'.c * 0 = +-0 and bg.c + (+-0) = bg.c for bg.c >= +0.
+            //   src-over with hue / saturation / color (12..14): cs = 0 makes set_sat return zeros and set_lum start from
+            //                      (l, l, l) with l = lum(cb); for 0 <= l <= 1 clip_color changes nothing, so the mixed colour
+            //                      is the finite (l, l, l) and the result is bg as for the separable modes.  l is evaluated here
+            //                      with the operations of the full formula (cb = bg.c * (1 / max(bg.a, 1e-15)), lum).
+            //                      (luminosity, 15, divides by lum(c) - min(c) of c = cb - l, which vanishes on grey
+            //                      backdrops: no shortcut.)
+            // Anything else (other compose operators, a backdrop outside [+0, 16], NaNs) performs the pending saves and takes
+            // the full formula.  The unsigned comparison of the bit patterns tests "+0 <= v <= limit".
+            bool fast = false;
+            if (clip_depth != 0u && pushed_depth <= level && alpha >= 0.0f && alpha < __builtin_inff()) {  // uniform
+                const bool plain = (blend & 0x7fffu) == 0u;
+                const uint32_t mixm = blend >> 8;
+                const bool separable = (blend & 0xffu) == 0u && mixm >= 1u && mixm <= 14u;
+                const bool needs_lum = mixm >= 12u;
+                if (plain || separable) {
+                    bool ok = true;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                V4 bg;
-                if (clip_depth < JL_BLEND_STACK_SPLIT) {
-                    switch (clip_depth) {
-                        case 0: bg = bs0[k]; break;
-                        case 1: bg = bs1[k]; break;
-                        case 2: bg = bs2[k]; break;
-                        default: bg = bs3[k]; break;
+                    for (int k = 0; k < 4; k++) ok = ok && f2u(area[k]) <= 0x3f800000u;
+                    if (!plain) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            ok = ok && f2u(rgba[k].x) <= 0x41800000u && f2u(rgba[k].y) <= 0x41800000u && f2u(rgba[k].z) <= 0x41800000u &&
+                                 f2u(rgba[k].w) <= 0x41800000u;
+                        if (needs_lum) {  // uniform
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const float inv_backdrop_a = 1.0f / fmax_(rgba[k].w, 1e-15f);  // blend.wgsl:293-294
+                                const float l = lum(v3(rgba[k].x * inv_backdrop_a, rgba[k].y * inv_backdrop_a, rgba[k].z * inv_backdrop_a));
+                                ok = ok && f2u(l) <= 0x3f800000u;
+                            }
+                        }
                     }
-                } else {
-                    uint32_t blend_in_scratch = clip_depth - JL_BLEND_STACK_SPLIT;
-                    uint32_t spill_base = blend_offset + blend_in_scratch * JL_TILE_WIDTH * JL_TILE_HEIGHT;
-                    bg = blend_spill.rd(spill_base + pix_spill(k));
+                    fast = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+                    if (fast && plain) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) rgba[k] = v4(rgba[k].x + 0.0f, rgba[k].y + 0.0f, rgba[k].z + 0.0f, rgba[k].w + 0.0f);
+                    }
                 }
-                V4 fg = v4(rgba[k].x * area[k] * alpha, rgba[k].y * area[k] * alpha, rgba[k].z * area[k] * alpha, rgba[k].w * area[k] * alpha);
-                rgba[k] = blend_mix_compose(bg, fg, blend);
             }
+            if (!fast) {
+                materialize();
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    V4 bg;
+                    if (level < JL_BLEND_STACK_SPLIT) {
+                        const float4 t = S.lvl[level & (JL_BLEND_STACK_SPLIT - 1u)][k][lane];  // (written by this lane: no synchronisation)
+                        bg = v4(t.x, t.y, t.z, t.w);
+                    } else {
+                        const uint32_t spill_base = blend_offset + (level - JL_BLEND_STACK_SPLIT) * JL_TILE_WIDTH * JL_TILE_HEIGHT;
+                        bg = blend_spill.rd(spill_base + pix_spill(k));
+                    }
+                    V4 src = v4(rgba[k].x * area[k] * alpha, rgba[k].y * area[k] * alpha, rgba[k].z * area[k] * alpha, rgba[k].w * area[k] * alpha);
+                    rgba[k] = blend_mix_compose(bg, src, blend);
+                }
+                pushed_depth = level;
+            }
+            clip_depth = level;
         } else if (tag == JL_CMD_JUMP) {
+            pc = W(1);
+            wbase = pc;
+            wcur = load_win(wbase);
+            wnext = load_win(wbase + 64u);
+            continue;
         } else if (!PAINTS && (tag == JL_CMD_LIN_GRAD || tag == JL_CMD_RAD_GRAD || tag == JL_CMD_SWEEP_GRAD || tag == JL_CMD_IMAGE)) {
             // This instantiation is only launched when no ramp and no image is bound: every texel fetch of the
             // WGSL returns 0 then, i.e. the command composites a transparent colour.
             have_fg = true;
+            pc += (tag == JL_CMD_IMAGE) ? 2u : 3u;
         } else if (PAINTS && tag == JL_CMD_LIN_GRAD) {
-            uint32_t index_mode = W1;
+            materialize();
+            pc += 3u;
+            uint32_t index_mode = W(1);
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
-            uint32_t io = W2;
+            uint32_t io = W(2);
             float line_x = u2f(I(io)), line_y = u2f(I(io + 1u)), line_c = u2f(I(io + 2u));
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -875,9 +943,11 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
                 rgba[k] = over(rgba[k], load_grad(x, index), area[k]);
             }
         } else if (PAINTS && tag == JL_CMD_RAD_GRAD) {
-            uint32_t index_mode = W1;
+            materialize();
+            pc += 3u;
+            uint32_t index_mode = W(1);
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
-            uint32_t io = W2;
+            uint32_t io = W(2);
             float m0 = u2f(I(io)), m1 = u2f(I(io + 1u)), m2 = u2f(I(io + 2u)), m3 = u2f(I(io + 3u));
             float xl0 = u2f(I(io + 4u)), xl1 = u2f(I(io + 5u));
             float focal_x = u2f(I(io + 6u));
@@ -920,9 +990,11 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
                 }
             }
         } else if (PAINTS && tag == JL_CMD_SWEEP_GRAD) {
-            uint32_t index_mode = W1;
+            materialize();
+            pc += 3u;
+            uint32_t index_mode = W(1);
             uint32_t index = index_mode >> 2, ext = index_mode & 3u;
-            uint32_t io = W2;
+            uint32_t io = W(2);
             float m0 = u2f(I(io)), m1 = u2f(I(io + 1u)), m2 = u2f(I(io + 2u)), m3 = u2f(I(io + 3u));
             float xl0 = u2f(I(io + 4u)), xl1 = u2f(I(io + 5u));
             float t0 = u2f(I(io + 6u)), t1 = u2f(I(io + 7u));
@@ -947,7 +1019,9 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
                 rgba[k] = over(rgba[k], load_grad(ramp_x, index), area[k]);
             }
         } else if (PAINTS && tag == JL_CMD_IMAGE) {
-            uint32_t io = W1;
+            materialize();
+            pc += 2u;
+            uint32_t io = W(1);
             float m0 = u2f(I(io)), m1 = u2f(I(io + 1u)), m2 = u2f(I(io + 2u)), m3 = u2f(I(io + 3u));
             float xl0 = u2f(I(io + 4u)), xl1 = u2f(I(io + 5u));
             uint32_t index = I(io + 6u);
@@ -999,12 +1073,10 @@ __global__ __launch_bounds__(64 * FINE_WAVES) __attribute__((amdgpu_waves_per_eu
             break;  // unknown tag: the WGSL would never advance; stop instead of hanging the GPU
         }
         if (have_fg) {  // uniform
+            materialize();
 #pragma unroll
             for (int k = 0; k < 4; k++) rgba[k] = over(rgba[k], fg, area[k]);
         }
-        pc = npc;
-#pragma unroll
-        for (int k = 0; k < 9; k++) wv[k] = nx[k];
     }
     // fine.wgsl:1092-1102: un-premultiply, store RGBA16F (four adjacent pixels = 32 bytes per lane; 4 lanes = one 128-B row)
     const uint32_t cx0 = tile_x * 16u + lx * 4u;
@@ -1082,7 +1154,7 @@ static int launch_fine(const JhLaunch& L, int aa) {
     const float* seg_ptr = (segments_n != 0u && L.b[1].ptr) ? (const float*)L.b[1].ptr : (const float*)cfg;  // see load_segraw_clamped
     if (seg_ptr == (const float*)cfg) segments_n = 0u;
 #define JH_FINE_LAUNCH(A, C, P)                                                                                                          \
-    hipLaunchKernelGGL((k_fine_area<A, C, P>), dim3((L.gx + FINE_WAVES - 1) / FINE_WAVES, trow1 - trow0), dim3(64 * FINE_WAVES), 0, L.stream, cfg, seg_ptr, \
+    hipLaunchKernelGGL((k_fine_area<A, C, P>), dim3((L.gx + FINE_WG_WAVES(C) - 1) / FINE_WG_WAVES(C), trow1 - trow0), dim3(64 * FINE_WG_WAVES(C)), 0, L.stream, cfg, seg_ptr, \
                        segments_n, (const uint32_t*)L.b[2].ptr, ptcl_n, (const uint32_t*)L.b[3].ptr, info_n, spill, (uint16_t*)out.ptr,         \
                        out.width, out.height, (const uint16_t*)grad.ptr, grad_h, imgs, L.gx, mask_lut, mask_lut_n, trow0)
 #define JH_FINE_PICK(A)                                  \

@@ -93,10 +93,15 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                                                   JlBump* __restrict__ bump, Buf<uint32_t> ptcl, uint32_t* __restrict__ cnt_seg,
                                                   uint32_t* __restrict__ cnt_chunk, uint32_t* __restrict__ cnt_blend,
                                                   const uint32_t* __restrict__ base_seg, const uint32_t* __restrict__ base_chunk,
-                                                  const uint32_t* __restrict__ base_blend, uint32_t bin_row0) {
+                                                  const uint32_t* __restrict__ base_blend, uint32_t bin_row0, uint32_t split) {
     // bin_row0: first bin row of the launch (band mode writes the PTCL of its band only; the counting pass always
     // covers the whole target, so that every allocation base is the one of the unsharded run)
+    // split (1, 2 or 4): a bin is shared by `split` workgroups (blockIdx.z), each owning 16 / split of its tile rows.
+    // The merge of the bin's element lists is repeated by each of them (cheap); the (draw, tile) include test and the
+    // per-tile command walk -- the expensive parts -- cover the workgroup's rows only.  With one workgroup per bin a
+    // 2048^2 target keeps 64 of 256 CUs busy and a 4096^2 target one wave per SIMD.
     const uint32_t bin_y = blockIdx.y + bin_row0;
+    const uint32_t part_rows = JL_N_TILE_Y / split, part_y0 = blockIdx.z * part_rows, part_y1 = part_y0 + part_rows;
     __shared__ uint32_t sh_bitmaps[8][JL_N_TILE];
     __shared__ uint32_t sh_part_count[JL_WG];
     __shared__ uint32_t sh_part_offsets[JL_WG];
@@ -114,7 +119,11 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     const uint32_t lid = threadIdx.x;
     const uint32_t width_in_bins = (cfg->width_in_tiles + JL_N_TILE_X - 1u) / JL_N_TILE_X;
     const uint32_t bin_ix = width_in_bins * bin_y + blockIdx.x;
-    const uint32_t slot = bin_ix * JL_N_TILE + lid;  // position in the canonical (bin, tile) order
+    const bool has_tile = lid < part_rows * JL_N_TILE_X;  // the first part_rows * 16 threads own a tile each
+    const uint32_t tile_x = lid % JL_N_TILE_X;
+    const uint32_t tile_y = part_y0 + (has_tile ? lid / JL_N_TILE_X : 0u);
+    const uint32_t my_xy = tile_y * JL_N_TILE_X + tile_x;        // the tile's index inside the bin
+    const uint32_t slot = bin_ix * JL_N_TILE + my_xy;            // position in the canonical (bin, tile) order
 
     {  // coarse.wgsl:161-176
         uint32_t failed = bump->failed & (JL_STAGE_BINNING | JL_STAGE_TILE_ALLOC | JL_STAGE_FLATTEN);
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             if (WRITE) {
                 if (blockIdx.x == 0u && blockIdx.y == 0u && lid == 0u) atomicOr(&bump->failed, failed);
             } else {
-                cnt_seg[slot] = 0u; cnt_chunk[slot] = 0u; cnt_blend[slot] = 0u;
+                if (has_tile) { cnt_seg[slot] = 0u; cnt_chunk[slot] = 0u; cnt_blend[slot] = 0u; }
             }
             return;
         }
@@ -131,8 +140,6 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     const uint32_t n_partitions = (cfg->layout.n_drawobj + JL_N_TILE - 1u) / JL_N_TILE;
     const uint32_t bin_tile_x = JL_N_TILE_X * blockIdx.x;
     const uint32_t bin_tile_y = JL_N_TILE_Y * bin_y;
-    const uint32_t tile_x = lid % JL_N_TILE_X;
-    const uint32_t tile_y = lid / JL_N_TILE_X;
     const uint32_t this_tile_ix = (bin_tile_y + tile_y) * cfg->width_in_tiles + bin_tile_x + tile_x;
     const uint32_t BLEND_CLIP = (128u << 8) | 0u;  // MIX_CLIP << 8 | COMPOSE_SRC_OVER (Jello numbering, blend.wgsl:199-202)
 
@@ -223,9 +230,9 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             int32_t dx = (int32_t)path.bbox[0] - (int32_t)bin_tile_x;
             int32_t dy = (int32_t)path.bbox[1] - (int32_t)bin_tile_y;
             int32_t x0 = iclamp_(dx, 0, JL_N_TILE_X);
-            int32_t y0 = iclamp_(dy, 0, JL_N_TILE_Y);
+            int32_t y0 = iclamp_(dy, (int32_t)part_y0, (int32_t)part_y1);
             int32_t x1 = iclamp_((int32_t)path.bbox[2] - (int32_t)bin_tile_x, 0, JL_N_TILE_X);
-            int32_t y1 = iclamp_((int32_t)path.bbox[3] - (int32_t)bin_tile_y, 0, JL_N_TILE_Y);
+            int32_t y1 = iclamp_((int32_t)path.bbox[3] - (int32_t)bin_tile_y, (int32_t)part_y0, (int32_t)part_y1);
             {   // width (<= 16) and ceil(2^16 / width): the include test divides pair indices (< 4096) by the width
                 const uint32_t wdt = (uint32_t)(x1 - x0);
                 n_r1.y = wdt | ((wdt ? (65536u + wdt - 1u) / wdt : 0u) << 5);
@@ -312,13 +319,13 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         // Write the per-tile command list for this tile (coarse.wgsl:344-444)
         // The walk is one wave per SIMD chasing LDS round trips (bitmap -> record -> cached Tile), so it is pipelined by
         // hand: the reads of the NEXT element are issued before the commands of the current one are written.
-        uint32_t slice_ix = 0u;
-        uint32_t bitmap = sh_bitmaps[0][lid];
+        uint32_t slice_ix = has_tile ? 0u : 7u;
+        uint32_t bitmap = has_tile ? sh_bitmaps[0][my_xy] : 0u;
         auto next_el = [&]() -> uint32_t {  // next set bit of this tile's bitmaps, ~0u at the end
             while (bitmap == 0u) {
                 slice_ix += 1u;
                 if (slice_ix == 8u) return 0xffffffffu;
-                bitmap = sh_bitmaps[slice_ix][lid];
+                bitmap = sh_bitmaps[slice_ix][my_xy];
             }
             const uint32_t e = slice_ix * 32u + (uint32_t)__builtin_ctz(bitmap);
             bitmap &= bitmap - 1u;
@@ -416,6 +423,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         __syncthreads();
     }
     uint32_t scratch_size = 0u;
+    if (!has_tile) return;
     bool in_target = bin_tile_x + tile_x < cfg->width_in_tiles && bin_tile_y + tile_y < cfg->height_in_tiles;
     if (in_target && max_blend_depth > JL_BLEND_STACK_SPLIT) scratch_size = (max_blend_depth - JL_BLEND_STACK_SPLIT) * JL_TILE_WIDTH * JL_TILE_HEIGHT;
     if (WRITE) {
@@ -455,18 +463,22 @@ int jh_launch_coarse(const JhLaunch& L) {
     auto tiles = mkbuf<JlTile>(L.b[6].ptr, L.b[6].size);
     JlBump* bump = (JlBump*)L.b[7].ptr;
     auto ptcl = mkbuf<uint32_t>(L.b[8].ptr, L.b[8].size);
-    dim3 grid(L.gx, L.gy), blk(JL_WG);
+    // workgroups per bin: enough to give every CU two workgroups (the LDS of one allows two per CU)
+    const uint32_t want = 2u * (uint32_t)(L.num_cus > 0 ? L.num_cus : 256);
+    uint32_t split = 1u;
+    while (split < 4u && L.gx * L.gy * split < want) split *= 2u;
+    dim3 grid(L.gx, L.gy, split), blk(JL_WG);
     const uint32_t row0 = L.band_row0 < L.gy ? L.band_row0 : L.gy, row1 = L.band_row1 < L.gy ? L.band_row1 : L.gy;
-    dim3 grid_w(L.gx, row1 > row0 ? row1 - row0 : 0u);
+    dim3 grid_w(L.gx, row1 > row0 ? row1 - row0 : 0u, split);
     const bool clips = !(L.cfg_host && L.cfg_host->layout.n_clip == 0u);  // host shadow of the uploaded ConfigUniform
 #define JH_COARSE(W, C, G, ...) hipLaunchKernelGGL((k_coarse<W, C>), G, blk, 0, L.stream, cfg, scene, dm, bh, ibd, paths, tiles, bump, ptcl, __VA_ARGS__)
-    if (clips) JH_COARSE(false, true, grid, cnt_seg, cnt_chunk, cnt_blend, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
-    else JH_COARSE(false, false, grid, cnt_seg, cnt_chunk, cnt_blend, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
+    if (clips) JH_COARSE(false, true, grid, cnt_seg, cnt_chunk, cnt_blend, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, split);
+    else JH_COARSE(false, false, grid, cnt_seg, cnt_chunk, cnt_blend, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, split);
     int rc = jh_scan3_u32(L, cnt_seg, base_seg, n, &bump->segments, &bump->ptcl, &bump->blend);
     if (rc) return rc;
     if (grid_w.y == 0u) return 0;
-    if (clips) JH_COARSE(true, true, grid_w, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend, row0);
-    else JH_COARSE(true, false, grid_w, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend, row0);
+    if (clips) JH_COARSE(true, true, grid_w, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend, row0, split);
+    else JH_COARSE(true, false, grid_w, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend, row0, split);
 #undef JH_COARSE
     return 0;
 }

@@ -129,7 +129,10 @@ JD V4 blend_compose(V3 cb, V3 cs, float ab, float as_, uint32_t mode) {  // blen
     float ab_fb = ab * fb;
     return v4(as_fa * cs.x + ab_fb * cb.x, as_fa * cs.y + ab_fb * cb.y, as_fa * cs.z + ab_fb * cb.z, fmin_(as_fa + ab_fb, 1.0f));
 }
-JD V4 blend_mix_compose(V4 backdrop, V4 src, uint32_t mode) {  // blend.wgsl:288-310
+// Not inlined: with the sixteen mix modes and fourteen compose operators expanded for each of a lane's four pixels the
+// clip + paint instantiation was 68 KB of code -- more than the 64 KB instruction cache -- and with lazy layers the full
+// formula is the rare case.
+__device__ __attribute__((noinline)) V4 blend_mix_compose(V4 backdrop, V4 src, uint32_t mode) {  // blend.wgsl:288-310
     const float EPSILON = 1e-15f;
     if ((mode & 0x7fffu) == 0u) {
         float k = 1.0f - src.w;

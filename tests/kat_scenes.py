@@ -1,0 +1,98 @@
+"""The tiny scenes of tests/golden/kat_words.json (hand-derived word-level known answers) and the
+checks shared by the CPU (oracle) and GPU (HIP buffers) tests."""
+import json
+import os
+
+import numpy as np
+
+import jello_amd
+from jello_amd import Brush, ColorStop, Compose, Fill, Join, Cap, Mix, Path, RenderParams, Scene, Stroke
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_words.json")))
+RGBA = (0.25, 0.5, 0.75, 1.0)
+
+
+def nested_plain_clips():
+    s = Scene()
+    s.push_layer(Mix.Clip, Compose.SrcOver, 1.0, None, Path.rect(40, 40, 200, 200))
+    s.push_layer(Mix.Clip, Compose.SrcOver, 1.0, None, Path.rect(72, 56, 232, 232))
+    s.fill(Fill.NonZero, None, Brush.solid(RGBA), None, Path.rect(0, 0, 256, 256))
+    s.pop_layer()
+    s.pop_layer()
+    return s, RenderParams(256, 256)
+
+
+def blend_layer():
+    s = Scene()
+    s.push_layer(Mix.Multiply, Compose.SrcOver, 0.5, None, Path.rect(40, 40, 200, 200))
+    s.fill(Fill.NonZero, None, Brush.solid(RGBA), None, Path.rect(0, 0, 256, 256))
+    s.pop_layer()
+    return s, RenderParams(256, 256)
+
+
+def five_blend_layers():
+    s = Scene()
+    for _ in range(5):
+        s.push_layer(Mix.Multiply, Compose.SrcOver, 0.5, None, Path.rect(-16, -16, 80, 80))
+    s.fill(Fill.NonZero, None, Brush.solid(RGBA), None, Path.rect(-16, -16, 80, 80))
+    for _ in range(5):
+        s.pop_layer()
+    return s, RenderParams(64, 64)
+
+
+def bevel_join_collinear():
+    s = Scene()
+    p = Path().move_to(10, 10).line_to(30, 10).line_to(50, 10)
+    s.stroke(Stroke(4.0, Join.Bevel, 4.0, Cap.Butt, Cap.Butt), None, Brush.solid((1, 0, 0, 1)), None, p)
+    return s, RenderParams(128, 128)
+
+
+def gradient_in_clip():
+    s = Scene()
+    s.push_layer(Mix.Clip, Compose.SrcOver, 1.0, None, Path.rect(0, 0, 10, 10))
+    s.fill(Fill.NonZero, None, Brush.linear((0, 0), (10, 0), [ColorStop(0.0, (1, 0, 0, 1)), ColorStop(1.0, (0, 0, 1, 1))]), None, Path.rect(0, 0, 10, 10))
+    s.pop_layer()
+    return s, RenderParams(16, 16)
+
+
+def words(xs):
+    return [int(x, 16) for x in xs]
+
+
+def f32_words(rows):
+    return [int(np.float32(v).view(np.uint32)) for r in rows for v in r]
+
+
+def check_nested_plain_clips(get, cfg):
+    k = KAT["nested_plain_clips"]
+    assert cfg["n_clip"] == k["n_clip"] and cfg["n_drawobj"] == k["n_drawobj"]
+    assert list(get("clipBboxBuf", np.uint32)[:16]) == f32_words(k["clip_bboxes_f32"])
+    assert list(get("drawBboxBuf", np.uint32)[:20]) == f32_words(k["draw_bboxes_f32"])
+    ptcl = get("ptclBuf", np.uint32)
+    for tile, want in k["ptcl"].items():
+        w = words(want)
+        assert list(ptcl[int(tile) * 64:int(tile) * 64 + len(w)]) == w, "tile %s" % tile
+
+
+def check_blend_layer(get, cfg):
+    k = KAT["blend_layer"]
+    ptcl = get("ptclBuf", np.uint32)
+    for tile, want in k["ptcl"].items():
+        w = words(want)
+        assert list(ptcl[int(tile) * 64:int(tile) * 64 + len(w)]) == w, "tile %s" % tile
+
+
+def check_five_blend_layers(get, cfg, bump):
+    k = KAT["five_blend_layers"]
+    assert bump["blend"] == k["bump_blend"] and bump["failed"] == 0
+    ptcl = get("ptclBuf", np.uint32)
+    tail = words(k["tile_list_after_blend_ix"])
+    for y in range(4):
+        for x in range(4):
+            t = 4 * y + x
+            assert ptcl[t * 64] == 256 * t, (x, y)
+            assert list(ptcl[t * 64 + 1:t * 64 + 1 + len(tail)]) == tail, (x, y)
+
+
+def check_bevel(bump):
+    assert bump["lines"] == KAT["bevel_join_collinear"]["lines"] and bump["failed"] == 0

@@ -1,0 +1,61 @@
+"""-m gpu: the HIP buffers against the hand-derived word-level known answers of tests/golden/kat_words.json -- directly,
+without the oracle in between (the same words pin the oracle in tests/test_kat_words.py)."""
+import numpy as np
+import pytest
+
+import jello_amd
+from jello_amd.engine import RUN_DISPATCHES, RUN_UPLOADS
+
+import kat_scenes as K
+
+pytestmark = pytest.mark.gpu
+BUMP = ["failed", "binning", "ptcl", "tile", "seg_counts", "segments", "blend", "lines"]
+
+
+def run_gpu(engine, scene_params):
+    s, p = scene_params
+    p.bump = jello_amd.BumpSizes(blend_spill=1 << 14)
+    rec = jello_amd.Host().record(s, p)
+    engine.run(rec, RUN_UPLOADS | RUN_DISPATCHES)
+    engine.sync()
+    bufs = {}
+
+    def get(name, dt):
+        if name not in bufs:
+            bufs[name] = engine.download(rec.buffer(name)[0], dtype=np.uint8).copy()
+        return bufs[name].view(dt)
+    bump = dict(zip(BUMP, [int(v) for v in get("bumpBuf", np.uint32)[:8]]))
+    return get, rec, bump
+
+
+def test_nested_plain_clips(engine):
+    get, rec, bump = run_gpu(engine, K.nested_plain_clips())
+    try:
+        assert bump["failed"] == 0
+        K.check_nested_plain_clips(get, rec.config)
+    finally:
+        engine.release(rec)
+
+
+def test_blend_layer(engine):
+    get, rec, bump = run_gpu(engine, K.blend_layer())
+    try:
+        K.check_blend_layer(get, rec.config)
+    finally:
+        engine.release(rec)
+
+
+def test_five_blend_layers_spill_offsets(engine):
+    get, rec, bump = run_gpu(engine, K.five_blend_layers())
+    try:
+        K.check_five_blend_layers(get, rec.config, bump)
+    finally:
+        engine.release(rec)
+
+
+def test_bevel_join_between_collinear_segments(engine):
+    get, rec, bump = run_gpu(engine, K.bevel_join_collinear())
+    try:
+        K.check_bevel(bump)
+    finally:
+        engine.release(rec)

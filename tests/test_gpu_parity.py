@@ -222,3 +222,17 @@ def test_undersized_buffers_fail_cleanly_without_regrow(engine):
     p.bump = BumpSizes(bin_data=256, tiles=512, lines=1024, seg_counts=1024, segments=1024, blend_spill=256, ptcl=1 << 14)
     rec, bump, attempts = engine.render(s, p, robust=False, retain=False)
     assert bump["failed"] != 0 and attempts == 1
+
+
+def test_c4_full_size(engine):
+    """BASELINE.json configs[3] at its stated size: 30 k paths, 9000 clip layers (all 16 mix modes), radial gradients,
+    2048x2048 -- sized by the estimator, every buffer and the image bit-exact against the oracle (16 host threads)."""
+    from oracle import oracle_engine
+    s, p = scenes.scene_c4(30_000, 2048)
+    p.bump = s.bump_sizes(p.width, p.height)
+    oracle_engine.lib().oracle_set_threads(16)
+    try:
+        r = compare(engine, s, p)
+    finally:
+        oracle_engine.lib().oracle_set_threads(1)
+    assert r["bump"]["failed"] == 0 and r["ptcl_live_words"] > 10_000_000

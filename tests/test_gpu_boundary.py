@@ -139,14 +139,16 @@ def test_too_small_buffers_are_refused_not_read(engine):
     # path_count_setup: [bump, indirect] with a 16-byte bump buffer
     b = (Binding * 2)(Binding(1, 0, small, None), Binding(1, 0, big, None))
     assert hip.jh_dispatch(ctx, 14, 1, 1, 1, b, 2) < 0
-    # an imported (caller-owned) buffer cannot be grown by an upload
-    import torch
-    mem = torch.zeros(64, dtype=torch.uint8, device="cuda")
-    assert hip.jh_buffer_import(ctx, 0x5513, mem.data_ptr(), 64) == 0
+    # an imported (caller-owned) buffer cannot be grown by an upload (the "caller's" memory here is another buffer of the
+    # context: importing torch just for 64 bytes can take minutes on a cold box)
+    assert hip.jh_buffer_create(ctx, 0x5514, 4096) == 0
+    mem_ptr = hip.jh_buffer_device_ptr(ctx, 0x5514)
+    assert mem_ptr
+    assert hip.jh_buffer_import(ctx, 0x5513, mem_ptr, 64) == 0
     assert hip.jh_upload(ctx, 0x5513, z.ctypes.data, 4096) < 0
     assert hip.jh_upload(ctx, 0x5513, z.ctypes.data, 64) == 0
     engine.sync()
-    for i in (small, big, 0x5513):
+    for i in (small, big, 0x5513, 0x5514):
         assert hip.jh_free(ctx, i) == 0
     s, p = scenes.scene_c1()
     rec, bump, attempts = engine.render(s, p, retain=False)  # the context is still usable

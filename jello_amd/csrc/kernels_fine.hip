@@ -207,10 +207,10 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #define FINE_LEAN_WAVES_PER_EU 6
 #endif
 #ifndef FINE_CLIP_WAVES_PER_EU
-#define FINE_CLIP_WAVES_PER_EU 2  // the clip / blend stack lives in LDS (16 KiB per tile-wave): LDS, not registers, bounds the occupancy
+#define FINE_CLIP_WAVES_PER_EU 3  // ~133 VGPRs; LDS (8 KiB of stack + 5.4 KiB per tile-wave) allows 11 waves per CU
 #endif
 #ifndef FINE_CLIP_MS_WAVES_PER_EU
-#define FINE_CLIP_MS_WAVES_PER_EU 2
+#define FINE_CLIP_MS_WAVES_PER_EU 3
 #endif
 #ifndef FINE_WAVES
 #define FINE_WAVES 2
@@ -482,10 +482,13 @@ JD void fill_path_ms(MsLds& T, uint32_t lane, uint32_t size_and_rule, uint32_t s
 template <int AA> struct FineLdsSel { typedef MsLds type; };
 template <> struct FineLdsSel<0> { typedef FillLds type; };
 // The first JL_BLEND_STACK_SPLIT levels of the clip / blend stack (fine.wgsl:938-973 keeps them in registers; deeper
-// levels go to blend_spill): wave-private LDS, one float4 per pixel, lane-contiguous (conflict-free 16-byte accesses),
-// addressed by the (uniform) level.  In registers the four levels needed a four-way switch with sixteen moves per case
-// and 64 VGPRs: 219 VGPRs and ~290 VALU instructions per command for the clip instantiations.
-template <bool CLIPS> struct FineStackSel { struct type { float4 lvl[JL_BLEND_STACK_SPLIT][4][64]; }; };
+// levels go to blend_spill), one float4 per pixel, lane-contiguous (conflict-free 16-byte accesses), addressed by the
+// (uniform) level: levels 0 and 1 in wave-private LDS (8 KiB), levels 2 and 3 in a per-tile slice of a global scratch
+// array (with lazy layers only layers that really draw are saved, and few of those nest three deep; all four levels in
+// LDS held the clip instantiations at 7 waves per CU).  In registers the four levels needed a four-way switch with
+// sixteen moves per case and 64 VGPRs: 219 VGPRs and ~290 VALU instructions per command.
+#define FINE_LDS_LEVELS 2u
+template <bool CLIPS> struct FineStackSel { struct type { float4 lvl[FINE_LDS_LEVELS][4][64]; }; };
 template <> struct FineStackSel<false> { struct type { float4 lvl[1][1][1]; }; };
 
 // Pixel ownership = the WGSL's: lane = ly*4 + lx (workgroup (4,16)), pixel i = 0..3 at column 4*lx + i.
@@ -499,7 +502,8 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                                                   uint32_t info_n, Buf<V4> blend_spill, uint16_t* __restrict__ output, uint32_t out_w,
                                                   uint32_t out_h, const uint16_t* __restrict__ gradients, uint32_t grad_h, FineImages images,
                                                   uint32_t tiles_x, const uint32_t* __restrict__ mask_lut, uint32_t mask_lut_n,
-                                                  uint32_t tile_row0) {  // first tile row of the launch (band mode)
+                                                  uint32_t tile_row0,  // first tile row of the launch (band mode)
+                                                  float4* __restrict__ clip_scratch) {  // CLIPS: stack levels 2, 3: [tile][2][4][64]
     const uint32_t tile_y = blockIdx.y + tile_row0;
     // FINE_WAVES independent waves (= tiles, side by side in x) per workgroup: the CU runs at most 16 workgroups, so
     // single-wave workgroups would cap the occupancy at 4 waves per SIMD.  The waves never synchronise with each other.
@@ -515,6 +519,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t ly = lane >> 2, lx = lane & 3u;
     const uint32_t tile_ix = tile_y * cfg->width_in_tiles + tile_x;
+    const uint32_t scratch_tile = blockIdx.y * tiles_x + tile_x;  // this tile's slice of clip_scratch
     const float xyx = (float)((tile_x * 4u + lx) * 4u);  // WGSL xy.x = f32(global_id.x * 4)
     const float xyy = (float)(tile_y * 16u + ly);         // WGSL xy.y
     V4 rgba[4];
@@ -725,9 +730,13 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
     auto materialize = [&]() {  // perform the pending saves of BEGIN_CLIP (fine.wgsl:938-950), outermost first
         if constexpr (CLIPS) {
             while (pushed_depth < clip_depth) {  // uniform
-                if (pushed_depth < JL_BLEND_STACK_SPLIT) {
+                if (pushed_depth < FINE_LDS_LEVELS) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) S.lvl[pushed_depth][k][lane] = make_float4(rgba[k].x, rgba[k].y, rgba[k].z, rgba[k].w);
+                } else if (pushed_depth < JL_BLEND_STACK_SPLIT) {
+                    float4* g = clip_scratch + (((size_t)scratch_tile * 2u + (pushed_depth - FINE_LDS_LEVELS)) * 4u) * 64u + lane;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) g[k * 64] = make_float4(rgba[k].x, rgba[k].y, rgba[k].z, rgba[k].w);
                 } else {
                     const uint32_t spill_base = blend_offset + (pushed_depth - JL_BLEND_STACK_SPLIT) * JL_TILE_WIDTH * JL_TILE_HEIGHT;
 #pragma unroll
@@ -907,8 +916,11 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     V4 bg;
-                    if (level < JL_BLEND_STACK_SPLIT) {
-                        const float4 t = S.lvl[level & (JL_BLEND_STACK_SPLIT - 1u)][k][lane];  // (written by this lane: no synchronisation)
+                    if (level < FINE_LDS_LEVELS) {
+                        const float4 t = S.lvl[level & (FINE_LDS_LEVELS - 1u)][k][lane];  // (written by this lane: no synchronisation)
+                        bg = v4(t.x, t.y, t.z, t.w);
+                    } else if (level < JL_BLEND_STACK_SPLIT) {
+                        const float4 t = clip_scratch[(((size_t)scratch_tile * 2u + (level - FINE_LDS_LEVELS)) * 4u + (uint32_t)k) * 64u + lane];
                         bg = v4(t.x, t.y, t.z, t.w);
                     } else {
                         const uint32_t spill_base = blend_offset + (level - JL_BLEND_STACK_SPLIT) * JL_TILE_WIDTH * JL_TILE_HEIGHT;
@@ -1156,10 +1168,15 @@ static int launch_fine(const JhLaunch& L, int aa) {
     if (trow1 <= trow0) return 0;
     const float* seg_ptr = (segments_n != 0u && L.b[1].ptr) ? (const float*)L.b[1].ptr : (const float*)cfg;  // see load_segraw_clamped
     if (seg_ptr == (const float*)cfg) segments_n = 0u;
+    float4* clip_scratch = nullptr;
+    if (clips) {  // stack levels 2 and 3 of every tile of the launch: 2 x 4 KiB each
+        clip_scratch = (float4*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)L.gx * (trow1 - trow0) * 2u * 4096u);
+        if (!clip_scratch) return -5;
+    }
 #define JH_FINE_LAUNCH(A, C, P)                                                                                                          \
     hipLaunchKernelGGL((k_fine_area<A, C, P>), dim3((L.gx + FINE_WG_WAVES(C) - 1) / FINE_WG_WAVES(C), trow1 - trow0), dim3(64 * FINE_WG_WAVES(C)), 0, L.stream, cfg, seg_ptr, \
                        segments_n, (const uint32_t*)L.b[2].ptr, ptcl_n, (const uint32_t*)L.b[3].ptr, info_n, spill, (uint16_t*)out.ptr,         \
-                       out.width, out.height, (const uint16_t*)grad.ptr, grad_h, imgs, L.gx, mask_lut, mask_lut_n, trow0)
+                       out.width, out.height, (const uint16_t*)grad.ptr, grad_h, imgs, L.gx, mask_lut, mask_lut_n, trow0, clip_scratch)
 #define JH_FINE_PICK(A)                                  \
     do {                                                 \
         if (clips && paints) JH_FINE_LAUNCH(A, true, true);   \

@@ -295,7 +295,7 @@ def committed_counters(args, fine_ms):
     tools/pmc_fine.sh) and carry the commit and workload they were measured on; null when that file does not describe
     this workload."""
     out = {"traffic": None, "traffic_source": None, "issue_bound_ms": None}
-    pm = os.path.join(ROOT, "profiles", "fine_counters.json")
+    pm = os.path.join(ROOT, "profiles", "fine_counters.json" if args.scene == "c3" else "fine_counters_%s.json" % args.scene)
     if not os.path.exists(pm):
         return out
     try:
@@ -305,7 +305,7 @@ def committed_counters(args, fine_ms):
     if c.get("scene") != args.scene or c.get("paths") != args.paths or c.get("size") != args.size or c.get("aa") != args.aa:
         return out
     out["traffic"] = c.get("hbm_bytes_per_launch")
-    out["traffic_source"] = "profiles/fine_counters.json: rocprofv3 --pmc passes at commit %s (not re-measured in this run)" % c.get("commit", "?")
+    out["traffic_source"] = "profiles/%s: rocprofv3 --pmc passes at commit %s (not re-measured in this run)" % (os.path.basename(pm), c.get("commit", "?"))
     # VALU issue bound: a wave64 VALU instruction occupies its SIMD for 4 cycles (16 lanes per SIMD)
     if c.get("valu_insts_per_launch") and c.get("simds") and c.get("clock_ghz"):
         ib = c["valu_insts_per_launch"] * 4.0 / (c["simds"] * c["clock_ghz"] * 1e9) * 1e3

@@ -1281,103 +1281,152 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
 JD uint32_t fkey(float f) { uint32_t b = f2u(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 JD float fkey_inv(uint32_t k) { return u2f((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
-// Path bounding boxes (flatten.wgsl:807, :893-899).  The WGSL keeps one box per invocation (tag byte) and merges it into
-// the path's box only if it has an extent.  A tag's three work items are adjacent in the canonical order, so its lines
-// are [bases[3g], bases[3g+3]).  One wave takes 64 consecutive tags: their lines are one contiguous range, streamed
-// with coalesced loads; each line finds its tag by a 6-step search over the lanes' range ends and folds into the tag's
-// box in LDS; finally lane g tests the extent and merges (integer min/max on the path boxes are order-free).
+// Path bounding boxes (flatten.wgsl:807, :893-899).  The WGSL keeps one box per invocation (tag byte), grown by every
+// line it emits from (1e31, 1e31, -1e31, -1e31), and merges floor/ceil of it into the path's box only if it has an
+// extent.  floor, ceil and the saturating conversion are monotone, so the merged result is the min/max over the tag's
+// lines of their own integer boxes; and a line that has an extent itself proves that its tag's box has one.  The
+// kernel therefore streams the lines in their final order, a wave per 1...8 x 64 consecutive lines, and folds
+// them by path index (non-decreasing along the lines) with a segmented DPP scan.  Only a line WITHOUT extent (both
+// end points equal: none in ordinary scenes) has to look at its tag: it finds the tag's line range in `bases` (a tag's
+// three work items are adjacent in the canonical order, so its lines are [bases[3g], bases[3g+3])) and folds that
+// range as the WGSL does.  A path folded by one wave is merged with a plain read-modify-write; only a path that
+// crosses a range boundary by 64 lines or more is shared between waves and merged with integer atomics (order-free).
+JD bool fb_tag_has_extent(const uint32_t* __restrict__ bases, uint32_t n_tags, const JlLineSoup* lines, uint32_t total, uint32_t pos) {
+    uint32_t g = 0u, ge = n_tags;  // the last tag whose first line is at or before pos
+    while (ge - g > 1u) {
+        const uint32_t mid = g + (ge - g) / 2u;
+        if (umin_(bases[3u * mid], total) <= pos) g = mid; else ge = mid;
+    }
+    const uint32_t lo = umin_(bases[3u * g], total);
+    const uint32_t hi = (g + 1u < n_tags) ? umin_(bases[3u * g + 3u], total) : total;
+    float bx0 = 1e31f, by0 = 1e31f, bx1 = -1e31f, by1 = -1e31f;
+    for (uint32_t i = lo; i < hi; i++) {
+        const JlLineSoup l = lines[i];
+        bx0 = fmin_(bx0, fmin_(l.p0[0], l.p1[0])); by0 = fmin_(by0, fmin_(l.p0[1], l.p1[1]));
+        bx1 = fmax_(bx1, fmax_(l.p0[0], l.p1[0])); by1 = fmax_(by1, fmax_(l.p0[1], l.p1[1]));
+    }
+    return bx1 > bx0 || by1 > by0;
+}
+
+JD void fb_merge(Buf<JlPathBbox> path_bboxes, uint32_t path_ix, int32_t x0, int32_t y0, int32_t x1, int32_t y1, bool atomic) {
+    if (!path_bboxes.ok(path_ix)) return;
+    if (x0 == 0x7fffffff && y0 == 0x7fffffff && x1 == (int32_t)0x80000000 && y1 == (int32_t)0x80000000) return;  // nothing merged
+    JlPathBbox* out = &path_bboxes.p[path_ix];
+    if (!atomic) {
+        out->x0 = imin_(out->x0, x0); out->y0 = imin_(out->y0, y0);
+        out->x1 = imax_(out->x1, x1); out->y1 = imax_(out->y1, y1);
+    } else {
+        // a path spread over many waves (one outline of 200 k segments): the box only grows, so a wave whose box is
+        // already inside what it reads (possibly stale, i.e. smaller) has nothing to add
+        const int32_t cx0 = __hip_atomic_load(&out->x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t cy0 = __hip_atomic_load(&out->y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t cx1 = __hip_atomic_load(&out->x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t cy1 = __hip_atomic_load(&out->y1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (x0 < cx0) atomicMin(&out->x0, x0);
+        if (y0 < cy0) atomicMin(&out->y0, y0);
+        if (x1 > cx1) atomicMax(&out->x1, x1);
+        if (y1 > cy1) atomicMax(&out->y1, y1);
+    }
+}
+
+#define FB_NONE 0xffffffffu
+#ifndef FB_TARGET_WAVES
+#define FB_TARGET_WAVES 2048u  // ranges grow from one batch to eight once the scene has more batches than this
+#endif
 __global__ __launch_bounds__(JL_WG) void k_flatten_bbox(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump,
                                                         const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines,
-                                                        Buf<JlPathBbox> path_bboxes, uint32_t tags_per_wave) {
-    // tags_per_wave (a power of two <= 64): 64 for large scenes; fewer when the scene has so few tags that 64 per wave
-    // would leave most of the device idle while a handful of waves stream all the lines (20 large circles: 37 us)
-    __shared__ uint32_t sh_box[JL_WG / 64][64][4];
+                                                        Buf<JlPathBbox> path_bboxes) {
     const uint32_t n_tags = n_slots / 3u;
     const uint32_t total = umin_(umin_(bump->lines, cfg->lines_size), lines.n);
-    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint32_t waves = (gridDim.x * JL_WG) >> 6;
-    for (uint32_t g0 = ((blockIdx.x * JL_WG + threadIdx.x) >> 6) * tags_per_wave; g0 < n_tags; g0 += waves * tags_per_wave) {
-        const uint32_t g = g0 + umin_(lane, tags_per_wave - 1u);  // lanes behind the wave's tags repeat its last tag ...
-        uint32_t lo = total, hi = total;
-        if (g < n_tags) {
-            lo = umin_(bases[3u * g], total);
-            hi = (3u * g + 3u < n_slots) ? umin_(bases[3u * g + 3u], total) : total;
-            if (hi < lo) hi = lo;
-        }
-        if (lane >= tags_per_wave) lo = hi;  // ... with an empty range of their own
-        const uint32_t LO = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
-        const uint32_t HI = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
-        sh_box[wv][lane][0] = fkey(1e31f); sh_box[wv][lane][1] = fkey(1e31f);
-        sh_box[wv][lane][2] = fkey(-1e31f); sh_box[wv][lane][3] = fkey(-1e31f);
-        wave_fence();
-        for (uint32_t base = LO; base < HI; base += 64u) {
+    const uint32_t lane = lane_id();
+    const uint32_t n_waves = (gridDim.x * JL_WG) >> 6;
+    // The host sizes the grid for the buffer's capacity (capped); the line count is only known here.  A small scene is
+    // folded a batch per wave (a handful of waves running eight batches one after the other took 40 us longer), a
+    // large one in ranges of up to eight batches; a wave takes every n_waves-th range if the grid is too small.
+    const uint32_t batches = umin_(umax_(((total + 63u) / 64u) / FB_TARGET_WAVES, 1u), 8u);
+    for (uint64_t start64 = (uint64_t)((blockIdx.x * JL_WG + threadIdx.x) >> 6) * batches * 64u; start64 < total;
+         start64 += (uint64_t)n_waves * batches * 64u) {  // uniform per wave
+        const uint32_t start = (uint32_t)start64;
+        const uint32_t end = (uint32_t)(start64 + (uint64_t)batches * 64u < total ? start64 + (uint64_t)batches * 64u : total);
+        // Who folds a path that crosses a range boundary?  If it ends within the 64 lines behind the boundary, the wave
+        // of the earlier range takes those lines too (one more batch, `ext`) and the later one skips them: the path
+        // has one owner and is merged without atomics.  Only a path that runs on for 64 lines or more is shared, and
+        // then both sides see that from the same 64 lines and use atomics for it.
+        uint32_t p_before = FB_NONE;  // the path of the line before the range ...
+        if (start > 0u) p_before = lines.p[start - 1u].path_ix;
+        bool skip_before = false;     // ... whose lines at the head of the range belong to the previous wave
+        uint32_t p_shared = FB_NONE;  // or are shared with it
+        // the segment that is still open at the end of a batch travels on in uniform registers
+        uint32_t c_path = FB_NONE;
+        int32_t cx0 = 0x7fffffff, cy0 = 0x7fffffff, cx1 = (int32_t)0x80000000, cy1 = (int32_t)0x80000000;
+        JlLineSoup l_next = {};
+        if (start + lane < total) l_next = lines.p[start + lane];
+        for (uint32_t base = start; base < total; base += 64u) {
+            const bool ext = base >= end;  // the batch behind the range
+            if (ext && c_path == FB_NONE) break;
             const uint32_t pos = base + lane;
-            uint32_t own = 0u;  // first lane whose range end exceeds pos (all lanes take part in the shuffles)
-#pragma unroll
-            for (uint32_t step = 32u; step > 0u; step >>= 1) {
-                const uint32_t probe = own + step;
-                const uint32_t h = (uint32_t)__shfl((int)hi, (int)(probe - 1u), 64);
-                if (h <= pos) own = probe;
+            const JlLineSoup l = l_next;
+            if (!ext && pos + 64u < total) l_next = lines.p[pos + 64u];  // the next batch's lines travel while this one is folded
+            bool valid = pos < (ext ? total : end);
+            uint32_t pix = valid ? l.path_ix : FB_NONE;
+            const uint32_t p63 = (uint32_t)__builtin_amdgcn_readlane((int)pix, 63);
+            if (base == start && p_before != FB_NONE) {
+                // (in a range shorter than a batch lane 63 is invalid: the previous wave saw the same in its `ext` batch)
+                if (p63 == p_before) p_shared = p_before; else skip_before = true;
             }
-            own = umin_(own, 63u);
-            if (pos < HI) {
-                const JlLineSoup l = lines.p[pos];
-                atomicMin(&sh_box[wv][own][0], fkey(fmin_(l.p0[0], l.p1[0])));
-                atomicMin(&sh_box[wv][own][1], fkey(fmin_(l.p0[1], l.p1[1])));
-                atomicMax(&sh_box[wv][own][2], fkey(fmax_(l.p0[0], l.p1[0])));
-                atomicMax(&sh_box[wv][own][3], fkey(fmax_(l.p0[1], l.p1[1])));
-            }
-        }
-        wave_fence();
-        // per-tag result (integer box, or "nothing" if the tag's box has no extent), then folded per path inside the
-        // wave: the 64 tags touch fewer than 64 consecutive paths; a path strictly between the paths of the wave's
-        // first and last line has all its lines in this wave, so its box is stored plainly -- atomics only at the edges.
-        int32_t ix0 = 0x7fffffff, iy0 = 0x7fffffff, ix1 = (int32_t)0x80000000, iy1 = (int32_t)0x80000000;
-        bool valid = false;
-        uint32_t path_ix = 0u;
-        if (hi > lo) {
-            const float bx0 = fkey_inv(sh_box[wv][lane][0]), by0 = fkey_inv(sh_box[wv][lane][1]);
-            const float bx1 = fkey_inv(sh_box[wv][lane][2]), by1 = fkey_inv(sh_box[wv][lane][3]);
-            path_ix = lines.p[lo].path_ix;
-            if (bx1 > bx0 || by1 > by0) {
-                valid = true;
-                ix0 = to_i32(floor_(bx0)); iy0 = to_i32(floor_(by0)); ix1 = to_i32(ceil_(bx1)); iy1 = to_i32(ceil_(by1));
-            }
-        }
-        if (HI > LO) {  // uniform
-            const uint32_t p_first = lines.p[LO].path_ix, p_last = lines.p[HI - 1u].path_ix;
-            wave_fence();
-            sh_box[wv][lane][0] = 0x7fffffffu; sh_box[wv][lane][1] = 0x7fffffffu;
-            sh_box[wv][lane][2] = 0x80000000u; sh_box[wv][lane][3] = 0x80000000u;
-            wave_fence();
-            const uint32_t local = path_ix - p_first;
-            if (valid && local < 64u) {
-                atomicMin((int32_t*)&sh_box[wv][local][0], ix0); atomicMin((int32_t*)&sh_box[wv][local][1], iy0);
-                atomicMax((int32_t*)&sh_box[wv][local][2], ix1); atomicMax((int32_t*)&sh_box[wv][local][3], iy1);
-            } else if (valid && path_bboxes.ok(path_ix)) {  // (cannot happen for a well-formed scene)
-                JlPathBbox* out = &path_bboxes.p[path_ix];
-                atomicMin(&out->x0, ix0); atomicMin(&out->y0, iy0); atomicMax(&out->x1, ix1); atomicMax(&out->y1, iy1);
-            }
-            wave_fence();
-            const uint32_t P = p_first + lane;
-            const int32_t fx0 = (int32_t)sh_box[wv][lane][0], fy0 = (int32_t)sh_box[wv][lane][1];
-            const int32_t fx1 = (int32_t)sh_box[wv][lane][2], fy1 = (int32_t)sh_box[wv][lane][3];
-            if (P <= p_last && fx0 != 0x7fffffff && path_bboxes.ok(P)) {
-                JlPathBbox* out = &path_bboxes.p[P];
-                if (P > p_first && P < p_last) {
-                    out->x0 = imin_(out->x0, fx0); out->y0 = imin_(out->y0, fy0);
-                    out->x1 = imax_(out->x1, fx1); out->y1 = imax_(out->y1, fy1);
-                } else {
-                    // a path spread over many waves (one outline of 200 k segments): the box only grows, so a wave whose
-                    // box is already inside what it reads (possibly stale, i.e. smaller) has nothing to add
-                    if (fx0 < __hip_atomic_load(&out->x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&out->x0, fx0);
-                    if (fy0 < __hip_atomic_load(&out->y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&out->y0, fy0);
-                    if (fx1 > __hip_atomic_load(&out->x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&out->x1, fx1);
-                    if (fy1 > __hip_atomic_load(&out->y1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&out->y1, fy1);
+            if (ext) {
+                if (p63 == c_path) {  // the open path runs on: shared
+                    if (lane == 0u) fb_merge(path_bboxes, c_path, cx0, cy0, cx1, cy1, true);
+                    c_path = FB_NONE;
+                    break;
                 }
+                valid = valid && pix == c_path;  // only its remaining lines (a prefix of the batch)
+                pix = valid ? pix : FB_NONE;
             }
+            int32_t x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = (int32_t)0x80000000, y1 = (int32_t)0x80000000;
+            const bool skipped = skip_before && base == start && pix == p_before;
+            if (valid && !skipped) {
+                const float lx0 = fmin_(1e31f, fmin_(l.p0[0], l.p1[0])), ly0 = fmin_(1e31f, fmin_(l.p0[1], l.p1[1]));
+                const float lx1 = fmax_(-1e31f, fmax_(l.p0[0], l.p1[0])), ly1 = fmax_(-1e31f, fmax_(l.p0[1], l.p1[1]));
+                bool counts = lx1 > lx0 || ly1 > ly0;
+                if (!counts) counts = fb_tag_has_extent(bases, n_tags, lines.p, total, pos);
+                if (counts) { x0 = to_i32(floor_(lx0)); y0 = to_i32(floor_(ly0)); x1 = to_i32(ceil_(lx1)); y1 = to_i32(ceil_(ly1)); }
+            }
+            // a carried segment that does not continue in this batch is complete
+            const uint32_t p_lane0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pix);
+            if (c_path != FB_NONE && c_path != p_lane0) {
+                if (lane == 0u) fb_merge(path_bboxes, c_path, cx0, cy0, cx1, cy1, c_path == p_shared);
+                c_path = FB_NONE;
+            }
+#define FB_SEG_STEP(CTRL, ROWS)                                                                                        \
+    {                                                                                                                  \
+        const bool take = (uint32_t)__builtin_amdgcn_update_dpp((int)~pix, (int)pix, CTRL, ROWS, 0xf, false) == pix;   \
+        const int32_t a = imin_(x0, __builtin_amdgcn_update_dpp(x0, x0, CTRL, ROWS, 0xf, false));                      \
+        const int32_t b = imin_(y0, __builtin_amdgcn_update_dpp(y0, y0, CTRL, ROWS, 0xf, false));                      \
+        const int32_t c = imax_(x1, __builtin_amdgcn_update_dpp(x1, x1, CTRL, ROWS, 0xf, false));                      \
+        const int32_t d = imax_(y1, __builtin_amdgcn_update_dpp(y1, y1, CTRL, ROWS, 0xf, false));                      \
+        if (take) { x0 = a; y0 = b; x1 = c; y1 = d; }                                                                   \
+    }
+            FB_SEG_STEP(JK_DPP_ROW_SHR(1), 0xf)
+            FB_SEG_STEP(JK_DPP_ROW_SHR(2), 0xf)
+            FB_SEG_STEP(JK_DPP_ROW_SHR(4), 0xf)
+            FB_SEG_STEP(JK_DPP_ROW_SHR(8), 0xf)
+            FB_SEG_STEP(JK_DPP_ROW_BCAST15, 0xa)
+            FB_SEG_STEP(JK_DPP_ROW_BCAST31, 0xc)
+#undef FB_SEG_STEP
+            if (pix == c_path) {  // (only the values of the segment's last lane are used)
+                x0 = imin_(x0, cx0); y0 = imin_(y0, cy0); x1 = imax_(x1, cx1); y1 = imax_(y1, cy1);
+            }
+            // lane i reads the path of lane i + 1 (wave_shl:1); lane 63 has no source: its segment stays open
+            const uint32_t pix_next = (uint32_t)__builtin_amdgcn_update_dpp((int)pix, (int)pix, 0x130, 0xf, 0xf, false);
+            if (valid && !skipped && pix_next != pix) fb_merge(path_bboxes, pix, x0, y0, x1, y1, pix == p_shared);
+            c_path = (uint32_t)__builtin_amdgcn_readlane((int)pix, 63);
+            cx0 = __builtin_amdgcn_readlane(x0, 63); cy0 = __builtin_amdgcn_readlane(y0, 63);
+            cx1 = __builtin_amdgcn_readlane(x1, 63); cy1 = __builtin_amdgcn_readlane(y1, 63);
+            if (ext) break;
         }
-        wave_fence();
+        // still open: the lines ended with it (a shared path if it also began before the range)
+        if (c_path != FB_NONE && lane == 0u) fb_merge(path_bboxes, c_path, cx0, cy0, cx1, cy1, c_path == p_shared);
     }
 }
 
@@ -1435,11 +1484,10 @@ int jh_launch_flatten(const JhLaunch& L) {
     hipLaunchKernelGGL(k_flatten_lines, dim3(gp), dim3(JL_WG), 0, L.stream, cfg, scene, (const uint32_t*)counters, (const uint32_t*)tinfo,
                        (const uint4*)pieces, (const uint4*)ends, tcap, (const JlLineSoup*)tlines, (const uint2*)tkeys, (const uint32_t*)chunk_used,
                        g, FL_CHUNK, (const uint32_t*)bases, n_slots, lines);
-    uint32_t tags_per_wave = 64u;  // fewer when that would give the device less than one wave per SIMD
-    while (tags_per_wave > 1u && n_tags / tags_per_wave < gp_cap / 2u) tags_per_wave >>= 1;
-    uint64_t gb64 = ((uint64_t)(n_tags + tags_per_wave - 1u) / tags_per_wave + 3u) / 4u;  // four waves per workgroup
-    uint32_t gb = gb64 > gp_cap ? gp_cap : (uint32_t)gb64;
-    hipLaunchKernelGGL(k_flatten_bbox, dim3(gb), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, (const uint32_t*)bases, n_slots, lines, pb,
-                       tags_per_wave);
+    // a wave per 64 lines of the buffer's capacity (the line count is only known on the device), at most 16 waves
+    // per SIMD: the kernel lengthens the ranges to match
+    uint64_t gb64 = ((uint64_t)lines.n + 255u) / 256u;  // four waves per workgroup
+    uint32_t gb = gb64 > 4ull * gp_cap ? 4u * gp_cap : (uint32_t)(gb64 < 1u ? 1u : gb64);
+    hipLaunchKernelGGL(k_flatten_bbox, dim3(gb), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, (const uint32_t*)bases, n_slots, lines, pb);
     return 0;
 }

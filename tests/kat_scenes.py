@@ -55,6 +55,23 @@ def gradient_in_clip():
     return s, RenderParams(16, 16)
 
 
+def bbox_extent_rule():
+    s = Scene()
+    a = Path().move_to(0, 0).line_to(1, 0).move_to(5e20, 5e20).line_to(6e20, 5e20).line_to(6e20, 6e20)
+    s.fill(Fill.NonZero, (1e-20, 0, 0, 1e-20, 100, 100), Brush.solid(RGBA), None, a)
+    s.fill(Fill.NonZero, (0, 0, 0, 0, 50, 60), Brush.solid(RGBA), None, Path.rect(0, 0, 10, 10))
+    s.fill(Fill.NonZero, None, Brush.solid(RGBA), None, Path.rect(3.5, 4.25, 20.75, 9))
+    return s, RenderParams(64, 64)
+
+
+def check_bbox_extent_rule(get, cfg):
+    """flatten.wgsl:893-899: a segment whose lines have no extent leaves the path's box alone."""
+    boxes = get("pathBboxBuf", np.uint32)[:cfg["n_path"] * 6].reshape(-1, 6)[:, :4]
+    want = [words(r) for r in KAT["bbox_extent_rule"]["path_bbox_x0y0x1y1"]]
+    assert cfg["n_path"] == 3
+    assert [[int(v) for v in row] for row in boxes] == want
+
+
 def words(xs):
     return [int(x, 16) for x in xs]
 

@@ -53,6 +53,15 @@ def test_five_blend_layers_spill_offsets(engine):
         engine.release(rec)
 
 
+def test_bbox_extent_rule(engine):
+    get, rec, bump = run_gpu(engine, K.bbox_extent_rule())
+    try:
+        assert bump["failed"] == 0
+        K.check_bbox_extent_rule(get, rec.config)
+    finally:
+        engine.release(rec)
+
+
 def test_bevel_join_between_collinear_segments(engine):
     get, rec, bump = run_gpu(engine, K.bevel_join_collinear())
     try:

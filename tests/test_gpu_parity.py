@@ -93,6 +93,20 @@ def test_dense_polygon_and_long_lines(engine):
     assert r["max_tile_segments"] > 1024
 
 
+def test_lines_without_extent(engine):
+    """Segments whose lines collapse to a point (flatten.wgsl:893-899 merges a segment's box only if it has an extent):
+    paths that are all points, points next to real segments, and strokes squeezed onto a vertical line, whose point-like
+    lines belong to segments that do have an extent."""
+    import kat_scenes as K
+    from jello_amd import Brush, Cap, Fill, Join, Path, Stroke
+    s, p = K.bbox_extent_rule()
+    for i, (join, cap) in enumerate([(Join.Round, Cap.Round), (Join.Miter, Cap.Square), (Join.Bevel, Cap.Butt)]):
+        path = Path().move_to(2, 5 + i).line_to(9, 5 + i).line_to(9, 30).cubic_to(20, 40, 0, 50, 7, 60 - i)
+        s.stroke(Stroke(3.0 + i, join, 4.0, cap, cap), (0, 0, 0, 1, 30 + i, 0), Brush.solid((0.2, 0.3, 0.4, 1.0)), None, path)
+        s.fill(Fill.EvenOdd, (0, 0, 0.5, 0, 10 * i, 7), Brush.solid((0.2, 0.3, 0.4, 1.0)), None, path)
+    compare(engine, s, p)
+
+
 def test_big_path_takes_the_list_route(engine):
     """A single path with far more tile crossings than PC_BIG_PATH next to small ones: both rank routes of path_count."""
     s, p = scenes.scene_big_path()

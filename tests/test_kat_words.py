@@ -43,6 +43,12 @@ def test_bevel_join_between_collinear_segments(built):
     K.check_bevel(bump)
 
 
+def test_bbox_extent_rule(built):
+    get, cfg, bump = run_oracle(K.bbox_extent_rule())
+    assert bump["failed"] == 0
+    K.check_bbox_extent_rule(get, cfg)
+
+
 def test_gradient_in_clip_encoder_streams(built):
     k = K.KAT["gradient_in_clip_streams"]
     s, p = K.gradient_in_clip()

@@ -693,7 +693,15 @@ JD Seg load_seg(const Scene& s, uint32_t ix) {
 // reserves the block's range, every lane writes its own slots.  (A per-lane atomicAdd on two hot
 // words costs ~3.7 ms for 1.2 M items on MI355X; this costs ~10 us.)  List order is irrelevant for the
 // result but this keeps it nearly sorted by tag, i.e. coalesced scene reads and line writes later on.
-#define FL_CLASSIFY_TAGS 4u  // tag bytes per thread: fewer workgroups => fewer atomics on the two hot list counters
+#ifndef FL_CLASSIFY_TAGS
+#define FL_CLASSIFY_TAGS 8u  // C3: 32 / 25 / 28 us with 4 / 8 / 16
+#endif
+// counters: [0] heavy items, [2] next overflow temp slot, [3] longest used chunk prefix, [FL_CTR_LIGHT] light items -- the
+// two list counters are hot (every workgroup of k_flatten_classify waits for its two returns) and live in different
+// memory channels
+#define FL_CTR_LIGHT 256u
+#define FL_CTR_WORDS 512u
+// tag bytes per thread: fewer workgroups => fewer atomics on the two hot list counters
 __global__ __launch_bounds__(JL_WG) void k_flatten_classify(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
                                                             Buf<JlPathBbox> path_bboxes, uint32_t* __restrict__ list,
                                                             uint32_t* __restrict__ counters, uint32_t cap, uint32_t n_tags,
@@ -742,7 +750,7 @@ __global__ __launch_bounds__(JL_WG) void k_flatten_classify(const JlConfig* __re
     MonoidK<2> ex = block_excl_scan_monoid<2>(m, sh, &tot);
     if (threadIdx.x == 0) {  // one atomic pair per workgroup (a hot word sustains only ~88 atomics/us)
         sh_base[0] = tot.v[0] ? atomicAdd(&counters[0], tot.v[0]) : 0u;
-        sh_base[1] = tot.v[1] ? atomicAdd(&counters[1], tot.v[1]) : 0u;
+        sh_base[1] = tot.v[1] ? atomicAdd(&counters[FL_CTR_LIGHT], tot.v[1]) : 0u;
     }
     __syncthreads();
     uint32_t ph = sh_base[0] + ex.v[0], pl = sh_base[1] + ex.v[1];
@@ -977,7 +985,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
     __shared__ FlBatch sh_batch[JL_WG / 64];
     Scene s;
     s.cfg = cfg; s.scene = scene; s.tag_monoids = tag_monoids;
-    uint32_t n_heavy = umin_(counters[0], cap), n_light = umin_(counters[1], cap - n_heavy);
+    uint32_t n_heavy = umin_(counters[0], cap), n_light = umin_(counters[FL_CTR_LIGHT], cap - n_heavy);
     uint32_t n = n_heavy + n_light;
     if (blockIdx.x * 64u >= n) return;  // uniform: this workgroup's share of the list is empty
     if (threadIdx.x == 0) {
@@ -1140,14 +1148,16 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
     if (lane == 0u) {
         const uint32_t used = umin_(sh_next, chunk + FL_CHUNK) - chunk;
         atomicMax(&chunk_used[chunk / FL_CHUNK], used);
-        atomicMax(&counters[3], used);  // the longest used chunk prefix: k_flatten_lines visits no batch behind it
+        // the longest used chunk prefix: k_flatten_lines visits no batch behind it (5120 waves on one word: only a wave
+        // that would raise what it reads -- possibly stale, i.e. smaller -- sends the atomic)
+        if (used > __hip_atomic_load(&counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&counters[3], used);
     }
 }
 
 // One thread per temporary slot: the Euler line (or the directly emitted line) that lives there, moved to
 // lines[bases[slot] + k], the canonical (tag byte, emission order) LineSoup position.
 #ifndef FL_LINES_WAVES_PER_EU
-#define FL_LINES_WAVES_PER_EU 5  // 6 and 8 measured the same: the kernel is bound by its scattered memory accesses
+#define FL_LINES_WAVES_PER_EU 4  // C3: 152 / 121 / 106 / 120 / 159 us at 2 / 3 / 4 / 5 / 8 (tools/sweep_flatten.sh)
 #endif
 __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_WAVES_PER_EU, FL_LINES_WAVES_PER_EU))) void k_flatten_lines(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, const uint32_t* __restrict__ counters,
                                                          const uint32_t* __restrict__ tinfo, const uint4* __restrict__ pieces,
@@ -1164,30 +1174,42 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
     const uint32_t units_chunks = n_chunks * chunk_batches;
     const uint32_t ov_start = n_chunks * FL_CHUNK;
     const uint32_t units = units_chunks + (n_t > ov_start ? (n_t - ov_start + JL_WG - 1u) / JL_WG : 0u);
+    // first slot of work unit u (FL_INVALID for a batch in the unused tail of its chunk) and the number of its slots in use
+    auto unit_slot = [&](uint32_t u, uint32_t& lim) -> uint32_t {
+        lim = JL_WG;
+        if (u >= units) return FL_INVALID;
+        if (u >= units_chunks) return ov_start + (u - units_chunks) * JL_WG;
+        // (batch bi of chunk uc; the rotation by bi keeps a workgroup whose stride is a multiple of n_chunks from
+        // walking ONE chunk from end to end -- chunks are filled unevenly, and the fullest one set the kernel's time)
+        const uint32_t bi = u / n_chunks, uc = (u % n_chunks + bi * 61u) % n_chunks;
+        const uint32_t used = chunk_used[uc];
+        if (bi * JL_WG >= used) return FL_INVALID;
+        lim = used - bi * JL_WG;
+        return uc * FL_CHUNK + bi * JL_WG;
+    };
+    // The markers of the NEXT unit are fetched before this one is worked on: a unit is a chain of dependent round
+    // trips (chunk fill -> markers -> piece record -> line base), and the first two now overlap the previous unit.
+    uint32_t lim_next;
+    uint32_t t0_next = unit_slot(blockIdx.x, lim_next);
+    uint32_t v_next = (t0_next != FL_INVALID && t0_next + threadIdx.x < n_t) ? tinfo[t0_next + threadIdx.x] : 0u;
     for (uint32_t u = blockIdx.x; u < units; u += gridDim.x) {  // uniform per workgroup
-        uint32_t t0;
-        if (u < units_chunks) {
-            const uint32_t uc = u % n_chunks, bi = u / n_chunks;
-            if (bi * JL_WG >= chunk_used[uc]) continue;
-            t0 = uc * FL_CHUNK + bi * JL_WG;
-        } else {
-            t0 = ov_start + (u - units_chunks) * JL_WG;
-        }
+        const uint32_t t0 = t0_next, lim = lim_next;
+        uint32_t v = v_next;
+        t0_next = unit_slot(u + gridDim.x, lim_next);
+        v_next = (t0_next != FL_INVALID && t0_next + threadIdx.x < n_t) ? tinfo[t0_next + threadIdx.x] : 0u;
+        if (t0 == FL_INVALID) continue;
         const uint32_t t = t0 + threadIdx.x;
         // which piece covers slot t?  Its first slot carries the marker (pieces have at most 100 lines).  The wave looks
         // at its 64 markers together: the nearest marker at or before a lane (DPP running maximum); only lanes before
         // the wave's first marker walk back through memory.
-        uint32_t v = t < n_t ? tinfo[t] : 0u;
         const uint32_t mark = wave_incl_max_u32(v != 0u ? lane + 1u : 0u);  // 1 + lane of the nearest marker, 0 = none
         uint32_t tp = t;
         if (mark != 0u) {
             v = (uint32_t)__shfl((int)v, (int)(mark - 1u), 64);
             tp = t - (lane - (mark - 1u));
         }
-        if (t >= n_t) continue;
         // the workgroups' reserved chunks are the first n_chunks * FL_CHUNK slots; their unused tails hold nothing
-        const uint32_t c = t / FL_CHUNK;
-        if (c < n_chunks && t - c * FL_CHUNK >= chunk_used[c]) continue;
+        if (t >= n_t || threadIdx.x >= lim) continue;
         if (mark == 0u) {
             for (uint32_t back = lane + 1u; back <= 100u && back <= t; back++) {
                 v = tinfo[t - back];
@@ -1468,10 +1490,10 @@ int jh_launch_flatten(const JhLaunch& L) {
     uint32_t* tinfo = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_H, (uint64_t)tcap * 4);
     uint4* pieces = (uint4*)jh_scratch_get(L.scratch, JH_SCR_I, (uint64_t)tcap * 64);
     uint4* ends = (uint4*)jh_scratch_get(L.scratch, JH_SCR_F, (uint64_t)tcap * 16);
-    uint32_t* counters = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, 64 + (uint64_t)g * 4);
+    uint32_t* counters = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, FL_CTR_WORDS * 4 + (uint64_t)g * 4);
     if (!counts || !bases || !list || !counters || !tlines || !tkeys || !tinfo || !pieces || !ends) return -5;
-    uint32_t* chunk_used = counters + 16;  // one word per workgroup chunk (g <= 2048 workgroups)
-    (void)hipMemsetAsync(counters, 0, 64 + (size_t)g * 4, L.stream);
+    uint32_t* chunk_used = counters + FL_CTR_WORDS;  // one word per workgroup chunk (g <= 2048 workgroups)
+    (void)hipMemsetAsync(counters, 0, FL_CTR_WORDS * 4 + (size_t)g * 4, L.stream);
     hipLaunchKernelGGL(k_flatten_classify, dim3((L.gx + FL_CLASSIFY_TAGS - 1) / FL_CLASSIFY_TAGS), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list,
                        counters, n_slots, n_tags, g * FL_CHUNK, counts);
     hipLaunchKernelGGL(k_flatten_items, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, (const uint32_t*)list, counters, n_slots, counts,
@@ -1480,7 +1502,10 @@ int jh_launch_flatten(const JhLaunch& L) {
     if (rc) return rc;
     uint32_t gp = (tcap + JL_WG - 1) / JL_WG;
     uint32_t gp_cap = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * 8u;
-    if (gp > gp_cap) gp = gp_cap;
+    // k_flatten_lines strides over its work units: exactly the workgroups that are resident together (more would run
+    // as a second, partly filled round behind the first)
+    uint32_t gl_cap = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * FL_LINES_WAVES_PER_EU;
+    if (gp > gl_cap) gp = gl_cap;
     hipLaunchKernelGGL(k_flatten_lines, dim3(gp), dim3(JL_WG), 0, L.stream, cfg, scene, (const uint32_t*)counters, (const uint32_t*)tinfo,
                        (const uint4*)pieces, (const uint4*)ends, tcap, (const JlLineSoup*)tlines, (const uint2*)tkeys, (const uint32_t*)chunk_used,
                        g, FL_CHUNK, (const uint32_t*)bases, n_slots, lines);

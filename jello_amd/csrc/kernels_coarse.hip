@@ -26,7 +26,8 @@ struct Cmd {
     JlBump* bump;
     Buf<uint32_t> ptcl;
     uint32_t cmd_offset, cmd_limit;
-    uint32_t chunk_base;   // word offset (relative to ptcl_dyn_start) of this tile's first chunk
+    uint32_t dyn_start;    // first word behind the tiles' initial allocations (coarse.wgsl:75)
+    uint32_t chunk_base;   // word offset (relative to dyn_start) of this tile's first chunk
     uint32_t chunk_words;  // PTCL words of dynamic chunks taken so far
     uint32_t seg_base, seg_used;
 };
@@ -34,6 +35,8 @@ struct Cmd {
 // PTCL words leave as 16-byte stores where a command has four or more words (dword-aligned addresses: gfx950 runs in
 // unaligned-access mode; a 4-byte store per word costs three times the write requests).
 struct __attribute__((packed, aligned(4))) PtclQuad { uint32_t a, b, c, d; };
+struct __attribute__((packed, aligned(4))) PtclTriple { uint32_t a, b, c; };
+struct __attribute__((packed, aligned(4))) PtclPair { uint32_t a, b; };
 JD void ptcl_wr4(const Buf<uint32_t>& ptcl, uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     if (i + 3u < ptcl.n && i + 3u >= i) {
         PtclQuad q; q.a = a; q.b = b; q.c = c; q.d = d;
@@ -46,8 +49,7 @@ JD void ptcl_wr4(const Buf<uint32_t>& ptcl, uint32_t i, uint32_t a, uint32_t b, 
 template <bool WRITE>
 JD void alloc_cmd(Cmd& c, uint32_t size) {  // coarse.wgsl:70-88
     if (c.cmd_offset + size >= c.cmd_limit) {
-        uint32_t ptcl_dyn_start = c.cfg->width_in_tiles * c.cfg->height_in_tiles * JL_PTCL_INITIAL_ALLOC;
-        uint32_t new_cmd = ptcl_dyn_start + c.chunk_base + c.chunk_words;
+        uint32_t new_cmd = c.dyn_start + c.chunk_base + c.chunk_words;
         c.chunk_words += JL_PTCL_INCREMENT;
         if (WRITE) {
             if (new_cmd + JL_PTCL_INCREMENT > c.cfg->ptcl_size) {
@@ -83,7 +85,25 @@ JD void write_path(Cmd& c, const Buf<JlTile>& tiles, JlTile tile, uint32_t tile_
 }
 
 #define COARSE_UNROLL 4u
-#define COARSE_TILE_CACHE 4096u
+#ifndef COARSE_TILE_CACHE
+#define COARSE_TILE_CACHE 1536u  // with the rest of the LDS 36.5 KiB: four workgroups per CU (>= 256: the pairs of one element)
+#endif
+#ifndef COARSE_WG_PER_CU
+#define COARSE_WG_PER_CU 4u
+#endif
+#ifndef COARSE_MAX_SPLIT
+#define COARSE_MAX_SPLIT 16u
+#endif
+
+// Element record, word 0 (see stage2 in k_coarse)
+#define CM_CLIP 1u             // BEGIN_CLIP or END_CLIP (draw tag bit 0)
+#define CM_BLEND 2u            // ... whose blend word is not the plain clip
+#define CM_EVENODD_INCLUDE 4u  // even-odd rule in the (draw, tile) include test (draw flags bit 0)
+#define CM_EVENODD_FILL 8u     // even-odd rule in the FILL command
+#define CM_PATH 16u            // a path command (FILL or SOLID) precedes the brush command
+#define CM_BEGIN 32u
+#define CM_END 64u
+#define CM_NBRUSH_SHIFT 8u     // words of the brush command (0 ... 5)
 
 // CLIPS = false: instantiation for scenes without clip layers (ConfigUniform.n_clip == 0): no BEGIN/END_CLIP draw
 // objects can occur, which removes the clip-depth state and half of the divergent control flow of the command walk.
@@ -96,7 +116,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                                                   const uint32_t* __restrict__ base_blend, uint32_t bin_row0, uint32_t split) {
     // bin_row0: first bin row of the launch (band mode writes the PTCL of its band only; the counting pass always
     // covers the whole target, so that every allocation base is the one of the unsharded run)
-    // split (1, 2 or 4): a bin is shared by `split` workgroups (blockIdx.z), each owning 16 / split of its tile rows.
+    // split (1 ... 16): a bin is shared by `split` workgroups (blockIdx.z), each owning 16 / split of its tile rows.
     // The merge of the bin's element lists is repeated by each of them (cheap); the (draw, tile) include test and the
     // per-tile command walk -- the expensive parts -- cover the workgroup's rows only.  With one workgroup per bin a
     // 2048^2 target keeps 64 of 256 CUs busy and a 4096^2 target one wave per SIMD.
@@ -114,7 +134,10 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     __shared__ uint4 sh_r1[JL_WG];  // x0 | y0 << 16, width, first (draw, tile) pair of the draw in the batch, info offset
     __shared__ uint4 sh_r2[JL_WG];  // scene[dd .. dd+3]: colour / ramp index / blend+alpha
     __shared__ uint32_t sh_scan[8];
-    __shared__ uint2 sh_tile_cache[COARSE_TILE_CACHE];  // (backdrop, segment count) of the batch's first (draw, tile) pairs
+    // (backdrop, segment count) of the (draw, tile) pairs of the current window of elements.  The command walk reads Tiles
+    // from here ONLY: a global load inside its loop makes every trip wait for the PTCL stores of the trip before
+    // (vmcnt counts loads and stores in one order) -- 1 us per trip in the write pass.
+    __shared__ uint2 sh_tile_cache[COARSE_TILE_CACHE];
 
     const uint32_t lid = threadIdx.x;
     const uint32_t width_in_bins = (cfg->width_in_tiles + JL_N_TILE_X - 1u) / JL_N_TILE_X;
@@ -147,6 +170,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     c.cfg = cfg; c.bump = bump; c.ptcl = ptcl;
     c.cmd_offset = this_tile_ix * JL_PTCL_INITIAL_ALLOC;
     c.cmd_limit = c.cmd_offset + (JL_PTCL_INITIAL_ALLOC - JL_PTCL_HEADROOM);
+    c.dyn_start = cfg->width_in_tiles * cfg->height_in_tiles * JL_PTCL_INITIAL_ALLOC;
     c.chunk_base = WRITE ? base_chunk[slot] : 0u;
     c.chunk_words = 0u;
     c.seg_base = WRITE ? base_seg[slot] : 0u;
@@ -199,11 +223,10 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         return (lid + rd_ix < wr_ix) ? sh_drawobj_ix[lid] : 0xffffffffu;
     };
     // first-level loads of an element: tag and draw monoid
-    uint32_t n_obj = 0xffffffffu, n_tag = JL_DRAWTAG_NOP;
+    uint32_t n_tag = JL_DRAWTAG_NOP;
     JlDrawMonoid n_dm;
     n_dm.path_ix = 0u; n_dm.clip_ix = 0u; n_dm.scene_offset = 0u; n_dm.info_offset = 0u;
     auto stage1 = [&](uint32_t obj) {
-        n_obj = obj;
         n_tag = JL_DRAWTAG_NOP;
         if (obj != 0xffffffffu) {
             n_tag = scene.rd(cfg->layout.drawtag_base + obj);
@@ -211,19 +234,47 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         }
     };
     // second-level loads and the record (r1.z is filled in after the batch's tile-count scan)
-    uint4 n_r0 = make_uint4(JL_DRAWTAG_NOP, 0u, 0u, 0u), n_r1 = make_uint4(0u, 0u, 0u, 0u), n_r2 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 n_r0 = make_uint4(0u, 0u, 0u, 0u), n_r1 = make_uint4(0u, 0u, 0u, 0u), n_r2 = make_uint4(0u, 0u, 0u, 0u);
     uint32_t n_tile_count = 0u;
+    // The record is laid out for the command walk, which runs once per (element, tile) and must not branch on the draw
+    // tag: the tag is decoded HERE, once per element, into a few flag bits and the words of the brush command.
+    //   r0 = (meta, brush word 0, tile base of bin-relative tile (0,0), tile stride)
+    //   r1 = (x0 | y0 << 16, width | ceil(2^16 / width) << 5, first (draw, tile) pair of the draw in the batch, -)
+    //   r2 = brush words 1..4
     auto stage2 = [&]() {
         const uint32_t tag = n_tag;
         n_tile_count = 0u;
-        n_r0 = make_uint4(tag, 0u, 0u, 0u); n_r1 = make_uint4(0u, 0u, 0u, 0u); n_r2 = make_uint4(0u, 0u, 0u, 0u);
+        n_r0 = make_uint4(0u, 0u, 0u, 0u); n_r1 = make_uint4(0u, 0u, 0u, 0u); n_r2 = make_uint4(0u, 0u, 0u, 0u);
         if (tag != JL_DRAWTAG_NOP) {
             const JlDrawMonoid dm0 = n_dm;
             uint32_t path_ix = dm0.path_ix;
             uint32_t dd0 = cfg->layout.drawdata_base + dm0.scene_offset;
-            n_r1.w = dm0.info_offset;
-            n_r0.y = info_bin_data.rd(dm0.info_offset);
-            n_r2 = make_uint4(scene.rd(dd0), scene.rd(dd0 + 1u), scene.rd(dd0 + 2u), scene.rd(dd0 + 3u));
+            const uint32_t di = dm0.info_offset;
+            const uint32_t draw_flags = info_bin_data.rd(di);
+            const uint4 sc = make_uint4(scene.rd(dd0), scene.rd(dd0 + 1u), scene.rd(dd0 + 2u), scene.rd(dd0 + 3u));
+            uint32_t meta = (draw_flags & 1u) != 0u ? CM_EVENODD_INCLUDE : 0u;
+            if ((tag & 1u) != 0u) {
+                meta |= CM_CLIP;
+                if (sc.x != BLEND_CLIP) meta |= CM_BLEND;
+            }
+            if (tag == JL_DRAWTAG_FILL_COLOR) {
+                meta |= CM_PATH | (meta & CM_EVENODD_INCLUDE ? CM_EVENODD_FILL : 0u) | (5u << CM_NBRUSH_SHIFT);
+                n_r0.y = JL_CMD_COLOR; n_r2 = sc;
+            } else if (tag == JL_DRAWTAG_FILL_LIN_GRADIENT || tag == JL_DRAWTAG_FILL_RAD_GRADIENT || tag == JL_DRAWTAG_FILL_SWEEP_GRADIENT) {
+                meta |= CM_PATH | (meta & CM_EVENODD_INCLUDE ? CM_EVENODD_FILL : 0u) | (3u << CM_NBRUSH_SHIFT);
+                n_r0.y = tag == JL_DRAWTAG_FILL_LIN_GRADIENT ? JL_CMD_LIN_GRAD : (tag == JL_DRAWTAG_FILL_RAD_GRADIENT ? JL_CMD_RAD_GRAD : JL_CMD_SWEEP_GRAD);
+                n_r2.x = sc.x; n_r2.y = di + 1u;
+            } else if (tag == JL_DRAWTAG_FILL_IMAGE) {
+                meta |= CM_PATH | (meta & CM_EVENODD_INCLUDE ? CM_EVENODD_FILL : 0u) | (2u << CM_NBRUSH_SHIFT);
+                n_r0.y = JL_CMD_IMAGE; n_r2.x = di + 1u;
+            } else if (CLIPS && tag == JL_DRAWTAG_BEGIN_CLIP) {
+                meta |= CM_BEGIN | (1u << CM_NBRUSH_SHIFT);
+                n_r0.y = JL_CMD_BEGIN_CLIP;
+            } else if (CLIPS && tag == JL_DRAWTAG_END_CLIP) {
+                meta |= CM_END | CM_PATH | (3u << CM_NBRUSH_SHIFT);  // (its path command is never even-odd: coarse.wgsl:423)
+                n_r0.y = JL_CMD_END_CLIP; n_r2.x = sc.x; n_r2.y = sc.y;
+            }
+            n_r0.x = meta;
             JlPath path = paths.rd(path_ix);
             uint32_t stride = path.bbox[2] - path.bbox[0];
             n_r0.w = stride;
@@ -257,10 +308,18 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         rd_ix += JL_N_TILE;
         const bool has_next = !(rd_ix >= ready_ix && partition_ix >= n_partitions);  // uniform
         if (has_next) stage1(gather());
-        // (draw, tile) include test, coarse.wgsl:318-341.  The workgroup is alone on its CU (one workgroup per bin), so
-        // the Tile loads are issued four at a time per thread instead of one dependent load per iteration, and what
-        // they return is kept in LDS for the command walk below.
-        for (uint32_t base = 0u; base < total_tile_count; base += COARSE_UNROLL * JL_N_TILE) {
+        // A batch is worked on in windows of elements whose (draw, tile) pairs fit the Tile cache -- one window unless
+        // the batch holds large paths (C4's clip rectangles); include test and command walk alternate per window.
+        uint32_t win_e0 = 0u, win_p0 = 0u;
+        bool did_stage2 = false;
+        for (;;) {
+        uint32_t win_e1 = win_e0;  // largest e1 with sh_tile_count[e1 - 1] - win_p0 <= COARSE_TILE_CACHE (uniform)
+        for (uint32_t step = 256u; step > 0u; step >>= 1)
+            if (win_e1 + step <= JL_N_TILE && sh_tile_count[win_e1 + step - 1u] - win_p0 <= COARSE_TILE_CACHE) win_e1 += step;
+        const uint32_t win_p1 = sh_tile_count[win_e1 - 1u];
+        // (draw, tile) include test, coarse.wgsl:318-341.  The Tile loads are issued four at a time per thread instead
+        // of one dependent load per iteration, and what they return is kept in LDS for the command walk below.
+        for (uint32_t base = win_p0; base < win_p1; base += COARSE_UNROLL * JL_N_TILE) {
             uint32_t p_el[COARSE_UNROLL], p_xy[COARSE_UNROLL], p_tile[COARSE_UNROLL];
             JlTile p_t[COARSE_UNROLL];
 #pragma unroll
@@ -268,7 +327,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                 const uint32_t ix = base + u * JL_N_TILE + lid;
                 p_el[u] = 0xffffffffu; p_xy[u] = 0u; p_tile[u] = 0u;
                 p_t[u].backdrop = 0; p_t[u].segment_count_or_ix = 0u;
-                if (ix < total_tile_count) {
+                if (ix < win_p1) {
                     uint32_t el_ix = 0u;
 #pragma unroll
                     for (uint32_t i = 0; i < 8u; i++) {
@@ -295,17 +354,10 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                 const uint32_t ix = base + u * JL_N_TILE + lid;
                 const uint32_t el_ix = p_el[u];
                 const JlTile tile = p_t[u];
-                if (ix < COARSE_TILE_CACHE) sh_tile_cache[ix] = make_uint2((uint32_t)tile.backdrop, tile.segment_count_or_ix);
-                const uint4 q0 = sh_r0[el_ix];
-                uint32_t d_tag = q0.x;
-                bool is_clip = (d_tag & 1u) != 0u;
-                bool is_blend = false;
-                if (is_clip) {
-                    uint32_t blend = sh_r2[el_ix].x;
-                    is_blend = blend != BLEND_CLIP;
-                }
-                uint32_t draw_flags = q0.y;
-                bool even_odd = (draw_flags & 1u) != 0u;
+                sh_tile_cache[ix - win_p0] = make_uint2((uint32_t)tile.backdrop, tile.segment_count_or_ix);
+                const uint32_t meta = sh_r0[el_ix].x;
+                const bool is_clip = (meta & CM_CLIP) != 0u, is_blend = (meta & CM_BLEND) != 0u;
+                const bool even_odd = (meta & CM_EVENODD_INCLUDE) != 0u;
                 uint32_t n_segs = tile.segment_count_or_ix;
                 int32_t bd = tile.backdrop;
                 int32_t absbd = bd < 0 ? (int32_t)(0u - (uint32_t)bd) : bd;
@@ -314,13 +366,14 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                 if (include_tile) atomicOr(&sh_bitmaps[el_ix / 32u][p_xy[u]], 1u << (el_ix & 31u));
             }
         }
-        if (has_next) stage2();
+        if (has_next && !did_stage2) { stage2(); did_stage2 = true; }
         __syncthreads();
         // Write the per-tile command list for this tile (coarse.wgsl:344-444)
         // The walk is one wave per SIMD chasing LDS round trips (bitmap -> record -> cached Tile), so it is pipelined by
         // hand: the reads of the NEXT element are issued before the commands of the current one are written.
-        uint32_t slice_ix = has_tile ? 0u : 7u;
-        uint32_t bitmap = has_tile ? sh_bitmaps[0][my_xy] : 0u;
+        // (bits of later windows are not set yet: the walk of a window ends by itself at win_e1)
+        uint32_t slice_ix = has_tile ? win_e0 / 32u : 7u;
+        uint32_t bitmap = has_tile && win_e0 < JL_N_TILE ? sh_bitmaps[slice_ix][my_xy] & (0xffffffffu << (win_e0 & 31u)) : 0u;
         auto next_el = [&]() -> uint32_t {  // next set bit of this tile's bitmaps, ~0u at the end
             while (bitmap == 0u) {
                 slice_ix += 1u;
@@ -339,85 +392,84 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             w_q0 = sh_r0[e]; w_q1 = sh_r1[e]; w_q2 = sh_r2[e];
             // the pair's slot in the include-test order: what that pass loaded is still in LDS
             const uint32_t pair = w_q1.z + (tile_y - (w_q1.x >> 16)) * (w_q1.y & 31u) + (tile_x - (w_q1.x & 0xffffu));
-            if (pair < COARSE_TILE_CACHE) {
-                const uint2 tc = sh_tile_cache[pair];
-                w_tile.backdrop = (int32_t)tc.x;
-                w_tile.segment_count_or_ix = tc.y;
-            } else {
-                w_tile = tiles.rd(w_q0.z + w_q0.w * tile_y + tile_x);
-            }
+            const uint2 tc = sh_tile_cache[pair - win_p0];
+            w_tile.backdrop = (int32_t)tc.x;
+            w_tile.segment_count_or_ix = tc.y;
         };
         uint32_t el_next = next_el();
         fetch(el_next);
+        // One trip per element of the tile.  The body is written with selects, not branches: the wave's 64 tiles walk
+        // different elements (fills with and without segments, clips that are open, empty or skipped), and as a tree
+        // of divergent branches a trip cost ~1500 cycles of exec-mask bookkeeping for ~30 useful instructions.
         while (el_next != 0xffffffffu) {
-            const uint4 q0 = w_q0, q1 = w_q1, q2 = w_q2;
+            const uint4 q0 = w_q0, q2 = w_q2;
             const JlTile tile = w_tile;
             el_next = next_el();
             fetch(el_next);
-            uint32_t drawtag = q0.x;
-            uint32_t di = q1.w;
-            uint32_t draw_flags = q0.y;
-            if (!CLIPS || clip_zero_depth == 0u) {
-                uint32_t tile_ix = q0.z + q0.w * tile_y + tile_x;
-                if (drawtag == JL_DRAWTAG_FILL_COLOR) {  // by far the most frequent draw object: tested first
-                    write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);
-                    alloc_cmd<WRITE>(c, 5u);
-                    if (WRITE) {
-                        ptcl_wr4(c.ptcl, c.cmd_offset, JL_CMD_COLOR, q2.x, q2.y, q2.z);
-                        c.ptcl.wr(c.cmd_offset + 4u, q2.w);
-                    }
-                    c.cmd_offset += 5u;
-                } else if (drawtag == JL_DRAWTAG_FILL_LIN_GRADIENT || drawtag == JL_DRAWTAG_FILL_RAD_GRADIENT ||
-                           drawtag == JL_DRAWTAG_FILL_SWEEP_GRADIENT) {
-                    write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);
-                    alloc_cmd<WRITE>(c, 3u);
-                    if (WRITE) {
-                        uint32_t ty = drawtag == JL_DRAWTAG_FILL_LIN_GRADIENT ? JL_CMD_LIN_GRAD
-                                      : (drawtag == JL_DRAWTAG_FILL_RAD_GRADIENT ? JL_CMD_RAD_GRAD : JL_CMD_SWEEP_GRAD);
-                        c.ptcl.wr(c.cmd_offset, ty);
-                        c.ptcl.wr(c.cmd_offset + 1u, q2.x);
-                        c.ptcl.wr(c.cmd_offset + 2u, di + 1u);
-                    }
-                    c.cmd_offset += 3u;
-                } else if (drawtag == JL_DRAWTAG_FILL_IMAGE) {
-                    write_path<WRITE>(c, tiles, tile, tile_ix, draw_flags);
-                    alloc_cmd<WRITE>(c, 2u);
-                    if (WRITE) {
-                        c.ptcl.wr(c.cmd_offset, JL_CMD_IMAGE);
-                        c.ptcl.wr(c.cmd_offset + 1u, di + 1u);
-                    }
-                    c.cmd_offset += 2u;
-                } else if (CLIPS && drawtag == JL_DRAWTAG_BEGIN_CLIP) {
-                    if (tile.segment_count_or_ix == 0u && tile.backdrop == 0) {
-                        clip_zero_depth = clip_depth + 1u;
-                    } else {
-                        alloc_cmd<WRITE>(c, 1u);
-                        if (WRITE) c.ptcl.wr(c.cmd_offset, JL_CMD_BEGIN_CLIP);
-                        c.cmd_offset += 1u;
+            const uint32_t meta = q0.x;
+            const uint32_t n_segs = tile.segment_count_or_ix;
+            const bool is_begin = CLIPS && (meta & CM_BEGIN) != 0u, is_end = CLIPS && (meta & CM_END) != 0u;
+            const bool active = !CLIPS || clip_zero_depth == 0u;  // coarse.wgsl:352
+            const bool zero_tile = n_segs == 0u && tile.backdrop == 0;
+            const bool emit_path = active && (meta & CM_PATH) != 0u;
+            const bool emit_brush = active && !(is_begin && zero_tile);
+            if (CLIPS) {  // clip state, coarse.wgsl:398-441
+                if (is_begin) {
+                    if (active && zero_tile) clip_zero_depth = clip_depth + 1u;
+                    if (active && !zero_tile) {
                         render_blend_depth += 1u;
                         max_blend_depth = umax_(max_blend_depth, render_blend_depth);
                     }
                     clip_depth += 1u;
-                } else if (CLIPS && drawtag == JL_DRAWTAG_END_CLIP) {
-                    clip_depth -= 1u;
-                    write_path<WRITE>(c, tiles, tile, tile_ix, 0u);
-                    alloc_cmd<WRITE>(c, 3u);
-                    if (WRITE) {
-                        c.ptcl.wr(c.cmd_offset, JL_CMD_END_CLIP);
-                        c.ptcl.wr(c.cmd_offset + 1u, q2.x);
-                        c.ptcl.wr(c.cmd_offset + 2u, q2.y);
-                    }
-                    c.cmd_offset += 3u;
-                    render_blend_depth -= 1u;
                 }
-            } else if (CLIPS) {
-                if (drawtag == JL_DRAWTAG_BEGIN_CLIP) {
-                    clip_depth += 1u;
-                } else if (drawtag == JL_DRAWTAG_END_CLIP) {
-                    if (clip_depth == clip_zero_depth) clip_zero_depth = 0u;
+                if (is_end) {
+                    if (active) render_blend_depth -= 1u;
+                    if (!active && clip_depth == clip_zero_depth) clip_zero_depth = 0u;
                     clip_depth -= 1u;
                 }
             }
+            // path command: FILL (4 words) if the tile has segments, else SOLID (1 word); coarse.wgsl:90-112
+            const uint32_t s1 = emit_path ? (n_segs != 0u ? 4u : 1u) : 0u;
+            const uint32_t seg_ix = c.seg_base + c.seg_used;
+            if (emit_path) c.seg_used += n_segs;
+            if (emit_path) alloc_cmd<WRITE>(c, s1);
+            // (one bounds check for the element's eight words at most; the stores themselves are unchecked)
+            const bool room = c.cmd_offset + 16u <= c.ptcl.n && c.cmd_offset + 16u > c.cmd_offset;
+            if (WRITE) {
+                if (s1 == 4u) {
+                    const uint32_t tile_ix = q0.z + q0.w * tile_y + tile_x;
+                    if (tiles.ok(tile_ix)) tiles.p[tile_ix].segment_count_or_ix = ~seg_ix;
+                    const uint32_t rule = (n_segs << 1) | ((meta & CM_EVENODD_FILL) != 0u ? 1u : 0u);
+                    if (room) { PtclQuad q; q.a = JL_CMD_FILL; q.b = rule; q.c = seg_ix; q.d = (uint32_t)tile.backdrop; *(PtclQuad*)(c.ptcl.p + c.cmd_offset) = q; }
+                    else ptcl_wr4(c.ptcl, c.cmd_offset, JL_CMD_FILL, rule, seg_ix, (uint32_t)tile.backdrop);
+                }
+                if (s1 == 1u) c.ptcl.wr(c.cmd_offset, JL_CMD_SOLID);
+            }
+            c.cmd_offset += s1;
+            // brush command: the words stage2 prepared
+            const uint32_t s2 = emit_brush ? ((meta >> CM_NBRUSH_SHIFT) & 7u) : 0u;
+            if (s2 != 0u) alloc_cmd<WRITE>(c, s2);
+            if (WRITE) {
+                if (room) {
+                    uint32_t* P = c.ptcl.p + c.cmd_offset;
+                    if (s2 >= 4u) { PtclQuad q; q.a = q0.y; q.b = q2.x; q.c = q2.y; q.d = q2.z; *(PtclQuad*)P = q; }
+                    if (s2 == 5u) P[4] = q2.w;
+                    if (s2 == 3u) { PtclTriple t; t.a = q0.y; t.b = q2.x; t.c = q2.y; *(PtclTriple*)P = t; }
+                    if (s2 == 2u) { PtclPair t; t.a = q0.y; t.b = q2.x; *(PtclPair*)P = t; }
+                    if (s2 == 1u) P[0] = q0.y;
+                } else {
+                    if (s2 >= 1u) c.ptcl.wr(c.cmd_offset, q0.y);
+                    if (s2 >= 2u) c.ptcl.wr(c.cmd_offset + 1u, q2.x);
+                    if (s2 >= 3u) c.ptcl.wr(c.cmd_offset + 2u, q2.y);
+                    if (s2 >= 4u) c.ptcl.wr(c.cmd_offset + 3u, q2.z);
+                    if (s2 == 5u) c.ptcl.wr(c.cmd_offset + 4u, q2.w);
+                }
+            }
+            c.cmd_offset += s2;
+        }
+        if (win_p1 >= total_tile_count) break;
+        __syncthreads();  // the next window's include test overwrites the Tile cache
+        win_e0 = win_e1; win_p0 = win_p1;
         }
         if (!has_next) break;
         __syncthreads();
@@ -463,10 +515,10 @@ int jh_launch_coarse(const JhLaunch& L) {
     auto tiles = mkbuf<JlTile>(L.b[6].ptr, L.b[6].size);
     JlBump* bump = (JlBump*)L.b[7].ptr;
     auto ptcl = mkbuf<uint32_t>(L.b[8].ptr, L.b[8].size);
-    // workgroups per bin: enough to give every CU two workgroups (the LDS of one allows two per CU)
-    const uint32_t want = 2u * (uint32_t)(L.num_cus > 0 ? L.num_cus : 256);
+    // workgroups per bin: enough to give every CU four workgroups (the LDS of one allows four per CU)
+    const uint32_t want = COARSE_WG_PER_CU * (uint32_t)(L.num_cus > 0 ? L.num_cus : 256);
     uint32_t split = 1u;
-    while (split < 4u && L.gx * L.gy * split < want) split *= 2u;
+    while (split < COARSE_MAX_SPLIT && L.gx * L.gy * split < want) split *= 2u;
     dim3 grid(L.gx, L.gy, split), blk(JL_WG);
     const uint32_t row0 = L.band_row0 < L.gy ? L.band_row0 : L.gy, row1 = L.band_row1 < L.gy ? L.band_row1 : L.gy;
     dim3 grid_w(L.gx, row1 > row0 ? row1 - row0 : 0u, split);

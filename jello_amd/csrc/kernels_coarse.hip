@@ -48,10 +48,10 @@ JD void ptcl_wr4(const Buf<uint32_t>& ptcl, uint32_t i, uint32_t a, uint32_t b, 
 
 template <bool WRITE>
 JD void alloc_cmd(Cmd& c, uint32_t size) {  // coarse.wgsl:70-88
-    if (c.cmd_offset + size >= c.cmd_limit) {
-        uint32_t new_cmd = c.dyn_start + c.chunk_base + c.chunk_words;
-        c.chunk_words += JL_PTCL_INCREMENT;
-        if (WRITE) {
+    const bool need = c.cmd_offset + size >= c.cmd_limit;
+    uint32_t new_cmd = c.dyn_start + c.chunk_base + c.chunk_words;
+    if (WRITE) {
+        if (need) {  // (rare: once per 254 words)
             if (new_cmd + JL_PTCL_INCREMENT > c.cfg->ptcl_size) {
                 new_cmd = 0u;
                 atomicOr(&c.bump->failed, (uint32_t)JL_STAGE_COARSE);
@@ -59,41 +59,11 @@ JD void alloc_cmd(Cmd& c, uint32_t size) {  // coarse.wgsl:70-88
             c.ptcl.wr(c.cmd_offset, JL_CMD_JUMP);
             c.ptcl.wr(c.cmd_offset + 1u, new_cmd);
         }
-        c.cmd_offset = new_cmd;
-        c.cmd_limit = c.cmd_offset + (JL_PTCL_INCREMENT - JL_PTCL_HEADROOM);
     }
+    c.chunk_words += need ? JL_PTCL_INCREMENT : 0u;
+    c.cmd_offset = need ? new_cmd : c.cmd_offset;
+    c.cmd_limit = need ? new_cmd + (JL_PTCL_INCREMENT - JL_PTCL_HEADROOM) : c.cmd_limit;
 }
-
-template <bool WRITE>
-JD void write_path(Cmd& c, const Buf<JlTile>& tiles, JlTile tile, uint32_t tile_ix, uint32_t draw_flags) {  // coarse.wgsl:90-112
-    uint32_t n_segs = tile.segment_count_or_ix;
-    if (n_segs != 0u) {
-        uint32_t seg_ix = c.seg_base + c.seg_used;
-        c.seg_used += n_segs;
-        alloc_cmd<WRITE>(c, 4u);
-        if (WRITE) {
-            if (tiles.ok(tile_ix)) tiles.p[tile_ix].segment_count_or_ix = ~seg_ix;
-            bool even_odd = (draw_flags & 1u) != 0u;
-            ptcl_wr4(c.ptcl, c.cmd_offset, JL_CMD_FILL, (n_segs << 1) | (even_odd ? 1u : 0u), seg_ix, (uint32_t)tile.backdrop);
-        }
-        c.cmd_offset += 4u;
-    } else {
-        alloc_cmd<WRITE>(c, 1u);
-        if (WRITE) c.ptcl.wr(c.cmd_offset, JL_CMD_SOLID);
-        c.cmd_offset += 1u;
-    }
-}
-
-#define COARSE_UNROLL 4u
-#ifndef COARSE_TILE_CACHE
-#define COARSE_TILE_CACHE 1536u  // with the rest of the LDS 36.5 KiB: four workgroups per CU (>= 256: the pairs of one element)
-#endif
-#ifndef COARSE_WG_PER_CU
-#define COARSE_WG_PER_CU 4u
-#endif
-#ifndef COARSE_MAX_SPLIT
-#define COARSE_MAX_SPLIT 16u
-#endif
 
 // Element record, word 0 (see stage2 in k_coarse)
 #define CM_CLIP 1u             // BEGIN_CLIP or END_CLIP (draw tag bit 0)
@@ -104,6 +74,23 @@ JD void write_path(Cmd& c, const Buf<JlTile>& tiles, JlTile tile, uint32_t tile_
 #define CM_BEGIN 32u
 #define CM_END 64u
 #define CM_NBRUSH_SHIFT 8u     // words of the brush command (0 ... 5)
+
+// The command walk of one tile: its PTCL write position, clip state and the element it looks at next.  A lane can walk
+// COARSE_TPL tiles side by side; measured with 2: exactly twice the time per trip (C3 78+60 -> 124+83 us, C4 552+316 ->
+// 1121+608 us).  With one walking wave per SIMD the walk is bound by the instructions it issues, not by the latency
+// of its LDS chain, so independent chains have nothing to hide in -- what pays is fewer instructions per trip.
+#ifndef COARSE_TPL
+#define COARSE_TPL 1u
+#endif
+struct Walk {
+    Cmd c;
+    uint32_t blend_offset, clip_zero_depth, clip_depth, render_blend_depth, max_blend_depth;
+    uint32_t tile_x, tile_y, my_xy, slot;
+    bool has_tile;
+    uint32_t slice_ix, bitmap, nz, el_next;  // nz: slices behind slice_ix that hold elements of this tile
+    uint4 q0, q2;
+    JlTile tile;
+};
 
 // CLIPS = false: instantiation for scenes without clip layers (ConfigUniform.n_clip == 0): no BEGIN/END_CLIP draw
 // objects can occur, which removes the clip-depth state and half of the divergent control flow of the command walk.
@@ -142,11 +129,18 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     const uint32_t lid = threadIdx.x;
     const uint32_t width_in_bins = (cfg->width_in_tiles + JL_N_TILE_X - 1u) / JL_N_TILE_X;
     const uint32_t bin_ix = width_in_bins * bin_y + blockIdx.x;
-    const bool has_tile = lid < part_rows * JL_N_TILE_X;  // the first part_rows * 16 threads own a tile each
-    const uint32_t tile_x = lid % JL_N_TILE_X;
-    const uint32_t tile_y = part_y0 + (has_tile ? lid / JL_N_TILE_X : 0u);
-    const uint32_t my_xy = tile_y * JL_N_TILE_X + tile_x;        // the tile's index inside the bin
-    const uint32_t slot = bin_ix * JL_N_TILE + my_xy;            // position in the canonical (bin, tile) order
+    // the first part_tiles / COARSE_TPL threads walk COARSE_TPL tiles each: tiles t = lid + k * walkers of the workgroup's part
+    const uint32_t part_tiles = part_rows * JL_N_TILE_X, walkers = part_tiles / COARSE_TPL;
+    Walk W[COARSE_TPL];
+#pragma unroll
+    for (uint32_t k = 0; k < COARSE_TPL; k++) {
+        W[k].has_tile = lid < walkers;
+        const uint32_t t = W[k].has_tile ? lid + k * walkers : 0u;
+        W[k].tile_x = t % JL_N_TILE_X;
+        W[k].tile_y = part_y0 + t / JL_N_TILE_X;
+        W[k].my_xy = W[k].tile_y * JL_N_TILE_X + W[k].tile_x;  // the tile's index inside the bin
+        W[k].slot = bin_ix * JL_N_TILE + W[k].my_xy;           // position in the canonical (bin, tile) order
+    }
 
     {  // coarse.wgsl:161-176
         uint32_t failed = bump->failed & (JL_STAGE_BINNING | JL_STAGE_TILE_ALLOC | JL_STAGE_FLATTEN);
@@ -155,7 +149,9 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             if (WRITE) {
                 if (blockIdx.x == 0u && blockIdx.y == 0u && lid == 0u) atomicOr(&bump->failed, failed);
             } else {
-                if (has_tile) { cnt_seg[slot] = 0u; cnt_chunk[slot] = 0u; cnt_blend[slot] = 0u; }
+#pragma unroll
+                for (uint32_t k = 0; k < COARSE_TPL; k++)
+                    if (W[k].has_tile) { cnt_seg[W[k].slot] = 0u; cnt_chunk[W[k].slot] = 0u; cnt_blend[W[k].slot] = 0u; }
             }
             return;
         }
@@ -163,24 +159,27 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     const uint32_t n_partitions = (cfg->layout.n_drawobj + JL_N_TILE - 1u) / JL_N_TILE;
     const uint32_t bin_tile_x = JL_N_TILE_X * blockIdx.x;
     const uint32_t bin_tile_y = JL_N_TILE_Y * bin_y;
-    const uint32_t this_tile_ix = (bin_tile_y + tile_y) * cfg->width_in_tiles + bin_tile_x + tile_x;
     const uint32_t BLEND_CLIP = (128u << 8) | 0u;  // MIX_CLIP << 8 | COMPOSE_SRC_OVER (Jello numbering, blend.wgsl:199-202)
-
-    Cmd c;
-    c.cfg = cfg; c.bump = bump; c.ptcl = ptcl;
-    c.cmd_offset = this_tile_ix * JL_PTCL_INITIAL_ALLOC;
-    c.cmd_limit = c.cmd_offset + (JL_PTCL_INITIAL_ALLOC - JL_PTCL_HEADROOM);
-    c.dyn_start = cfg->width_in_tiles * cfg->height_in_tiles * JL_PTCL_INITIAL_ALLOC;
-    c.chunk_base = WRITE ? base_chunk[slot] : 0u;
-    c.chunk_words = 0u;
-    c.seg_base = WRITE ? base_seg[slot] : 0u;
-    c.seg_used = 0u;
-
-    uint32_t clip_zero_depth = 0u, clip_depth = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < COARSE_TPL; k++) {
+        Walk& w = W[k];
+        const uint32_t this_tile_ix = (bin_tile_y + w.tile_y) * cfg->width_in_tiles + bin_tile_x + w.tile_x;
+        w.c.cfg = cfg; w.c.bump = bump; w.c.ptcl = ptcl;
+        w.c.cmd_offset = this_tile_ix * JL_PTCL_INITIAL_ALLOC;
+        w.c.cmd_limit = w.c.cmd_offset + (JL_PTCL_INITIAL_ALLOC - JL_PTCL_HEADROOM);
+        w.c.dyn_start = cfg->width_in_tiles * cfg->height_in_tiles * JL_PTCL_INITIAL_ALLOC;
+        w.c.chunk_base = WRITE ? base_chunk[w.slot] : 0u;
+        w.c.chunk_words = 0u;
+        w.c.seg_base = WRITE ? base_seg[w.slot] : 0u;
+        w.c.seg_used = 0u;
+        w.clip_zero_depth = 0u; w.clip_depth = 0u; w.render_blend_depth = 0u; w.max_blend_depth = 0u;
+        w.blend_offset = w.c.cmd_offset;
+        w.c.cmd_offset += 1u;
+        w.slice_ix = 7u; w.bitmap = 0u; w.nz = 0u; w.el_next = 0xffffffffu;
+        w.q0 = make_uint4(0u, 0u, 0u, 0u); w.q2 = w.q0;
+        w.tile.backdrop = 0; w.tile.segment_count_or_ix = 0u;
+    }
     uint32_t partition_ix = 0u, rd_ix = 0u, wr_ix = 0u, part_start_ix = 0u, ready_ix = 0u;
-    uint32_t render_blend_depth = 0u, max_blend_depth = 0u;
-    const uint32_t blend_offset = c.cmd_offset;
-    c.cmd_offset += 1u;
 
     // The batch loop is software-pipelined: an element's record needs three dependent memory round trips (bin_data ->
     // tag / draw monoid -> info, draw data, path), which used to sit in front of every batch.  Now the next batch is
@@ -368,104 +367,130 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         }
         if (has_next && !did_stage2) { stage2(); did_stage2 = true; }
         __syncthreads();
-        // Write the per-tile command list for this tile (coarse.wgsl:344-444)
-        // The walk is one wave per SIMD chasing LDS round trips (bitmap -> record -> cached Tile), so it is pipelined by
-        // hand: the reads of the NEXT element are issued before the commands of the current one are written.
-        // (bits of later windows are not set yet: the walk of a window ends by itself at win_e1)
-        uint32_t slice_ix = has_tile ? win_e0 / 32u : 7u;
-        uint32_t bitmap = has_tile && win_e0 < JL_N_TILE ? sh_bitmaps[slice_ix][my_xy] & (0xffffffffu << (win_e0 & 31u)) : 0u;
-        auto next_el = [&]() -> uint32_t {  // next set bit of this tile's bitmaps, ~0u at the end
-            while (bitmap == 0u) {
-                slice_ix += 1u;
-                if (slice_ix == 8u) return 0xffffffffu;
-                bitmap = sh_bitmaps[slice_ix][my_xy];
+        // Write the per-tile command lists (coarse.wgsl:344-444).  The reads of a tile's NEXT element (bitmap -> record ->
+        // cached Tile) are issued before the commands of the current one are written.
+        auto next_el = [&](Walk& w) -> uint32_t {  // next set bit of the tile's bitmaps, ~0u at the end
+            if (w.bitmap == 0u) {  // on to the next slice that holds something (a tile of C3 sees 10 of a batch's 256 elements)
+                if (w.nz == 0u) return 0xffffffffu;
+                w.slice_ix = (uint32_t)__builtin_ctz(w.nz);
+                w.nz &= w.nz - 1u;
+                w.bitmap = sh_bitmaps[w.slice_ix][w.my_xy];
             }
-            const uint32_t e = slice_ix * 32u + (uint32_t)__builtin_ctz(bitmap);
-            bitmap &= bitmap - 1u;
+            const uint32_t e = w.slice_ix * 32u + (uint32_t)__builtin_ctz(w.bitmap);
+            w.bitmap &= w.bitmap - 1u;
             return e;
         };
-        uint4 w_q0 = make_uint4(0u, 0u, 0u, 0u), w_q1 = w_q0, w_q2 = w_q0;
-        JlTile w_tile;
-        w_tile.backdrop = 0; w_tile.segment_count_or_ix = 0u;
-        auto fetch = [&](uint32_t e) {  // record and Tile of element e for this tile (the bit is only set for tiles inside its box)
-            if (e == 0xffffffffu) return;
-            w_q0 = sh_r0[e]; w_q1 = sh_r1[e]; w_q2 = sh_r2[e];
-            // the pair's slot in the include-test order: what that pass loaded is still in LDS
-            const uint32_t pair = w_q1.z + (tile_y - (w_q1.x >> 16)) * (w_q1.y & 31u) + (tile_x - (w_q1.x & 0xffffu));
-            const uint2 tc = sh_tile_cache[pair - win_p0];
-            w_tile.backdrop = (int32_t)tc.x;
-            w_tile.segment_count_or_ix = tc.y;
+        auto fetch = [&](Walk& w) {  // record and Tile of element el_next for this tile (nothing useful if there is none)
+            const uint32_t e = w.el_next & (JL_N_TILE - 1u);
+            const uint4 q1 = sh_r1[e];
+            w.q0 = sh_r0[e]; w.q2 = sh_r2[e];
+            // the pair's slot in the include-test order: what that pass loaded is in LDS
+            const uint32_t pair = q1.z + (w.tile_y - (q1.x >> 16)) * (q1.y & 31u) + (w.tile_x - (q1.x & 0xffffu));
+            const uint2 tc = sh_tile_cache[umin_(pair - win_p0, COARSE_TILE_CACHE - 1u)];
+            w.tile.backdrop = (int32_t)tc.x;
+            w.tile.segment_count_or_ix = tc.y;
         };
-        uint32_t el_next = next_el();
-        fetch(el_next);
-        // One trip per element of the tile.  The body is written with selects, not branches: the wave's 64 tiles walk
-        // different elements (fills with and without segments, clips that are open, empty or skipped), and as a tree
-        // of divergent branches a trip cost ~1500 cycles of exec-mask bookkeeping for ~30 useful instructions.
-        while (el_next != 0xffffffffu) {
-            const uint4 q0 = w_q0, q2 = w_q2;
-            const JlTile tile = w_tile;
-            el_next = next_el();
-            fetch(el_next);
-            const uint32_t meta = q0.x;
-            const uint32_t n_segs = tile.segment_count_or_ix;
-            const bool is_begin = CLIPS && (meta & CM_BEGIN) != 0u, is_end = CLIPS && (meta & CM_END) != 0u;
-            const bool active = !CLIPS || clip_zero_depth == 0u;  // coarse.wgsl:352
-            const bool zero_tile = n_segs == 0u && tile.backdrop == 0;
-            const bool emit_path = active && (meta & CM_PATH) != 0u;
-            const bool emit_brush = active && !(is_begin && zero_tile);
-            if (CLIPS) {  // clip state, coarse.wgsl:398-441
-                if (is_begin) {
-                    if (active && zero_tile) clip_zero_depth = clip_depth + 1u;
-                    if (active && !zero_tile) {
-                        render_blend_depth += 1u;
-                        max_blend_depth = umax_(max_blend_depth, render_blend_depth);
+        bool any = false;
+#pragma unroll
+        for (uint32_t k = 0; k < COARSE_TPL; k++) {
+            Walk& w = W[k];
+            // (bits of later windows are not set yet: the walk of a window ends by itself at win_e1)
+            const bool walks = w.has_tile && win_e0 < JL_N_TILE;
+            w.slice_ix = walks ? win_e0 / 32u : 7u;
+            uint32_t sl[8];
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; i++) sl[i] = sh_bitmaps[i][w.my_xy];
+            w.bitmap = 0u; w.nz = 0u;
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; i++) {
+                if (walks && i == w.slice_ix) w.bitmap = sl[i] & (0xffffffffu << (win_e0 & 31u));
+                if (walks && i > w.slice_ix && sl[i] != 0u) w.nz |= 1u << i;
+            }
+            w.el_next = next_el(w);
+            fetch(w);
+            any = any || w.el_next != 0xffffffffu;
+        }
+        // One trip per element and tile.  The body is written with selects, not branches: a wave's tiles walk different
+        // elements (fills with and without segments, clips that are open, empty or skipped), and as a tree of divergent
+        // branches a trip cost ~1500 cycles of exec-mask bookkeeping for ~30 useful instructions.  A tile that has run
+        // out of elements goes through the motions with an empty record (meta 0: no command, no state change).
+        while (any) {
+            any = false;
+#pragma unroll
+            for (uint32_t k = 0; k < COARSE_TPL; k++) {
+                Walk& w = W[k];
+                Cmd& c = w.c;
+                const bool live = w.el_next != 0xffffffffu;
+                const uint4 q0 = w.q0, q2 = w.q2;
+                const JlTile tile = w.tile;
+                if (live) w.el_next = next_el(w);
+                fetch(w);
+                any = any || w.el_next != 0xffffffffu;
+                // Everything below is 0/1 integer arithmetic on vector registers: as bools the compiler keeps the
+                // conditions in scalar mask registers, and the scalar <-> vector hand-overs cost more than the ops.
+                const uint32_t meta = live ? q0.x : 0u;
+                const uint32_t n_segs = tile.segment_count_or_ix;
+                const uint32_t is_begin = CLIPS ? (meta / CM_BEGIN) & 1u : 0u, is_end = CLIPS ? (meta / CM_END) & 1u : 0u;
+                const uint32_t has_path = (meta / CM_PATH) & 1u;
+                const uint32_t active = CLIPS ? 1u - umin_(w.clip_zero_depth, 1u) : 1u;  // coarse.wgsl:352
+                const uint32_t has_segs = umin_(n_segs, 1u);
+                const uint32_t zero_tile = 1u - umin_(n_segs | (uint32_t)tile.backdrop, 1u);
+                if (CLIPS) {  // clip state, coarse.wgsl:398-441
+                    const uint32_t open = is_begin & active;  // BEGIN_CLIP seen by a live tile: skipped from here if the clip is empty, ...
+                    const uint32_t opened = open & (1u - zero_tile);  // ... else one more blend level
+                    // (clip_zero_depth is 0 whenever `active`; END_CLIP of a skipped stretch ends it at its own depth)
+                    const uint32_t ends_skip = is_end & (1u - active) & (1u - umin_(w.clip_depth ^ w.clip_zero_depth, 1u));
+                    w.clip_zero_depth = (w.clip_zero_depth + (open & zero_tile) * (w.clip_depth + 1u)) * (1u - ends_skip);
+                    w.render_blend_depth += opened;
+                    w.max_blend_depth = umax_(w.max_blend_depth, w.render_blend_depth);
+                    w.render_blend_depth -= is_end & active;
+                    w.clip_depth += is_begin - is_end;
+                }
+                const uint32_t emit_path = active & has_path;
+                const uint32_t emit_brush = active & (1u - (is_begin & zero_tile));
+                // path command: FILL (4 words) if the tile has segments, else SOLID (1 word); coarse.wgsl:90-112
+                const uint32_t s1 = emit_path * (1u + 3u * has_segs);
+                const uint32_t seg_ix = c.seg_base + c.seg_used;
+                c.seg_used += emit_path * n_segs;
+                alloc_cmd<WRITE>(c, s1);  // (no-op for s1 == 0: cmd_offset < cmd_limit between commands)
+                // Stores: a command of fewer than four words is written as four -- the words behind it belong to this
+                // tile's chunk (cmd_offset + 1 < cmd_limit and the two words of headroom) and are either overwritten
+                // by the next command or never reached -- so that a trip has three predicated stores instead of eight.
+                if (WRITE) {
+                    const bool room = c.cmd_offset + 8u <= c.ptcl.n && c.cmd_offset + 8u > c.cmd_offset;
+                    const uint32_t rule = (n_segs << 1) | ((meta / CM_EVENODD_FILL) & 1u);
+                    if (s1 == 4u) {
+                        const uint32_t tile_ix = q0.z + q0.w * w.tile_y + w.tile_x;
+                        if (tiles.ok(tile_ix)) tiles.p[tile_ix].segment_count_or_ix = ~seg_ix;
                     }
-                    clip_depth += 1u;
+                    if (s1 != 0u) {
+                        PtclQuad q; q.a = has_segs ? JL_CMD_FILL : JL_CMD_SOLID; q.b = rule; q.c = seg_ix; q.d = (uint32_t)tile.backdrop;
+                        if (room) *(PtclQuad*)(c.ptcl.p + c.cmd_offset) = q;
+                        else if (s1 == 4u) ptcl_wr4(c.ptcl, c.cmd_offset, q.a, q.b, q.c, q.d);
+                        else c.ptcl.wr(c.cmd_offset, q.a);
+                    }
                 }
-                if (is_end) {
-                    if (active) render_blend_depth -= 1u;
-                    if (!active && clip_depth == clip_zero_depth) clip_zero_depth = 0u;
-                    clip_depth -= 1u;
-                }
-            }
-            // path command: FILL (4 words) if the tile has segments, else SOLID (1 word); coarse.wgsl:90-112
-            const uint32_t s1 = emit_path ? (n_segs != 0u ? 4u : 1u) : 0u;
-            const uint32_t seg_ix = c.seg_base + c.seg_used;
-            if (emit_path) c.seg_used += n_segs;
-            if (emit_path) alloc_cmd<WRITE>(c, s1);
-            // (one bounds check for the element's eight words at most; the stores themselves are unchecked)
-            const bool room = c.cmd_offset + 16u <= c.ptcl.n && c.cmd_offset + 16u > c.cmd_offset;
-            if (WRITE) {
-                if (s1 == 4u) {
-                    const uint32_t tile_ix = q0.z + q0.w * tile_y + tile_x;
-                    if (tiles.ok(tile_ix)) tiles.p[tile_ix].segment_count_or_ix = ~seg_ix;
-                    const uint32_t rule = (n_segs << 1) | ((meta & CM_EVENODD_FILL) != 0u ? 1u : 0u);
-                    if (room) { PtclQuad q; q.a = JL_CMD_FILL; q.b = rule; q.c = seg_ix; q.d = (uint32_t)tile.backdrop; *(PtclQuad*)(c.ptcl.p + c.cmd_offset) = q; }
-                    else ptcl_wr4(c.ptcl, c.cmd_offset, JL_CMD_FILL, rule, seg_ix, (uint32_t)tile.backdrop);
-                }
-                if (s1 == 1u) c.ptcl.wr(c.cmd_offset, JL_CMD_SOLID);
-            }
-            c.cmd_offset += s1;
-            // brush command: the words stage2 prepared
-            const uint32_t s2 = emit_brush ? ((meta >> CM_NBRUSH_SHIFT) & 7u) : 0u;
-            if (s2 != 0u) alloc_cmd<WRITE>(c, s2);
-            if (WRITE) {
-                if (room) {
-                    uint32_t* P = c.ptcl.p + c.cmd_offset;
-                    if (s2 >= 4u) { PtclQuad q; q.a = q0.y; q.b = q2.x; q.c = q2.y; q.d = q2.z; *(PtclQuad*)P = q; }
-                    if (s2 == 5u) P[4] = q2.w;
-                    if (s2 == 3u) { PtclTriple t; t.a = q0.y; t.b = q2.x; t.c = q2.y; *(PtclTriple*)P = t; }
-                    if (s2 == 2u) { PtclPair t; t.a = q0.y; t.b = q2.x; *(PtclPair*)P = t; }
-                    if (s2 == 1u) P[0] = q0.y;
-                } else {
-                    if (s2 >= 1u) c.ptcl.wr(c.cmd_offset, q0.y);
-                    if (s2 >= 2u) c.ptcl.wr(c.cmd_offset + 1u, q2.x);
-                    if (s2 >= 3u) c.ptcl.wr(c.cmd_offset + 2u, q2.y);
-                    if (s2 >= 4u) c.ptcl.wr(c.cmd_offset + 3u, q2.z);
+                c.cmd_offset += s1;
+                // brush command: the words stage2 prepared
+                const uint32_t s2 = emit_brush * ((meta >> CM_NBRUSH_SHIFT) & 7u);
+                alloc_cmd<WRITE>(c, s2);
+                if (WRITE) {
+                    const bool room = c.cmd_offset + 8u <= c.ptcl.n && c.cmd_offset + 8u > c.cmd_offset;
+                    if (s2 != 0u) {
+                        if (room) {
+                            PtclQuad q; q.a = q0.y; q.b = q2.x; q.c = q2.y; q.d = q2.z;
+                            *(PtclQuad*)(c.ptcl.p + c.cmd_offset) = q;
+                        } else {
+                            c.ptcl.wr(c.cmd_offset, q0.y);
+                            if (s2 >= 2u) c.ptcl.wr(c.cmd_offset + 1u, q2.x);
+                            if (s2 >= 3u) c.ptcl.wr(c.cmd_offset + 2u, q2.y);
+                            if (s2 >= 4u) c.ptcl.wr(c.cmd_offset + 3u, q2.z);
+                        }
+                    }
                     if (s2 == 5u) c.ptcl.wr(c.cmd_offset + 4u, q2.w);
                 }
+                c.cmd_offset += s2;
             }
-            c.cmd_offset += s2;
         }
         if (win_p1 >= total_tile_count) break;
         __syncthreads();  // the next window's include test overwrites the Tile cache
@@ -474,24 +499,28 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         if (!has_next) break;
         __syncthreads();
     }
-    uint32_t scratch_size = 0u;
-    if (!has_tile) return;
-    bool in_target = bin_tile_x + tile_x < cfg->width_in_tiles && bin_tile_y + tile_y < cfg->height_in_tiles;
-    if (in_target && max_blend_depth > JL_BLEND_STACK_SPLIT) scratch_size = (max_blend_depth - JL_BLEND_STACK_SPLIT) * JL_TILE_WIDTH * JL_TILE_HEIGHT;
-    if (WRITE) {
-        if (in_target) {
-            c.ptcl.wr(c.cmd_offset, JL_CMD_END);
-            uint32_t blend_ix = 0u;
-            if (scratch_size != 0u) {
-                blend_ix = base_blend[slot];
-                if (blend_ix + scratch_size > cfg->blend_size) atomicOr(&bump->failed, (uint32_t)JL_STAGE_COARSE);
+#pragma unroll
+    for (uint32_t k = 0; k < COARSE_TPL; k++) {
+        Walk& w = W[k];
+        if (!w.has_tile) continue;
+        uint32_t scratch_size = 0u;
+        const bool in_target = bin_tile_x + w.tile_x < cfg->width_in_tiles && bin_tile_y + w.tile_y < cfg->height_in_tiles;
+        if (in_target && w.max_blend_depth > JL_BLEND_STACK_SPLIT) scratch_size = (w.max_blend_depth - JL_BLEND_STACK_SPLIT) * JL_TILE_WIDTH * JL_TILE_HEIGHT;
+        if (WRITE) {
+            if (in_target) {
+                w.c.ptcl.wr(w.c.cmd_offset, JL_CMD_END);
+                uint32_t blend_ix = 0u;
+                if (scratch_size != 0u) {
+                    blend_ix = base_blend[w.slot];
+                    if (blend_ix + scratch_size > cfg->blend_size) atomicOr(&bump->failed, (uint32_t)JL_STAGE_COARSE);
+                }
+                w.c.ptcl.wr(w.blend_offset, blend_ix);
             }
-            c.ptcl.wr(blend_offset, blend_ix);
+        } else {
+            cnt_seg[w.slot] = w.c.seg_used;
+            cnt_chunk[w.slot] = w.c.chunk_words;
+            cnt_blend[w.slot] = scratch_size;
         }
-    } else {
-        cnt_seg[slot] = c.seg_used;
-        cnt_chunk[slot] = c.chunk_words;
-        cnt_blend[slot] = scratch_size;
     }
 }
 

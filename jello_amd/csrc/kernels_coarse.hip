@@ -65,6 +65,17 @@ JD void alloc_cmd(Cmd& c, uint32_t size) {  // coarse.wgsl:70-88
     c.cmd_limit = need ? new_cmd + (JL_PTCL_INCREMENT - JL_PTCL_HEADROOM) : c.cmd_limit;
 }
 
+#define COARSE_UNROLL 4u
+#ifndef COARSE_TILE_CACHE
+#define COARSE_TILE_CACHE 1536u  // with the rest of the LDS 37.5 KiB: four workgroups per CU (>= 256: the pairs of one element)
+#endif
+#ifndef COARSE_WG_PER_CU
+#define COARSE_WG_PER_CU 4u
+#endif
+#ifndef COARSE_MAX_SPLIT
+#define COARSE_MAX_SPLIT 16u
+#endif
+
 // Element record, word 0 (see stage2 in k_coarse)
 #define CM_CLIP 1u             // BEGIN_CLIP or END_CLIP (draw tag bit 0)
 #define CM_BLEND 2u            // ... whose blend word is not the plain clip

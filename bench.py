@@ -37,8 +37,10 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scene", choices=["c3", "c4"], default="c3",
-                    help="c3 = the headline scene (BASELINE.json configs[2]); c4 = configs[3]: nested clips + radial gradients + blends")
+    ap.add_argument("--scene", choices=["c3", "c4", "c4n"], default="c3",
+                    help="c3 = the headline scene (BASELINE.json configs[2]); c4 = configs[3]: nested clips + radial gradients + blends "
+                         "(clip circles at independent positions: nearly every paint is clipped away); c4n = the same with concentric "
+                         "clips and the paths inside them (visible paints)")
     ap.add_argument("--paths", type=int, default=0, help="default: 100000 (c3) / 30000 (c4)")
     ap.add_argument("--size", type=int, default=0, help="default: 4096 (c3) / 2048 (c4)")
     ap.add_argument("--aa", choices=["area", "msaa8", "msaa16"], default="area", help="coverage mode of the fine stage (the headline is area)")
@@ -101,9 +103,13 @@ def run_rank(args, world):
     if args.scene == "c3":
         scene, params = scenes.scene_c3(args.paths, args.size, seed=sharding.scene_seed_for_rank(seed_off))
         what = "C3: %d random stroked+filled cubic Beziers" % args.paths
-    else:
+    elif args.scene == "c4":
         scene, params = scenes.scene_c4(args.paths, args.size, seed=scenes.SEED + 4 + seed_off)
         what = "C4: %d paths in groups of 10 under 3-deep clip layers (16 mix modes), every 3rd brush a radial gradient" % args.paths
+    else:
+        scene, params = scenes.scene_c4_nested(args.paths, args.size, seed=scenes.SEED + 14 + seed_off)
+        what = ("C4 (nested variant): %d paths in groups of 10 inside 3 concentric clip layers (16 mix modes), every 3rd brush a "
+                "radial gradient" % args.paths)
     params.aa = {"area": jello_amd.Aa.Area, "msaa8": jello_amd.Aa.Msaa8, "msaa16": jello_amd.Aa.Msaa16}[args.aa]
     fine_stage = {"area": "fine_area", "msaa8": "fine_msaa8", "msaa16": "fine_msaa16"}[args.aa]
     eng = jello_amd.Engine(dev.index)
@@ -353,8 +359,10 @@ def cpu_baseline(host, args):
     n, size = args.paths, args.size
     if args.scene == "c3":
         scene, params = scenes.scene_c3(n, size)
-    else:
+    elif args.scene == "c4":
         scene, params = scenes.scene_c4(n, size)
+    else:
+        scene, params = scenes.scene_c4_nested(n, size)
     import jello_amd
     params.aa = {"area": jello_amd.Aa.Area, "msaa8": jello_amd.Aa.Msaa8, "msaa16": jello_amd.Aa.Msaa16}[args.aa]
     params.bump = BumpSizes(lines=1 << 23, seg_counts=1 << 24, segments=1 << 24, tiles=1 << 23, ptcl=1 << 27, bin_data=1 << 22, blend_spill=1 << 22)

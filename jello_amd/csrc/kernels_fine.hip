@@ -887,21 +887,24 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                 const bool separable = (blend & 0xffu) == 0u && mixm >= 1u && mixm <= 14u;
                 const bool needs_lum = mixm >= 12u;
                 if (plain || separable) {
-                    bool ok = true;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) ok = ok && f2u(area[k]) <= 0x3f800000u;
+                    // (the range tests are unsigned comparisons of bit patterns: one comparison of the MAXIMUM pattern per
+                    // group of values -- v_max3_u32 -- instead of one comparison and one mask operation per value)
+                    auto umax3 = [](uint32_t a, uint32_t b, uint32_t c) -> uint32_t { return umax_(umax_(a, b), c); };
+                    bool ok = umax_(umax3(f2u(area[0]), f2u(area[1]), f2u(area[2])), f2u(area[3])) <= 0x3f800000u;
                     if (!plain) {
+                        uint32_t m[4];
 #pragma unroll
-                        for (int k = 0; k < 4; k++)
-                            ok = ok && f2u(rgba[k].x) <= 0x41800000u && f2u(rgba[k].y) <= 0x41800000u && f2u(rgba[k].z) <= 0x41800000u &&
-                                 f2u(rgba[k].w) <= 0x41800000u;
+                        for (int k = 0; k < 4; k++) m[k] = umax_(umax3(f2u(rgba[k].x), f2u(rgba[k].y), f2u(rgba[k].z)), f2u(rgba[k].w));
+                        ok = ok && umax_(umax3(m[0], m[1], m[2]), m[3]) <= 0x41800000u;
                         if (needs_lum) {  // uniform
+                            uint32_t lm = 0u;
 #pragma unroll
                             for (int k = 0; k < 4; k++) {
                                 const float inv_backdrop_a = 1.0f / fmax_(rgba[k].w, 1e-15f);  // blend.wgsl:293-294
                                 const float l = lum(v3(rgba[k].x * inv_backdrop_a, rgba[k].y * inv_backdrop_a, rgba[k].z * inv_backdrop_a));
-                                ok = ok && f2u(l) <= 0x3f800000u;
+                                lm = umax_(lm, f2u(l));
                             }
+                            ok = ok && lm <= 0x3f800000u;
                         }
                     }
                     fast = __builtin_amdgcn_ballot_w64(!ok) == 0ull;

@@ -145,6 +145,46 @@ def scene_c4(n_paths=30_000, size=2048, seed=SEED + 4, group=10, depth=3):
     return s, RenderParams(size, size, base_color=(0, 0, 0, 1))
 
 
+def scene_c4_nested(n_paths=30_000, size=2048, seed=SEED + 14, group=10, depth=3):
+    """C4 with clips that nest the way an SVG's do: each group's `depth` clip circles are (nearly) concentric, every one a
+    little smaller than its parent and nudged off centre, and the group's paths start inside the innermost.  scene_c4 draws
+    its three circles at independent random positions: their intersection is empty almost everywhere, so of its 30 k paths
+    92 fills reach the PTCL and the frame is 212 empty blend layers per tile -- a stress of the clip stack, not of
+    compositing.  Here the paints are visible: gradients and blends are composited at scale."""
+    r = SplitMix64(seed)
+    s = Scene()
+    i = 0
+    gi = 0
+    while i < n_paths:
+        cx, cy = r.uniform(0, size), r.uniform(0, size)
+        layers = 0
+        for d in range(depth):
+            mix = Mix(gi % 16) if d == 0 else Mix.Clip
+            rad = 128.0 + 64.0 * (depth - d)
+            s.push_layer(mix, Compose.SrcOver, 0.8 if d == 0 else 1.0, None,
+                         Path.circle(cx + r.uniform(-24, 24) * d, cy + r.uniform(-24, 24) * d, rad))
+            layers += 1
+            gi += 1
+        for _ in range(group):
+            if i >= n_paths:
+                break
+            ax, ay = cx + r.uniform(-160, 160), cy + r.uniform(-160, 160)
+            p = Path().move_to(ax, ay)
+            p.cubic_to(ax + r.uniform(-96, 96), ay + r.uniform(-96, 96), ax + r.uniform(-96, 96), ay + r.uniform(-96, 96),
+                       ax + r.uniform(-96, 96), ay + r.uniform(-96, 96))
+            if i % 3 == 2:
+                stops = [ColorStop(0.0, (r.uniform(), r.uniform(), r.uniform(), 1.0)), ColorStop(0.5, (r.uniform(), r.uniform(), r.uniform(), 0.8)),
+                         ColorStop(1.0, (r.uniform(), r.uniform(), r.uniform(), 0.6))]
+                b = Brush.radial((ax, ay), 4.0, (ax + 10, ay + 5), 80.0, stops, Extend.Pad)
+            else:
+                b = Brush.solid((r.uniform(), r.uniform(), r.uniform(), r.uniform(0.2, 1.0)))
+            s.fill(Fill.NonZero, None, b, None, p)
+            i += 1
+        for _ in range(layers):
+            s.pop_layer()
+    return s, RenderParams(size, size, base_color=(0, 0, 0, 1))
+
+
 def scene_images(size=256, seed=SEED + 7):
     """Two RGBA8 (sRGB-encoded) images as brushes: one axis-aligned at 1:1, one rotated/scaled through the
     brush transform so that the bilinear taps and the extent test of fine.wgsl:1068-1087 are exercised, plus

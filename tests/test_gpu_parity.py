@@ -238,6 +238,30 @@ def test_undersized_buffers_fail_cleanly_without_regrow(engine):
     assert bump["failed"] != 0 and attempts == 1
 
 
+@pytest.mark.parametrize("n,size", [(1500, 512), (6000, 1024)])
+def test_c4_nested_clips_with_visible_paints(engine, n, size):
+    """scene_c4_nested: the clip circles of a group are concentric and its paths lie inside them, so gradients and all 16
+    mix modes are composited for real (scene_c4's independent circles clip nearly every paint away)."""
+    s, p = scenes.scene_c4_nested(n, size)
+    p.bump = s.bump_sizes(p.width, p.height)
+    r = compare(engine, s, p)
+    img = r["image"].view(np.float16).astype(np.float32)
+    assert (img[:, :, :3] != 0).any(axis=2).mean() > 0.5  # most of the target is painted
+
+
+def test_c4_nested_full_size(engine):
+    """The nested variant at configs[3]'s size: 30 k paths, 9000 clip layers, 2048x2048, against the oracle (16 threads)."""
+    from oracle import oracle_engine
+    s, p = scenes.scene_c4_nested(30_000, 2048)
+    p.bump = s.bump_sizes(p.width, p.height)
+    oracle_engine.lib().oracle_set_threads(16)
+    try:
+        r = compare(engine, s, p)
+    finally:
+        oracle_engine.lib().oracle_set_threads(1)
+    assert r["bump"]["failed"] == 0
+
+
 def test_c4_full_size(engine):
     """BASELINE.json configs[3] at its stated size: 30 k paths, 9000 clip layers (all 16 mix modes), radial gradients,
     2048x2048 -- sized by the estimator, every buffer and the image bit-exact against the oracle (16 host threads)."""

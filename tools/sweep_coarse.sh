@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 # performance-only macros (results do not change); the product library is rebuilt with the default flags on ANY exit
 trap 'make -s -C jello_amd/csrc > /dev/null 2>&1' EXIT
-CFGS=("4096 2 4" "1536 4 4" "1536 4 16" "1536 8 16" "768 8 16")
+CFGS=("1536 2 16" "1536 4 16" "768 6 16" "512 8 16")
 for cfg in "${CFGS[@]}"; do
   set -- $cfg
   make -s -C jello_amd/csrc EXTRA="-DCOARSE_TILE_CACHE=${1}u -DCOARSE_WG_PER_CU=${2}u -DCOARSE_MAX_SPLIT=${3}u" > /dev/null 2>&1

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Everything profiles/ holds for one state of the code (run on the GPU box): kernel statistics and bench lines of C3,
+# C4 and the nested C4 variant, the fine counter summaries, PTCL statistics, the other-scene timings.
+#   tools/collect_profiles.sh <commit-id>   ->  gpurun_out/collect/
+R="$(cd "$(dirname "$0")/.." && pwd)"
+COMMIT=${1:-unknown}
+O=$R/gpurun_out/collect
+rm -rf "$O"; mkdir -p "$O"
+cd "$R"
+for S in c3 c4 c4n; do
+  bash tools/kprof.sh col_$S --scene $S > "$O/${S}_summary.txt" 2>&1 || exit 1
+  cp gpurun_out/kprof_col_$S/kernel_stats.csv "$O/${S}_kernel_stats.csv"
+  timeout -k 10 300 python3 bench.py --scene $S > "$O/${S}_bench.json" 2> "$O/${S}_bench.err" || exit 1
+  echo "bench $S done"
+done
+timeout -k 10 300 python3 bench.py --aa msaa8 --no-cpu-baseline > "$O/c3_msaa8_bench.json" 2>/dev/null
+timeout -k 10 300 python3 bench.py --aa msaa16 --no-cpu-baseline > "$O/c3_msaa16_bench.json" 2>/dev/null
+bash tools/pmc_fine.sh "$COMMIT" > "$O/pmc_c3.log" 2>&1 && echo "pmc c3 done"
+bash tools/pmc_fine.sh "$COMMIT" --scene c4 > "$O/pmc_c4.log" 2>&1 && echo "pmc c4 done"
+cp gpurun_out/fine_counters*.json "$O/" 2>/dev/null
+for S in c3 c4 c4n; do timeout -k 10 300 python3 tools/ptcl_stats.py $S > "$O/ptcl_stats_$S.json" 2>/dev/null; done
+echo "ptcl stats done"
+( timeout -k 10 300 python3 tools/time_configs.py; timeout -k 10 300 python3 tools/time_shapes.py ) > "$O/other_scenes.txt" 2>&1
+echo "other scenes done"

@@ -365,7 +365,7 @@ def cpu_baseline(host, args):
         scene, params = scenes.scene_c4_nested(n, size)
     import jello_amd
     params.aa = {"area": jello_amd.Aa.Area, "msaa8": jello_amd.Aa.Msaa8, "msaa16": jello_amd.Aa.Msaa16}[args.aa]
-    params.bump = BumpSizes(lines=1 << 23, seg_counts=1 << 24, segments=1 << 24, tiles=1 << 23, ptcl=1 << 27, bin_data=1 << 22, blend_spill=1 << 22)
+    params.bump = scene.bump_sizes(size, size)  # the estimator's sizes, as in the timed path
     rec = host.record(scene, params)
     # a one-GPU box shares its host: 16 cores are this job's share (more threads than that measured slower)
     threads = max(1, min(16, len(os.sched_getaffinity(0))))

@@ -72,6 +72,42 @@ def check_bbox_extent_rule(get, cfg):
     assert [[int(v) for v in row] for row in boxes] == want
 
 
+def rect_on_tile_boundaries():
+    s = Scene()
+    s.fill(Fill.NonZero, None, Brush.solid(RGBA), None, Path.rect(16, 16, 48, 48))
+    return s, RenderParams(64, 64)
+
+
+def check_rect_on_tile_boundaries(get, cfg, bump):
+    """path_count.wgsl:100,126: `<=` where the Go twin has `<`."""
+    k = KAT["rect_on_tile_boundaries"]
+    assert bump["failed"] == 0
+    for name, v in k["bump"].items():
+        assert bump[name] == v, name
+    tiles = get("tileBuf", np.uint32)[:8].reshape(4, 2)
+    assert [[int(a), int(b)] for a, b in tiles] == k["tiles_backdrop_count"]
+    ptcl = get("ptclBuf", np.uint32)
+    for tile, want in k["ptcl"].items():
+        w = words(want)
+        assert list(ptcl[int(tile) * 64:int(tile) * 64 + len(w)]) == w, "tile %s" % tile
+
+
+def radial_kinds():
+    s = Scene()
+    stops = [ColorStop(0.0, (1, 0, 0, 1)), ColorStop(1.0, (0, 0, 1, 1))]
+    for (c0, r0, c1, r1) in [((0, 0), 1.0, (4, 0), 1.000244140625), ((0, 0), 8.0, (16, 0), 0.0), ((0, 0), 0.0, (8, 0), 8.0)]:
+        s.fill(Fill.NonZero, None, Brush.radial(c0, r0, c1, r1, stops), None, Path.rect(0, 0, 64, 64))
+    return s, RenderParams(64, 64)
+
+
+def check_radial_kinds(get, cfg):
+    """draw_leaf.wgsl:164 (`<=`), :182-191 (points and radii swapped)."""
+    info = get("infoBinDataBuf", np.uint32)
+    want = [words(r) for r in KAT["radial_kinds"]["info_words_7_8_9"]]
+    got = [[int(v) for v in info[10 * i + 7:10 * i + 10]] for i in range(3)]
+    assert got == want
+
+
 def words(xs):
     return [int(x, 16) for x in xs]
 

@@ -62,6 +62,23 @@ def test_bbox_extent_rule(engine):
         engine.release(rec)
 
 
+def test_rect_on_tile_boundaries(engine):
+    get, rec, bump = run_gpu(engine, K.rect_on_tile_boundaries())
+    try:
+        K.check_rect_on_tile_boundaries(get, rec.config, bump)
+    finally:
+        engine.release(rec)
+
+
+def test_radial_kinds(engine):
+    get, rec, bump = run_gpu(engine, K.radial_kinds())
+    try:
+        assert bump["failed"] == 0
+        K.check_radial_kinds(get, rec.config)
+    finally:
+        engine.release(rec)
+
+
 def test_bevel_join_between_collinear_segments(engine):
     get, rec, bump = run_gpu(engine, K.bevel_join_collinear())
     try:

@@ -49,6 +49,17 @@ def test_bbox_extent_rule(built):
     K.check_bbox_extent_rule(get, cfg)
 
 
+def test_rect_on_tile_boundaries(built):
+    get, cfg, bump = run_oracle(K.rect_on_tile_boundaries())
+    K.check_rect_on_tile_boundaries(get, cfg, bump)
+
+
+def test_radial_kinds(built):
+    get, cfg, bump = run_oracle(K.radial_kinds())
+    assert bump["failed"] == 0
+    K.check_radial_kinds(get, cfg)
+
+
 def test_gradient_in_clip_encoder_streams(built):
     k = K.KAT["gradient_in_clip_streams"]
     s, p = K.gradient_in_clip()

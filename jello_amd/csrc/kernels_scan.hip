@@ -19,9 +19,14 @@ using namespace jd;
 // Two launches: SCAN_G workgroups each own a contiguous range of ceil(n / SCAN_G) elements (rounded to whole tiles).
 // (Measured on MI355X, round 2: the same two phases in ONE launch with a grid barrier in between -- an arrival counter,
 // relaxed device-scope atomics only, all 512 workgroups resident -- took 26.7 us per scan against 15.2 us for the two
-// launches: 512 arrivals on one word plus the polling cost more than the second launch.  Decoupled look-back has the
-// same problem on this part: every workgroup is resident at once, so the last tile looks back over hundreds of
-// aggregates across eight L2s.)
+// launches: 512 arrivals on one word plus the polling cost more than the second launch.  Decoupled look-back was
+// built and measured too: one launch, every workgroup publishes its range's sum as ONE 64-bit descriptor (epoch << 32 |
+// sum, relaxed device-scope atomics, no fences; the epoch lives in device memory and is advanced by the last workgroup
+// to leave, so there is no reset launch and hipGraph replay works) and sums the descriptors before its own.  Bit-exact
+// on the whole GPU suite, but 21.1 us per scan with the descriptors packed and 19.6 us with one per 128 bytes, against
+// 15.5 us: all 512 workgroups are resident at once and finish their first phase together, so they poll 512 x 512
+// descriptors through the device-coherent path (the eight L2s are not coherent with each other) while they wait --
+// that costs more than the ~4.5 us a second launch does.)
 // Pass 1 reduces the range to one sum; pass 2 first turns the (at most SCAN_G) sums before its own into its carry-in
 // with one block reduction -- cheaper than a third single-workgroup launch in between -- then scans its range.
 #define SCAN_G 512u

@@ -5,12 +5,14 @@
 // MI355X design: the WGSL hands out segment slices, 256-word PTCL chunks and blend-spill space with
 // atomicAdd, so seg_data / JUMP targets / blend_ix differ from run to run.  Here coarse runs twice
 // over the same templated body:
-//   k_coarse<false>  walks every tile's command stream WITHOUT writing it and records, per tile,
-//                    the segments, PTCL chunk words and blend-spill pixels it will need;
-//   3 exclusive scans in (bin, tile-in-bin) order -- the order of the reference's sequential twin
-//                    (shaders/cpu/cpu.go:1096-1270) -- give every tile its bases, totals land in
-//                    bump.{segments,ptcl,blend};
-//   k_coarse<true>   walks again and writes PTCL + ~seg_ix with those bases.
+//   k_coarse<false>  walks every tile's command stream WITHOUT writing it and records, per tile and
+//                    summed per workgroup, the segments, PTCL chunk words and blend-spill pixels it
+//                    will need;
+//   k_coarse<true>   turns them into bases -- exclusive prefixes in (bin, tile-in-bin) order, the
+//                    order of the reference's sequential twin (shaders/cpu/cpu.go:1096-1270): the sums
+//                    of the workgroups before its own plus a prefix inside its own, no scan launch in
+//                    between -- reports the totals in bump.{segments,ptcl,blend}, walks again and
+//                    writes PTCL + ~seg_ix.
 // => bit-identical PTCL on every run.  One 256-thread workgroup per bin, one thread per tile, bin
 // bitmaps (8 x 256 u32) and per-draw tile rectangles staged in 16 KiB of LDS, as in the WGSL.
 // Algorithmic bytes: 4 B per (draw,bin) bin_data + 32 B Path + 8 B Tile per (draw,tile) + PTCL out.
@@ -93,6 +95,9 @@ JD void alloc_cmd(Cmd& c, uint32_t size) {  // coarse.wgsl:70-88
 #ifndef COARSE_TPL
 #define COARSE_TPL 1u
 #endif
+#if COARSE_TPL != 1
+#error "the write pass derives a tile's bases from its thread index: one tile per lane"
+#endif
 struct Walk {
     Cmd c;
     uint32_t blend_offset, clip_zero_depth, clip_depth, render_blend_depth, max_blend_depth;
@@ -110,8 +115,10 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                                                   Buf<JlBinHeader> bin_headers, Buf<uint32_t> info_bin_data, Buf<JlPath> paths, Buf<JlTile> tiles,
                                                   JlBump* __restrict__ bump, Buf<uint32_t> ptcl, uint32_t* __restrict__ cnt_seg,
                                                   uint32_t* __restrict__ cnt_chunk, uint32_t* __restrict__ cnt_blend,
-                                                  const uint32_t* __restrict__ base_seg, const uint32_t* __restrict__ base_chunk,
-                                                  const uint32_t* __restrict__ base_blend, uint32_t bin_row0, uint32_t split) {
+                                                  uint32_t* __restrict__ wg_tot, uint32_t n_wg, uint32_t bin_row0, uint32_t split) {
+    // cnt_*[slot]: what the counting pass found per tile; wg_tot[c * n_wg + wg]: their sums per workgroup, wg = bin * split
+    // + strip -- the canonical (bin, tile) order is workgroup-major, so the write pass gets a tile's bases as (sum over
+    // the workgroups before its own) + (exclusive prefix inside its own): it scans for itself, no scan launches between.
     // bin_row0: first bin row of the launch (band mode writes the PTCL of its band only; the counting pass always
     // covers the whole target, so that every allocation base is the one of the unsharded run)
     // split (1 ... 16): a bin is shared by `split` workgroups (blockIdx.z), each owning 16 / split of its tile rows.
@@ -132,6 +139,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     __shared__ uint4 sh_r1[JL_WG];  // x0 | y0 << 16, width, first (draw, tile) pair of the draw in the batch, info offset
     __shared__ uint4 sh_r2[JL_WG];  // scene[dd .. dd+3]: colour / ramp index / blend+alpha
     __shared__ uint32_t sh_scan[8];
+    __shared__ uint32_t sh_red[12];
     // (backdrop, segment count) of the (draw, tile) pairs of the current window of elements.  The command walk reads Tiles
     // from here ONLY: a global load inside its loop makes every trip wait for the PTCL stores of the trip before
     // (vmcnt counts loads and stores in one order) -- 1 us per trip in the write pass.
@@ -163,6 +171,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
 #pragma unroll
                 for (uint32_t k = 0; k < COARSE_TPL; k++)
                     if (W[k].has_tile) { cnt_seg[W[k].slot] = 0u; cnt_chunk[W[k].slot] = 0u; cnt_blend[W[k].slot] = 0u; }
+                if (lid < 3u) wg_tot[lid * n_wg + bin_ix * split + blockIdx.z] = 0u;
             }
             return;
         }
@@ -171,6 +180,37 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     const uint32_t bin_tile_x = JL_N_TILE_X * blockIdx.x;
     const uint32_t bin_tile_y = JL_N_TILE_Y * bin_y;
     const uint32_t BLEND_CLIP = (128u << 8) | 0u;  // MIX_CLIP << 8 | COMPOSE_SRC_OVER (Jello numbering, blend.wgsl:199-202)
+    uint32_t my_base_seg = 0u, my_base_chunk = 0u, my_base_blend = 0u;
+    if (WRITE) {
+        const uint32_t my_wg = bin_ix * split + blockIdx.z;
+        MonoidK<3> before, all;
+#pragma unroll
+        for (int c = 0; c < 3; c++) { before.v[c] = 0u; all.v[c] = 0u; }
+        const bool totals = blockIdx.x == 0u && blockIdx.y == 0u && blockIdx.z == 0u;  // (uniform) this workgroup also reports the frame's totals
+        for (uint32_t j = lid; j < (totals ? n_wg : my_wg); j += JL_WG) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const uint32_t v = wg_tot[(uint32_t)c * n_wg + j];
+                all.v[c] += v;
+                if (j < my_wg) before.v[c] += v;
+            }
+        }
+        const MonoidK<3> carry = block_reduce_monoid<3>(before, sh_red);
+        __syncthreads();
+        if (totals) {
+            const MonoidK<3> t = block_reduce_monoid<3>(all, sh_red);
+            if (lid == 0u) { bump->segments = t.v[0]; bump->ptcl = t.v[1]; bump->blend = t.v[2]; }
+            __syncthreads();
+        }
+        const bool mine = W[0].has_tile;
+        uint32_t tot;
+        my_base_seg = carry.v[0] + block_excl_scan_u32(mine ? cnt_seg[W[0].slot] : 0u, sh_scan, &tot);
+        __syncthreads();
+        my_base_chunk = carry.v[1] + block_excl_scan_u32(mine ? cnt_chunk[W[0].slot] : 0u, sh_scan, &tot);
+        __syncthreads();
+        my_base_blend = carry.v[2] + block_excl_scan_u32(mine ? cnt_blend[W[0].slot] : 0u, sh_scan, &tot);
+        __syncthreads();
+    }
 #pragma unroll
     for (uint32_t k = 0; k < COARSE_TPL; k++) {
         Walk& w = W[k];
@@ -179,9 +219,9 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         w.c.cmd_offset = this_tile_ix * JL_PTCL_INITIAL_ALLOC;
         w.c.cmd_limit = w.c.cmd_offset + (JL_PTCL_INITIAL_ALLOC - JL_PTCL_HEADROOM);
         w.c.dyn_start = cfg->width_in_tiles * cfg->height_in_tiles * JL_PTCL_INITIAL_ALLOC;
-        w.c.chunk_base = WRITE ? base_chunk[w.slot] : 0u;
+        w.c.chunk_base = my_base_chunk;
         w.c.chunk_words = 0u;
-        w.c.seg_base = WRITE ? base_seg[w.slot] : 0u;
+        w.c.seg_base = my_base_seg;
         w.c.seg_used = 0u;
         w.clip_zero_depth = 0u; w.clip_depth = 0u; w.render_blend_depth = 0u; w.max_blend_depth = 0u;
         w.blend_offset = w.c.cmd_offset;
@@ -510,6 +550,8 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         if (!has_next) break;
         __syncthreads();
     }
+    MonoidK<3> my_tot;
+    my_tot.v[0] = 0u; my_tot.v[1] = 0u; my_tot.v[2] = 0u;
 #pragma unroll
     for (uint32_t k = 0; k < COARSE_TPL; k++) {
         Walk& w = W[k];
@@ -522,7 +564,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                 w.c.ptcl.wr(w.c.cmd_offset, JL_CMD_END);
                 uint32_t blend_ix = 0u;
                 if (scratch_size != 0u) {
-                    blend_ix = base_blend[w.slot];
+                    blend_ix = my_base_blend;
                     if (blend_ix + scratch_size > cfg->blend_size) atomicOr(&bump->failed, (uint32_t)JL_STAGE_COARSE);
                 }
                 w.c.ptcl.wr(w.blend_offset, blend_ix);
@@ -531,8 +573,26 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
             cnt_seg[w.slot] = w.c.seg_used;
             cnt_chunk[w.slot] = w.c.chunk_words;
             cnt_blend[w.slot] = scratch_size;
+            my_tot.v[0] = w.c.seg_used; my_tot.v[1] = w.c.chunk_words; my_tot.v[2] = scratch_size;
         }
     }
+    if (!WRITE) {
+        const MonoidK<3> t = block_reduce_monoid<3>(my_tot, sh_red);
+        if (lid < 3u) wg_tot[lid * n_wg + bin_ix * split + blockIdx.z] = lid == 0u ? t.v[0] : (lid == 1u ? t.v[1] : t.v[2]);
+    }
+}
+
+// The frame's totals when the band of the write pass is empty (otherwise its first workgroup reports them).
+__global__ __launch_bounds__(JL_WG) void k_coarse_totals(const uint32_t* __restrict__ wg_tot, uint32_t n_wg, JlBump* __restrict__ bump) {
+    __shared__ uint32_t sh_red[12];
+    MonoidK<3> all;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        all.v[c] = 0u;
+        for (uint32_t j = threadIdx.x; j < n_wg; j += JL_WG) all.v[c] += wg_tot[(uint32_t)c * n_wg + j];
+    }
+    const MonoidK<3> t = block_reduce_monoid<3>(all, sh_red);
+    if (threadIdx.x == 0u) { bump->segments = t.v[0]; bump->ptcl = t.v[1]; bump->blend = t.v[2]; }
 }
 
 }  // namespace
@@ -542,10 +602,6 @@ int jh_launch_coarse(const JhLaunch& L) {
     if (L.nb < 9) return -1;
     if (L.gx == 0 || L.gy == 0) return 0;
     uint32_t n = L.gx * L.gy * JL_N_TILE;
-    uint32_t* scr = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)n * 4 * 6);
-    if (!scr) return -5;
-    uint32_t *cnt_seg = scr, *cnt_chunk = scr + n, *cnt_blend = scr + 2 * (size_t)n;
-    uint32_t *base_seg = scr + 3 * (size_t)n, *base_chunk = scr + 4 * (size_t)n, *base_blend = scr + 5 * (size_t)n;
     auto cfg = (const JlConfig*)L.b[0].ptr;
     auto scene = mkbuf<uint32_t>(L.b[1].ptr, L.b[1].size);
     auto dm = mkbuf<JlDrawMonoid>(L.b[2].ptr, L.b[2].size);
@@ -559,18 +615,21 @@ int jh_launch_coarse(const JhLaunch& L) {
     const uint32_t want = COARSE_WG_PER_CU * (uint32_t)(L.num_cus > 0 ? L.num_cus : 256);
     uint32_t split = 1u;
     while (split < COARSE_MAX_SPLIT && L.gx * L.gy * split < want) split *= 2u;
+    const uint32_t n_wg = L.gx * L.gy * split;
+    uint32_t* scr = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, ((uint64_t)n + n_wg) * 4 * 3);
+    if (!scr) return -5;
+    uint32_t *cnt_seg = scr, *cnt_chunk = scr + n, *cnt_blend = scr + 2 * (size_t)n, *wg_tot = scr + 3 * (size_t)n;
     dim3 grid(L.gx, L.gy, split), blk(JL_WG);
     const uint32_t row0 = L.band_row0 < L.gy ? L.band_row0 : L.gy, row1 = L.band_row1 < L.gy ? L.band_row1 : L.gy;
     dim3 grid_w(L.gx, row1 > row0 ? row1 - row0 : 0u, split);
     const bool clips = !(L.cfg_host && L.cfg_host->layout.n_clip == 0u);  // host shadow of the uploaded ConfigUniform
-#define JH_COARSE(W, C, G, ...) hipLaunchKernelGGL((k_coarse<W, C>), G, blk, 0, L.stream, cfg, scene, dm, bh, ibd, paths, tiles, bump, ptcl, __VA_ARGS__)
-    if (clips) JH_COARSE(false, true, grid, cnt_seg, cnt_chunk, cnt_blend, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, split);
-    else JH_COARSE(false, false, grid, cnt_seg, cnt_chunk, cnt_blend, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, split);
-    int rc = jh_scan3_u32(L, cnt_seg, base_seg, n, &bump->segments, &bump->ptcl, &bump->blend);
-    if (rc) return rc;
-    if (grid_w.y == 0u) return 0;
-    if (clips) JH_COARSE(true, true, grid_w, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend, row0, split);
-    else JH_COARSE(true, false, grid_w, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend, row0, split);
+#define JH_COARSE(W, C, G, ROW0) hipLaunchKernelGGL((k_coarse<W, C>), G, blk, 0, L.stream, cfg, scene, dm, bh, ibd, paths, tiles, bump, ptcl, cnt_seg, cnt_chunk, cnt_blend, wg_tot, n_wg, ROW0, split)
+    if (clips) JH_COARSE(false, true, grid, 0u); else JH_COARSE(false, false, grid, 0u);
+    if (grid_w.y == 0u) {  // an empty band: nobody to report the totals (otherwise the write pass's first workgroup does)
+        hipLaunchKernelGGL(k_coarse_totals, dim3(1), blk, 0, L.stream, (const uint32_t*)wg_tot, n_wg, bump);
+        return 0;
+    }
+    if (clips) JH_COARSE(true, true, grid_w, row0); else JH_COARSE(true, false, grid_w, row0);
 #undef JH_COARSE
     return 0;
 }

@@ -153,10 +153,17 @@ __global__ __launch_bounds__(JL_WG) void k_tile_alloc_count(const JlConfig* __re
         paths.p[drawobj_ix] = p;
     }
 }
+JD void tile_zero_part(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tiles, uint32_t block, uint32_t blocks);
+// Workgroups [0, write_blocks) write Path.tiles, the rest clear the allocated tiles (two jobs without a dependency on
+// each other in one launch: a launch of their own costs each of them ~4.5 us).
 __global__ __launch_bounds__(JL_WG) void k_tile_alloc_write(const JlConfig* __restrict__ cfg, JlBump* __restrict__ bump, Buf<JlPath> paths,
                                                             Buf<JlTile> tiles, const uint32_t* __restrict__ counts,
-                                                            const uint32_t* __restrict__ offsets, uint32_t n_total) {
+                                                            const uint32_t* __restrict__ offsets, uint32_t n_total, uint32_t write_blocks) {
     if ((bump->failed & (JL_STAGE_BINNING | JL_STAGE_FLATTEN)) != 0u) return;
+    if (blockIdx.x >= write_blocks) {  // uniform
+        tile_zero_part(cfg, bump, tiles, blockIdx.x - write_blocks, gridDim.x - write_blocks);
+        return;
+    }
     uint32_t wg_first = blockIdx.x * JL_WG;
     uint32_t drawobj_ix = wg_first + threadIdx.x;
     uint32_t wg_off = offsets[wg_first];
@@ -173,13 +180,12 @@ __global__ __launch_bounds__(JL_WG) void k_tile_alloc_write(const JlConfig* __re
 // The WGSL zeroes a workgroup's tiles with that workgroup's 256 threads (tile_alloc.wgsl:107-111): two workgroups
 // clearing the 1.7 M tiles of 300 large circles take 0.3 ms.  All allocated tiles form the range [0, bump.tile), so
 // one device-wide pass clears them (in the failure case the contents of the buffer are unspecified anyway).
-__global__ __launch_bounds__(JL_WG) void k_tile_zero(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tiles) {
-    if ((bump->failed & (JL_STAGE_BINNING | JL_STAGE_FLATTEN)) != 0u) return;
+JD void tile_zero_part(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tiles, uint32_t block, uint32_t blocks) {
     const uint32_t n = umin_(umin_(bump->tile, cfg->tiles_size), tiles.n);
     uint4* p = (uint4*)tiles.p;  // two tiles per store
     const uint32_t n2 = n >> 1;
-    for (uint32_t i = blockIdx.x * JL_WG + threadIdx.x; i < n2; i += gridDim.x * JL_WG) p[i] = make_uint4(0u, 0u, 0u, 0u);
-    if ((n & 1u) != 0u && blockIdx.x == 0u && threadIdx.x == 0u) {
+    for (uint32_t i = block * JL_WG + threadIdx.x; i < n2; i += blocks * JL_WG) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    if ((n & 1u) != 0u && block == 0u && threadIdx.x == 0u) {
         JlTile z;
         z.backdrop = 0;
         z.segment_count_or_ix = 0u;
@@ -533,14 +539,34 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
 // every path its own tile range), hence
 //   seg_within_slice(k) = #{ j < k : key[j] == key[k] },   Tile.segment_count = that number + #{ j > k : ... } + 1,
 // the canonical (line, crossing) order by construction, from one ballot per DISTINCT tile of the path.
+struct PcScatterArgs {  // the list route's scatter pass rides in the same launch (its last `blocks` workgroups): it and the
+    const uint2* tile_of;   // ranking of the small paths touch different tiles and crossings, and both follow the
+    const uint32_t* list_base;  // list-base scan; a launch of its own cost 4.7 us even when no path takes the route)
+    uint32_t tiles_cap;
+    uint32_t* list;
+    const uint32_t* kbig;
+    uint32_t* gate;
+    uint32_t* dense;
+    uint32_t dense_cap, blocks;
+};
+JD void pc_scatter_part(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
+                        const uint2* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
+                        uint32_t tiles_cap, uint32_t* __restrict__ list, const uint32_t* __restrict__ kbig,
+                        uint32_t* __restrict__ gate, uint32_t* __restrict__ dense, uint32_t dense_cap, uint32_t block, uint32_t blocks);
 __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
                                                          const uint32_t* __restrict__ keys, uint32_t n_cap, const uint32_t* __restrict__ pfirst,
                                                          const uint32_t* __restrict__ plast, const uint32_t* __restrict__ counts,
                                                          const uint32_t* __restrict__ seg_bases, uint32_t n_paths,
-                                                         Buf<JlSegmentCount> seg_counts) {
+                                                         Buf<JlSegmentCount> seg_counts, PcScatterArgs sc) {
+    const uint32_t rank_blocks = gridDim.x - sc.blocks;  // the scatter workgroups come last: they only look at the gate when it is closed
+    if (blockIdx.x >= rank_blocks) {  // uniform
+        pc_scatter_part(cfg, bump, tile, sc.tile_of, n_cap, sc.list_base, sc.tiles_cap, sc.list, sc.kbig, sc.gate, sc.dense, sc.dense_cap,
+                        blockIdx.x - rank_blocks, sc.blocks);
+        return;
+    }
     const uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
     const uint32_t lane = lane_id();
-    const uint32_t waves = (gridDim.x * JL_WG) >> 6;
+    const uint32_t waves = (rank_blocks * JL_WG) >> 6;
     uint32_t P = (blockIdx.x * JL_WG + threadIdx.x) >> 6;
     uint32_t nps = 0u, npe = 0u;  // range of the path after this one (prefetched: the loop is a chain of dependent loads)
     if (P < n_paths) path_range(P, pfirst, plast, counts, seg_bases, nps, npe);
@@ -590,14 +616,14 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restr
 #define PC_DENSE_LDS 1024u  // entries of a tile's list staged per pass and wave
 // pass 3: scatter crossing indices into per-tile lists; the slot inside a list is the (arbitrary but unique)
 // arrival number the count atomic returned in pass 2, so no further atomics are needed.
-__global__ __launch_bounds__(JL_WG) void k_pc_scatter(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
-                                                      const uint2* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
-                                                      uint32_t tiles_cap, uint32_t* __restrict__ list, const uint32_t* __restrict__ kbig,
-                                                      uint32_t* __restrict__ gate, uint32_t* __restrict__ dense, uint32_t dense_cap) {
+JD void pc_scatter_part(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tile,
+                        const uint2* __restrict__ tile_of, uint32_t n_cap, const uint32_t* __restrict__ list_base,
+                        uint32_t tiles_cap, uint32_t* __restrict__ list, const uint32_t* __restrict__ kbig,
+                        uint32_t* __restrict__ gate, uint32_t* __restrict__ dense, uint32_t dense_cap, uint32_t block, uint32_t blocks) {
     if (*gate == 0u) return;  // no big path in this frame
     uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
     const uint32_t lane = lane_id();
-    for (uint32_t k0 = blockIdx.x * JL_WG + (threadIdx.x & ~63u); k0 < n; k0 += gridDim.x * JL_WG) {  // uniform per wave
+    for (uint32_t k0 = block * JL_WG + (threadIdx.x & ~63u); k0 < n; k0 += blocks * JL_WG) {  // uniform per wave
         const uint32_t k = k0 + lane;
         bool first_of_dense = false;  // the crossing that arrived first in a tile with a long list announces the tile
         uint32_t t = 0u;
@@ -961,9 +987,8 @@ int jh_launch_tile_alloc(const JhLaunch& L) {
     hipLaunchKernelGGL(k_tile_alloc_count, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, scene, db, (const JlBump*)bump, paths, counts);
     int rc = jh_scan_u32(L, counts, 1, offsets, n, nullptr, &bump->tile);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tile_alloc_write, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, bump, paths, tiles, (const uint32_t*)counts,
-                       (const uint32_t*)offsets, n);
-    hipLaunchKernelGGL(k_tile_zero, dim3(stride_grid(L, (uint64_t)tiles.n / 2u + 1u)), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tiles);
+    hipLaunchKernelGGL(k_tile_alloc_write, dim3(L.gx + stride_grid(L, (uint64_t)tiles.n / 2u + 1u)), dim3(JL_WG), 0, L.stream, cfg, bump, paths, tiles,
+                       (const uint32_t*)counts, (const uint32_t*)offsets, n, L.gx);
     return 0;
 }
 
@@ -1023,14 +1048,15 @@ int jh_launch_path_count(const JhLaunch& L) {
     // per-tile list bases = exclusive scan of Tile.segment_count_or_ix, scatter into the lists, rank inside the list.
     rc = jh_scan_u32(L, ((const uint32_t*)tile.p) + 1, 2, list_base, tiles_cap, gate, nullptr);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_pc_scatter, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint2*)tile_of, seg_cap,
-                       (const uint32_t*)list_base, tiles_cap, list, (const uint32_t*)kbig, gate, dense, dense_cap);
+    // the atomics-free ranks of everything else, with the scatter pass of the list route in the same launch
+    PcScatterArgs sc;
+    sc.tile_of = tile_of; sc.list_base = list_base; sc.tiles_cap = tiles_cap; sc.list = list; sc.kbig = kbig; sc.gate = gate; sc.dense = dense;
+    sc.dense_cap = dense_cap; sc.blocks = gs;
+    hipLaunchKernelGGL(k_pc_rank_small, dim3(gs + stride_grid(L, (uint64_t)n_paths * 64u)), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile,
+                       (const uint32_t*)keys, seg_cap, cpf, cpl, cc, cb, n_paths, segc, sc);
     hipLaunchKernelGGL(k_pc_rank, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint2*)tile_of, seg_cap,
                        (const uint32_t*)list_base, tiles_cap, (const uint32_t*)list, segc, (const uint32_t*)kbig, (const uint32_t*)gate,
                        (const uint32_t*)dense, dense_cap);
-    // everything else: atomics-free ranks
-    hipLaunchKernelGGL(k_pc_rank_small, dim3(stride_grid(L, (uint64_t)n_paths * 64u)), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile,
-                       (const uint32_t*)keys, seg_cap, cpf, cpl, cc, cb, n_paths, segc);
     return 0;
 }
 

@@ -25,6 +25,7 @@ struct JhScratch {
     void* base[JH_SCR_COUNT];  // what hipMalloc returned (ptr may be offset into it)
     uint64_t cap[JH_SCR_COUNT];
     std::vector<void*> retired;  // old allocations kept until the next sync (kernels may still use them)
+    uint32_t clean_flags;        // JH_CLEAN_*: see kcommon.h
     jh_ctx* ctx;
 };
 
@@ -147,11 +148,14 @@ void* jh_scratch_get(JhScratch* s, int slot, uint64_t bytes) {
         s->ctx->generation++;  // a captured graph may hold the old pointer
     }
     s->base[slot] = p;
+    s->clean_flags = 0u;  // (new memory holds anything)
     p = (char*)p + (uint64_t)slot * JH_SCR_SKEW;
     s->ptr[slot] = p;
     s->cap[slot] = cap;
     return p;
 }
+
+uint32_t* jh_scratch_flags(JhScratch* s) { return &s->clean_flags; }
 
 static void scratch_release_retired(JhScratch* s) {
     for (void* p : s->retired) (void)hipFree(p);
@@ -234,6 +238,7 @@ int jh_create(jh_ctx** out, int device) {
     std::memset(&ctx->scratch.ptr, 0, sizeof ctx->scratch.ptr);
     std::memset(&ctx->scratch.cap, 0, sizeof ctx->scratch.cap);
     std::memset(&ctx->scratch.base, 0, sizeof ctx->scratch.base);
+    ctx->scratch.clean_flags = 0u;
     ctx->scratch.ctx = ctx;
     *out = ctx;
     return JH_OK;

@@ -1357,7 +1357,9 @@ JD void fb_merge(Buf<JlPathBbox> path_bboxes, uint32_t path_ix, int32_t x0, int3
 #endif
 __global__ __launch_bounds__(JL_WG) void k_flatten_bbox(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump,
                                                         const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines,
-                                                        Buf<JlPathBbox> path_bboxes) {
+                                                        Buf<JlPathBbox> path_bboxes, uint32_t* __restrict__ zero, uint32_t zero_n) {
+    // (the stage's counters, which no kernel needs any more, go back to zero for the next frame: kcommon.h, JH_CLEAN_*)
+    for (uint32_t i = blockIdx.x * JL_WG + threadIdx.x; i < zero_n; i += gridDim.x * JL_WG) zero[i] = 0u;
     const uint32_t n_tags = n_slots / 3u;
     const uint32_t total = umin_(umin_(bump->lines, cfg->lines_size), lines.n);
     const uint32_t lane = lane_id();
@@ -1490,10 +1492,12 @@ int jh_launch_flatten(const JhLaunch& L) {
     uint32_t* tinfo = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_H, (uint64_t)tcap * 4);
     uint4* pieces = (uint4*)jh_scratch_get(L.scratch, JH_SCR_I, (uint64_t)tcap * 64);
     uint4* ends = (uint4*)jh_scratch_get(L.scratch, JH_SCR_F, (uint64_t)tcap * 16);
-    uint32_t* counters = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, FL_CTR_WORDS * 4 + (uint64_t)g * 4);
+    uint32_t* counters = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_FL_CTR, FL_CTR_WORDS * 4 + 2048u * 4);  // (g <= 2048)
     if (!counts || !bases || !list || !counters || !tlines || !tkeys || !tinfo || !pieces || !ends) return -5;
     uint32_t* chunk_used = counters + FL_CTR_WORDS;  // one word per workgroup chunk (g <= 2048 workgroups)
-    (void)hipMemsetAsync(counters, 0, FL_CTR_WORDS * 4 + (size_t)g * 4, L.stream);
+    uint32_t* clean = jh_scratch_flags(L.scratch);
+    if ((*clean & JH_CLEAN_FL_CTR) == 0u) (void)hipMemsetAsync(counters, 0, FL_CTR_WORDS * 4 + (size_t)g * 4, L.stream);
+    *clean &= ~(uint32_t)JH_CLEAN_FL_CTR;
     hipLaunchKernelGGL(k_flatten_classify, dim3((L.gx + FL_CLASSIFY_TAGS - 1) / FL_CLASSIFY_TAGS), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list,
                        counters, n_slots, n_tags, g * FL_CHUNK, counts);
     hipLaunchKernelGGL(k_flatten_items, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, (const uint32_t*)list, counters, n_slots, counts,
@@ -1513,6 +1517,8 @@ int jh_launch_flatten(const JhLaunch& L) {
     // per SIMD: the kernel lengthens the ranges to match
     uint64_t gb64 = ((uint64_t)lines.n + 255u) / 256u;  // four waves per workgroup
     uint32_t gb = gb64 > 4ull * gp_cap ? 4u * gp_cap : (uint32_t)(gb64 < 1u ? 1u : gb64);
-    hipLaunchKernelGGL(k_flatten_bbox, dim3(gb), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, (const uint32_t*)bases, n_slots, lines, pb);
+    hipLaunchKernelGGL(k_flatten_bbox, dim3(gb), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, (const uint32_t*)bases, n_slots, lines, pb,
+                       counters, FL_CTR_WORDS + g);
+    *clean |= JH_CLEAN_FL_CTR;
     return 0;
 }

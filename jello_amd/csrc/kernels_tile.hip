@@ -325,10 +325,13 @@ JD LineSetup line_setup(const JlLineSoup& line, const Buf<JlPath>& paths) {
 // pass 1: crossings per line
 __global__ __launch_bounds__(JL_WG) void k_pc_count(const JlBump* __restrict__ bump, const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines,
                                                     Buf<JlPath> paths, uint32_t* __restrict__ counts, uint32_t counts_n,
-                                                    uint32_t* __restrict__ zero, uint32_t zero_n, uint32_t* __restrict__ line_path) {
+                                                    uint32_t* __restrict__ zero, uint32_t zero_n, uint32_t* __restrict__ line_path,
+                                                    unsigned long long* __restrict__ bd_ctr) {
     // (the path ranges, the gate and the dense-tile counter of the later passes start from zero: cleared here, this
-    // kernel does not use them, instead of by a separate fill launch)
+    // kernel does not use them, instead of by a separate fill launch; likewise the wide-row counter of the backdrop
+    // stage that follows: kcommon.h, JH_CLEAN_*)
     for (uint32_t i = blockIdx.x * JL_WG + threadIdx.x; i < zero_n; i += gridDim.x * JL_WG) zero[i] = 0u;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) *bd_ctr = 0ull;
     uint32_t n_lines = umin_(bump->lines, counts_n);
     uint32_t n_threads = umin_(ind->x * JL_WG, counts_n);
     for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
@@ -1034,8 +1037,11 @@ int jh_launch_path_count(const JhLaunch& L) {
     if (!counts || !bases || !tile_of || !list || !list_base || !keys || !kbig || !prange) return -5;
     uint32_t *pfirst = prange, *plast = prange + n_paths, *gate = prange + 2 * (size_t)n_paths;
     uint32_t gl = stride_grid(L, lines_cap), gs = stride_grid(L, seg_cap);
+    unsigned long long* bd_ctr = (unsigned long long*)jh_scratch_get(L.scratch, JH_SCR_BD_CTR, 64);
+    if (!bd_ctr) return -5;
     hipLaunchKernelGGL(k_pc_count, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, paths, counts, lines_cap, prange,
-                       n_paths * 2u + 64u, line_path);
+                       n_paths * 2u + 64u, line_path, bd_ctr);
+    *jh_scratch_flags(L.scratch) |= JH_CLEAN_BD_CTR;
     int rc = jh_scan_u32(L, counts, 1, bases, lines_cap, &bump->lines, &bump->seg_counts);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pc_paths, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, (const uint32_t*)line_path, (const uint32_t*)counts,
@@ -1069,10 +1075,12 @@ int jh_launch_backdrop_dyn(const JhLaunch& L) {
     const uint32_t wide_cap = paths.n;
     // [counter (entries << 40 | rows) | list of (first global row, first tile, width, rows)]
     uint8_t* w = (uint8_t*)jh_scratch_get(L.scratch, JH_SCR_A, 64 + (uint64_t)wide_cap * sizeof(uint4));
-    if (!w) return -5;
-    unsigned long long* wide_ctr = (unsigned long long*)w;
+    unsigned long long* wide_ctr = (unsigned long long*)jh_scratch_get(L.scratch, JH_SCR_BD_CTR, 64);
+    if (!w || !wide_ctr) return -5;
     uint4* wide_list = (uint4*)(w + 64);
-    (void)hipMemsetAsync(wide_ctr, 0, 8, L.stream);
+    uint32_t* clean = jh_scratch_flags(L.scratch);
+    if ((*clean & JH_CLEAN_BD_CTR) == 0u) (void)hipMemsetAsync(wide_ctr, 0, 8, L.stream);  // (path_count did not run in front)
+    *clean &= ~(uint32_t)JH_CLEAN_BD_CTR;
     // one thread per row is the better deal only when there are enough paths to fill the device with such threads
     const uint32_t wide_min = L.gx < 64u ? 2u : BD_WIDE;
     hipLaunchKernelGGL(k_backdrop_dyn, dim3(L.gx), dim3(JL_WG), 0, L.stream, (const JlConfig*)L.b[0].ptr, (const JlBump*)L.b[1].ptr, paths, tiles,

@@ -126,6 +126,40 @@ def test_stale_graph_is_refused(engine):
     engine.graph_destroy(g)
 
 
+def test_graph_replays_and_eager_frames_interleave(engine):
+    """A captured frame contains no fill launches for the counters its kernels clean themselves (flatten's list counters,
+    backdrop's wide-row counter): replays, and eager frames of another scene in between, must leave them clean."""
+    def frame(rec):
+        t = rec.target
+        return (engine.download_image(t["id"], t["width"], t["height"]).copy(),
+                engine.download(rec.buffer("bumpBuf")[0], dtype=np.uint32)[:8].copy())
+    host = jello_amd.Host()
+    sa, pa = scenes.scene_large_shapes()        # wide rows: the backdrop list route
+    sb, pb = scenes.scene_c3(3000, 512)
+    pb.bump = BumpSizes(ptcl=1 << 22)
+    ra, rb = host.record(sa, pa), host.record(sb, pb)
+    engine.run(ra, RUN_UPLOADS | RUN_DISPATCHES)
+    engine.sync()
+    img_a, bump_a = frame(ra)
+    assert bump_a[0] == 0
+    g = engine.capture(ra)
+    engine.run(rb, RUN_UPLOADS | RUN_DISPATCHES)
+    engine.sync()
+    img_b, bump_b = frame(rb)
+    for _ in range(3):
+        engine.replay(g)
+        engine.sync()
+        i, b = frame(ra)
+        assert np.array_equal(i, img_a) and np.array_equal(b, bump_a)
+        engine.run(rb, RUN_DISPATCHES)
+        engine.sync()
+        i, b = frame(rb)
+        assert np.array_equal(i, img_b) and np.array_equal(b, bump_b)
+    engine.graph_destroy(g)
+    engine.release(ra)
+    engine.release(rb)
+
+
 def test_too_small_buffers_are_refused_not_read(engine):
     hip, ctx = engine.hip, engine.ctx
     hip.jh_dispatch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(Binding), ctypes.c_int]

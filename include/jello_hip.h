@@ -158,10 +158,11 @@ int jh_dispatch_indirect(jh_ctx* ctx, int stage, uint64_t indirect_buffer_id, ui
  * profiling must not be issued while capturing, and every buffer and scratch array must already exist
  * (run the recording once eagerly first).  A graph bakes in device pointers and the kernel instantiations chosen at
  * capture time: it stays valid only until a buffer or image it uses is freed, regrown or re-imported, or an eager run
- * makes a scratch array grow.  Two internal counters (flatten's work lists, backdrop's wide-row list) are zeroed by
- * kernels of the frame itself instead of by fill launches, so a captured frame contains no fill for them: it assumes,
- * like every frame, that the frame before it ran to its end (a stage that fails half-way makes the next EAGER stage
- * fill again; a graph replayed right after such a failure would not).  jh_graph_launch detects this (a generation counter) and returns JH_ERR_INVALID. */
+ * makes a scratch array grow.  jh_graph_launch detects this (a generation counter) and returns JH_ERR_INVALID.
+ * Two internal counters (flatten's work lists, backdrop's wide-row list) are zeroed by kernels of the frame itself
+ * instead of by fill launches, so a captured frame contains no fill for them: it assumes, like every frame, that the
+ * frame before it ran to its end (a stage that fails half-way makes the next EAGER stage fill again; a graph replayed
+ * right after such a failure would not -- run one eager frame first). */
 int jh_graph_begin(jh_ctx* ctx);
 int jh_graph_end(jh_ctx* ctx, void** graph_exec);
 int jh_graph_launch(jh_ctx* ctx, void* graph_exec);

@@ -849,9 +849,16 @@ JD void run_item(const JlConfig* cfg, const Scene& s, Out<EMIT>& o, uint32_t slo
 // overflows, or a tree goes deeper than FLQ_MAX_LEVEL (dt < 2^-9; none of the test scenes goes below 2^-6), the
 // unfinished jobs of the batch fall back to the sequential walk.
 // ------------------------------------------------------------------------------------------------
+// (capacities, overridable only so that tools/soak_flatten_fallback.sh can force the fall-back: results do not depend on them)
+#ifndef FLQ_STACK
 #define FLQ_STACK 448u
+#endif
+#ifndef FLQ_LEAVES
 #define FLQ_LEAVES 640u
+#endif
+#ifndef FLQ_MAX_LEVEL
 #define FLQ_MAX_LEVEL 9u  // deeper trees (t0 no longer fits the 9 key bits) take the sequential walk
+#endif
 struct FlBatch {
     uint32_t jhead[64];                // newest piece of the job + 1 (0 = none), lane = job
     uint32_t jpend[64];                // nodes of the job that are still unresolved

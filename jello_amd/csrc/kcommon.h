@@ -242,8 +242,6 @@ uint32_t* jh_scratch_flags(JhScratch* s);
 int jh_scan_u32(const JhLaunch& L, const uint32_t* in, uint32_t in_stride, uint32_t* out, uint32_t n_max, const uint32_t* n_dev,
                 uint32_t* total_dev);
 
-// Three scans at once: in/out hold 3 arrays of n back to back.
-int jh_scan3_u32(const JhLaunch& L, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total0, uint32_t* total1, uint32_t* total2);
 
 int jh_launch_pathtag(const JhLaunch& L, int stage);
 int jh_launch_bbox_clear(const JhLaunch& L);

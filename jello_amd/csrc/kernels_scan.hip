@@ -107,80 +107,6 @@ int jh_scan_u32(const JhLaunch& L, const uint32_t* in, uint32_t in_stride, uint3
     return 0;
 }
 
-// Three independent exclusive scans over arrays laid out back to back (in[c*n + i]) in one pair of launches:
-// blockIdx.y selects the channel.  Used by coarse (segments / PTCL words / blend pixels per tile).
-__global__ __launch_bounds__(JL_WG) void k_scan3_block_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ block_sums) {
-    __shared__ uint32_t sh[8];
-    const uint32_t* src = in + (size_t)blockIdx.y * n;
-    const uint32_t len = scan_range_len(n);
-    const uint32_t lo = blockIdx.x * len, hi = umin_(lo + len, n);
-    uint32_t s = 0;
-    for (uint32_t base = lo + threadIdx.x * SCAN_ITEMS; base < hi; base += SCAN_TILE) {
-#pragma unroll
-        for (int i = 0; i < SCAN_ITEMS; i++) {
-            uint32_t ix = base + i;
-            if (ix < hi) s += src[ix];
-        }
-    }
-    MonoidK<1> m;
-    m.v[0] = s;
-    MonoidK<1> t = block_reduce_monoid<1>(m, sh);
-    if (threadIdx.x == 0) block_sums[blockIdx.y * SCAN_G + blockIdx.x] = t.v[0];
-}
-__global__ __launch_bounds__(JL_WG) void k_scan3_apply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n,
-                                                       const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ t0, uint32_t* __restrict__ t1,
-                                                       uint32_t* __restrict__ t2) {
-    __shared__ uint32_t sh[8];
-    const uint32_t* src = in + (size_t)blockIdx.y * n;
-    uint32_t* dst = out + (size_t)blockIdx.y * n;
-    const uint32_t* bs = block_sums + (size_t)blockIdx.y * SCAN_G;
-    uint32_t* total_dev = blockIdx.y == 0 ? t0 : (blockIdx.y == 1 ? t1 : t2);
-    const uint32_t len = scan_range_len(n);
-    const uint32_t lo = blockIdx.x * len, hi = umin_(lo + len, n);
-    MonoidK<1> m;
-    {
-        const uint32_t a = threadIdx.x, b2 = threadIdx.x + JL_WG;
-        uint32_t va = bs[a], vb = bs[b2];
-        m.v[0] = (a < blockIdx.x ? va : 0u) + (b2 < blockIdx.x ? vb : 0u);
-        if (blockIdx.x == SCAN_G - 1u && total_dev) {
-            MonoidK<1> all;
-            all.v[0] = va + vb;
-            MonoidK<1> t = block_reduce_monoid<1>(all, sh);
-            if (threadIdx.x == 0) *total_dev = t.v[0];
-            __syncthreads();
-        }
-    }
-    uint32_t carry = block_reduce_monoid<1>(m, sh).v[0];
-    for (uint32_t base0 = lo; base0 < hi; base0 += SCAN_TILE) {
-        const uint32_t base = base0 + threadIdx.x * SCAN_ITEMS;
-        uint32_t v[SCAN_ITEMS];
-        uint32_t s = 0;
-#pragma unroll
-        for (int i = 0; i < SCAN_ITEMS; i++) {
-            uint32_t ix = base + i;
-            v[i] = ix < hi ? src[ix] : 0u;
-            s += v[i];
-        }
-        uint32_t tot;
-        uint32_t excl = block_excl_scan_u32(s, sh, &tot) + carry;
-#pragma unroll
-        for (int i = 0; i < SCAN_ITEMS; i++) {
-            uint32_t ix = base + i;
-            if (ix < hi) dst[ix] = excl;
-            excl += v[i];
-        }
-        carry += tot;
-        __syncthreads();
-    }
-}
-int jh_scan3_u32(const JhLaunch& L, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total0, uint32_t* total1, uint32_t* total2) {
-    uint32_t* block_sums = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_SCAN_TMP, (uint64_t)SCAN_G * 12);
-    if (!block_sums) return -5;
-    hipLaunchKernelGGL(k_scan3_block_sums, dim3(SCAN_G, 3), dim3(JL_WG), 0, L.stream, in, n, block_sums);
-    hipLaunchKernelGGL(k_scan3_apply, dim3(SCAN_G, 3), dim3(JL_WG), 0, L.stream, in, out, n, (const uint32_t*)block_sums, total0, total1, total2);
-    return 0;
-}
-
 // ------------------------------------------------------------------------------------------------
 // pathtag (K1-K4)
 // ------------------------------------------------------------------------------------------------

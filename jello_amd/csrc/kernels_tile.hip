@@ -14,7 +14,7 @@
 //   path_count  per-line crossing counts -> scan -> SegmentCount slots; per-tile counts by
 //               no-return atomics (a sum, order-free); the per-tile arrival rank
 //               `seg_within_slice` is computed afterwards as the rank of the crossing's global
-//               index inside its tile's list (k_pc_scatter/k_pc_rank); the value the count atomic
+//               index inside its tile's list (pc_scatter_part in k_pc_rank_small's launch / k_pc_rank); the value the count atomic
 //               happened to return is only used as a unique slot inside that temporary list.
 // The WGSL indirect dispatches become grid-stride loops bounded by the IndirectCount the setup
 // kernels write, so no host readback is needed.  All of this is HBM/atomic-bound integer work.
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
             P = lines.p[gid].path_ix;
             s = line_setup(lines.p[gid], paths);
         }
-        // big path (or a path index outside the table): arrival slots by atomics, as k_pc_scatter / k_pc_rank expect
+        // big path (or a path index outside the table): arrival slots by atomics, as the scatter pass / k_pc_rank expect
         bool big = true;
         uint32_t seg_base = 0u;
         if (s.valid) {

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     const uint32_t lid = threadIdx.x;
     const uint32_t width_in_bins = (cfg->width_in_tiles + JL_N_TILE_X - 1u) / JL_N_TILE_X;
     const uint32_t bin_ix = width_in_bins * bin_y + blockIdx.x;
+    if (bin_ix * split + blockIdx.z >= n_wg) return;  // (uniform) a ConfigUniform that contradicts the dispatch: nothing to index the scratch with
     // the first part_tiles / COARSE_TPL threads walk COARSE_TPL tiles each: tiles t = lid + k * walkers of the workgroup's part
     const uint32_t part_tiles = part_rows * JL_N_TILE_X, walkers = part_tiles / COARSE_TPL;
     Walk W[COARSE_TPL];

@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 # performance-only macros (results do not change); the product library is rebuilt with the default flags on ANY exit
 trap 'make -s -C jello_amd/csrc > /dev/null 2>&1' EXIT
-FL_CFGS=("24 3 3" "24 4 4" "32 4 4" "24 4 5" "24 5 5")
+FL_CFGS=("24 3 5" "24 3 4" "24 3 6" "24 3 8" "24 4 5" "24 2 5")
 for cfg in "${FL_CFGS[@]}"; do
   set -- $cfg
   make -s -C jello_amd/csrc EXTRA="-DFL_REFILL_LANES=${1}u -DFL_WAVES_PER_EU=$2 -DFL_BLOCKS_PER_CU=$3" > /dev/null 2>&1

@@ -160,6 +160,40 @@ def test_graph_replays_and_eager_frames_interleave(engine):
     engine.release(rb)
 
 
+def test_two_graphs_for_two_output_buffers(engine):
+    """bench.py's N > 1 path renders into two caller-owned images in turn (the RCCL gather of frame i reads one while
+    frame i + 1 is rendered into the other): one captured graph per output, replayed alternately.  Re-importing the
+    target under another pointer must not invalidate the graph captured for the first one."""
+    hip, ctx = engine.hip, engine.ctx
+    s, p = scenes.scene_c3(2000, 256)
+    rec = jello_amd.Host().record(s, p)
+    t = rec.target
+    nbytes = t["width"] * t["height"] * 8
+    ids = (0x6601, 0x6602)
+    ptrs = []
+    for i in ids:
+        assert hip.jh_buffer_create(ctx, i, nbytes) == 0
+        ptrs.append(hip.jh_buffer_device_ptr(ctx, i))
+        assert ptrs[-1]
+    engine.run(rec, RUN_UPLOADS | RUN_DISPATCHES, ptrs[0])
+    engine.sync()
+    want = engine.download(ids[0], nbytes).copy()
+    assert want.any()
+    graphs = [engine.capture(rec, q) for q in ptrs]
+    for i in ids:
+        engine.clear(i)
+    for k in range(6):
+        engine.replay(graphs[k & 1])
+    engine.sync()
+    for i in ids:
+        assert np.array_equal(engine.download(i, nbytes), want)
+    for g in graphs:
+        engine.graph_destroy(g)
+    engine.release(rec)
+    for i in ids:
+        assert hip.jh_free(ctx, i) == 0
+
+
 def test_too_small_buffers_are_refused_not_read(engine):
     hip, ctx = engine.hip, engine.ctx
     hip.jh_dispatch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(Binding), ctypes.c_int]

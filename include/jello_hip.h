@@ -152,7 +152,7 @@ int jh_dispatch(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uint32_t gz, c
 int jh_dispatch_indirect(jh_ctx* ctx, int stage, uint64_t indirect_buffer_id, uint64_t offset, const jh_binding* bindings,
                          int n_bindings);
 
-/* ---- hipGraph capture of a replayed recording (a frame is ~40 short launches: launch-bound on the host) ----
+/* ---- hipGraph capture of a replayed recording (a frame is ~35 short launches: launch-bound on the host) ----
  * jh_graph_begin starts capturing everything enqueued on the context's stream (dispatches, clears);
  * jh_graph_end returns an executable graph; jh_graph_launch replays it.  Uploads/downloads/frees and
  * profiling must not be issued while capturing, and every buffer and scratch array must already exist

@@ -38,16 +38,19 @@ JD void bbox_intersect(const float* a, const float* b, float* o) {  // shared/bb
 template <int PASS>
 __global__ __launch_bounds__(JL_WG) void k_binning(const JlConfig* __restrict__ cfg, Buf<JlDrawMonoid> draw_monoids, Buf<JlPathBbox> path_bbox_buf,
                                                    Buf<Bb4> clip_bbox_buf, Buf<Bb4> intersected_bbox, JlBump* __restrict__ bump,
-                                                   Buf<uint32_t> bin_data, Buf<JlBinHeader> bin_header, uint32_t* __restrict__ counts,
-                                                   const uint32_t* __restrict__ offsets) {
+                                                   Buf<uint32_t> bin_data, Buf<JlBinHeader> bin_header, uint32_t* __restrict__ wg_tot) {
+    // PASS 0 leaves the workgroup's total element count in wg_tot[workgroup]; PASS 1 derives its chunk offsets from the
+    // totals of the workgroups before it and a prefix over its own bins (the canonical order is workgroup-major, then
+    // bin), so no scan launch sits between the two passes.
     __shared__ uint32_t sh_bitmaps[8][JL_N_TILE];
+    __shared__ uint32_t sh[8];
     const float SX = 0.00390625f, SY = 0.00390625f;
     uint32_t lid = threadIdx.x;
     uint32_t gid = blockIdx.x * JL_WG + lid;
     for (uint32_t i = 0; i < 8u; i++) sh_bitmaps[i][lid] = 0u;
     if (bump->lines > cfg->lines_size) {  // binning.wgsl:67-78 (uniform: read of a value written by an earlier stage)
         if (PASS == 1 && gid == 0u) atomicOr(&bump->failed, (uint32_t)JL_STAGE_FLATTEN);
-        if (PASS == 0) counts[gid] = 0u;
+        if (PASS == 0 && lid == 0u) wg_tot[blockIdx.x] = 0u;
         return;
     }
     __syncthreads();
@@ -92,10 +95,24 @@ __global__ __launch_bounds__(JL_WG) void k_binning(const JlConfig* __restrict__ 
     uint32_t element_count = 0u;
     for (uint32_t i = 0; i < 8u; i++) element_count += __popc(sh_bitmaps[i][lid]);
     if (PASS == 0) {
-        counts[gid] = element_count;
+        MonoidK<1> m;
+        m.v[0] = element_count;
+        const uint32_t tot = block_reduce_monoid<1>(m, sh).v[0];
+        if (lid == 0u) wg_tot[blockIdx.x] = tot;
         return;
     }
-    uint32_t chunk_offset = offsets[gid];
+    MonoidK<2> part;  // elements of the workgroups before mine / of all workgroups (bump.binning)
+    part.v[0] = 0u; part.v[1] = 0u;
+    for (uint32_t j = lid; j < gridDim.x; j += JL_WG) {
+        const uint32_t v = wg_tot[j];
+        part.v[1] += v;
+        if (j < blockIdx.x) part.v[0] += v;
+    }
+    const MonoidK<2> sums = block_reduce_monoid<2>(part, sh);
+    __syncthreads();
+    if (gid == 0u) bump->binning = sums.v[1];
+    uint32_t wg_elements;
+    uint32_t chunk_offset = sums.v[0] + block_excl_scan_u32(element_count, sh, &wg_elements);
     if (chunk_offset + element_count > cfg->binning_size) {
         chunk_offset = 0u;
         atomicOr(&bump->failed, (uint32_t)JL_STAGE_BINNING);
@@ -122,10 +139,13 @@ __global__ __launch_bounds__(JL_WG) void k_binning(const JlConfig* __restrict__ 
 // tile_alloc.  PASS 0: bbox + tile counts.  PASS 1: offsets known -> Path.tiles, zero the tiles.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(JL_WG) void k_tile_alloc_count(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<Bb4> draw_bboxes,
-                                                            const JlBump* __restrict__ bump, Buf<JlPath> paths, uint32_t* __restrict__ counts) {
+                                                            const JlBump* __restrict__ bump, Buf<JlPath> paths, uint32_t* __restrict__ counts,
+                                                            uint32_t* __restrict__ wg_tot) {
+    __shared__ uint32_t sh[8];
     uint32_t drawobj_ix = blockIdx.x * JL_WG + threadIdx.x;
     if ((bump->failed & (JL_STAGE_BINNING | JL_STAGE_FLATTEN)) != 0u) {  // tile_alloc.wgsl:43-50
         counts[drawobj_ix] = 0u;
+        if (threadIdx.x == 0u) wg_tot[blockIdx.x] = 0u;
         return;
     }
     const float SX = 1.0f / 16.0f, SY = 1.0f / 16.0f;
@@ -145,31 +165,50 @@ __global__ __launch_bounds__(JL_WG) void k_tile_alloc_count(const JlConfig* __re
     uint32_t uy0 = (uint32_t)iclamp_(y0, 0, (int32_t)cfg->height_in_tiles);
     uint32_t ux1 = (uint32_t)iclamp_(x1, 0, (int32_t)cfg->width_in_tiles);
     uint32_t uy1 = (uint32_t)iclamp_(y1, 0, (int32_t)cfg->height_in_tiles);
-    counts[drawobj_ix] = (ux1 - ux0) * (uy1 - uy0);
+    const uint32_t count = (ux1 - ux0) * (uy1 - uy0);
+    counts[drawobj_ix] = count;
     if (drawobj_ix < cfg->layout.n_drawobj && paths.ok(drawobj_ix)) {
         JlPath p;
         p.bbox[0] = ux0; p.bbox[1] = uy0; p.bbox[2] = ux1; p.bbox[3] = uy1;
         p.tiles = 0u; p.pad[0] = 0u; p.pad[1] = 0u; p.pad[2] = 0u;
         paths.p[drawobj_ix] = p;
     }
+    // the workgroup's total: the write pass turns the totals of the workgroups before it and a prefix inside its own
+    // into the offsets (draw-object order = workgroup-major), so no scan launch sits between the two passes
+    MonoidK<1> m;
+    m.v[0] = count;
+    const uint32_t tot = block_reduce_monoid<1>(m, sh).v[0];
+    if (threadIdx.x == 0u) wg_tot[blockIdx.x] = tot;
 }
-JD void tile_zero_part(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tiles, uint32_t block, uint32_t blocks);
+JD void tile_zero_part(const JlConfig* __restrict__ cfg, uint32_t total, Buf<JlTile> tiles, uint32_t block, uint32_t blocks);
 // Workgroups [0, write_blocks) write Path.tiles, the rest clear the allocated tiles (two jobs without a dependency on
 // each other in one launch: a launch of their own costs each of them ~4.5 us).
 __global__ __launch_bounds__(JL_WG) void k_tile_alloc_write(const JlConfig* __restrict__ cfg, JlBump* __restrict__ bump, Buf<JlPath> paths,
                                                             Buf<JlTile> tiles, const uint32_t* __restrict__ counts,
-                                                            const uint32_t* __restrict__ offsets, uint32_t n_total, uint32_t write_blocks) {
+                                                            const uint32_t* __restrict__ wg_tot, uint32_t write_blocks) {
+    __shared__ uint32_t sh[8];
     if ((bump->failed & (JL_STAGE_BINNING | JL_STAGE_FLATTEN)) != 0u) return;
+    // sum of the workgroup totals before mine (and of all of them: bump.tile, tile_alloc.wgsl:90)
+    const uint32_t me = blockIdx.x < write_blocks ? blockIdx.x : write_blocks;
+    MonoidK<2> part;
+    part.v[0] = 0u; part.v[1] = 0u;
+    for (uint32_t j = threadIdx.x; j < write_blocks; j += JL_WG) {
+        const uint32_t v = wg_tot[j];
+        part.v[1] += v;
+        if (j < me) part.v[0] += v;
+    }
+    const MonoidK<2> sums = block_reduce_monoid<2>(part, sh);
+    __syncthreads();
+    const uint32_t wg_off = sums.v[0], total = sums.v[1];
     if (blockIdx.x >= write_blocks) {  // uniform
-        tile_zero_part(cfg, bump, tiles, blockIdx.x - write_blocks, gridDim.x - write_blocks);
+        tile_zero_part(cfg, total, tiles, blockIdx.x - write_blocks, gridDim.x - write_blocks);
         return;
     }
+    if (blockIdx.x == 0u && threadIdx.x == 0u) bump->tile = total;
     uint32_t wg_first = blockIdx.x * JL_WG;
     uint32_t drawobj_ix = wg_first + threadIdx.x;
-    uint32_t wg_off = offsets[wg_first];
-    uint32_t last = wg_first + JL_WG - 1u;
-    uint32_t wg_cnt = (last < n_total ? offsets[last] + counts[last] : 0u) - wg_off;
-    uint32_t my_sub = offsets[drawobj_ix] - wg_off;
+    uint32_t wg_cnt;
+    uint32_t my_sub = block_excl_scan_u32(counts[drawobj_ix], sh, &wg_cnt);
     uint32_t offset = wg_off;
     if (offset + wg_cnt > cfg->tiles_size) {  // tile_alloc.wgsl:93-99
         offset = 0u;
@@ -180,8 +219,8 @@ __global__ __launch_bounds__(JL_WG) void k_tile_alloc_write(const JlConfig* __re
 // The WGSL zeroes a workgroup's tiles with that workgroup's 256 threads (tile_alloc.wgsl:107-111): two workgroups
 // clearing the 1.7 M tiles of 300 large circles take 0.3 ms.  All allocated tiles form the range [0, bump.tile), so
 // one device-wide pass clears them (in the failure case the contents of the buffer are unspecified anyway).
-JD void tile_zero_part(const JlConfig* __restrict__ cfg, const JlBump* __restrict__ bump, Buf<JlTile> tiles, uint32_t block, uint32_t blocks) {
-    const uint32_t n = umin_(umin_(bump->tile, cfg->tiles_size), tiles.n);
+JD void tile_zero_part(const JlConfig* __restrict__ cfg, uint32_t total, Buf<JlTile> tiles, uint32_t block, uint32_t blocks) {
+    const uint32_t n = umin_(umin_(total, cfg->tiles_size), tiles.n);
     uint4* p = (uint4*)tiles.p;  // two tiles per store
     const uint32_t n2 = n >> 1;
     for (uint32_t i = block * JL_WG + threadIdx.x; i < n2; i += blocks * JL_WG) p[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -953,10 +992,8 @@ static inline uint32_t stride_grid(const JhLaunch& L, uint64_t n_items) {
 int jh_launch_binning(const JhLaunch& L) {
     if (L.nb < 8) return -1;
     if (L.gx == 0) return 0;
-    uint32_t n = L.gx * JL_WG;
-    uint32_t* counts = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)n * 4);
-    uint32_t* offsets = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_B, (uint64_t)n * 4);
-    if (!counts || !offsets) return -5;
+    uint32_t* wg_tot = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)L.gx * 4);
+    if (!wg_tot) return -5;
     auto cfg = (const JlConfig*)L.b[0].ptr;
     auto dm = mkbuf<JlDrawMonoid>(L.b[1].ptr, L.b[1].size);
     auto pb = mkbuf<JlPathBbox>(L.b[2].ptr, L.b[2].size);
@@ -965,11 +1002,8 @@ int jh_launch_binning(const JhLaunch& L) {
     JlBump* bump = (JlBump*)L.b[5].ptr;
     auto bd = mkbuf<uint32_t>(L.b[6].ptr, L.b[6].size);
     auto bh = mkbuf<JlBinHeader>(L.b[7].ptr, L.b[7].size);
-    hipLaunchKernelGGL(k_binning<0>, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, dm, pb, cb, ib, bump, bd, bh, counts, (const uint32_t*)nullptr);
-    int rc = jh_scan_u32(L, counts, 1, offsets, n, nullptr, &bump->binning);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_binning<1>, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, dm, pb, cb, ib, bump, bd, bh, (uint32_t*)nullptr,
-                       (const uint32_t*)offsets);
+    hipLaunchKernelGGL(k_binning<0>, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, dm, pb, cb, ib, bump, bd, bh, wg_tot);
+    hipLaunchKernelGGL(k_binning<1>, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, dm, pb, cb, ib, bump, bd, bh, wg_tot);
     return 0;
 }
 
@@ -979,19 +1013,17 @@ int jh_launch_tile_alloc(const JhLaunch& L) {
     if (L.gx == 0) return 0;
     uint32_t n = L.gx * JL_WG;
     uint32_t* counts = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)n * 4);
-    uint32_t* offsets = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_B, (uint64_t)n * 4);
-    if (!counts || !offsets) return -5;
+    uint32_t* wg_tot = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_B, (uint64_t)L.gx * 4);
+    if (!counts || !wg_tot) return -5;
     auto cfg = (const JlConfig*)L.b[0].ptr;
     auto scene = mkbuf<uint32_t>(L.b[1].ptr, L.b[1].size);
     auto db = mkbuf<Bb4>(L.b[2].ptr, L.b[2].size);
     JlBump* bump = (JlBump*)L.b[3].ptr;
     auto paths = mkbuf<JlPath>(L.b[4].ptr, L.b[4].size);
     auto tiles = mkbuf<JlTile>(L.b[5].ptr, L.b[5].size);
-    hipLaunchKernelGGL(k_tile_alloc_count, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, scene, db, (const JlBump*)bump, paths, counts);
-    int rc = jh_scan_u32(L, counts, 1, offsets, n, nullptr, &bump->tile);
-    if (rc) return rc;
+    hipLaunchKernelGGL(k_tile_alloc_count, dim3(L.gx), dim3(JL_WG), 0, L.stream, cfg, scene, db, (const JlBump*)bump, paths, counts, wg_tot);
     hipLaunchKernelGGL(k_tile_alloc_write, dim3(L.gx + stride_grid(L, (uint64_t)tiles.n / 2u + 1u)), dim3(JL_WG), 0, L.stream, cfg, bump, paths, tiles,
-                       (const uint32_t*)counts, (const uint32_t*)offsets, n, L.gx);
+                       (const uint32_t*)counts, (const uint32_t*)wg_tot, L.gx);
     return 0;
 }
 

@@ -1523,7 +1523,12 @@ int jh_launch_flatten(const JhLaunch& L) {
     // a wave per 64 lines of the buffer's capacity (the line count is only known on the device), at most 16 waves
     // per SIMD: the kernel lengthens the ranges to match
     uint64_t gb64 = ((uint64_t)lines.n + 255u) / 256u;  // four waves per workgroup
-    uint32_t gb = gb64 > 4ull * gp_cap ? 4u * gp_cap : (uint32_t)(gb64 < 1u ? 1u : gb64);
+#ifdef FB_MAX_BLOCKS  // (tools/soak_flatten_fallback.sh: a tiny grid, so that every wave strides over many ranges)
+    const uint32_t gb_max = FB_MAX_BLOCKS;
+#else
+    const uint32_t gb_max = 4u * gp_cap;
+#endif
+    uint32_t gb = gb64 > gb_max ? gb_max : (uint32_t)(gb64 < 1u ? 1u : gb64);
     hipLaunchKernelGGL(k_flatten_bbox, dim3(gb), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, (const uint32_t*)bases, n_slots, lines, pb,
                        counters, FL_CTR_WORDS + g);
     *clean |= JH_CLEAN_FL_CTR;

@@ -13,8 +13,9 @@
 //                    of the workgroups before its own plus a prefix inside its own, no scan launch in
 //                    between -- reports the totals in bump.{segments,ptcl,blend}, walks again and
 //                    writes PTCL + ~seg_ix.
-// => bit-identical PTCL on every run.  One 256-thread workgroup per bin, one thread per tile, bin
-// bitmaps (8 x 256 u32) and per-draw tile rectangles staged in 16 KiB of LDS, as in the WGSL.
+// => bit-identical PTCL on every run.  A bin is shared by 1 ... 16 workgroups of 256 threads (strips of
+// tile rows), one thread per tile in the command walk; bin bitmaps (8 x 256 u32), the batch's element
+// records and the Tiles of the current window of elements live in 37 KiB of LDS.
 // Algorithmic bytes: 4 B per (draw,bin) bin_data + 32 B Path + 8 B Tile per (draw,tile) + PTCL out.
 #include "kcommon.h"
 
@@ -34,11 +35,9 @@ struct Cmd {
     uint32_t seg_base, seg_used;
 };
 
-// PTCL words leave as 16-byte stores where a command has four or more words (dword-aligned addresses: gfx950 runs in
-// unaligned-access mode; a 4-byte store per word costs three times the write requests).
+// PTCL words leave as 16-byte stores (dword-aligned addresses: gfx950 runs in unaligned-access mode; a 4-byte store
+// per word costs three times the write requests).
 struct __attribute__((packed, aligned(4))) PtclQuad { uint32_t a, b, c, d; };
-struct __attribute__((packed, aligned(4))) PtclTriple { uint32_t a, b, c; };
-struct __attribute__((packed, aligned(4))) PtclPair { uint32_t a, b; };
 JD void ptcl_wr4(const Buf<uint32_t>& ptcl, uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     if (i + 3u < ptcl.n && i + 3u >= i) {
         PtclQuad q; q.a = a; q.b = b; q.c = c; q.d = d;

@@ -5,14 +5,16 @@
 // LineSoup order run-dependent.  Here the stage is classify -> items -> scan -> lines -> bbox:
 //   k_flatten_classify   one thread per tag byte: splits it into up to 3 work items (see below) and appends them
 //                        to a heavy / light list; writes PathBbox.draw_flags/trans_ix;
-//   k_flatten_items      one lane per item: caps / joins / lines are written to a temporary buffer (LDS-chunked,
-//                        order-free allocation) with a key (item slot, k); an Euler job runs the adaptive subdivision
-//                        and leaves one 64-byte record per accepted piece in the temp slots the piece reserves;
-//                        counts[slot] = lines of the item; idle lanes are refilled from the workgroup's item queue;
+//   k_flatten_items      a wave per batch of 64 items: caps / joins / lines are written to a temporary buffer
+//                        (LDS-chunked, order-free allocation) with a key (item slot, k); the Euler jobs of the batch
+//                        are subdivided together -- the nodes of their subdivision trees sit on one LDS stack and 64
+//                        are tested per step, whichever jobs they belong to -- and leave one 64-byte record per
+//                        accepted piece in the temp slots the piece reserves; counts[slot] = lines of the item;
 //   jh_scan_u32          line base per slot; the total lands in bump.lines;
 //   k_flatten_lines      one thread per temp slot: evaluates the line's end point from the piece record and writes the
 //                        line to lines[bases[slot] + k] (its start is the end point of the line before it);
-//   k_flatten_bbox       per-tag boxes of the finished lines -> path bounding boxes.
+//   k_flatten_bbox       streams the finished lines and folds their boxes by path (segmented wave scan), honouring the
+//                        WGSL's per-tag extent rule -> path bounding boxes.
 // Result: lines are ordered by (tag byte, emission order) -- the reference's own sequential order
 // (shaders/cpu/flatten.go:664-823) -- with the subdivision arithmetic executed exactly once.
 // Algorithmic traffic: scene bytes + 20 B / tag word in, 24 B / line out (+ 64-80 B / piece through the temp).

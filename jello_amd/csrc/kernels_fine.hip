@@ -215,6 +215,7 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #ifndef FINE_WAVES
 #define FINE_WAVES 2
 #endif
+#define FINE_TRIP_WORDS 13u  // PTCL words one trip of the command loop may consume
 #define FB_STRIDE 65  // 64 pairs + the all-zero slot 64 (odd stride: conflict-free)
 struct SegRaw { float p0x, p0y, p1x, p1y, ye; };
 struct FillLds {
@@ -749,10 +750,11 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         }
     };
     for (uint32_t guard = 0; guard < (1u << 24); guard++) {
-        if (pc - wbase > 64u - 9u) {  // uniform: fewer than nine words of the command are in `wcur`
+        // (a trip consumes at most FINE_TRIP_WORDS words: up to three BEGIN_CLIPs and a SOLID in front of a command of up to nine)
+        if (pc - wbase > 64u - FINE_TRIP_WORDS) {  // uniform: fewer words than a trip may need are in `wcur`
             // Re-base the window at pc: lane k takes word pc + k from the two windows (ds_bpermute: a lane shuffle through
             // the LDS crossbar, no LDS storage), and the window behind the new one is requested.
-            const uint32_t sh = pc - wbase;  // 56 .. 64: a command advances pc by at most nine words (jumps reload)
+            const uint32_t sh = pc - wbase;  // <= 64: a trip advances pc by at most FINE_TRIP_WORDS words (jumps reload)
             const uint32_t src = lane + sh;
             const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src & 63u) << 2), (int)wcur);
             const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src & 63u) << 2), (int)wnext);
@@ -760,9 +762,26 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             wbase = pc;
             wnext = load_win(wbase + 64u);
         }
-        const uint32_t woff = pc - wbase;  // <= 55: the nine words a command may have are all in wcur
+        uint32_t woff = pc - wbase;  // <= 64 - FINE_TRIP_WORDS: the words this trip may consume are all in wcur
         auto W = [&](uint32_t k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)wcur, (int)(woff + k)); };
-        const uint32_t tag = W(0);
+        uint32_t tag = W(0);
+        if constexpr (CLIPS) {
+            // BEGIN_CLIP only counts (the save is deferred, see pushed_depth) and SOLID only sets the area: both are
+            // consumed in front of the command that follows instead of in trips of their own -- a trip of this loop
+            // carries the sixteen colour registers around its back edge, which costs far more than these commands do.
+            // (BEGIN_CLIP SOLID END_CLIP is what a tile in the middle of an empty clip layer sees: C4 has 213 per tile.)
+            for (int it = 0; it < 3 && tag == JL_CMD_BEGIN_CLIP; it++) {  // uniform
+                clip_depth += 1u;
+                pc += 1u; woff += 1u;
+                tag = W(0);
+            }
+            if (tag == JL_CMD_SOLID) {  // uniform
+#pragma unroll
+                for (int k = 0; k < 4; k++) area[k] = 1.0f;
+                pc += 1u; woff += 1u;
+                tag = W(0);
+            }
+        }
         if (tag == JL_CMD_END) break;
         // A solid colour (uniform: it sits in scalar registers) is composited at ONE place below, whichever command brought
         // it -- one definition of rgba per trip keeps the sixteen colour registers where they are (three composite sites
@@ -857,7 +876,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             have_fg = true;
             pc += 5u;
         } else if (CLIPS && tag == JL_CMD_BEGIN_CLIP) {
-            clip_depth += 1u;  // (the save is deferred, see pushed_depth)
+            clip_depth += 1u;  // (a fourth BEGIN_CLIP in a row; the save is deferred, see pushed_depth)
             pc += 1u;
         } else if (CLIPS && tag == JL_CMD_END_CLIP) {
             pc += 3u;

@@ -173,6 +173,18 @@ struct FineImages {
 };
 
 JD uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// LDS byte addresses as integers (stage 4 of fill_path walks addresses)
+#define JK_LDS __attribute__((address_space(3)))
+JD uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(JK_LDS const void*)p; }
+typedef float jk_v4f __attribute__((ext_vector_type(4)));
+typedef float jk_v2f __attribute__((ext_vector_type(2)));
+#if defined(__HIP_DEVICE_COMPILE__)
+JD float4 lds_ld_f4(uint32_t a) { const jk_v4f v = *(const JK_LDS jk_v4f*)a; return make_float4(v.x, v.y, v.z, v.w); }
+JD void lds_st_u16(uint32_t a, uint16_t v) { *(JK_LDS uint16_t*)a = v; }
+#else  // (the host pass only parses the kernels)
+JD float4 lds_ld_f4(uint32_t) { return make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+JD void lds_st_u16(uint32_t, uint16_t) {}
+#endif
 
 // rgba = rgba * (1 - fg.a*area) + fg*area  (fine.wgsl:923-926 and the gradient/image arms)
 JD V4 over(V4 bg, V4 fg, float area) {
@@ -215,18 +227,26 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #ifndef FINE_WAVES
 #define FINE_WAVES 2
 #endif
+#define FB_PLANE 65
 #define FINE_TRIP_WORDS 13u  // PTCL words one trip of the command loop may consume
-#define FB_STRIDE 65  // 64 pairs + the all-zero slot 64 (odd stride: conflict-free)
-struct SegRaw { float p0x, p0y, p1x, p1y, ye; };
+// Everything a batch leaves behind for stage 4 lives in LDS, not in registers: the command loop then carries no per-lane
+// batch state around its back edge (as registers the nine values cost ~30 moves per command: the compiler keeps a second
+// copy of every loop-carried value that a nested loop redefines).
 struct FillLds {
-    float seg[4][64];            // window segments (lane-indexed): p0x p0y dx dy
-    float contrib[16][FB_STRIDE];  // [tile column][pair]: a*dy; pair slot 64 stays +0 ("no pair"); column-major so that
-                                 // lane = pair writes and lane = pixel reads are conflict-free
+    alignas(16) float4 pre[64];    // the NEXT window's segments (p0x p0y p1x p1y), written by global_load_lds (no registers)
+    alignas(16) float4 ent[4][FB_PLANE]; // the batch's (segment,row) pairs SORTED BY ROW (segment order inside a row): [pixel quad]
+                                   // [position] = the pair's a*dy for the quad's 4 pixels of its row.  One plane per quad: lane = pair
+                                   // writes and lane = pixel quad reads both touch consecutive 16-byte slots (the plane stride is
+                                   // 65 slots, so the four quads of one position lie in different banks)
+    float pre_ye[64];              // ... and their y_edge
+    float2 edge[64];               // window segments: y_edge, sign(dx)  (read by stage 4 at a uniform index: a broadcast)
+    uint64_t rowmask[16];          // per pixel row: bit j = pair j of the batch lies in this row
+    uint32_t lanest[64];           // lane = pixel quad: LDS address of my row's first entry (my quad of it) | entries consumed << 16
+    uint8_t first[68];             // first pair of window segment s (segments behind the batch and [64]: the number of pairs)
     union {
-        uint32_t pairflag[64];   // batch set-up: pair -> (window segment + 1) at the first pair of each segment, else 0
-        uint16_t speclist[FB_SPEC];  // stage 3: crossing pixels, pair << 4 | column
+        uint32_t pairflag[64];       // batch set-up: pair -> (window segment + 1) at the first pair of each segment, else 0
+        uint16_t speclist[FB_SPEC];  // stage 3: crossing pixels, position << 10 | pair << 4 | column
     };
-    uint32_t nspec;
 };
 // The load is unconditional (index clamped) so that it can stay in flight as a prefetch; out-of-range segments are
 // zeroed when the registers are consumed (robust-access rule) -- a predicated load would be waited for at once.
@@ -543,9 +563,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
     // no per-word address arithmetic, and no memory latency between short commands (a scalar load per command had
     // ~1 us of it: fatal for streams of hundreds of one-word clip commands).
     uint32_t pc = uni(tile_ix * JL_PTCL_INITIAL_ALLOC);  // absolute word index of the next command
-    if constexpr (AA == 0) {
-        if (lane < 16u) F.contrib[lane][64] = 0.0f;  // the "no pair" slot
-    } else {
+    if constexpr (AA != 0) {
         if (lane == 0u) F.seg_win_valid = 0u;  // fill_path_ms: no segment window yet
     }
     wave_sync();
@@ -561,158 +579,163 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
     };
     auto pix_i = [&](int k) -> float { return (float)k; };
     auto pix_spill = [&](int k) -> uint32_t { return ly * JL_TILE_WIDTH + lx * 4u + (uint32_t)k; };
-    // segment window (64 segments: current in LDS, next prefetched in registers) and batch state
-    float nx_p0x = 0.0f, nx_p0y = 0.0f, nx_p1x = 0.0f, nx_p1y = 0.0f, nx_ye = 0.0f;  // prefetched (plain scalars: a struct here ends up in scratch)
-    uint32_t cur_base = 0u, nxt_base = 0xffffffffu;            // nxt_base: "nothing prefetched"
-    float my_ye = 0.0f, my_sg = 0.0f;                          // its y_edge and sign(dx), read by stage 4 with v_readlane
-    uint32_t my_meta = 0u;                                     // its pairs in the current batch: first pair | cnt << 12 | ra << 17
-    uint32_t batch_lo = 0u, batch_hi = 0u;                     // segments [batch_lo, batch_hi) are evaluated
+    // Segment window and batch state.  All of it is uniform (scalar registers) or in F (LDS).
+    uint32_t cur_base = 0u, nxt_base = 0xffffffffu;  // window base; base of the window in flight to F.pre ("none")
+    uint32_t batch_hi = 0u;                          // segments [cur_base, batch_hi) are evaluated
+    uint32_t n_pairs = 0u;                           // pairs of the batch
+    uint64_t edge_mask = 0ull;                       // window segments of the batch with a y_edge term
+    uint32_t next_seg = 0xffffffffu;                 // the segment the rows' consumed counts stand in front of
     const float lyf = (float)ly;
+    uint32_t ent_lds = 0u;  // LDS byte address of my quad's plane of entries (stage 4 walks addresses)
+    if constexpr (AA == 0) ent_lds = lds_addr(&F.ent[lx][0]);
 
     // Evaluate the batch that starts at segment `so` (uniform).
     auto build_batch = [&](uint32_t so) {
       if constexpr (AA == 0) {
         wave_sync();  // stage 4 of the previous batch is done with F
-        // The window always starts at the batch's first segment (so every batch can fill its 64 pair slots);
-        // it was prefetched while the previous batch was evaluated unless the fills are not contiguous.
-        SegRaw cur;
+        // The window always starts at the batch's first segment (so every batch can fill its 64 pair slots); it was
+        // requested while the previous batch was evaluated (straight into LDS) unless the fills are not contiguous.
+        float c_p0x, c_p0y, c_p1x, c_p1y, c_ye;
         if (nxt_base == so) {
-            cur.p0x = nx_p0x; cur.p0y = nx_p0y; cur.p1x = nx_p1x; cur.p1y = nx_p1y; cur.ye = nx_ye;
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the window has arrived in F.pre
+            wave_sync();
+            const float4 t = F.pre[lane];
+            c_p0x = t.x; c_p0y = t.y; c_p1x = t.z; c_p1y = t.w; c_ye = F.pre_ye[lane];
         } else {
-            load_segraw_clamped(segments, segments_n, so + lane, cur.p0x, cur.p0y, cur.p1x, cur.p1y, cur.ye);
+            load_segraw_clamped(segments, segments_n, so + lane, c_p0x, c_p0y, c_p1x, c_p1y, c_ye);
         }
         {
             const bool ok = so + lane < segments_n;  // robust access: out-of-range segments read as zero
-            cur.p0x = ok ? cur.p0x : 0.0f; cur.p0y = ok ? cur.p0y : 0.0f; cur.p1x = ok ? cur.p1x : 0.0f; cur.p1y = ok ? cur.p1y : 0.0f;
-            cur.ye = ok ? cur.ye : 0.0f;
+            c_p0x = ok ? c_p0x : 0.0f; c_p0y = ok ? c_p0y : 0.0f; c_p1x = ok ? c_p1x : 0.0f; c_p1y = ok ? c_p1y : 0.0f;
+            c_ye = ok ? c_ye : 0.0f;
         }
         cur_base = so;
-        {
-            const float dlx = cur.p1x - cur.p0x, dly = cur.p1y - cur.p0y;
-            F.seg[0][lane] = cur.p0x; F.seg[1][lane] = cur.p0y; F.seg[2][lane] = dlx; F.seg[3][lane] = dly;
-            my_ye = cur.ye;
-            my_sg = sign_(dlx);
-        }
+        const float dlx = c_p1x - c_p0x, dly = c_p1y - c_p0y;
+        F.edge[lane] = make_float2(c_ye, sign_(dlx));
         // stage 1: conservative superset of the rows with dy != 0.  Coordinates are tile relative (|v| <= 16
         // for what path_tiling writes): with |v| <= 64 every rounding error of the WGSL's row arithmetic is
         // < 1e-4, so widening by 1e-3 is safe; anything else takes all 16 rows.
-        uint32_t my_cnt, my_ra;
-        {
-            bool sane = abs_(cur.p0x) <= 64.0f && abs_(cur.p0y) <= 64.0f && abs_(cur.p1x) <= 64.0f && abs_(cur.p1y) <= 64.0f;
-            int32_t ra = 0, rb = 16;
-            if (sane) {
-                ra = iclamp_((int32_t)floor_(fmin_(cur.p0y, cur.p1y) - 1.0e-3f), 0, 16);
-                rb = iclamp_((int32_t)ceil_(fmax_(cur.p0y, cur.p1y) + 1.0e-3f), 0, 16);
-            }
-            my_cnt = (uint32_t)imax_(rb - ra, 0);
-            my_ra = (uint32_t)ra;
+        const bool sane = abs_(c_p0x) <= 64.0f && abs_(c_p0y) <= 64.0f && abs_(c_p1x) <= 64.0f && abs_(c_p1y) <= 64.0f;
+        int32_t ra = 0, rb = 16;
+        if (sane) {
+            ra = iclamp_((int32_t)floor_(fmin_(c_p0y, c_p1y) - 1.0e-3f), 0, 16);
+            rb = iclamp_((int32_t)ceil_(fmax_(c_p0y, c_p1y) + 1.0e-3f), 0, 16);
         }
-        const uint32_t rel0 = 0u;
-        uint32_t incl = wave_incl_scan_u32(my_cnt);
-        uint64_t fit = __builtin_amdgcn_ballot_w64(incl <= 64u);
-        const uint32_t e_rel = (uint32_t)__builtin_popcountll(fit);  // > 0: one segment has at most 16 pairs
-        const uint32_t npairs = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(e_rel - 1u));
+        const uint32_t my_cnt = (uint32_t)imax_(rb - ra, 0);
+        const uint32_t incl = wave_incl_scan_u32(my_cnt);
+        const uint64_t fit = __builtin_amdgcn_ballot_w64(incl <= 64u);   // a prefix of the lanes (incl is monotone)
+        const uint32_t e_rel = (uint32_t)__builtin_popcountll(fit);       // > 0: one segment has at most 16 pairs
+        n_pairs = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(e_rel - 1u));
         const uint32_t first = incl - my_cnt;
-        my_meta = first | (my_cnt << 12) | (my_ra << 17) | ((my_ye < 16.0f) ? (1u << 22) : 0u);  // bit 22: has a y_edge term
+        F.first[lane] = (uint8_t)(lane < e_rel ? first : n_pairs);
+        if (lane == 0u) F.first[64] = (uint8_t)n_pairs;
+        // y_edge >= 16 (path_tiling's "no edge" value is 1e9) clamps to 0 for every row of the tile
+        edge_mask = __builtin_amdgcn_ballot_w64(c_ye < 16.0f) & fit;
+        const uint32_t meta = first | ((uint32_t)ra << 8) | (sane ? (1u << 16) : 0u);
         nxt_base = so + e_rel;
-        load_segraw_clamped(segments, segments_n, nxt_base + lane, nx_p0x, nx_p0y, nx_p1x, nx_p1y, nx_ye);  // prefetch; consumed much later
+        {   // request the next window: 16 + 4 bytes per lane straight into F.pre / F.pre_ye (index clamped: robust access)
+            const float* gp = segments + (size_t)umin_(nxt_base + lane, umax_(segments_n, 1u) - 1u) * 6;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (JK_LDS void*)&F.pre[0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + 4), (JK_LDS void*)&F.pre_ye[0], 4, 0, 0);
+        }
         F.pairflag[lane] = 0u;
-        if (lane == 0u) F.nspec = 0u;
-        batch_lo = so;
-        batch_hi = cur_base + e_rel;
+        if (lane < 16u) F.rowmask[lane] = 0ull;
+        batch_hi = so + e_rel;
         wave_sync();
-        if (lane >= rel0 && lane < e_rel && my_cnt != 0u) F.pairflag[first & 63u] = lane + 1u;
+        if (lane < e_rel && my_cnt != 0u) F.pairflag[first & 63u] = lane + 1u;
         wave_sync();
-        // pair -> segment: running maximum of the start flags; its row from the segment's meta word
+        // pair -> segment: running maximum of the start flags; the segment's values come from its lane (ds_bpermute)
         const uint32_t owner = wave_incl_max_u32(F.pairflag[lane]);
         const uint32_t pseg = (owner - 1u) & 63u;
-        const uint32_t pmeta = __shfl(my_meta, (int)pseg, 64);
-        // stage 2
-        uint32_t ms = 0u, spos = 0u;
-        float s2_dy = 0.0f, s2_tx0 = 0.0f, s2_tx1 = 0.0f, s2_p0x = 0.0f;  // read by stage 3 lanes with ds_bpermute
-        if (lane < npairs) {
-            const uint32_t j = lane;
-            const uint32_t row = ((pmeta >> 17) & 31u) + (j - (pmeta & 0xfffu));
-            const float rowf = (float)row;
-            const float p0x = F.seg[0][pseg], p0y = F.seg[1][pseg], dlx = F.seg[2][pseg], dly = F.seg[3][pseg];
-            const float y = p0y - rowf;
-            const float y0 = clamp_(y, 0.0f, 1.0f);
-            const float y1 = clamp_(y + dly, 0.0f, 1.0f);
-            const float dy = y0 - y1;
+        const uint32_t pmeta = __shfl(meta, (int)pseg, 64);
+        const float p0x = __shfl(c_p0x, (int)pseg, 64), p0y = __shfl(c_p0y, (int)pseg, 64);
+        const float sdx = __shfl(dlx, (int)pseg, 64), sdy = __shfl(dly, (int)pseg, 64);
+        // stage 2, lane = pair: the WGSL's y-part, then a conservative classification of the row's 16 pixels from the
+        // x-span as group 0 (startx = p0x) computes it.  The WGSL evaluates x0 / x1 once per group of four pixels as
+        // fl(fl(p0x - 4g) + tx); all of these are within 4 roundings at magnitude <= 128 (< 4e-5) of the group-0
+        // value minus 4g, so with a margin of 1e-3
+        //   pixels X >= ceil(xmax0 + 1e-3)  have fl(xmax0_g - i) <= 0, i.e. a == 1 exactly: they contribute dy,
+        //   pixels X <  floor(xmin0 - 1e-3) have fl(xmin0_g - i) >= 1, i.e. a == +0 exactly: they contribute +-0,
+        // and everything in between takes the full formula in stage 3 (which reproduces a == 1 / a == +0 by itself
+        // where the margin was not needed).
+        const bool is_pair = lane < n_pairs;
+        const uint32_t row = is_pair ? ((((pmeta >> 8) & 31u) + (lane - (pmeta & 0xffu))) & 15u) : 0u;
+        const float y = p0y - (float)row;
+        const float y0 = clamp_(y, 0.0f, 1.0f);
+        const float y1 = clamp_(y + sdy, 0.0f, 1.0f);
+        const float s2_dy = y0 - y1;
+        const float vec_y_recip = 1.0f / sdy;  // fine.wgsl:845
+        const float t0 = (y0 - y) * vec_y_recip;
+        const float t1 = (y1 - y) * vec_y_recip;
+        const float s2_tx0 = t0 * sdx, s2_tx1 = t1 * sdx;  // (s2_*: read by stage 3 lanes with ds_bpermute)
+        const float gx0 = p0x + s2_tx0, gx1 = p0x + s2_tx1;
+        const float xmin0 = fmin_(gx0, gx1), xmax0 = fmax_(gx0, gx1);
+        // (NaN or far-off spans, and segments stage 1 found insane: every pixel takes the full formula)
+        const bool guard = (pmeta & (1u << 16)) != 0u && abs_(xmin0) <= 40.0f && abs_(xmax0) <= 40.0f;
+        const int32_t c1 = guard ? iclamp_((int32_t)ceil_(xmax0 + 1.0e-3f), 0, 16) : 16;
+        const int32_t n0 = guard ? iclamp_((int32_t)floor_(xmin0 - 1.0e-3f), 0, 16) : 0;
+        const uint32_t ncross = (is_pair && s2_dy != 0.0f) ? (uint32_t)imax_(c1 - n0, 0) : 0u;
+        if (is_pair) atomicOr((unsigned long long*)&F.rowmask[row], 1ull << lane);
+        wave_sync();
+        // position of the pair's entry: rows in ascending order, pairs of a row in pair (= segment) order
+        const uint64_t rm_pair = F.rowmask[row];
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(rm_pair >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm_pair, 0u));
+        const uint32_t c16 = (uint32_t)__builtin_popcountll(F.rowmask[lane & 15u]);
+        uint32_t inc16 = c16;  // inclusive prefix inside each 16-lane DPP row (every row of lanes holds the 16 pixel rows)
+        inc16 += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc16, JK_DPP_ROW_SHR(1), 0xf, 0xf, false);
+        inc16 += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc16, JK_DPP_ROW_SHR(2), 0xf, 0xf, false);
+        inc16 += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc16, JK_DPP_ROW_SHR(4), 0xf, 0xf, false);
+        inc16 += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc16, JK_DPP_ROW_SHR(8), 0xf, 0xf, false);
+        const uint32_t excl16 = inc16 - c16;
+        const uint32_t pos = (__shfl(excl16, (int)row, 64) + rank) & 63u;
+        F.lanest[lane] = ent_lds + __shfl(excl16, (int)ly, 64) * 16u;  // nothing consumed yet
+        next_seg = so;
+        if (is_pair) {
             float cv[16];
 #pragma unroll
-            for (int q = 0; q < 16; q++) cv[q] = 0.0f;
-            if (dy != 0.0f) {
-                const float vec_y_recip = 1.0f / dly;  // fine.wgsl:845
-                const float t0 = (y0 - y) * vec_y_recip;
-                const float t1 = (y1 - y) * vec_y_recip;
-                const float tx0 = t0 * dlx, tx1 = t1 * dlx;
-                s2_dy = dy; s2_tx0 = tx0; s2_tx1 = tx1; s2_p0x = p0x;
+            for (int q = 0; q < 16; q++) cv[q] = (q >= c1) ? s2_dy : 0.0f;
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const float startx = p0x - (float)(4 * g);
-                    const float x0 = startx + tx0;
-                    const float x1 = startx + tx1;
-                    const float xmin0 = fmin_(x0, x1);
-                    const float xmax0 = fmax_(x0, x1);
-                    // Classification with integer thresholds (no per-pixel mask logic):
-                    //   a == 1  <=>  fl(xmax0 - i) <= 0   <=>  i >= ceil(xmax0)   (a float difference has the exact sign)
-                    //   a == +0 <=>  fl(xmin0 - i) >= 1   <=>  i <  floor(xmin0)  (xmin0 - i in [0.5, 1) is exact, so it
-                    //                                                              cannot round up to 1)
-                    // Outside |x| <= 17 (never for path_tiling's output; also NaN) every pixel takes the full formula.
-                    const bool guard = abs_(xmin0) <= 17.0f && abs_(xmax0) <= 17.0f;
-                    const int32_t c1 = guard ? iclamp_((int32_t)ceil_(xmax0), 0, 4) : 4;   // pixels i >= c1 contribute dy
-                    const int32_t n0 = guard ? iclamp_((int32_t)floor_(xmin0), 0, 4) : 0;  // pixels i <  n0 contribute nothing
-                    // pixels n0 <= i < c1 cross the span (empty when n0 >= c1)
-                    const uint32_t below_c1 = (1u << c1) - 1u, below_n0 = (1u << n0) - 1u;
-                    ms |= (below_c1 & ~below_n0) << (4 * g);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) cv[4 * g + i] = (i >= c1) ? dy : 0.0f;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 16; q++) F.contrib[q][j] = cv[q];
-            if (ms != 0u) spos = atomicAdd(&F.nspec, (uint32_t)__builtin_popcount(ms));
+            for (int q = 0; q < 4; q++) F.ent[q][pos] = make_float4(cv[4 * q], cv[4 * q + 1], cv[4 * q + 2], cv[4 * q + 3]);
         }
-        wave_sync();
-        const uint32_t nspec = (uint32_t)__builtin_amdgcn_readfirstlane((int)F.nspec);
+        const uint32_t sincl = wave_incl_scan_u32(ncross);
+        const uint32_t spos = sincl - ncross;
+        const uint32_t nspec = (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
         // stage 3, in passes of FB_SPEC crossing pixels (one pass unless the batch is full of long flat segments)
         for (uint32_t pass = 0u; pass < nspec; pass += FB_SPEC) {
-            if (pass != 0u) wave_sync();
+            wave_sync();  // (the entries above / the previous pass's list reads are done)
             {
-                uint32_t bits = ms, k = spos - pass;
-                while (bits != 0u) {
-                    uint32_t X = (uint32_t)__builtin_ctz(bits);
-                    bits &= bits - 1u;
-                    if (k < FB_SPEC) F.speclist[k] = (uint16_t)((lane << 4) | X);
-                    k++;
+                uint32_t code = (pos << 10) | (lane << 4) | (uint32_t)n0;
+                uint32_t k = spos - pass;
+#pragma clang loop unroll(disable)
+                for (uint32_t t = 0u; t < ncross; t++, k++, code++) {
+                    if (k < FB_SPEC) F.speclist[k] = (uint16_t)code;
                 }
             }
             wave_sync();
             const uint32_t n_here = umin_(nspec - pass, FB_SPEC);
             for (uint32_t k0 = 0u; k0 < n_here; k0 += 64u) {
-                uint32_t k = k0 + lane;
-                uint32_t j = 0u, X = 0u;
+                const uint32_t k = k0 + lane;
+                uint32_t j = 0u, X = 0u, epos = 0u;
                 if (k < n_here) {
-                    uint32_t e = F.speclist[k];
-                    j = e >> 4; X = e & 15u;
+                    const uint32_t e = F.speclist[k];
+                    epos = e >> 10; j = (e >> 4) & 63u; X = e & 15u;
                 }
-                // the pair lane's y-part results (same operations as in stage 2, so the same bits)
+                // the pair lane's y-part results
                 const float dy = __shfl(s2_dy, (int)j, 64), tx0 = __shfl(s2_tx0, (int)j, 64), tx1 = __shfl(s2_tx1, (int)j, 64);
-                const float p0x = __shfl(s2_p0x, (int)j, 64);
+                const float q0x = __shfl(p0x, (int)j, 64);
                 if (k < n_here) {
                     const uint32_t g = X >> 2;
                     const float i_f = (float)(X & 3u);
-                    const float startx = p0x - (float)(4u * g);
+                    const float startx = q0x - (float)(4u * g);
                     const float x0 = startx + tx0, x1 = startx + tx1;
-                    const float xmin0 = fmin_(x0, x1), xmax0 = fmax_(x0, x1);
-                    float xmin = fmin_(xmin0 - i_f, 1.0f) - 1.0e-6f;
-                    float xmax = xmax0 - i_f;
+                    const float xmn0 = fmin_(x0, x1), xmx0 = fmax_(x0, x1);
+                    float xmin = fmin_(xmn0 - i_f, 1.0f) - 1.0e-6f;
+                    float xmax = xmx0 - i_f;
                     float b = fmin_(xmax, 1.0f);
                     float c = fmax_(b, 0.0f);
                     float d = fmax_(xmin, 0.0f);
                     float a = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
-                    F.contrib[X][j] = a * dy;
+                    ((float*)&F.ent[X >> 2][epos])[X & 3u] = a * dy;
                 }
             }
         }
@@ -804,49 +827,61 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             for (int k = 0; k < 4; k++) area[k] = backdrop_f;
             uint32_t sa = seg_data, remaining = n_segs;
             while (remaining != 0u) {  // uniform
-                if (sa - batch_lo >= batch_hi - batch_lo) build_batch(sa);
-                uint32_t take = umin_(remaining, batch_hi - sa);
-                uint32_t r0 = sa - cur_base;  // window-relative segments [r0, r0 + take)
-                // two segments per trip: both LDS reads are in flight before the (ordered) adds (four measured the same)
-                auto seg_fetch = [&](uint32_t q, float (&cv)[4], uint32_t& has_edge, int& sl) {
-                    sl = (int)((r0 + q) & 63u);
-                    uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)my_meta, sl);
-                    has_edge = m & (1u << 22);
-                    uint32_t t = ly - ((m >> 17) & 31u);
-                    // the segment's pair for my row, or the all-zero slot 64 (adding +0 is a no-op)
-                    uint32_t j = (t < ((m >> 12) & 31u)) ? (((m & 0xfffu) + t) & 63u) : 64u;
-                    const float* cp = &F.contrib[lx * 4u][j];
-                    cv[0] = cp[0]; cv[1] = cp[FB_STRIDE]; cv[2] = cp[2 * FB_STRIDE]; cv[3] = cp[3 * FB_STRIDE];
-                };
-                auto seg_apply = [&](const float (&cv)[4], uint32_t has_edge, int sl) {
-                    area[0] += cv[0]; area[1] += cv[1]; area[2] += cv[2]; area[3] += cv[3];
-                    // y_edge >= 16 (path_tiling's "no edge" value is 1e9) clamps to 0 for every row of the tile
-                    if (has_edge != 0u) {  // uniform (a bit of the segment's meta word)
-                        float ye_s = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(my_ye), sl));
-                        float sg_s = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(my_sg), sl));
-                        float y_edge = sg_s * clamp_(lyf - ye_s + 1.0f, 0.0f, 1.0f);
+                if (sa - cur_base >= batch_hi - cur_base) build_batch(sa);
+                const uint32_t take = umin_(remaining, batch_hi - sa);
+                const uint32_t r0 = sa - cur_base;  // window-relative segments [r0, r0 + take)
+                auto below = [](uint32_t P) -> uint64_t { return P >= 64u ? ~0ull : ((1ull << P) - 1ull); };
+                // stage 4, lane = pixel quad of row ly: the entries of my row are in segment order, so the terms of the WGSL's
+                // loop that can change my sum -- a*dy of the segments with a pair in my row -- are added in its order by
+                // walking my row's list; a segment with a y_edge term (uniform: a bit of edge_mask) ends a run of such
+                // additions for all rows, the term is added, and the walk goes on behind it.
+                const uint64_t my_rowmask = F.rowmask[ly];
+                const uint32_t st = F.lanest[lane];
+                const uint32_t row_addr = st & 0xffffu;
+                uint32_t done = st >> 16;  // entries of my row consumed so far
+                if (sa != next_seg) done = (uint32_t)__builtin_popcountll(my_rowmask & below(uni(F.first[r0])));  // (a fill that does not continue the previous one)
+                uint32_t cur = row_addr + done * 16u;
+                uint64_t em = edge_mask & (below(r0 + take) & ~below(r0));
+                for (;;) {  // uniform
+                    const uint32_t e_sl = em != 0ull ? (uint32_t)__builtin_ctzll(em) : 0u;
+                    const uint32_t seg_end = em != 0ull ? e_sl + 1u : r0 + take;  // the run covers window segments < seg_end
+                    done = (uint32_t)__builtin_popcountll(my_rowmask & below(uni(F.first[seg_end])));
+                    const uint32_t hi = row_addr + done * 16u;
+                    // Walk my row's entries [cur, hi): lanes drop out of EXEC as their rows run out (no lane comes back inside
+                    // a run), the loop ends when none is left.  Written in assembly: as C++ the compiler keeps two copies of the
+                    // area registers around this loop (four moves per trip) and cannot mask the loads.
+                    {
+                        jk_v2f a01 = {area[0], area[1]}, a23 = {area[2], area[3]};
+                        uint64_t sv;
+                        asm volatile(
+                            "s_mov_b64 %[sv], exec\n"
+                            "1:\n"
+                            "v_cmpx_lt_u32_e32 vcc, %[cur], %[hi]\n"
+                            "s_cbranch_execz 2f\n"
+                            "ds_read_b128 v[76:79], %[cur]\n"
+                            "v_add_u32_e32 %[cur], 16, %[cur]\n"
+                            "s_waitcnt lgkmcnt(0)\n"
+                            "v_pk_add_f32 %[a01], %[a01], v[76:77]\n"
+                            "v_pk_add_f32 %[a23], %[a23], v[78:79]\n"
+                            "s_branch 1b\n"
+                            "2:\n"
+                            "s_mov_b64 exec, %[sv]\n"
+                            : [cur] "+v"(cur), [a01] "+v"(a01), [a23] "+v"(a23), [sv] "=&s"(sv)
+                            : [hi] "v"(hi)
+                            : "vcc", "memory", "v76", "v77", "v78", "v79");
+                        area[0] = a01.x; area[1] = a01.y; area[2] = a23.x; area[3] = a23.y;
+                    }
+                    cur = hi;
+                    if (em == 0ull) break;
+                    {
+                        const float2 ed = F.edge[e_sl];
+                        const float y_edge = ed.y * clamp_(lyf - ed.x + 1.0f, 0.0f, 1.0f);
                         area[0] += y_edge; area[1] += y_edge; area[2] += y_edge; area[3] += y_edge;
                     }
-                };
-                uint32_t q = 0u;
-                {
-                    for (; q + 1u < take; q += 2u) {
-                        float ca[4], cb[4];
-                        uint32_t ya, yb;
-                        int sa_l, sb_l;
-                        seg_fetch(q, ca, ya, sa_l);
-                        seg_fetch(q + 1u, cb, yb, sb_l);
-                        seg_apply(ca, ya, sa_l);
-                        seg_apply(cb, yb, sb_l);
-                    }
-                    if (q < take) {
-                        float ca[4];
-                        uint32_t ya;
-                        int sa_l;
-                        seg_fetch(q, ca, ya, sa_l);
-                        seg_apply(ca, ya, sa_l);
-                    }
+                    em &= em - 1ull;
                 }
+                lds_st_u16(lds_addr(&F.lanest[lane]) + 2u, (uint16_t)done);
+                next_seg = sa + take;
                 sa += take;
                 remaining -= take;
             }
@@ -1115,6 +1150,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             for (int k = 0; k < 4; k++) rgba[k] = over(rgba[k], fg, area[k]);
         }
     }
+    if constexpr (AA == 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no window may still be in flight to this wave's LDS when it ends
     // fine.wgsl:1092-1102: un-premultiply, store RGBA16F (four adjacent pixels = 32 bytes per lane; 4 lanes = one 128-B row)
     const uint32_t cx0 = tile_x * 16u + lx * 4u;
     const uint32_t cy = tile_y * 16u + ly;

@@ -16,8 +16,10 @@ class HostLibraryMissing(RuntimeError):
 
 
 def lib_paths():
+    # JELLO_HIP_LIB: an experiment library built with `make -C jello_amd/csrc VARIANT=...` (tools/ only; the tests and
+    # bench.py's default run never set it)
     return {
-        "hip": os.path.join(_HERE, "libjello_hip.so"),
+        "hip": os.environ.get("JELLO_HIP_LIB") or os.path.join(_HERE, "libjello_hip.so"),
         "host": os.path.join(_HERE, "libjello_host.so"),
     }
 

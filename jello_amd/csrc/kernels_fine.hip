@@ -228,6 +228,15 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #define FINE_WAVES 2
 #endif
 #define FB_PLANE 65
+// FINE_SKIP (differential builds, `make VARIANT=... EXTRA=-DFINE_SKIP=n`; results are WRONG, only counters and times of
+// such a library are of interest -- tools/fine_split.sh): 1 no crossing-pixel formula (stage 3), 2 no row walk / y_edge
+// terms (stage 4), 3 no pair evaluation (stages 2 + 3), 4 no batches at all, 5 no compositing of solid colours
+#ifndef FINE_SKIP
+#define FINE_SKIP 0
+#endif
+#if FINE_SKIP != 0 && !defined(JH_VARIANT_BUILD)
+#error "FINE_SKIP changes results: build it as a variant library (make VARIANT=name EXTRA='-DJH_VARIANT_BUILD -DFINE_SKIP=n')"
+#endif
 #define FINE_TRIP_WORDS 13u  // PTCL words one trip of the command loop may consume
 // Everything a batch leaves behind for stage 4 lives in LDS, not in registers: the command loop then carries no per-lane
 // batch state around its back edge (as registers the nine values cost ~30 moves per command: the compiler keeps a second
@@ -242,10 +251,10 @@ struct FillLds {
     float2 edge[64];               // window segments: y_edge, sign(dx)  (read by stage 4 at a uniform index: a broadcast)
     uint64_t rowmask[16];          // per pixel row: bit j = pair j of the batch lies in this row
     uint32_t lanest[64];           // lane = pixel quad: LDS address of my row's first entry (my quad of it) | entries consumed << 16
-    uint8_t first[68];             // first pair of window segment s (segments behind the batch and [64]: the number of pairs)
+    uint8_t first[64];             // first pair of window segment s (segments behind the batch: the number of pairs)
     union {
         uint32_t pairflag[64];       // batch set-up: pair -> (window segment + 1) at the first pair of each segment, else 0
-        uint16_t speclist[FB_SPEC];  // stage 3: crossing pixels, position << 10 | pair << 4 | column
+        uint8_t specmark[FB_SPEC];   // stage 3: crossing pixel k of the pass is the first one of pair specmark[k] - 1 (0: of none)
     };
 };
 // The load is unconditional (index clamped) so that it can stay in flight as a prefetch; out-of-range segments are
@@ -623,12 +632,12 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         }
         const uint32_t my_cnt = (uint32_t)imax_(rb - ra, 0);
         const uint32_t incl = wave_incl_scan_u32(my_cnt);
-        const uint64_t fit = __builtin_amdgcn_ballot_w64(incl <= 64u);   // a prefix of the lanes (incl is monotone)
+        // (at most 63 segments and 63 pairs per batch: every "pairs / segments in front of P" mask is (1 << P) - 1 with P < 64)
+        const uint64_t fit = __builtin_amdgcn_ballot_w64(incl <= 63u) & 0x7fffffffffffffffull;  // a prefix of the lanes (incl is monotone)
         const uint32_t e_rel = (uint32_t)__builtin_popcountll(fit);       // > 0: one segment has at most 16 pairs
         n_pairs = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(e_rel - 1u));
         const uint32_t first = incl - my_cnt;
         F.first[lane] = (uint8_t)(lane < e_rel ? first : n_pairs);
-        if (lane == 0u) F.first[64] = (uint8_t)n_pairs;
         // y_edge >= 16 (path_tiling's "no edge" value is 1e9) clamps to 0 for every row of the tile
         edge_mask = __builtin_amdgcn_ballot_w64(c_ye < 16.0f) & fit;
         const uint32_t meta = first | ((uint32_t)ra << 8) | (sane ? (1u << 16) : 0u);
@@ -658,7 +667,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         //   pixels X <  floor(xmin0 - 1e-3) have fl(xmin0_g - i) >= 1, i.e. a == +0 exactly: they contribute +-0,
         // and everything in between takes the full formula in stage 3 (which reproduces a == 1 / a == +0 by itself
         // where the margin was not needed).
-        const bool is_pair = lane < n_pairs;
+        const bool is_pair = FINE_SKIP == 3 ? false : lane < n_pairs;
         const uint32_t row = is_pair ? ((((pmeta >> 8) & 31u) + (lane - (pmeta & 0xffu))) & 15u) : 0u;
         const float y = p0y - (float)row;
         const float y0 = clamp_(y, 0.0f, 1.0f);
@@ -699,31 +708,32 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         }
         const uint32_t sincl = wave_incl_scan_u32(ncross);
         const uint32_t spos = sincl - ncross;
-        const uint32_t nspec = (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
-        // stage 3, in passes of FB_SPEC crossing pixels (one pass unless the batch is full of long flat segments)
+        const uint32_t nspec = (FINE_SKIP == 1 || FINE_SKIP == 3) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
+        // stage 3, lane = crossing pixel, in passes of FB_SPEC of them (one pass unless the batch is full of long flat
+        // segments).  Crossing pixel k of the batch belongs to the last pair whose first crossing pixel (spos) is <= k:
+        // the pairs mark their starts in a byte array, a running maximum over the lanes turns the marks into owners.
+        const uint32_t packed = (uint32_t)n0 | (pos << 4) | (spos << 10);
         for (uint32_t pass = 0u; pass < nspec; pass += FB_SPEC) {
-            wave_sync();  // (the entries above / the previous pass's list reads are done)
-            {
-                uint32_t code = (pos << 10) | (lane << 4) | (uint32_t)n0;
-                uint32_t k = spos - pass;
-#pragma clang loop unroll(disable)
-                for (uint32_t t = 0u; t < ncross; t++, k++, code++) {
-                    if (k < FB_SPEC) F.speclist[k] = (uint16_t)code;
-                }
-            }
+            wave_sync();  // (the entries above / the previous pass's mark reads are done)
+            ((uint16_t*)F.specmark)[lane] = 0u;
             wave_sync();
+            if (ncross != 0u && spos - pass < FB_SPEC) F.specmark[spos - pass] = (uint8_t)(lane + 1u);
+            wave_sync();
+            // the pair the first position of the pass belongs to when it does not start there
+            const uint64_t before = __builtin_amdgcn_ballot_w64(ncross != 0u && spos < pass);
+            uint32_t carry = before != 0ull ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
             const uint32_t n_here = umin_(nspec - pass, FB_SPEC);
             for (uint32_t k0 = 0u; k0 < n_here; k0 += 64u) {
-                const uint32_t k = k0 + lane;
-                uint32_t j = 0u, X = 0u, epos = 0u;
-                if (k < n_here) {
-                    const uint32_t e = F.speclist[k];
-                    epos = e >> 10; j = (e >> 4) & 63u; X = e & 15u;
-                }
+                const uint32_t own = umax_(wave_incl_max_u32(F.specmark[k0 + lane]), carry);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)own, 63);
+                const uint32_t j = (own - 1u) & 63u;
                 // the pair lane's y-part results
                 const float dy = __shfl(s2_dy, (int)j, 64), tx0 = __shfl(s2_tx0, (int)j, 64), tx1 = __shfl(s2_tx1, (int)j, 64);
                 const float q0x = __shfl(p0x, (int)j, 64);
-                if (k < n_here) {
+                const uint32_t pk = __shfl(packed, (int)j, 64);
+                if (k0 + lane < n_here) {
+                    const uint32_t X = ((pk & 15u) + (pass + k0 + lane - (pk >> 10))) & 15u;
+                    const uint32_t epos = (pk >> 4) & 63u;
                     const uint32_t g = X >> 2;
                     const float i_f = (float)(X & 3u);
                     const float startx = q0x - (float)(4u * g);
@@ -827,48 +837,68 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             for (int k = 0; k < 4; k++) area[k] = backdrop_f;
             uint32_t sa = seg_data, remaining = n_segs;
             while (remaining != 0u) {  // uniform
+#if FINE_SKIP == 4
+                batch_hi = sa + remaining;
+                cur_base = sa;
+#else
                 if (sa - cur_base >= batch_hi - cur_base) build_batch(sa);
+#endif
                 const uint32_t take = umin_(remaining, batch_hi - sa);
                 const uint32_t r0 = sa - cur_base;  // window-relative segments [r0, r0 + take)
-                auto below = [](uint32_t P) -> uint64_t { return P >= 64u ? ~0ull : ((1ull << P) - 1ull); };
+                auto below = [](uint32_t P) -> uint64_t { return (1ull << (P & 63u)) - 1ull; };  // P <= 63
                 // stage 4, lane = pixel quad of row ly: the entries of my row are in segment order, so the terms of the WGSL's
                 // loop that can change my sum -- a*dy of the segments with a pair in my row -- are added in its order by
                 // walking my row's list; a segment with a y_edge term (uniform: a bit of edge_mask) ends a run of such
                 // additions for all rows, the term is added, and the walk goes on behind it.
                 const uint64_t my_rowmask = F.rowmask[ly];
                 const uint32_t st = F.lanest[lane];
+                const uint32_t my_first = F.first[lane];  // lane = window segment: read off with v_readlane below
+                auto first_of = [&](uint32_t sl) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)my_first, (int)(sl & 63u)); };
                 const uint32_t row_addr = st & 0xffffu;
                 uint32_t done = st >> 16;  // entries of my row consumed so far
-                if (sa != next_seg) done = (uint32_t)__builtin_popcountll(my_rowmask & below(uni(F.first[r0])));  // (a fill that does not continue the previous one)
+                if (sa != next_seg) done = (uint32_t)__builtin_popcountll(my_rowmask & below(first_of(r0)));  // (a fill that does not continue the previous one)
                 uint32_t cur = row_addr + done * 16u;
                 uint64_t em = edge_mask & (below(r0 + take) & ~below(r0));
-                for (;;) {  // uniform
+                for (; FINE_SKIP != 2 && FINE_SKIP != 4;) {  // uniform
                     const uint32_t e_sl = em != 0ull ? (uint32_t)__builtin_ctzll(em) : 0u;
                     const uint32_t seg_end = em != 0ull ? e_sl + 1u : r0 + take;  // the run covers window segments < seg_end
-                    done = (uint32_t)__builtin_popcountll(my_rowmask & below(uni(F.first[seg_end])));
+                    done = (uint32_t)__builtin_popcountll(my_rowmask & below(first_of(seg_end)));
                     const uint32_t hi = row_addr + done * 16u;
-                    // Walk my row's entries [cur, hi): lanes drop out of EXEC as their rows run out (no lane comes back inside
-                    // a run), the loop ends when none is left.  Written in assembly: as C++ the compiler keeps two copies of the
-                    // area registers around this loop (four moves per trip) and cannot mask the loads.
+                    // Walk my row's entries [cur, hi), two per trip (both loads in flight before the ordered adds): lanes drop
+                    // out of EXEC as their rows run out (no lane comes back inside a run), the loop ends when none is left.
+                    // Written in assembly: as C++ the compiler keeps two copies of the area registers around this loop (four
+                    // moves per trip) and cannot mask the loads (lanes reading a dummy entry collide with the live ones).
                     {
                         jk_v2f a01 = {area[0], area[1]}, a23 = {area[2], area[3]};
-                        uint64_t sv;
+                        uint64_t sv, s1;
+                        uint32_t t;
                         asm volatile(
                             "s_mov_b64 %[sv], exec\n"
                             "1:\n"
                             "v_cmpx_lt_u32_e32 vcc, %[cur], %[hi]\n"
-                            "s_cbranch_execz 2f\n"
-                            "ds_read_b128 v[76:79], %[cur]\n"
-                            "v_add_u32_e32 %[cur], 16, %[cur]\n"
+                            "s_cbranch_execz 3f\n"
+                            "ds_read_b128 v[72:75], %[cur]\n"
+                            "v_add_u32_e32 %[t], 16, %[cur]\n"
+                            "v_cmp_lt_u32_e32 vcc, %[t], %[hi]\n"
+                            "s_mov_b64 %[s1], exec\n"
+                            "s_and_b64 exec, exec, vcc\n"
+                            "ds_read_b128 v[76:79], %[cur] offset:16\n"
+                            "s_mov_b64 exec, %[s1]\n"
+                            "v_add_u32_e32 %[cur], 32, %[cur]\n"
+                            "s_waitcnt lgkmcnt(1)\n"
+                            "v_pk_add_f32 %[a01], %[a01], v[72:73]\n"
+                            "v_pk_add_f32 %[a23], %[a23], v[74:75]\n"
+                            "s_and_b64 exec, exec, vcc\n"
                             "s_waitcnt lgkmcnt(0)\n"
                             "v_pk_add_f32 %[a01], %[a01], v[76:77]\n"
                             "v_pk_add_f32 %[a23], %[a23], v[78:79]\n"
+                            "s_mov_b64 exec, %[s1]\n"
                             "s_branch 1b\n"
-                            "2:\n"
+                            "3:\n"
                             "s_mov_b64 exec, %[sv]\n"
-                            : [cur] "+v"(cur), [a01] "+v"(a01), [a23] "+v"(a23), [sv] "=&s"(sv)
+                            : [cur] "+v"(cur), [a01] "+v"(a01), [a23] "+v"(a23), [sv] "=&s"(sv), [s1] "=&s"(s1), [t] "=&v"(t)
                             : [hi] "v"(hi)
-                            : "vcc", "memory", "v76", "v77", "v78", "v79");
+                            : "vcc", "memory", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79");
                         area[0] = a01.x; area[1] = a01.y; area[2] = a23.x; area[3] = a23.y;
                     }
                     cur = hi;
@@ -1147,7 +1177,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         if (have_fg) {  // uniform
             materialize();
 #pragma unroll
-            for (int k = 0; k < 4; k++) rgba[k] = over(rgba[k], fg, area[k]);
+            for (int k = 0; k < 4; k++) rgba[k] = FINE_SKIP == 5 ? v4(rgba[k].x + area[k], rgba[k].y + fg.x, rgba[k].z + fg.y, rgba[k].w + fg.z * fg.w) : over(rgba[k], fg, area[k]);
         }
     }
     if constexpr (AA == 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no window may still be in flight to this wave's LDS when it ends

@@ -181,9 +181,11 @@ typedef float jk_v2f __attribute__((ext_vector_type(2)));
 #if defined(__HIP_DEVICE_COMPILE__)
 JD float4 lds_ld_f4(uint32_t a) { const jk_v4f v = *(const JK_LDS jk_v4f*)a; return make_float4(v.x, v.y, v.z, v.w); }
 JD void lds_st_u16(uint32_t a, uint16_t v) { *(JK_LDS uint16_t*)a = v; }
+JD float lds_ld_f32(uint32_t a) { return *(const JK_LDS float*)a; }
 #else  // (the host pass only parses the kernels)
 JD float4 lds_ld_f4(uint32_t) { return make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
 JD void lds_st_u16(uint32_t, uint16_t) {}
+JD float lds_ld_f32(uint32_t) { return 0.0f; }
 #endif
 
 // rgba = rgba * (1 - fg.a*area) + fg*area  (fine.wgsl:923-926 and the gradient/image arms)
@@ -545,7 +547,8 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
     auto& S = S_all[CLIPS ? wave_in_wg : 0u];  // (one dummy element per wave when !CLIPS: 16 bytes)
     const uint32_t tile_x = blockIdx.x * WV + wave_in_wg;
     if (tile_x >= tiles_x) return;  // tiles_x = the dispatch's x size
-    if (ptcl_n == 0u || ptcl[0] == ~0u) return;  // fine.wgsl:889-893
+    if (ptcl_n == 0u) return;
+    const uint32_t ptcl_head = ptcl[0];  // ~0: an earlier stage failed (fine.wgsl:889-893); tested once the tile's first loads are under way
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t ly = lane >> 2, lx = lane & 3u;
     const uint32_t tile_ix = tile_y * cfg->width_in_tiles + tile_x;
@@ -608,8 +611,8 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         if (nxt_base == so) {
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the window has arrived in F.pre
             wave_sync();
-            const float4 t = F.pre[lane];
-            c_p0x = t.x; c_p0y = t.y; c_p1x = t.z; c_p1y = t.w; c_ye = F.pre_ye[lane];
+            const float4 t = lds_ld_f4(lds_addr(&F.pre[lane]));  // (explicit LDS loads: merged with the other arm they become flat loads)
+            c_p0x = t.x; c_p0y = t.y; c_p1x = t.z; c_p1y = t.w; c_ye = lds_ld_f32(lds_addr(&F.pre_ye[lane]));
         } else {
             load_segraw_clamped(segments, segments_n, so + lane, c_p0x, c_p0y, c_p1x, c_p1y, c_ye);
         }
@@ -700,9 +703,12 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         F.lanest[lane] = ent_lds + __shfl(excl16, (int)ly, 64) * 16u;  // nothing consumed yet
         next_seg = so;
         if (is_pair) {
+            // pixel q contributes dy from column c1 on: clamp(q + 1 - c1, 0, 1) is exactly 1 or 0, and dy * 0 = +-0 is what the
+            // WGSL's a * dy gives left of the span (no compare + select pairs, which also need wait states)
+            const float c1f = (float)c1;
             float cv[16];
 #pragma unroll
-            for (int q = 0; q < 16; q++) cv[q] = (q >= c1) ? s2_dy : 0.0f;
+            for (int q = 0; q < 16; q++) cv[q] = clamp_((float)(q + 1) - c1f, 0.0f, 1.0f) * s2_dy;
 #pragma unroll
             for (int q = 0; q < 4; q++) F.ent[q][pos] = make_float4(cv[4 * q], cv[4 * q + 1], cv[4 * q + 2], cv[4 * q + 3]);
         }
@@ -761,6 +767,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
     };
     uint32_t wbase = pc;
     uint32_t wcur = load_win(wbase), wnext = load_win(wbase + 64u);
+    if (ptcl_head == ~0u) return;  // fine.wgsl:889-893
     auto materialize = [&]() {  // perform the pending saves of BEGIN_CLIP (fine.wgsl:938-950), outermost first
         if constexpr (CLIPS) {
             while (pushed_depth < clip_depth) {  // uniform

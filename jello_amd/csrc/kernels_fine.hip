@@ -519,7 +519,10 @@ template <> struct FineLdsSel<0> { typedef FillLds type; };
 // array (with lazy layers only layers that really draw are saved, and few of those nest three deep; all four levels in
 // LDS held the clip instantiations at 7 waves per CU).  In registers the four levels needed a four-way switch with
 // sixteen moves per case and 64 VGPRs: 219 VGPRs and ~290 VALU instructions per command.
-#define FINE_LDS_LEVELS 2u
+#ifndef FINE_LDS_LEVELS
+#define FINE_LDS_LEVELS 1u  // (two levels in LDS: 11 instead of 12 tile-waves per CU; C4 fine 1.50 instead of 1.37 ms)
+#endif
+#define FINE_SCR_LEVELS (JL_BLEND_STACK_SPLIT - FINE_LDS_LEVELS)  // levels kept in the global scratch array
 template <bool CLIPS> struct FineStackSel { struct type { float4 lvl[FINE_LDS_LEVELS][4][64]; }; };
 template <> struct FineStackSel<false> { struct type { float4 lvl[1][1][1]; }; };
 
@@ -775,7 +778,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
 #pragma unroll
                     for (int k = 0; k < 4; k++) S.lvl[pushed_depth][k][lane] = make_float4(rgba[k].x, rgba[k].y, rgba[k].z, rgba[k].w);
                 } else if (pushed_depth < JL_BLEND_STACK_SPLIT) {
-                    float4* g = clip_scratch + (((size_t)scratch_tile * 2u + (pushed_depth - FINE_LDS_LEVELS)) * 4u) * 64u + lane;
+                    float4* g = clip_scratch + (((size_t)scratch_tile * FINE_SCR_LEVELS + (pushed_depth - FINE_LDS_LEVELS)) * 4u) * 64u + lane;
 #pragma unroll
                     for (int k = 0; k < 4; k++) g[k * 64] = make_float4(rgba[k].x, rgba[k].y, rgba[k].z, rgba[k].w);
                 } else {
@@ -1014,7 +1017,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                         const float4 t = S.lvl[level & (FINE_LDS_LEVELS - 1u)][k][lane];  // (written by this lane: no synchronisation)
                         bg = v4(t.x, t.y, t.z, t.w);
                     } else if (level < JL_BLEND_STACK_SPLIT) {
-                        const float4 t = clip_scratch[(((size_t)scratch_tile * 2u + (level - FINE_LDS_LEVELS)) * 4u + (uint32_t)k) * 64u + lane];
+                        const float4 t = clip_scratch[(((size_t)scratch_tile * FINE_SCR_LEVELS + (level - FINE_LDS_LEVELS)) * 4u + (uint32_t)k) * 64u + lane];
                         bg = v4(t.x, t.y, t.z, t.w);
                     } else {
                         const uint32_t spill_base = blend_offset + (level - JL_BLEND_STACK_SPLIT) * JL_TILE_WIDTH * JL_TILE_HEIGHT;
@@ -1265,7 +1268,7 @@ static int launch_fine(const JhLaunch& L, int aa) {
     if (seg_ptr == (const float*)cfg) segments_n = 0u;
     float4* clip_scratch = nullptr;
     if (clips) {  // stack levels 2 and 3 of every tile of the launch: 2 x 4 KiB each
-        clip_scratch = (float4*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)L.gx * (trow1 - trow0) * 2u * 4096u);
+        clip_scratch = (float4*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)L.gx * (trow1 - trow0) * FINE_SCR_LEVELS * 4096u);
         if (!clip_scratch) return -5;
     }
 #define JH_FINE_LAUNCH(A, C, P)                                                                                                          \

@@ -185,6 +185,11 @@ int jh_profile_collect_tree(jh_ctx* ctx, jh_profile_node* out, int max);
  * 3 acos, 4 asin, 5 |a|^(2/3), 6 a/b, 7 sqrt, 8 round-to-even, 9 u32(a), 10 i32(a), 11 f32->f16 bits,
  * 12 a*b+a (uncontracted), 13 floor(a*b+0.5), 14 min(a,b), 15 max(a,b), 16 clamp(a,0,1), 17 clamp(a*b,0,1). */
 int jh_selftest_math(jh_ctx* ctx, int op, const float* a, const float* b, float* out, uint32_t n);
+/* Fills every per-context scratch allocation (the count / offset arrays and counters of the deterministic allocators)
+ * with `byte` and forgets that any counter was left clean -- the state of freshly allocated device memory that happens
+ * not to be zero.  Tests use it to show that no stage relies on what an earlier frame (or hipMalloc) left behind, the
+ * way the reference's pooled buffers hold stale data (engine/wgpu_engine/wgpu.go:772-808). */
+int jh_debug_poison_scratch(jh_ctx* ctx, int byte);
 
 /* ---- introspection ---- */
 int jh_device_info(jh_ctx* ctx, char* name, int name_len, int* compute_units, uint64_t* total_mem);

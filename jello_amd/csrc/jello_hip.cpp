@@ -350,8 +350,23 @@ int jh_upload(jh_ctx* ctx, uint64_t id, const void* data, uint64_t size) {
     Alloc* a;
     int rc = buffer_get_or_create(ctx, id, size, &a);
     if (rc) return rc;
-    if (size == sizeof(JlConfig)) std::memcpy(&ctx->config_shadow[id], data, sizeof(JlConfig));
-    else ctx->config_shadow.erase(id);
+    // The launchers pick kernel instantiations and grids from the host shadow of the ConfigUniform (clip / no-clip fine and
+    // coarse, ...), so a captured frame is only valid for the uniform it was captured with: a different uniform under the
+    // same id makes every captured graph stale (jh_graph_launch then answers JH_ERR_INVALID instead of replaying kernels
+    // that would stop at the first BEGIN_CLIP).
+    {
+        auto sh = ctx->config_shadow.find(id);
+        const bool had = sh != ctx->config_shadow.end();
+        if (size == sizeof(JlConfig)) {
+            if (!had || std::memcmp(&sh->second, data, sizeof(JlConfig)) != 0) {
+                if (had) ctx->generation++;
+                std::memcpy(&ctx->config_shadow[id], data, sizeof(JlConfig));
+            }
+        } else if (had) {
+            ctx->config_shadow.erase(sh);
+            ctx->generation++;
+        }
+    }
     if (size) {
         // The host slice is only valid for the duration of the call (reference: queue.WriteBuffer copies, wgpu.go:360):
         // it is copied into the pinned arena here and the DMA is left in flight -- no stream synchronisation per upload.
@@ -372,7 +387,7 @@ int jh_clear(jh_ctx* ctx, uint64_t id, uint64_t offset, int64_t size) {
     uint64_t n = size < 0 ? a.size - offset : (uint64_t)size;
     if (offset + n > a.size) n = a.size - offset;
     if (n) HIP_TRY(ctx, hipMemsetAsync((char*)a.ptr + offset, 0, n, ctx->stream));
-    if (n && offset < sizeof(JlConfig)) ctx->config_shadow.erase(id);  // the shadow no longer describes the device copy
+    if (n && offset < sizeof(JlConfig) && ctx->config_shadow.erase(id)) ctx->generation++;  // the shadow no longer describes the device copy
     return JH_OK;
 }
 
@@ -859,6 +874,15 @@ int jh_selftest_math(jh_ctx* ctx, int op, const float* a, const float* b, float*
     (void)hipFree(da); (void)hipFree(dout);
     if (db) (void)hipFree(db);
     return rc == 0 ? JH_OK : fail(ctx, JH_ERR_DEVICE, "selftest launch failed");
+}
+
+int jh_debug_poison_scratch(jh_ctx* ctx, int byte) {
+    if (!ctx) return JH_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < JH_SCR_COUNT; i++)
+        if (ctx->scratch.ptr[i] && ctx->scratch.cap[i]) HIP_TRY(ctx, hipMemsetAsync(ctx->scratch.ptr[i], byte, ctx->scratch.cap[i], ctx->stream));
+    ctx->scratch.clean_flags = 0u;
+    return JH_OK;
 }
 
 int jh_device_info(jh_ctx* ctx, char* name, int name_len, int* compute_units, uint64_t* total_mem) {

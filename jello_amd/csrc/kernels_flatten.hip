@@ -1505,7 +1505,9 @@ int jh_launch_flatten(const JhLaunch& L) {
     if (!counts || !bases || !list || !counters || !tlines || !tkeys || !tinfo || !pieces || !ends) return -5;
     uint32_t* chunk_used = counters + FL_CTR_WORDS;  // one word per workgroup chunk (g <= 2048 workgroups)
     uint32_t* clean = jh_scratch_flags(L.scratch);
-    if ((*clean & JH_CLEAN_FL_CTR) == 0u) (void)hipMemsetAsync(counters, 0, FL_CTR_WORDS * 4 + (size_t)g * 4, L.stream);
+    // (always the whole fixed range, not this frame's g words: a later frame with more workgroups on the same, not regrown
+    // slot would otherwise read chunk_used words no frame has zeroed -- ADVICE r02)
+    if ((*clean & JH_CLEAN_FL_CTR) == 0u) (void)hipMemsetAsync(counters, 0, FL_CTR_WORDS * 4 + 2048u * 4, L.stream);
     *clean &= ~(uint32_t)JH_CLEAN_FL_CTR;
     hipLaunchKernelGGL(k_flatten_classify, dim3((L.gx + FL_CLASSIFY_TAGS - 1) / FL_CLASSIFY_TAGS), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list,
                        counters, n_slots, n_tags, g * FL_CHUNK, counts);
@@ -1532,7 +1534,7 @@ int jh_launch_flatten(const JhLaunch& L) {
 #endif
     uint32_t gb = gb64 > gb_max ? gb_max : (uint32_t)(gb64 < 1u ? 1u : gb64);
     hipLaunchKernelGGL(k_flatten_bbox, dim3(gb), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, (const uint32_t*)bases, n_slots, lines, pb,
-                       counters, FL_CTR_WORDS + g);
+                       counters, FL_CTR_WORDS + 2048u);
     *clean |= JH_CLEAN_FL_CTR;
     return 0;
 }

@@ -237,6 +237,12 @@ class Engine:
                 eng._check(eng.hip.jh_profile_group_end(eng.ctx), "profile_group_end")
         return _G()
 
+    def debug_poison_scratch(self, byte=0xA5):
+        """jh_debug_poison_scratch: scratch memory as a fresh, non-zero allocation would be (tests only)."""
+        rc = self.hip.jh_debug_poison_scratch(self.ctx, int(byte))
+        if rc != 0:
+            raise RuntimeError("jh_debug_poison_scratch failed: %d" % rc)
+
     def device_info(self):
         name = ctypes.create_string_buffer(256)
         cus, mem = ctypes.c_int(), ctypes.c_uint64()

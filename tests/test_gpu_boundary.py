@@ -126,6 +126,33 @@ def test_stale_graph_is_refused(engine):
     engine.graph_destroy(g)
 
 
+def test_graph_is_stale_after_a_different_config_uniform(engine):
+    """The launchers choose kernel instantiations (clip / no-clip fine and coarse) and grids from the host shadow of the
+    uploaded ConfigUniform at capture time: uploading a DIFFERENT uniform under the same buffer id must make the captured
+    frame stale (JH_ERR_INVALID), re-uploading the SAME bytes must not."""
+    from jello_amd.engine import CMD
+    s, p = scenes.scene_c1()
+    rec = jello_amd.Host().record(s, p)
+    engine.run(rec, RUN_UPLOADS | RUN_DISPATCHES)
+    g = engine.capture(rec)
+    engine.replay(g)
+    engine.sync()
+    cfg = [c for c in rec.commands() if c["kind"] == CMD.UPLOAD_UNIFORM][0]
+    same = np.frombuffer(cfg["data"], dtype=np.uint8).copy()
+    hip = engine.hip
+    hip.jh_upload.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+    assert hip.jh_upload(engine.ctx, cfg["buf_id"], same.ctypes.data, same.nbytes) == 0
+    engine.replay(g)  # identical uniform: still valid
+    engine.sync()
+    other = same.copy()
+    other.view(np.uint32)[10] = 3  # ConfigUniform.n_clip: the clip instantiations would be needed
+    assert hip.jh_upload(engine.ctx, cfg["buf_id"], other.ctypes.data, other.nbytes) == 0
+    assert hip.jh_graph_launch(engine.ctx, g) < 0
+    assert b"stale" in hip.jh_last_error(engine.ctx)
+    engine.graph_destroy(g)
+    engine.release(rec)
+
+
 def test_graph_replays_and_eager_frames_interleave(engine):
     """A captured frame contains no fill launches for the counters its kernels clean themselves (flatten's list counters,
     backdrop's wide-row counter): replays, and eager frames of another scene in between, must leave them clean."""

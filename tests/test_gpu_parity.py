@@ -274,3 +274,25 @@ def test_c4_full_size(engine):
     finally:
         oracle_engine.lib().oracle_set_threads(1)
     assert r["bump"]["failed"] == 0 and r["ptcl_live_words"] > 10_000_000
+
+
+def test_poisoned_scratch_and_growing_scenes(engine):
+    """The deterministic allocators keep counters in per-context scratch that a frame leaves zeroed for the next one
+    ("self-cleaning", kcommon.h JH_CLEAN_*).  Nothing may depend on what else that memory held: poison it the way a fresh
+    non-zero allocation would look, render a small scene (few workgroups touch few counters), then a larger one on the
+    same, not regrown allocations -- flatten's per-workgroup chunk counters beyond the small frame's workgroups must
+    have been zeroed all the same -- and a clip scene after a second poisoning."""
+    def sized(sp):
+        s, p = sp
+        p.bump = BumpSizes(lines=1 << 21, seg_counts=1 << 21, segments=1 << 21, tiles=1 << 21, ptcl=1 << 24, bin_data=1 << 20)
+        return s, p
+    big, small = sized(scenes.scene_c3(20000, 1024)), sized(scenes.scene_c3(300, 256))
+    compare(engine, *big)  # grows every scratch slot to the size the big scene needs
+    engine.debug_poison_scratch(0xA5)
+    compare(engine, *small)
+    r = compare(engine, *big)
+    assert r["bump"]["lines"] > 20000
+    engine.debug_poison_scratch(0xFF)
+    s, p = scenes.scene_c4(1500, 512)
+    compare(engine, s, p)
+    compare(engine, *small)

@@ -47,6 +47,11 @@ def parse_args(argv=None):
     ap.add_argument("--aa", choices=["area", "msaa8", "msaa16"], default="area", help="coverage mode of the fine stage (the headline is area)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: time only the independent renders, no image gather")
+    ap.add_argument("--gather-dst", choices=["0", "rotate"], default="0",
+                    help="N > 1: where the finished frames are collected: on rank 0 (C5 as written: one compositor GPU; its inbound "
+                         "links bound the job) or on rank (step mod N) -- consecutive gathers then use disjoint inbound links and, "
+                         "being double-buffered on two communicators, overlap each other as well as the next render")
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; the line reports the median block")
     ap.add_argument("--bands", action="store_true",
                     help="N > 1: ONE scene, every rank runs the element stages on it and coarse+fine for its band of bin rows "
                          "(strong scaling of one frame; SURVEY 8e) instead of one independent scene per rank")
@@ -136,11 +141,16 @@ def run_rank(args, world):
     cfg = rec.config
 
     gather = world > 1 and not args.no_gather and not args.bands
+    rotate = gather and args.gather_dst == "rotate"
     # output images: torch owns the device memory (double-buffered for the overlapped gather)
     outs = [torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(2 if gather else 1)]
     gathered = None
-    if gather and rank == 0:
-        gathered = [[torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(world)] for _ in range(2)]
+    gather_groups = [None, None]
+    if gather:
+        # one communicator per buffer of the double buffer: two gathers on ONE communicator run one after the other
+        gather_groups = [dist.new_group(ranks=list(range(world))) for _ in range(2)]
+        if rank == 0 or rotate:
+            gathered = [[torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(world)] for _ in range(2)]
 
     if args.bands:  # (buffers were sized by the unsharded render above; from here on this rank owns its band only)
         hb = (cfg["height_in_tiles"] + 15) // 16
@@ -150,6 +160,15 @@ def run_rank(args, world):
             eng.set_band(*sharding.band_for_rank(hb, world, rank))
     eng.run(rec, RUN_UPLOADS | RUN_DISPATCHES, outs[0].data_ptr())  # uploads scene/config; allocates every buffer
     torch.cuda.synchronize(dev)
+
+    def frame_digest(o):
+        """SHA-256 of the bump allocators and of the finished image: what a frame IS, for the replay check below."""
+        import hashlib
+        h = hashlib.sha256()
+        h.update(eng.download(rec.buffer("bumpBuf")[0], dtype=np.uint32)[:8].tobytes())
+        h.update(o.cpu().numpy().tobytes())
+        return h.hexdigest()
+    eager_digest = frame_digest(outs[0])  # an eagerly launched frame; every timed frame must reproduce it
 
     # One frame is ~45 short launches, so the dispatch-only replay of the recording is captured once into a hipGraph
     # per output buffer and the timed steps replay it.
@@ -164,7 +183,8 @@ def run_rank(args, world):
                 pending[j] = None
 
     def timed(with_gather):
-        """W warmup steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        """W warmup steps, then --blocks blocks of exactly K steps, each between barrier + synchronize on both sides and
+        each the max over ranks; returns the block times (seconds), sorted."""
         def step(i):
             k = (i & 1) if with_gather else 0
             if pending[k] is not None:
@@ -175,32 +195,46 @@ def run_rank(args, world):
             else:
                 eng.run(rec, RUN_DISPATCHES, outs[k].data_ptr())
             if with_gather:
-                _, pending[k] = sharding.gather_images(dist, outs[k], rank, world, dst=0, async_op=True, out=gathered[k] if rank == 0 else None)
+                dst = sharding.gather_dst_for_step(i, world, args.gather_dst)
+                _, pending[k] = sharding.gather_images(dist, outs[k], rank, world, dst=dst, async_op=True,
+                                                       out=gathered[k] if rank == dst else None, group=gather_groups[k])
         for i in range(args.warmup):
             step(i)
-        drain()
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
-        drain()
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        el = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        return el
+        blocks = []
+        for _ in range(max(1, args.blocks)):
+            drain()
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                step(i)
+            drain()
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            blocks.append(el)
+        return sorted(blocks)
 
-    elapsed_plain = timed(False)
-    elapsed_gather = timed(True) if gather else None
-    elapsed = elapsed_gather if gather else elapsed_plain
+    blocks_plain = timed(False)
+    blocks_gather = timed(True) if gather else None
+    blocks = blocks_gather if gather else blocks_plain
+    elapsed_plain = blocks_plain[len(blocks_plain) // 2]
+    elapsed = blocks[len(blocks) // 2]  # the median block
+    # The frames that were timed are the frame that was checked: replayed (or re-run) frames must be bit-identical to the
+    # eager one -- image and bump allocators -- or the number describes something else.
+    for k, o in enumerate(outs):
+        d = frame_digest(o)
+        if d != eager_digest:
+            raise RuntimeError("rank %d: the timed frame in output buffer %d differs from the eagerly launched frame (SHA-256 %s vs %s)"
+                               % (rank, k, d[:16], eager_digest[:16]))
 
     # Per-stage device times: the same K steps once more, eagerly, with a hipEvent pair around every stage on the
     # launch stream (events cannot be read back from inside a replayed graph).
@@ -244,9 +278,15 @@ def run_rank(args, world):
         per = elapsed / args.steps
         mode = ("bin-row bands of one scene x%d" % world) if args.bands else \
             "scene-per-gpu x%d%s" % (world, " + RCCL image gather to rank 0 (overlapped, double-buffered)" if gather else "")
+        headline = args.scene == "c3" and args.paths == 100_000 and args.size == 4096
+        metric = "Mpixels/sec fine-raster + paths/sec, 100k-path 4096^2 scene" if headline else \
+            "Mpixels/sec fine-raster + paths/sec, %s scene, %d paths, %d^2 (NOT the headline configuration)" % (args.scene, args.paths, args.size)
         result = {
-            "metric": "Mpixels/sec fine-raster + paths/sec, 100k-path 4096^2 scene", "value": round(W * H * units / per / 1e6, 2), "unit": "Mpixels/s",
+            "metric": metric, "value": round(W * H * units / per / 1e6, 2), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per * 1e3, 4), "higher_is_better": True,
+            "blocks": len(blocks), "block_ms_per_step": [round(b / args.steps * 1e3, 4) for b in blocks],
+            "block_spread": round((blocks[-1] - blocks[0]) / elapsed, 4),
+            "timed_frames_verified": "SHA-256 of image + bump allocators equals an eagerly launched frame (%s...)" % eager_digest[:16],
             "scaling": "strong" if args.bands else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, %dx%d RGBA16F target, %s AA, %s" % (what, W, H, args.aa,
                                    "one scene split into bin-row bands" if args.bands else "one independent scene per GPU"),
@@ -268,9 +308,7 @@ def run_rank(args, world):
             result["ms_per_step_no_gather"] = round(pp * 1e3, 4)
             if gather:
                 result["value_with_gather"] = result["value"]
-                result["gather"] = {"bytes_per_rank_and_frame": W * H * 8, "into": "rank 0",
-                                    "link_bound_ms": round(W * H * 8 / 76.8e9 * 1e3, 3),
-                                    "note": "each source GPU reaches rank 0 over its own xGMI link (153.6 GB/s bidirectional = 76.8 GB/s one way)"}
+                result["gather"] = sharding.gather_model(world, pp * 1e3, W * H * 8, args.gather_dst)
     for g in graphs:
         eng.graph_destroy(g)
     eng.release(rec)
@@ -299,12 +337,22 @@ def measured_copy_gbs(torch, dev):
         return None
 
 
+def fine_source_sha256():
+    """What the fine kernel is built from: the counters below are only meaningful for exactly these bytes."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels_fine.hip", "kcommon.h", "dmath.h"):
+        h.update(open(os.path.join(ROOT, "jello_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def committed_counters(args, fine_ms):
     """Counter-derived figures of the fine kernel.  Hardware counters cannot be read from inside this process, so they
     come from the committed rocprofv3 --pmc summary of THIS command (profiles/fine_counters.json, regenerated with
     tools/pmc_fine.sh) and carry the commit and workload they were measured on; null when that file does not describe
-    this workload."""
-    out = {"traffic": None, "traffic_source": None, "issue_bound_ms": None}
+    this workload OR was measured on a different kernels_fine.hip (the summary records the SHA-256 of the kernel's
+    sources; a kernel that has changed since has different traffic)."""
+    out = {"traffic": None, "traffic_source": None, "valu_pipe_bound_ms": None}
     pm = os.path.join(ROOT, "profiles", "fine_counters.json" if args.scene == "c3" else "fine_counters_%s.json" % args.scene)
     if not os.path.exists(pm):
         return out
@@ -314,14 +362,22 @@ def committed_counters(args, fine_ms):
         return out
     if c.get("scene") != args.scene or c.get("paths") != args.paths or c.get("size") != args.size or c.get("aa") != args.aa:
         return out
+    if c.get("kernel_source_sha256") != fine_source_sha256():
+        out["traffic_source"] = ("profiles/%s was measured on other kernel sources (commit %s): not reported; regenerate it with "
+                                 "tools/pmc_fine.sh" % (os.path.basename(pm), c.get("commit", "?")))
+        return out
     out["traffic"] = c.get("hbm_bytes_per_launch")
-    out["traffic_source"] = "profiles/%s: rocprofv3 --pmc passes at commit %s (not re-measured in this run)" % (os.path.basename(pm), c.get("commit", "?"))
-    # VALU issue bound: a wave64 VALU instruction occupies its SIMD for 4 cycles (16 lanes per SIMD)
+    out["traffic_source"] = "profiles/%s: rocprofv3 --pmc passes at commit %s on these kernel sources (not re-measured in this run)" % (
+        os.path.basename(pm), c.get("commit", "?"))
+    # VALU pipe bound: gfx950's SIMDs are 32 lanes wide, a wave64 VALU instruction takes 2 cycles of its SIMD (4 for packed-f32
+    # and 64-bit operations; MI355X_MICROARCH.md) -- a floor no schedule can beat, not what one wave's dependent stream reaches
     if c.get("valu_insts_per_launch") and c.get("simds") and c.get("clock_ghz"):
-        ib = c["valu_insts_per_launch"] * 4.0 / (c["simds"] * c["clock_ghz"] * 1e9) * 1e3
-        out["issue_bound_ms"] = round(ib, 4)
-        out["issue_bound_note"] = ("%.3g VALU wave-instructions per launch x 4 cycles / (%d SIMDs x %.2f GHz); measured kernel time / bound = %.2f"
-                                   % (c["valu_insts_per_launch"], c["simds"], c["clock_ghz"], fine_ms / ib if ib > 0 else float("nan")))
+        ib = c["valu_insts_per_launch"] * 2.0 / (c["simds"] * c["clock_ghz"] * 1e9) * 1e3
+        out["valu_pipe_bound_ms"] = round(ib, 4)
+        out["valu_pipe_bound_note"] = ("%.3g VALU wave-instructions per launch x 2 cycles / (%d SIMD-32s x %.2f GHz); measured kernel time / bound = %.2f"
+                                       % (c["valu_insts_per_launch"], c["simds"], c["clock_ghz"], fine_ms / ib if ib > 0 else float("nan")))
+        out["insts_per_tile"] = {k: round(c[v] / c["tiles"], 1) for k, v in (("valu", "valu_insts_per_launch"), ("salu", "salu_insts_per_launch"),
+                                                                             ("lds", "lds_insts_per_launch")) if c.get(v) and c.get("tiles")}
     return out
 
 

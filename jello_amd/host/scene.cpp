@@ -58,15 +58,22 @@ BumpSizes Scene::bump_sizes(uint32_t width, uint32_t height) const {
     uint64_t info = 0;  // info words precede the bin data in the same buffer (resolve.go:271-276)
     for (uint32_t tag : encoding_.draw_tags) info += (tag >> 6) & 0xf;
     const uint64_t wt = (width + 15) / 16, ht = (height + 15) / 16;
-    auto cap = [](uint64_t v) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(v + v / 8 + 1024, 4096), 0xfffffff0ull); };
+    // The bounds are conservative (a path counts for every tile of its bounding box), so heavy overdraw or huge boxes can
+    // put them at many GiB although the frame would fit the reference's fixed sizes: the FIRST attempt is held to 16 x the
+    // reference constants (renderer/config.go:144-151; C3 needs 2.2 x at most) -- plus what cannot be less: the info words
+    // and the tiles' static PTCL heads -- and the regrow loop (hip_engine.cpp) covers a frame that really needs more.
+    auto cap = [](uint64_t v, uint64_t ref, uint64_t floor_) {
+        const uint64_t want = std::max<uint64_t>(v + v / 8 + 1024, 4096);
+        return (uint32_t)std::min<uint64_t>(std::min<uint64_t>(want, std::max<uint64_t>(16u * ref, floor_ + ref)), 0xfffffff0ull);
+    };
     BumpSizes b;
-    b.lines = cap(e.lines);
-    b.seg_counts = cap(e.seg_counts);
-    b.segments = cap(e.segments);
-    b.tiles = cap(tiles);
-    b.bin_data = cap(info + bins);
-    b.ptcl = cap(ptcl + wt * ht * JL_PTCL_INITIAL_ALLOC);
-    b.blend_spill = cap(blend);
+    b.lines = cap(e.lines, 1u << 21, 0);
+    b.seg_counts = cap(e.seg_counts, 1u << 21, 0);
+    b.segments = cap(e.segments, 1u << 21, 0);
+    b.tiles = cap(tiles, 1u << 21, 0);
+    b.bin_data = cap(info + bins, 1u << 18, info);
+    b.ptcl = cap(ptcl + wt * ht * JL_PTCL_INITIAL_ALLOC, 1u << 23, wt * ht * JL_PTCL_INITIAL_ALLOC);
+    b.blend_spill = cap(blend, 1u << 21, 0);
     return b;
 }
 

@@ -28,15 +28,44 @@ def band_for_rank(height_in_bins, world, rank):
     return y0, y1
 
 
-def gather_images(dist, local, rank, world, dst=0, async_op=False, out=None):
+def gather_dst_for_step(step, world, mode="0"):
+    """Destination rank of the image gather of frame `step`: "0" = always rank 0 (one compositor GPU, C5 as written),
+    "rotate" = rank (step mod world): consecutive gathers then arrive over disjoint inbound xGMI links."""
+    return int(step) % int(world) if mode == "rotate" else 0
+
+
+def gather_images(dist, local, rank, world, dst=0, async_op=False, out=None, group=None):
     """Gather every rank's finished image tensor to `dst`.  Returns (list of tensors on dst | None, work)."""
     import torch
     if world == 1:
         return [local], None
     if rank == dst and out is None:
         out = [torch.empty_like(local) for _ in range(world)]
-    work = dist.gather(local, out if rank == dst else None, dst=dst, async_op=async_op)
+    work = dist.gather(local, out if rank == dst else None, dst=dst, async_op=async_op, group=group)
     return (out if rank == dst else None), work
+
+
+XGMI_ONE_WAY_GBS = 76.8  # one xGMI link of an MI355X: 153.6 GB/s bidirectional; every GPU pair of a node has its own link
+
+
+def gather_model(world, render_ms, frame_bytes, mode="0", in_flight=2):
+    """What the wire allows for the image gather, as numbers (the job cannot be faster than this whatever the renderer does).
+
+    Every source GPU reaches the destination over its own point-to-point link, so one gather takes
+    frame_bytes / 76.8 GB/s however many sources there are.  dst = 0: the gathers of consecutive frames all end on rank 0's
+    inbound links and run one after the other: a step takes max(render, link) and the N-GPU job is at best
+    N * render / max(render, link) times one GPU.  dst = rotate: consecutive frames go to different destinations over
+    disjoint links, so the `in_flight` (= the double buffer's two) gathers that are under way at a time proceed together:
+    a step takes max(render, link / in_flight)."""
+    link_ms = frame_bytes / (XGMI_ONE_WAY_GBS * 1e9) * 1e3
+    eff = link_ms / (in_flight if mode == "rotate" else 1)
+    step_ms = max(render_ms, eff)
+    return {"bytes_per_rank_and_frame": int(frame_bytes), "into": "rank (step mod N)" if mode == "rotate" else "rank 0",
+            "link_bound_ms": round(link_ms, 3), "link_ms_per_step": round(eff, 3), "render_ms": round(render_ms, 4),
+            "ceiling_speedup": round(world * render_ms / step_ms, 2),
+            "ceiling_speedup_note": "N * render / max(render, link time per step): what %d GPUs can reach over one GPU with this "
+                                    "gather, from the wire alone" % world,
+            "note": "each source GPU reaches the destination over its own xGMI link (153.6 GB/s bidirectional = 76.8 GB/s one way)"}
 
 
 def assemble_bands(images, height_in_bins, world):

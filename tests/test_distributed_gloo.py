@@ -64,6 +64,75 @@ def test_scene_per_rank_and_gather(built):
     assert not np.array_equal(gathered[0], gathered[1])  # the two ranks rendered different scenes
 
 
+def _rotate_worker(rank, world, port, q):
+    """bench.py's N > 1 step loop with --gather-dst rotate, on gloo: double-buffered async gathers on two communicators,
+    destination = step mod world; every destination must end up with every rank's frame of ITS steps."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from jello_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        groups = [dist.new_group(ranks=list(range(world))) for _ in range(2)]
+        outs = [torch.zeros(64, dtype=torch.int32) for _ in range(2)]
+        gathered = [[torch.zeros(64, dtype=torch.int32) for _ in range(world)] for _ in range(2)]
+        pending = [None, None]
+        got = {}
+        steps = 6
+        for i in range(steps):
+            k = i & 1
+            if pending[k] is not None:
+                pending[k][0].wait()
+                if pending[k][1] is not None:  # this rank was the destination of that step
+                    got[pending[k][1]] = [int(t[0]) for t in gathered[k]]
+                pending[k] = None
+            outs[k].fill_(100 * i + rank)  # "render" frame i of this rank
+            dst = sharding.gather_dst_for_step(i, world, "rotate")
+            _, work = sharding.gather_images(dist, outs[k], rank, world, dst=dst, async_op=True,
+                                             out=gathered[k] if rank == dst else None, group=groups[k])
+            pending[k] = (work, i if rank == dst else None)
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k][0].wait()
+                if pending[k][1] is not None:
+                    got[pending[k][1]] = [int(t[0]) for t in gathered[k]]
+        q.put((rank, got))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rotating_gather_destination_double_buffered(built):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rotate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # rank 0 collected the even steps, rank 1 the odd ones, each with both ranks' frames of that step
+    assert results[0] == {i: [100 * i, 100 * i + 1] for i in (0, 2, 4)}
+    assert results[1] == {i: [100 * i, 100 * i + 1] for i in (1, 3, 5)}
+
+
+def test_gather_model_states_the_ceiling():
+    sys.path.insert(0, ROOT)
+    from jello_amd import sharding
+    frame = 4096 * 4096 * 8
+    g0 = sharding.gather_model(8, 1.19, frame, "0")
+    gr = sharding.gather_model(8, 1.19, frame, "rotate")
+    assert abs(g0["link_bound_ms"] - 1.748) < 0.01 and g0["ceiling_speedup"] < 6.0   # one compositor GPU: wire-bound below 6x
+    assert gr["link_ms_per_step"] < 1.19 and gr["ceiling_speedup"] == 8.0             # rotating destinations: render-bound
+    assert [sharding.gather_dst_for_step(i, 4, "rotate") for i in range(6)] == [0, 1, 2, 3, 0, 1]
+    assert [sharding.gather_dst_for_step(i, 4, "0") for i in range(3)] == [0, 0, 0]
+
+
 def test_band_assignment_covers_all_bin_rows():
     sys.path.insert(0, ROOT)
     from jello_amd import sharding

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Counter summary of the fine kernel for the default bench workload (run on the GPU box):
-#   tools/pmc_fine.sh <commit-id> [bench.py args...]  ->  profiles/fine_counters.json (+ gpurun_out/ copy)
+#   tools/pmc_fine.sh <commit-id> [bench.py args...]  ->  gpurun_out/fine_counters[_<scene>].json (copy it to profiles/ to have
+#   bench.py report `roofline.traffic`: the file records the SHA-256 of the kernel sources it was measured on)
 # Separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), kernel trace only, as
 # /opt/skills/guides/MI355X_MICROARCH.md prescribes; gfx950 correction: FETCH_SIZE x 2 for wide coalesced reads.
 R="$(cd "$(dirname "$0")/.." && pwd)"
@@ -15,8 +16,11 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/g$i" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-graph "$@" > "$OUT/g$i.log" 2>&1 || tail -3 "$OUT/g$i.log"
 done
 python3 - "$OUT" "$COMMIT" "$R" "$@" <<'PY'
-import csv, glob, json, sys, collections
+import csv, glob, hashlib, json, os, sys, collections
 out, commit, root = sys.argv[1], sys.argv[2], sys.argv[3]
+h = hashlib.sha256()
+for f in ("kernels_fine.hip", "kcommon.h", "dmath.h"):
+    h.update(open(os.path.join(root, "jello_amd", "csrc", f), "rb").read())
 args = sys.argv[4:]
 def opt(name, default):
     return args[args.index(name) + 1] if name in args else default
@@ -30,13 +34,15 @@ avg = {k: sum(v) / len(v) for k, v in agg.items()}
 fetch_kb, write_kb = avg.get("FETCH_SIZE"), avg.get("WRITE_SIZE")
 j = {"kernel": "k_fine_area", "scene": scene, "paths": int(opt("--paths", 100000 if scene == "c3" else 30000)),
      "size": int(opt("--size", 4096 if scene == "c3" else 2048)), "aa": opt("--aa", "area"), "commit": commit,
+     "kernel_source_sha256": h.hexdigest(),
      "source": "rocprofv3 --kernel-trace --pmc <group> (one pass per group: FETCH_SIZE | WRITE_SIZE | SQ_* x2), averages over the launches of bench.py --steps 2 --warmup 1 --no-graph",
      "counters_avg_per_launch": {k: round(v, 1) for k, v in sorted(avg.items())},
      "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
      "hbm_bytes_per_launch": None if fetch_kb is None or write_kb is None else int(fetch_kb * 1024 * 2 + write_kb * 1024),
      "correction": "bytes = KB * 1024; gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md: wide coalesced reads are tallied at half) -- an upper bound here, the kernel mixes 4/8/16-byte-per-lane loads; WRITE_SIZE exact",
      "valu_insts_per_launch": avg.get("SQ_INSTS_VALU"), "salu_insts_per_launch": avg.get("SQ_INSTS_SALU"),
-     "lds_insts_per_launch": avg.get("SQ_INSTS_LDS"), "simds": 1024, "clock_ghz": 2.4}
+     "lds_insts_per_launch": avg.get("SQ_INSTS_LDS"), "simds": 1024, "clock_ghz": 2.4,
+     "tiles": (int(opt("--size", 4096 if scene == "c3" else 2048)) // 16) ** 2}
 name = "fine_counters.json" if scene == "c3" else "fine_counters_%s.json" % scene
 json.dump(j, open(root + "/gpurun_out/" + name, "w"), indent=1)
 print(json.dumps(j, indent=1))

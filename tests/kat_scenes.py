@@ -149,3 +149,94 @@ def check_five_blend_layers(get, cfg, bump):
 
 def check_bevel(bump):
     assert bump["lines"] == KAT["bevel_join_collinear"]["lines"] and bump["failed"] == 0
+
+
+# ---- pixel-level known answers (tests/golden/kat_pixels.json, derived by tests/fine_by_hand.py) -----------------------
+PIX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_pixels.json")))
+
+
+def px_rect_fractional_edges():
+    s = Scene()
+    s.fill(Fill.NonZero, None, Brush.solid((1.0, 0.5, 0.25, 1.0)), None, Path.rect(2.5, 3.25, 9.5, 7.75))
+    return s, RenderParams(16, 16)
+
+
+def px_translucent_over_base():
+    s = Scene()
+    s.fill(Fill.NonZero, None, Brush.solid((0.5, 0.25, 0.125, 0.5)), None, Path.rect(0, 0, 16, 16))
+    return s, RenderParams(16, 16, base_color=(0.5, 0.25, 0.125, 0.5))
+
+
+def px_linear_gradient_extend():
+    s = Scene()
+    stops = [ColorStop(0.0, (1, 0, 0, 1)), ColorStop(1.0, (0, 0, 1, 1))]
+    for (y0, y1, ext) in [(0, 5, jello_amd.Extend.Pad), (5, 10, jello_amd.Extend.Repeat), (10, 16, jello_amd.Extend.Reflect)]:
+        s.fill(Fill.NonZero, None, Brush.linear((0, 0), (8, 0), stops, ext), None, Path.rect(0, y0, 16, y1))
+    return s, RenderParams(16, 16)
+
+
+def px_blend(mix):
+    s = Scene()
+    s.push_layer(mix, Compose.SrcOver, 1.0, None, Path.rect(0, 0, 16, 16))
+    s.fill(Fill.NonZero, None, Brush.solid((0.5, 0.5, 0.25, 1.0)), None, Path.rect(0, 0, 16, 16))
+    s.pop_layer()
+    return s, RenderParams(16, 16, base_color=(0.5, 0.25, 0.75, 1.0))
+
+
+def px_msaa8_half_pixel():
+    s = Scene()
+    s.fill(Fill.NonZero, None, Brush.solid((1, 1, 1, 1)), None, Path.rect(4.5, 0, 12, 16))
+    return s, RenderParams(16, 16, aa=jello_amd.Aa.Msaa8)
+
+
+def px_eps_tangent(handle_y):
+    s = Scene()
+    p = Path().move_to(20, 20).line_to(30, 20).cubic_to(30, 20 + handle_y, 40, 20, 50, 20)
+    s.stroke(Stroke(8.0, Join.Round, 4.0, Cap.Butt, Cap.Butt), None, Brush.solid((1, 0, 0, 1)), None, p)
+    return s, RenderParams(64, 64)
+
+
+def ramp_rows(rec):
+    """The gradient ramps the recording uploads (RGBA16F, 512 texels per row), as f16 bit patterns."""
+    ups = [c for c in rec.commands() if c["kind"] == jello_amd.CMD.UPLOAD_IMAGE]
+    c = ups[0]
+    return np.frombuffer(c["data"], np.uint16).reshape(c["img_h"], c["img_w"], 4)
+
+
+def check_pixels(img, want):
+    """img: (H, W, 4) uint16 f16 bit patterns; want: {"x,y": ["0x....", x4]}"""
+    for key, px in want.items():
+        x, y = [int(v) for v in key.split(",")]
+        got = ["0x%04x" % int(v) for v in img[y, x]]
+        assert got == px, "pixel (%d,%d): got %s, by hand %s" % (x, y, got, px)
+
+
+def check_px_rect_fractional_edges(get, img, bump):
+    k = PIX["rect_fractional_edges"]
+    assert bump["failed"] == 0 and bump["lines"] == 4 and bump["segments"] == 4
+    seg = get("segmentsBuf", np.float32)[:24].reshape(4, 6)[:, :5]
+    assert [[float(v) for v in r] for r in seg] == k["segments_p0x_p0y_p1x_p1y_yedge"]
+    check_pixels(img, k["pixels_rgba16f"])
+
+
+def check_px_linear_gradient(get, img, rec):
+    k = PIX["linear_gradient_extend"]
+    info = get("infoBinDataBuf", np.uint32)
+    for i in range(3):  # draw_leaf.wgsl: line_x, line_y, line_c behind the flags word of each gradient
+        assert ["0x%08x" % int(v) for v in info[4 * i + 1:4 * i + 4]] == k["info_line_x_line_y_line_c"], i
+    ramp = ramp_rows(rec)
+    for key, x in k["ramp_x"].items():
+        gx, gy = [int(v) for v in key.split(",")]
+        # opaque texels over a transparent base: the pixel IS the texel (rgba = 0 * (1 - a) + texel, a_inv = 1)
+        assert [int(v) for v in img[gy, gx]] == [int(v) for v in ramp[0, x]], (key, x)
+    assert [int(v) for v in ramp[0, 0]] == [0x3c00, 0, 0, 0x3c00] and [int(v) for v in ramp[0, 511]] == [0, 0, 0x3c00, 0x3c00]
+
+
+def check_px_eps_tangent_join(get, bump):
+    k = PIX["eps_tangent_round_join"]
+    n = bump["lines"]
+    lines = get("linesBuf", np.float32)[:n * 6].reshape(-1, 6)[:, 2:]
+    assert [float(v) for v in lines[2][:2]] == k["arc_begin"] and [float(v) for v in lines[4][2:]] == k["arc_end"]
+    assert [float(v) for v in lines[5]] == k["other_side_line"]
+    for i, want in enumerate(k["arc_interior_points_approx"]):
+        assert np.allclose(lines[2 + i][2:], want, atol=2e-4) and np.allclose(lines[3 + i][:2], want, atol=2e-4)

@@ -85,3 +85,69 @@ def test_bevel_join_between_collinear_segments(engine):
         K.check_bevel(bump)
     finally:
         engine.release(rec)
+
+
+# ---- pixel-level known answers (tests/golden/kat_pixels.json): the HIP image itself, not a comparison with the oracle ----
+def run_gpu_image(engine, scene_params):
+    get, rec, bump = run_gpu(engine, scene_params)
+    t = rec.target
+    return get, engine.download_image(t["id"], t["width"], t["height"]), rec, bump
+
+
+def test_px_rect_fractional_edges(engine):
+    get, img, rec, bump = run_gpu_image(engine, K.px_rect_fractional_edges())
+    try:
+        K.check_px_rect_fractional_edges(get, img, bump)
+    finally:
+        engine.release(rec)
+
+
+def test_px_translucent_over_base(engine):
+    get, img, rec, bump = run_gpu_image(engine, K.px_translucent_over_base())
+    try:
+        k = K.PIX["translucent_over_base"]
+        assert ["0x%08x" % int(v) for v in get("ptclBuf", np.uint32)[1:8]] == k["ptcl_words_1_to_7"]
+        K.check_pixels(img, k["pixels_rgba16f"])
+    finally:
+        engine.release(rec)
+
+
+def test_px_linear_gradient_extend_modes(engine):
+    get, img, rec, bump = run_gpu_image(engine, K.px_linear_gradient_extend())
+    try:
+        K.check_px_linear_gradient(get, img, rec)
+    finally:
+        engine.release(rec)
+
+
+@pytest.mark.parametrize("mix", ["multiply", "luminosity"])
+def test_px_end_clip_blend(engine, mix):
+    get, img, rec, bump = run_gpu_image(engine, K.px_blend({"multiply": jello_amd.Mix.Multiply, "luminosity": jello_amd.Mix.Luminosity}[mix]))
+    try:
+        K.check_pixels(img, K.PIX["blend_" + mix]["pixels_rgba16f"])
+    finally:
+        engine.release(rec)
+
+
+def test_px_msaa8_half_pixel(engine):
+    get, img, rec, bump = run_gpu_image(engine, K.px_msaa8_half_pixel())
+    try:
+        K.check_pixels(img, K.PIX["msaa8_half_pixel"]["pixels_rgba16f"])
+    finally:
+        engine.release(rec)
+
+
+def test_px_eps_tangent_rule_at_a_round_join(engine):
+    get, rec, bump = run_gpu(engine, K.px_eps_tangent(1e-4))
+    try:
+        K.check_px_eps_tangent_join(get, bump)
+    finally:
+        engine.release(rec)
+    get, rec, bump = run_gpu(engine, K.px_eps_tangent(1e-7))
+    try:
+        k = K.PIX["eps_tangent_round_join"]
+        assert bump["lines"] == k["lines_when_h_is_1e-7"]
+        lines = get("linesBuf", np.float32)[:8 * 6].reshape(-1, 6)[:, 2:]
+        assert [[float(v) for v in r] for r in lines] == [[float(v) for v in r] for r in k["lines_h_1e-7"]]
+    finally:
+        engine.release(rec)

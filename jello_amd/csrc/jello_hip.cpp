@@ -51,6 +51,21 @@ struct ProfEntry {
     hipEvent_t start = nullptr, stop = nullptr;  // query only
 };
 
+// A recorded command that has not been launched yet.  Four of the recording's dispatches are 1-thread or trivially small
+// kernels in front of a stage that can do their work in passing (bbox_clear and Clear(bump) in front of flatten,
+// path_count_setup / path_tiling_setup in front of their indirect dispatches; render.go:230-237,369-374,415-420): the
+// engine holds them back until the next command and lets that stage absorb them when it is the one they were waiting for
+// (same buffers) -- or launches them as recorded before anything else happens (any other command, a download, a sync, the
+// end of a graph capture).  What every buffer holds after each command is what the recording says.
+struct Deferred {
+    bool is_clear = false;
+    int stage = -1;
+    uint32_t gx = 0, gy = 0, gz = 0;
+    std::vector<JhBound> b;
+    void* clear_ptr = nullptr;
+    uint64_t clear_bytes = 0;
+};
+
 struct JhGraph {  // a captured frame plus the resource generation it was captured against
     hipGraphExec_t exec;
     uint64_t generation;
@@ -89,7 +104,15 @@ struct jh_ctx {
     void* image_table = nullptr;
     uint64_t image_table_cap = 0;
     std::vector<JhImageDesc> image_table_host;
+    std::vector<Deferred> deferred;  // held-back commands, in recording order
 };
+
+static int flush_deferred(jh_ctx* ctx);
+#define JH_FLUSH(ctx)                              \
+    do {                                           \
+        int frc__ = flush_deferred(ctx);           \
+        if (frc__ != JH_OK) return frc__;          \
+    } while (0)
 
 static int fail(jh_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->last_error = msg;
@@ -269,6 +292,7 @@ const char* jh_last_error(jh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : 
 
 int jh_set_stream(jh_ctx* ctx, void* hip_stream) {
     if (!ctx) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
     hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     if (next != ctx->stream && ctx->staging.used) {  // uploads still in flight on the old stream read the pinned arena
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -287,6 +311,7 @@ int jh_set_band(jh_ctx* ctx, uint32_t bin_row0, uint32_t bin_row1) {
 
 int jh_sync(jh_ctx* ctx) {
     if (!ctx) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     scratch_release_retired(&ctx->scratch);
@@ -303,7 +328,8 @@ static int buffer_get_or_create(jh_ctx* ctx, uint64_t id, uint64_t size, Alloc**
             return 0;
         }
         if (!it->second.owned) return fail(ctx, JH_ERR_INVALID, "imported buffer is smaller than the requested size (the caller owns it: cannot grow)");
-        // grow: return the old allocation to the pool
+        // grow: return the old allocation to the pool (a held-back command may still refer to it: launch those first)
+        JH_FLUSH(ctx);
         ctx->pool.insert({it->second.capacity, it->second.ptr});
         ctx->buffers.erase(it);
         ctx->generation++;
@@ -327,6 +353,7 @@ int jh_buffer_create(jh_ctx* ctx, uint64_t id, uint64_t size) {
 
 int jh_buffer_import(jh_ctx* ctx, uint64_t id, void* device_ptr, uint64_t size) {
     if (!ctx || !device_ptr) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
     auto it = ctx->buffers.find(id);
     if (it != ctx->buffers.end() && it->second.owned) {
         ctx->pool.insert({it->second.capacity, it->second.ptr});
@@ -346,6 +373,7 @@ int jh_buffer_import(jh_ctx* ctx, uint64_t id, void* device_ptr, uint64_t size) 
 
 int jh_upload(jh_ctx* ctx, uint64_t id, const void* data, uint64_t size) {
     if (!ctx || (!data && size)) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Alloc* a;
     int rc = buffer_get_or_create(ctx, id, size, &a);
@@ -386,13 +414,24 @@ int jh_clear(jh_ctx* ctx, uint64_t id, uint64_t offset, int64_t size) {
     if (offset > a.size) return fail(ctx, JH_ERR_INVALID, "jh_clear: offset out of range");
     uint64_t n = size < 0 ? a.size - offset : (uint64_t)size;
     if (offset + n > a.size) n = a.size - offset;
-    if (n) HIP_TRY(ctx, hipMemsetAsync((char*)a.ptr + offset, 0, n, ctx->stream));
+    const bool bump_like = n && offset == 0 && n == a.size && a.size == sizeof(JlBump);
+    for (const Deferred& d : ctx->deferred)
+        if (!(bump_like && !d.is_clear && d.stage == JH_BBOX_CLEAR)) { JH_FLUSH(ctx); break; }
+    if (bump_like) {
+        // (the recording's Clear(bump) in front of flatten, render.go:237: flatten's first kernel does it in passing)
+        Deferred d;
+        d.is_clear = true; d.clear_ptr = a.ptr; d.clear_bytes = n;
+        ctx->deferred.push_back(d);
+    } else if (n) {
+        HIP_TRY(ctx, hipMemsetAsync((char*)a.ptr + offset, 0, n, ctx->stream));
+    }
     if (n && offset < sizeof(JlConfig) && ctx->config_shadow.erase(id)) ctx->generation++;  // the shadow no longer describes the device copy
     return JH_OK;
 }
 
 int jh_download(jh_ctx* ctx, uint64_t id, void* dst, uint64_t offset, uint64_t size) {
     if (!ctx || !dst) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     auto it = ctx->buffers.find(id);
     if (it == ctx->buffers.end()) return fail(ctx, JH_ERR_INVALID, "jh_download: unknown buffer id");
@@ -404,6 +443,7 @@ int jh_download(jh_ctx* ctx, uint64_t id, void* dst, uint64_t offset, uint64_t s
 
 int jh_free(jh_ctx* ctx, uint64_t id) {
     if (!ctx) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
     auto it = ctx->buffers.find(id);
     if (it == ctx->buffers.end()) return JH_OK;  // the reference ignores frees of unknown ids (wgpu.go:601-603)
     if (it->second.owned) {
@@ -444,6 +484,7 @@ int jh_image_create(jh_ctx* ctx, uint64_t id, uint32_t width, uint32_t height, i
     auto it = ctx->images.find(id);
     if (it != ctx->images.end()) {
         if (it->second.width == width && it->second.height == height && it->second.format == format) return JH_OK;
+        JH_FLUSH(ctx);
         if (it->second.owned) ctx->pool.insert({it->second.capacity, it->second.ptr});
         ctx->images.erase(it);
         ctx->generation++;
@@ -458,6 +499,7 @@ int jh_image_create(jh_ctx* ctx, uint64_t id, uint32_t width, uint32_t height, i
 
 int jh_image_import(jh_ctx* ctx, uint64_t id, void* device_ptr, uint32_t width, uint32_t height, int format) {
     if (!ctx || !device_ptr) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
     uint64_t bpp = format_bpp(format);
     if (!bpp) return fail(ctx, JH_ERR_INVALID, "jh_image_import: bad format");
     auto it = ctx->images.find(id);
@@ -475,6 +517,7 @@ int jh_image_import(jh_ctx* ctx, uint64_t id, void* device_ptr, uint32_t width, 
 int jh_image_upload(jh_ctx* ctx, uint64_t id, uint32_t width, uint32_t height, int format, const void* data, uint64_t size) {
     int rc = jh_image_create(ctx, id, width, height, format);
     if (rc) return rc;
+    JH_FLUSH(ctx);
     if (!data && size) return JH_ERR_INVALID;
     Alloc& a = ctx->images[id];
     if (size > a.size) size = a.size;
@@ -496,6 +539,7 @@ int jh_image_upload(jh_ctx* ctx, uint64_t id, uint32_t width, uint32_t height, i
 // packed in `data`, into the rectangle (x, y, width, height) of the image.
 int jh_image_write(jh_ctx* ctx, uint64_t id, uint32_t x, uint32_t y, uint32_t width, uint32_t height, const void* data, uint64_t size) {
     if (!ctx || (!data && size)) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     auto it = ctx->images.find(id);
     if (it == ctx->images.end()) return fail(ctx, JH_ERR_INVALID, "jh_image_write: unknown image id (create it first)");
@@ -515,6 +559,7 @@ int jh_image_write(jh_ctx* ctx, uint64_t id, uint32_t x, uint32_t y, uint32_t wi
 
 int jh_image_download(jh_ctx* ctx, uint64_t id, void* dst, uint64_t size) {
     if (!ctx || !dst) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     auto it = ctx->images.find(id);
     if (it == ctx->images.end()) return fail(ctx, JH_ERR_INVALID, "jh_image_download: unknown image id");
@@ -526,6 +571,7 @@ int jh_image_download(jh_ctx* ctx, uint64_t id, void* dst, uint64_t size) {
 
 int jh_image_free(jh_ctx* ctx, uint64_t id) {
     if (!ctx) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
     auto it = ctx->images.find(id);
     if (it == ctx->images.end()) return JH_OK;
     if (it->second.owned) {
@@ -579,6 +625,57 @@ static int resolve_bindings(jh_ctx* ctx, const jh_binding* bindings, int n, std:
     return 0;
 }
 
+static int launch_stage(int stage, const JhLaunch& L) {
+    switch (stage) {
+        case JH_PATHTAG_REDUCE: case JH_PATHTAG_REDUCE2: case JH_PATHTAG_SCAN1: case JH_PATHTAG_SCAN_SMALL: case JH_PATHTAG_SCAN_LARGE:
+            return jh_launch_pathtag(L, stage);
+        case JH_BBOX_CLEAR: return jh_launch_bbox_clear(L);
+        case JH_FLATTEN: return jh_launch_flatten(L);
+        case JH_DRAW_REDUCE: return jh_launch_draw_reduce(L);
+        case JH_DRAW_LEAF: return jh_launch_draw_leaf(L);
+        case JH_CLIP_REDUCE: return jh_launch_clip_reduce(L);
+        case JH_CLIP_LEAF: return jh_launch_clip_leaf(L);
+        case JH_BINNING: return jh_launch_binning(L);
+        case JH_TILE_ALLOC: return jh_launch_tile_alloc(L);
+        case JH_BACKDROP_DYN: return jh_launch_backdrop_dyn(L);
+        case JH_PATH_COUNT_SETUP: return jh_launch_path_count_setup(L);
+        case JH_PATH_COUNT: return jh_launch_path_count(L);
+        case JH_COARSE: return jh_launch_coarse(L);
+        case JH_PATH_TILING_SETUP: return jh_launch_path_tiling_setup(L);
+        case JH_PATH_TILING: return jh_launch_path_tiling(L);
+        case JH_FINE_AREA: return jh_launch_fine_area(L);
+        case JH_FINE_MSAA8: return jh_launch_fine_msaa(L, 8);
+        case JH_FINE_MSAA16: return jh_launch_fine_msaa(L, 16);
+        default: return -9;
+    }
+}
+
+// Launches every held-back command as recorded (see Deferred).
+static int flush_deferred(jh_ctx* ctx) {
+    if (ctx->deferred.empty()) return JH_OK;
+    std::vector<Deferred> pending;
+    pending.swap(ctx->deferred);
+    for (const Deferred& d : pending) {
+        if (d.is_clear) {
+            HIP_TRY(ctx, hipMemsetAsync(d.clear_ptr, 0, d.clear_bytes, ctx->stream));
+            continue;
+        }
+        JhLaunch L;
+        std::memset(&L, 0, sizeof L);
+        L.stream = ctx->stream;
+        L.scratch = &ctx->scratch;
+        L.gx = d.gx; L.gy = d.gy; L.gz = d.gz;
+        L.b = d.b.data();
+        L.nb = (int)d.b.size();
+        L.num_cus = ctx->num_cus;
+        L.band_row0 = ctx->band_row0;
+        L.band_row1 = ctx->band_row1;
+        int rc = launch_stage(d.stage, L);
+        if (rc) return fail(ctx, JH_ERR_INVALID, std::string("deferred stage failed: ") + jh_stage_name(d.stage));
+    }
+    return JH_OK;
+}
+
 static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uint32_t gz, const uint32_t* indirect, const jh_binding* bindings,
                            int n_bindings) {
     if (!ctx || stage < 0 || stage >= JH_STAGE_COUNT || (n_bindings && !bindings)) return JH_ERR_INVALID;
@@ -593,10 +690,46 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
         if (too_small(sc.cfg, sizeof(JlConfig)) || too_small(sc.bump, sizeof(JlBump)) || too_small(sc.indirect, 12))
             return fail(ctx, JH_ERR_INVALID, std::string("bad bindings for stage ") + jh_stage_name(stage) + ": config / bump / indirect buffer too small");
     }
+    // Hold back the small stages a following stage can absorb (see Deferred); absorb or launch what is being held.
+    const bool deferrable = stage == JH_BBOX_CLEAR || stage == JH_PATH_COUNT_SETUP || stage == JH_PATH_TILING_SETUP;
+    uint32_t absorb = 0u;
+    JhBound extra;
+    std::memset(&extra, 0, sizeof extra);
+    if (deferrable) {
+        // (only one kind of thing waits at a time, except bbox_clear + Clear(bump) in front of flatten)
+        for (const Deferred& d : ctx->deferred)
+            if (!(stage == JH_BBOX_CLEAR && d.is_clear)) { JH_FLUSH(ctx); break; }
+    } else if (!ctx->deferred.empty()) {
+        bool all = true;
+        for (const Deferred& d : ctx->deferred) {
+            bool ok = false;
+            if (stage == JH_FLATTEN && b.size() >= 6) {
+                if (d.is_clear) ok = d.clear_ptr == b[4].ptr && d.clear_bytes == b[4].size && b[4].size == sizeof(JlBump);
+                else ok = d.stage == JH_BBOX_CLEAR && d.b[0].ptr == b[0].ptr && d.b[1].ptr == b[3].ptr && d.b[1].size == b[3].size;
+            } else if (stage == JH_PATH_COUNT && indirect && b.size() >= 6) {
+                ok = !d.is_clear && d.stage == JH_PATH_COUNT_SETUP && d.b[0].ptr == b[1].ptr && d.b[1].ptr == (void*)indirect;
+            } else if (stage == JH_PATH_TILING && indirect && b.size() >= 6) {
+                ok = !d.is_clear && d.stage == JH_PATH_TILING_SETUP && d.b[0].ptr == b[0].ptr && d.b[1].ptr == (void*)indirect;
+            }
+            all = all && ok;
+        }
+        if (all) {
+            for (const Deferred& d : ctx->deferred) {
+                if (d.is_clear) absorb |= JH_ABSORB_BUMP_CLEAR;
+                else if (d.stage == JH_BBOX_CLEAR) absorb |= JH_ABSORB_BBOX_CLEAR;
+                else { absorb |= JH_ABSORB_SETUP; if (d.stage == JH_PATH_TILING_SETUP) extra = d.b[2]; }
+            }
+            ctx->deferred.clear();
+        } else {
+            JH_FLUSH(ctx);
+        }
+    }
     JhLaunch L;
     L.stream = ctx->stream;
     L.scratch = &ctx->scratch;
     L.gx = gx; L.gy = gy; L.gz = gz;
+    L.absorb = absorb;
+    L.extra = extra;
     L.b = b.data();
     L.nb = (int)b.size();
     L.images = images.data();
@@ -654,30 +787,17 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
         pe.cpu_start_ms = now_ms();
         HIP_TRY(ctx, hipEventRecord(pe.start, ctx->stream));
     }
-    switch (stage) {
-        case JH_PATHTAG_REDUCE: case JH_PATHTAG_REDUCE2: case JH_PATHTAG_SCAN1: case JH_PATHTAG_SCAN_SMALL: case JH_PATHTAG_SCAN_LARGE:
-            rc = jh_launch_pathtag(L, stage);
-            break;
-        case JH_BBOX_CLEAR: rc = jh_launch_bbox_clear(L); break;
-        case JH_FLATTEN: rc = jh_launch_flatten(L); break;
-        case JH_DRAW_REDUCE: rc = jh_launch_draw_reduce(L); break;
-        case JH_DRAW_LEAF: rc = jh_launch_draw_leaf(L); break;
-        case JH_CLIP_REDUCE: rc = jh_launch_clip_reduce(L); break;
-        case JH_CLIP_LEAF: rc = jh_launch_clip_leaf(L); break;
-        case JH_BINNING: rc = jh_launch_binning(L); break;
-        case JH_TILE_ALLOC: rc = jh_launch_tile_alloc(L); break;
-        case JH_BACKDROP_DYN: rc = jh_launch_backdrop_dyn(L); break;
-        case JH_PATH_COUNT_SETUP: rc = jh_launch_path_count_setup(L); break;
-        case JH_PATH_COUNT: rc = jh_launch_path_count(L); break;
-        case JH_COARSE: rc = jh_launch_coarse(L); break;
-        case JH_PATH_TILING_SETUP: rc = jh_launch_path_tiling_setup(L); break;
-        case JH_PATH_TILING: rc = jh_launch_path_tiling(L); break;
-        case JH_FINE_AREA: rc = jh_launch_fine_area(L); break;
-        case JH_FINE_MSAA8: rc = jh_launch_fine_msaa(L, 8); break;
-        case JH_FINE_MSAA16: rc = jh_launch_fine_msaa(L, 16); break;
-        default:
+    if (deferrable) {  // held back: launched by the stage it waits for, or as recorded by the next flush
+        Deferred d;
+        d.stage = stage; d.gx = gx; d.gy = gy; d.gz = gz; d.b = b;
+        ctx->deferred.push_back(d);
+        rc = 0;
+    } else {
+        rc = launch_stage(stage, L);
+        if (rc == -9) {
             if (ctx->profiling) { ctx->free_events.push_back(pe.start); ctx->free_events.push_back(pe.stop); }
             return fail(ctx, JH_ERR_UNSUPPORTED, std::string("stage not implemented: ") + jh_stage_name(stage));
+        }
     }
     if (ctx->profiling) {
         HIP_TRY(ctx, hipEventRecord(pe.stop, ctx->stream));
@@ -706,6 +826,7 @@ int jh_dispatch_indirect(jh_ctx* ctx, int stage, uint64_t indirect_buffer_id, ui
 // ---- hipGraph capture ----
 int jh_graph_begin(jh_ctx* ctx) {
     if (!ctx) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
     if (ctx->profiling) return fail(ctx, JH_ERR_INVALID, "jh_graph_begin: disable profiling first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
@@ -716,8 +837,10 @@ int jh_graph_end(jh_ctx* ctx, void** graph_exec) {
     if (!ctx || !graph_exec) return JH_ERR_INVALID;
     *graph_exec = nullptr;
     hipGraph_t graph = nullptr;
+    const int frc = flush_deferred(ctx);  // held-back commands belong to the captured frame
     ctx->capturing = false;
     HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &graph));
+    if (frc != JH_OK) { if (graph) (void)hipGraphDestroy(graph); return frc; }
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
@@ -727,6 +850,7 @@ int jh_graph_end(jh_ctx* ctx, void** graph_exec) {
 }
 int jh_graph_launch(jh_ctx* ctx, void* graph_exec) {
     if (!ctx || !graph_exec) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
     JhGraph* g = (JhGraph*)graph_exec;
     // The graph holds raw device pointers (buffers, scratch, image table) and the kernel instantiations picked at capture
     // time: it is only valid while none of them has been freed, regrown or re-imported since.
@@ -858,6 +982,7 @@ int jh_selftest_math_launch(hipStream_t stream, int op, const float* a, const fl
 
 int jh_selftest_math(jh_ctx* ctx, int op, const float* a, const float* b, float* out, uint32_t n) {
     if (!ctx || !a || !out) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     float *da = nullptr, *db = nullptr, *dout = nullptr;
     size_t bytes = (size_t)n * 4;
@@ -878,6 +1003,7 @@ int jh_selftest_math(jh_ctx* ctx, int op, const float* a, const float* b, float*
 
 int jh_debug_poison_scratch(jh_ctx* ctx, int byte) {
     if (!ctx) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int i = 0; i < JH_SCR_COUNT; i++)
         if (ctx->scratch.ptr[i] && ctx->scratch.cap[i]) HIP_TRY(ctx, hipMemsetAsync(ctx->scratch.ptr[i], byte, ctx->scratch.cap[i], ctx->stream));

@@ -707,9 +707,23 @@ JD Seg load_seg(const Scene& s, uint32_t ix) {
 __global__ __launch_bounds__(JL_WG) void k_flatten_classify(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
                                                             Buf<JlPathBbox> path_bboxes, uint32_t* __restrict__ list,
                                                             uint32_t* __restrict__ counters, uint32_t cap, uint32_t n_tags,
-                                                            uint32_t temp_overflow_start, uint32_t* __restrict__ counts) {
+                                                            uint32_t temp_overflow_start, uint32_t* __restrict__ counts,
+                                                            uint32_t absorb, uint32_t* __restrict__ bump_words) {
     __shared__ uint32_t sh[12];
     if (blockIdx.x == 0u && threadIdx.x == 0u) counters[2] = temp_overflow_start;  // first temp slot behind the workgroup chunks
+    // Commands the engine held back for this stage (jello_hip.cpp, Deferred): bbox_clear (bbox_clear.wgsl:13-24; this kernel
+    // writes only the draw_flags / trans_ix words of the boxes, the min / max words are first used by k_flatten_bbox) and
+    // the recording's Clear(bump) (render.go:237; nothing of flatten touches bump before k_flatten_items).
+    if (absorb & JH_ABSORB_BBOX_CLEAR) {
+        const uint32_t n_clear = umin_(cfg->layout.n_path, path_bboxes.n);
+        for (uint32_t i = blockIdx.x * JL_WG + threadIdx.x; i < n_clear; i += gridDim.x * JL_WG) {
+            path_bboxes.p[i].x0 = 0x7fffffff;
+            path_bboxes.p[i].y0 = 0x7fffffff;
+            path_bboxes.p[i].x1 = (int32_t)0x80000000;
+            path_bboxes.p[i].y1 = (int32_t)0x80000000;
+        }
+    }
+    if ((absorb & JH_ABSORB_BUMP_CLEAR) && blockIdx.x == 0u && threadIdx.x < 8u) bump_words[threadIdx.x] = 0u;
     __shared__ uint32_t sh_base[2];
     Scene s;
     s.cfg = cfg; s.scene = scene; s.tag_monoids = tag_monoids;
@@ -1510,7 +1524,7 @@ int jh_launch_flatten(const JhLaunch& L) {
     if ((*clean & JH_CLEAN_FL_CTR) == 0u) (void)hipMemsetAsync(counters, 0, FL_CTR_WORDS * 4 + 2048u * 4, L.stream);
     *clean &= ~(uint32_t)JH_CLEAN_FL_CTR;
     hipLaunchKernelGGL(k_flatten_classify, dim3((L.gx + FL_CLASSIFY_TAGS - 1) / FL_CLASSIFY_TAGS), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list,
-                       counters, n_slots, n_tags, g * FL_CHUNK, counts);
+                       counters, n_slots, n_tags, g * FL_CHUNK, counts, L.absorb, (uint32_t*)bump);
     hipLaunchKernelGGL(k_flatten_items, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, (const uint32_t*)list, counters, n_slots, counts,
                        tlines, tkeys, tcap, FL_CHUNK, tinfo, pieces, ends, chunk_used);
     int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);

@@ -365,14 +365,23 @@ JD LineSetup line_setup(const JlLineSoup& line, const Buf<JlPath>& paths) {
 __global__ __launch_bounds__(JL_WG) void k_pc_count(const JlBump* __restrict__ bump, const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines,
                                                     Buf<JlPath> paths, uint32_t* __restrict__ counts, uint32_t counts_n,
                                                     uint32_t* __restrict__ zero, uint32_t zero_n, uint32_t* __restrict__ line_path,
-                                                    unsigned long long* __restrict__ bd_ctr) {
+                                                    unsigned long long* __restrict__ bd_ctr,
+                                                    JlIndirectCount* __restrict__ setup_out) {  // != nullptr: path_count_setup was held back (jello_hip.cpp,
+                                                                                                // Deferred): this kernel does its work (path_count_setup.wgsl:17-27)
     // (the path ranges, the gate and the dense-tile counter of the later passes start from zero: cleared here, this
     // kernel does not use them, instead of by a separate fill launch; likewise the wide-row counter of the backdrop
     // stage that follows: kcommon.h, JH_CLEAN_*)
     for (uint32_t i = blockIdx.x * JL_WG + threadIdx.x; i < zero_n; i += gridDim.x * JL_WG) zero[i] = 0u;
     if (blockIdx.x == 0u && threadIdx.x == 0u) *bd_ctr = 0ull;
     uint32_t n_lines = umin_(bump->lines, counts_n);
-    uint32_t n_threads = umin_(ind->x * JL_WG, counts_n);
+    uint32_t ind_x;
+    if (setup_out) {  // (every thread derives the count itself; one of them also stores it for the kernels that follow)
+        ind_x = bump->failed != 0u ? 0u : (bump->lines + (JL_WG - 1u)) / JL_WG;
+        if (blockIdx.x == 0u && threadIdx.x == 0u) { setup_out->x = ind_x; setup_out->y = 1u; setup_out->z = 1u; }
+    } else {
+        ind_x = ind->x;
+    }
+    uint32_t n_threads = umin_(ind_x * JL_WG, counts_n);
     for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
         uint32_t c = 0u, pix = 0xffffffffu;
         if (gid < n_threads && lines.ok(gid)) {
@@ -878,8 +887,21 @@ __global__ __launch_bounds__(JL_WG) void k_backdrop_wide(const JlBump* __restric
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(JL_WG) void k_path_tiling(const JlBump* __restrict__ bump, const JlIndirectCount* __restrict__ ind,
                                                        Buf<JlSegmentCount> seg_counts, Buf<JlLineSoup> lines, Buf<JlPath> paths, Buf<JlTile> tiles,
-                                                       Buf<JlSegment> segments) {
-    uint32_t n_segments = umin_(bump->seg_counts, ind->x * JL_WG);
+                                                       Buf<JlSegment> segments,
+                                                       JlIndirectCount* __restrict__ setup_out, Buf<uint32_t> setup_ptcl) {  // setup_out != nullptr: path_tiling_setup
+                                                                                   // was held back: this kernel does its work (path_tiling_setup.wgsl:20-32)
+    uint32_t ind_x;
+    if (setup_out) {
+        const bool failed = bump->failed != 0u;
+        ind_x = failed ? 0u : (bump->seg_counts + (JL_WG - 1u)) / JL_WG;
+        if (blockIdx.x == 0u && threadIdx.x == 0u) {
+            setup_out->x = ind_x; setup_out->y = 1u; setup_out->z = 1u;
+            if (failed) setup_ptcl.wr(0u, ~0u);
+        }
+    } else {
+        ind_x = ind->x;
+    }
+    uint32_t n_segments = umin_(bump->seg_counts, ind_x * JL_WG);
     for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_segments; gid += gridDim.x * JL_WG) {
         JlSegmentCount sc = seg_counts.rd(gid);
         JlLineSoup line = lines.rd(sc.line_ix);
@@ -1072,7 +1094,7 @@ int jh_launch_path_count(const JhLaunch& L) {
     unsigned long long* bd_ctr = (unsigned long long*)jh_scratch_get(L.scratch, JH_SCR_BD_CTR, 64);
     if (!bd_ctr) return -5;
     hipLaunchKernelGGL(k_pc_count, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, paths, counts, lines_cap, prange,
-                       n_paths * 2u + 64u, line_path, bd_ctr);
+                       n_paths * 2u + 64u, line_path, bd_ctr, (L.absorb & JH_ABSORB_SETUP) ? (JlIndirectCount*)L.indirect : (JlIndirectCount*)nullptr);
     *jh_scratch_flags(L.scratch) |= JH_CLEAN_BD_CTR;
     int rc = jh_scan_u32(L, counts, 1, bases, lines_cap, &bump->lines, &bump->seg_counts);
     if (rc) return rc;
@@ -1130,6 +1152,7 @@ int jh_launch_path_tiling(const JhLaunch& L) {
     uint32_t g = stride_grid(L, segc.n);
     hipLaunchKernelGGL(k_path_tiling, dim3(g), dim3(JL_WG), 0, L.stream, (const JlBump*)L.b[0].ptr, (const JlIndirectCount*)L.indirect, segc,
                        mkbuf<JlLineSoup>(L.b[2].ptr, L.b[2].size), mkbuf<JlPath>(L.b[3].ptr, L.b[3].size),
-                       mkbuf<JlTile>(L.b[4].ptr, L.b[4].size), mkbuf<JlSegment>(L.b[5].ptr, L.b[5].size));
+                       mkbuf<JlTile>(L.b[4].ptr, L.b[4].size), mkbuf<JlSegment>(L.b[5].ptr, L.b[5].size),
+                       (L.absorb & JH_ABSORB_SETUP) ? (JlIndirectCount*)L.indirect : (JlIndirectCount*)nullptr, mkbuf<uint32_t>(L.extra.ptr, L.extra.size));
     return 0;
 }

@@ -37,11 +37,12 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scene", choices=["c3", "c4", "c4n", "c2"], default="c3",
+    ap.add_argument("--scene", choices=["c3", "c4", "c4n", "c2", "c1"], default="c3",
                     help="c3 = the headline scene (BASELINE.json configs[2]); c4 = configs[3]: nested clips + radial gradients + blends "
                          "(clip circles at independent positions: nearly every paint is clipped away); c4n = the same with concentric "
                          "clips and the paths inside them (visible paints); c2 = configs[1]'s SUBSTITUTE (the Ghostscript tiger is not "
-                         "available here): 300 filled / stroked blobs at 1024x1024")
+                         "available here): 300 filled / stroked blobs at 1024x1024; c1 = configs[0]: one filled rectangle + one stroked "
+                         "cubic at 512x512 (a launch-bound frame)")
     ap.add_argument("--paths", type=int, default=0, help="default: 100000 (c3) / 30000 (c4)")
     ap.add_argument("--size", type=int, default=0, help="default: 4096 (c3) / 2048 (c4)")
     ap.add_argument("--aa", choices=["area", "msaa8", "msaa16"], default="area", help="coverage mode of the fine stage (the headline is area)")
@@ -60,9 +61,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     args = ap.parse_args(argv)
     if args.paths <= 0:
-        args.paths = {"c3": 100_000, "c2": 300}.get(args.scene, 30_000)
+        args.paths = {"c3": 100_000, "c2": 300, "c1": 2}.get(args.scene, 30_000)
     if args.size <= 0:
-        args.size = {"c3": 4096, "c2": 1024}.get(args.scene, 2048)
+        args.size = {"c3": 4096, "c2": 1024, "c1": 512}.get(args.scene, 2048)
     return args
 
 
@@ -109,6 +110,11 @@ def run_rank(args, world):
     if args.scene == "c3":
         scene, params = scenes.scene_c3(args.paths, args.size, seed=sharding.scene_seed_for_rank(seed_off))
         what = "C3: %d random stroked+filled cubic Beziers" % args.paths
+    elif args.scene == "c1":
+        scene, params = scenes.scene_c1()
+        W = H = args.size = 512
+        args.paths = 2
+        what = "C1: one filled rectangle + one stroked cubic"
     elif args.scene == "c2":
         scene, params = scenes.scene_c2(args.paths, args.size, seed=scenes.SEED + 2 + seed_off)
         what = "C2 SUBSTITUTE (no Ghostscript tiger in this image): %d blobs of 3-6 cubics, filled (some even-odd) and stroked" % args.paths
@@ -419,6 +425,8 @@ def cpu_baseline(host, args):
     n, size = args.paths, args.size
     if args.scene == "c3":
         scene, params = scenes.scene_c3(n, size)
+    elif args.scene == "c1":
+        scene, params = scenes.scene_c1()
     elif args.scene == "c2":
         scene, params = scenes.scene_c2(n, size)
     elif args.scene == "c4":

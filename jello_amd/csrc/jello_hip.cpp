@@ -179,6 +179,7 @@ void* jh_scratch_get(JhScratch* s, int slot, uint64_t bytes) {
 }
 
 uint32_t* jh_scratch_flags(JhScratch* s) { return &s->clean_flags; }
+uint64_t jh_scratch_cap(JhScratch* s, int slot) { return (slot >= 0 && slot < JH_SCR_COUNT) ? s->cap[slot] : 0; }
 
 static void scratch_release_retired(JhScratch* s) {
     for (void* p : s->retired) (void)hipFree(p);

@@ -236,8 +236,9 @@ enum {  // scratch slots
 // stage's own last kernel of the frame before, or a kernel of the stage in front) instead of by a fill launch of
 // ~4.4 us; a host-side flag per counter says whether that has happened since the counter was last used.  A stage that
 // finds its flag down (first frame, an aborted frame, a stage run on its own, a scratch reallocation) fills as before.
-enum { JH_CLEAN_FL_CTR = 1u, JH_CLEAN_BD_CTR = 2u };
+enum { JH_CLEAN_FL_CTR = 1u, JH_CLEAN_BD_CTR = 2u, JH_CLEAN_SCAN = 8u };
 uint32_t* jh_scratch_flags(JhScratch* s);
+uint64_t jh_scratch_cap(JhScratch* s, int slot);  // bytes the slot holds (>= what was last asked for)
 
 // Generic device-side exclusive scan of u32 (stride in words between consecutive inputs).
 // n is read from *n_dev when n_dev != nullptr (clamped to n_max), else n_max.  Writes out[0..n) and

@@ -97,14 +97,169 @@ __global__ __launch_bounds__(JL_WG) void k_scan_apply(const uint32_t* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Single-pass scan with decoupled look-back (Merrill & Garland 2016), the form the north star asks for: ONE launch, every
+// workgroup scans a tile of LB_TILE elements and gets the sum of everything before it from the tiles in front of it.
+//   * tile ids are handed out by an atomic counter in start order, so a tile only ever waits for tiles that already run
+//     (no deadlock whatever order the hardware starts workgroups in);
+//   * a tile publishes ONE 64-bit descriptor -- value << 2 | status (1 = the tile's own sum, 2 = the inclusive prefix up
+//     to and including it) -- with a relaxed device-scope store: value and validity travel in one word, no fence;
+//   * wave 0 of the workgroup looks back 64 descriptors at a time (one per lane): the nearest INCLUSIVE one ends the
+//     look-back, every descriptor between it and the tile must be valid (else re-read), their values are summed by the wave;
+//     then the tile publishes its inclusive prefix, which lets its successors stop early;
+//   * only the tiles that hold elements take part (the element count may live on the device); the last of them to finish
+//     puts the descriptors and both counters back to zero, so the next launch (or hipGraph replay) needs no reset.
+// Round 3, C3 on MI355X (profiles/r03_scan.md): 12.8 us (2.4 M slots) and 16.6 us (3.3 M lines) per scan against 19.6 us
+// for the two launches above (kept: JH_SCAN_LOOKBACK=0); with 4 K-element tiles it LOST (20.6 / 25.8 us), and reading four
+// or eight descriptors per lane and round made it slower still.
+#ifndef JH_SCAN_LOOKBACK
+#define JH_SCAN_LOOKBACK 1
+#endif
+#ifndef LB_ITEMS
+#define LB_ITEMS 64  // elements per thread: 16 K elements per tile (fewer, larger tiles: every look-back round is a device-coherent
+#endif               // round trip of ~2 us on this 8-XCD part, and tile i needs ~i/64 of them until prefixes have spread)
+#ifndef LB_LOOK
+#define LB_LOOK 1    // descriptors per lane and look-back round
+#endif
+#define LB_TILE (JL_WG * LB_ITEMS)
+JD unsigned long long lb_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+JD void lb_store(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(JL_WG) void k_scan_lookback(const uint32_t* __restrict__ in, uint32_t stride, uint32_t* __restrict__ out, uint32_t n_max,
+                                                         const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ total_dev,
+                                                         uint32_t* __restrict__ ctrl,            // [0] next tile id, [1] tiles finished
+                                                         unsigned long long* __restrict__ desc) {
+    __shared__ uint32_t sh[8];
+    __shared__ uint32_t s_tile, s_prefix;
+    const uint32_t n = n_dev ? umin_(*n_dev, n_max) : n_max;
+    const uint32_t n_tiles = (n + LB_TILE - 1u) / LB_TILE;
+    if (n_tiles == 0u) {
+        if (blockIdx.x == 0u && threadIdx.x == 0u && total_dev) *total_dev = 0u;
+        return;
+    }
+    if (blockIdx.x >= n_tiles) return;  // (uniform per workgroup: the counters only ever see n_tiles workgroups)
+    if (threadIdx.x == 0u) s_tile = __hip_atomic_fetch_add(&ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t base = tile * LB_TILE + threadIdx.x * LB_ITEMS;
+    uint32_t v[LB_ITEMS];
+    uint32_t s = 0u;
+    if (stride == 1u && base + LB_ITEMS <= n) {
+        const uint4* p = (const uint4*)(in + base);  // (base is a multiple of 16 elements: 64-byte aligned when `in` is)
+#pragma unroll
+        for (int q = 0; q < LB_ITEMS / 4; q++) {
+            const uint4 t = p[q];
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < LB_ITEMS; i++) v[i] = base + i < n ? in[(size_t)(base + i) * stride] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < LB_ITEMS; i++) s += v[i];
+    uint32_t tot;
+    uint32_t excl = block_excl_scan_u32(s, sh, &tot);
+    if (threadIdx.x == 0u) lb_store(&desc[tile], ((unsigned long long)tot << 2) | (tile == 0u ? 2ull : 1ull));
+    if (tile != 0u && threadIdx.x < 64u) {
+        const uint32_t lane = threadIdx.x;
+        uint32_t acc = 0u;
+        int32_t first = (int32_t)tile - 1;  // the descriptor lane 0 looks at
+        for (;;) {
+            // each lane folds LB_LOOK consecutive descriptors (nearest first) into one: the sum up to and including the
+            // first inclusive prefix among them (status 2), or of all of them (status 1), or "not published yet" (0)
+            uint32_t status = 1u, val = 0u;
+            unsigned long long d[LB_LOOK];
+#pragma unroll
+            for (int q = 0; q < LB_LOOK; q++) {
+                const int32_t idx = first - (int32_t)(lane * LB_LOOK) - q;
+                d[q] = idx >= 0 ? lb_load(&desc[idx]) : 2ull;  // (in front of tile 0: an inclusive prefix of 0)
+            }
+#pragma unroll
+            for (int q = 0; q < LB_LOOK; q++) {
+                const uint32_t st = (uint32_t)d[q] & 3u;
+                if (status == 1u) {
+                    if (st == 0u) status = 0u;
+                    else { val += (uint32_t)(d[q] >> 2); status = st; }
+                }
+            }
+            const uint64_t incl = __builtin_amdgcn_ballot_w64(status == 2u);
+            const uint64_t invalid = __builtin_amdgcn_ballot_w64(status == 0u);
+            const uint32_t stop = incl != 0ull ? (uint32_t)__builtin_ctzll(incl) : 63u;  // the window is lanes 0..stop
+            const uint64_t window = stop >= 63u ? ~0ull : ((2ull << stop) - 1ull);
+            if ((invalid & window) != 0ull) { __builtin_amdgcn_s_sleep(1); continue; }  // a tile in the window has not published yet
+            acc += wave_reduce_u32(lane <= stop ? val : 0u);
+            if (incl != 0ull) break;
+            first -= 64 * LB_LOOK;
+        }
+        if (lane == 0u) {
+            s_prefix = acc;
+            lb_store(&desc[tile], ((unsigned long long)(acc + tot) << 2) | 2ull);
+        }
+    }
+    __syncthreads();
+    const uint32_t prefix = tile != 0u ? s_prefix : 0u;
+    excl += prefix;
+    if (base + LB_ITEMS <= n) {
+        uint4* q = (uint4*)(out + base);
+#pragma unroll
+        for (int i = 0; i < LB_ITEMS / 4; i++) {
+            uint4 t;
+            t.x = excl; excl += v[4 * i];
+            t.y = excl; excl += v[4 * i + 1];
+            t.z = excl; excl += v[4 * i + 2];
+            t.w = excl; excl += v[4 * i + 3];
+            q[i] = t;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < LB_ITEMS; i++) {
+            if (base + i < n) out[base + i] = excl;
+            excl += v[i];
+        }
+    }
+    if (threadIdx.x == 0u) {
+        if (tile == n_tiles - 1u && total_dev) *total_dev = prefix + tot;
+        // every tile counts itself out when nothing of it reads descriptors any more; the last one resets the state
+        const uint32_t gone = __hip_atomic_fetch_add(&ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_tile = gone + 1u == n_tiles ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_tile != 0u) {  // (uniform) the last tile to finish
+        for (uint32_t i = threadIdx.x; i < n_tiles; i += JL_WG) lb_store(&desc[i], 0ull);
+        if (threadIdx.x == 0u) {
+            __hip_atomic_store(&ctrl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctrl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 int jh_scan_u32(const JhLaunch& L, const uint32_t* in, uint32_t in_stride, uint32_t* out, uint32_t n_max, const uint32_t* n_dev,
                 uint32_t* total_dev) {
+#if JH_SCAN_LOOKBACK
+    const uint64_t max_tiles = ((uint64_t)n_max + LB_TILE - 1u) / LB_TILE;
+    // [ctrl: 256 bytes][one descriptor per tile]: zero between launches (the kernel cleans up after itself; the flag says
+    // whether that has happened since the slot was allocated)
+    char* st = (char*)jh_scratch_get(L.scratch, JH_SCR_SCAN_TMP, 256u + (max_tiles + 1u) * 8u);
+    if (!st) return -5;
+    uint32_t* clean = jh_scratch_flags(L.scratch);
+    // (the WHOLE slot: a later scan of the frame may use more descriptors of the same allocation than this one)
+    if ((*clean & JH_CLEAN_SCAN) == 0u) (void)hipMemsetAsync(st, 0, jh_scratch_cap(L.scratch, JH_SCR_SCAN_TMP), L.stream);
+    *clean |= JH_CLEAN_SCAN;
+    if (max_tiles == 0u) {
+        if (total_dev) (void)hipMemsetAsync(total_dev, 0, 4, L.stream);
+        return 0;
+    }
+    hipLaunchKernelGGL(k_scan_lookback, dim3((uint32_t)max_tiles), dim3(JL_WG), 0, L.stream, in, in_stride, out, n_max, n_dev, total_dev,
+                       (uint32_t*)st, (unsigned long long*)(st + 256));
+    return 0;
+#else
     uint32_t* block_sums = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_SCAN_TMP, (uint64_t)SCAN_G * 12);
     if (!block_sums) return -5;
     hipLaunchKernelGGL(k_scan_block_sums, dim3(SCAN_G), dim3(JL_WG), 0, L.stream, in, in_stride, n_max, n_dev, block_sums);
     hipLaunchKernelGGL(k_scan_apply, dim3(SCAN_G), dim3(JL_WG), 0, L.stream, in, in_stride, out, n_max, n_dev, (const uint32_t*)block_sums,
                        total_dev);
     return 0;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -19,6 +19,8 @@
 // with/without gradient+image code (25 VGPRs); the launcher picks by ConfigUniform.n_clip and by whether
 // any ramp/image is bound.  The kernel is latency-bound (LDS round trips, short dependent loops), so
 // occupancy matters: 88 VGPRs and 6.5 KB LDS per wave give 5 waves per SIMD for the common variant.
+#include <cstring>
+
 #include "kcommon.h"
 #include "srgb_lut.h"
 
@@ -172,6 +174,10 @@ struct FineImages {
     const JhImageDesc* table;  // all n descriptors when n > FINE_MAX_IMAGES
 };
 
+struct FineCfg {  // ConfigUniform fields of the host shadow, by value (valid = 0: read them from the device copy)
+    uint32_t valid, width_in_tiles;
+    float base_color[4];
+};
 JD uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // LDS byte addresses as integers (stage 4 of fill_path walks addresses)
 #define JK_LDS __attribute__((address_space(3)))
@@ -532,7 +538,7 @@ template <> struct FineStackSel<false> { struct type { float4 lvl[1][1][1]; }; }
 // the occupancy at 4 waves per SIMD); one for the clip instantiations, whose 22 KB per wave then pack 7 to a CU instead of 6.
 #define FINE_WG_WAVES(CLIPS) ((CLIPS) ? 1 : FINE_WAVES)
 template <int AA, bool CLIPS, bool PAINTS>
-__global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_waves_per_eu(CLIPS ? (AA != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU), CLIPS ? (AA != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU)))) void k_fine_area(const JlConfig* __restrict__ cfg, const float* __restrict__ segments, uint32_t segments_n,
+__global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_waves_per_eu(CLIPS ? (AA != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU), CLIPS ? (AA != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU)))) void k_fine_area(const JlConfig* __restrict__ cfg, FineCfg fc, const float* __restrict__ segments, uint32_t segments_n,
                                                   const uint32_t* __restrict__ ptcl, uint32_t ptcl_n, const uint32_t* __restrict__ info,
                                                   uint32_t info_n, Buf<V4> blend_spill, uint16_t* __restrict__ output, uint32_t out_w,
                                                   uint32_t out_h, const uint16_t* __restrict__ gradients, uint32_t grad_h, FineImages images,
@@ -554,13 +560,17 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
     const uint32_t ptcl_head = ptcl[0];  // ~0: an earlier stage failed (fine.wgsl:889-893); tested once the tile's first loads are under way
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t ly = lane >> 2, lx = lane & 3u;
-    const uint32_t tile_ix = tile_y * cfg->width_in_tiles + tile_x;
+    // (the two config fields fine needs travel in the kernel arguments when the host has a shadow of the uniform: a wave's
+    // first load is then its PTCL window, not a scalar load it has to wait for first)
+    const uint32_t tile_ix = tile_y * (fc.valid ? fc.width_in_tiles : cfg->width_in_tiles) + tile_x;
     const uint32_t scratch_tile = blockIdx.y * tiles_x + tile_x;  // this tile's slice of clip_scratch
     const float xyx = (float)((tile_x * 4u + lx) * 4u);  // WGSL xy.x = f32(global_id.x * 4)
     const float xyy = (float)(tile_y * 16u + ly);         // WGSL xy.y
     V4 rgba[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) rgba[k] = v4(cfg->base_color[0], cfg->base_color[1], cfg->base_color[2], cfg->base_color[3]);
+    for (int k = 0; k < 4; k++)
+        rgba[k] = fc.valid ? v4(fc.base_color[0], fc.base_color[1], fc.base_color[2], fc.base_color[3])
+                           : v4(cfg->base_color[0], cfg->base_color[1], cfg->base_color[2], cfg->base_color[3]);
     uint32_t clip_depth = 0u;
     // Lazy layers.  BEGIN_CLIP saves the colour so far and starts the layer from zero; content such as the C4 scene opens
     // hundreds of layers over a tile of which only a few draw anything there.  So the save is DEFERRED: levels
@@ -1266,13 +1276,20 @@ static int launch_fine(const JhLaunch& L, int aa) {
     if (trow1 <= trow0) return 0;
     const float* seg_ptr = (segments_n != 0u && L.b[1].ptr) ? (const float*)L.b[1].ptr : (const float*)cfg;  // see load_segraw_clamped
     if (seg_ptr == (const float*)cfg) segments_n = 0u;
+    FineCfg fc;
+    std::memset(&fc, 0, sizeof fc);
+    if (L.cfg_host) {
+        fc.valid = 1u;
+        fc.width_in_tiles = L.cfg_host->width_in_tiles;
+        for (int i = 0; i < 4; i++) fc.base_color[i] = L.cfg_host->base_color[i];
+    }
     float4* clip_scratch = nullptr;
     if (clips) {  // stack levels 2 and 3 of every tile of the launch: 2 x 4 KiB each
         clip_scratch = (float4*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)L.gx * (trow1 - trow0) * FINE_SCR_LEVELS * 4096u);
         if (!clip_scratch) return -5;
     }
 #define JH_FINE_LAUNCH(A, C, P)                                                                                                          \
-    hipLaunchKernelGGL((k_fine_area<A, C, P>), dim3((L.gx + FINE_WG_WAVES(C) - 1) / FINE_WG_WAVES(C), trow1 - trow0), dim3(64 * FINE_WG_WAVES(C)), 0, L.stream, cfg, seg_ptr, \
+    hipLaunchKernelGGL((k_fine_area<A, C, P>), dim3((L.gx + FINE_WG_WAVES(C) - 1) / FINE_WG_WAVES(C), trow1 - trow0), dim3(64 * FINE_WG_WAVES(C)), 0, L.stream, cfg, fc, seg_ptr, \
                        segments_n, (const uint32_t*)L.b[2].ptr, ptcl_n, (const uint32_t*)L.b[3].ptr, info_n, spill, (uint16_t*)out.ptr,         \
                        out.width, out.height, (const uint16_t*)grad.ptr, grad_h, imgs, L.gx, mask_lut, mask_lut_n, trow0, clip_scratch)
 #define JH_FINE_PICK(A)                                  \

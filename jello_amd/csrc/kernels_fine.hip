@@ -233,7 +233,7 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #define FINE_CLIP_MS_WAVES_PER_EU 3
 #endif
 #ifndef FINE_WAVES
-#define FINE_WAVES 2
+#define FINE_WAVES 1  // tile-waves per workgroup (round 3, C3: 0.405 ms with 1, 0.421 with 2, 0.428 with 4: the CU takes 24 one-wave workgroups)
 #endif
 #define FB_PLANE 65
 // FINE_SKIP (differential builds, `make VARIANT=... EXTRA=-DFINE_SKIP=n`; results are WRONG, only counters and times of

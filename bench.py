@@ -415,9 +415,11 @@ def stage_roofline(cfg, bump, stage_ms, rec):
 
 def cpu_baseline(host, args):
     """The CPU restatement of the Jello/Vello pipeline (oracle/) timed on the host cores of this box on a bounded
-    sample of the same workload: whole frames of the scene the GPU just rendered, on every core the process may use
-    (the stages that parallelise over independent units do; the sequential-allocation stages stay serial), median of
-    up to 5 frames within ~25 s; plus one single-thread frame."""
+    sample of the same workload: whole frames of the scene the GPU just rendered, on ALL cores the process may use
+    (BASELINE.md 3): fine over tile rows, path_tiling over crossings, and the three stages that allocate in canonical
+    order -- flatten, path_count, coarse -- as count -> scan -> write over chunks (oracle.cpp, oracle_set_parallel_alloc;
+    tests/test_oracle_parallel.py: identical buffers).  Median of up to 5 frames within ~25 s, the best thread count of a
+    short sweep; plus one single-thread frame of the serial forms."""
     import numpy as np
     from jello_amd import BumpSizes, scenes
     from oracle import oracle_engine
@@ -437,11 +439,12 @@ def cpu_baseline(host, args):
     params.aa = {"area": jello_amd.Aa.Area, "msaa8": jello_amd.Aa.Msaa8, "msaa16": jello_amd.Aa.Msaa16}[args.aa]
     params.bump = scene.bump_sizes(size, size)  # the estimator's sizes, as in the timed path
     rec = host.record(scene, params)
-    # a one-GPU box shares its host: 16 cores are this job's share (more threads than that measured slower)
-    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    L = oracle_engine.lib()
+    cores = len(os.sched_getaffinity(0))
 
-    def one(nt):
-        oracle_engine.lib().oracle_set_threads(nt)
+    def one(nt, parallel_alloc):
+        L.oracle_set_threads(nt)
+        L.oracle_set_parallel_alloc(1 if parallel_alloc else 0)
         orc = OracleEngine()
         t0 = time.perf_counter()
         orc.run(rec)
@@ -450,24 +453,32 @@ def cpu_baseline(host, args):
             raise RuntimeError("oracle bump failure in cpu_baseline")
         return dt, {k: round(v, 4) for k, v in orc.stage_seconds.items()}
 
-    runs = []
-    budget = time.perf_counter() + 25.0
-    while len(runs) < 5 and (not runs or time.perf_counter() + runs[-1][0] < budget):
-        runs.append(one(threads))
-    runs.sort(key=lambda r: r[0])
-    dt, stages = runs[len(runs) // 2]
-    one_thread = one(1)[0] if threads > 1 and dt * 12 < 60 else None
-    oracle_engine.lib().oracle_set_threads(1)
+    try:
+        # every core the job may use is the default; a short sweep guards against a thread count that is slower on this host
+        # (memory-bound stages on a many-socket box), one frame each
+        candidates = sorted({cores, max(1, cores // 2), max(1, cores // 4), min(cores, 16)}, reverse=True)
+        sweep = {nt: one(nt, True)[0] for nt in candidates}
+        threads = min(sweep, key=sweep.get)
+        runs = []
+        budget = time.perf_counter() + 20.0
+        while len(runs) < 5 and (not runs or time.perf_counter() + runs[-1][0] < budget):
+            runs.append(one(threads, True))
+        runs.sort(key=lambda r: r[0])
+        dt, stages = runs[len(runs) // 2]
+        one_thread = one(1, False)[0] if dt * 20 < 60 else None
+    finally:
+        L.oracle_set_threads(1)
+        L.oracle_set_parallel_alloc(0)
     return {"value": round(size * size / dt / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-            "sample": "CPU restatement of the Jello/Vello pipeline (oracle/; OpenMP over independent units where the stage has them: fine over "
-                      "tile rows, path_tiling over crossings; the stages that allocate in canonical order -- flatten, path_count, coarse -- "
-                      "and the small scans stay serial), %s scene with %d paths at %dx%d = the "
-                      "workload of this line, whole frames incl. fine, median of %d" % (args.scene.upper(), n, size, size, len(runs)),
+            "sample": "CPU restatement of the Jello/Vello pipeline (oracle/), every stage on %d threads (OpenMP: fine over tile rows, "
+                      "path_tiling over crossings; flatten, path_count and coarse as count -> scan -> write over chunks of their canonical "
+                      "order, buffers identical to the serial forms), %s scene with %d paths at %dx%d = the workload of this line, whole "
+                      "frames incl. fine, median of %d" % (threads, args.scene.upper(), n, size, size, len(runs)),
             "seconds": round(dt, 3), "paths_per_s": round(n / dt, 1), "runs": len(runs),
-            "stage_seconds": stages,
+            "stage_seconds": stages, "thread_sweep_seconds": {str(k): round(v, 3) for k, v in sweep.items()},
             "value_1thread": None if one_thread is None else round(size * size / one_thread / 1e6, 3),
             "seconds_1thread": None if one_thread is None else round(one_thread, 3),
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(), "cpus_available_to_this_process": cores}
 
 
 if __name__ == "__main__":

@@ -27,6 +27,24 @@
 
 #include "omath.h"
 
+// Host threads (oracle_set_threads; default 1) for the stages whose invocations are independent (path_tiling: one segment
+// record per crossing; fine: disjoint pixels per tile), and -- only when oracle_set_parallel_alloc(1) -- for the three
+// stages that ALLOCATE in canonical order (flatten: lines; path_count: segment counts; coarse: PTCL chunks, segments,
+// blend space): those then run count -> exclusive scan -> write over chunks of their canonical order, every chunk writing
+// at the offset the serial walk would have reached there, so the buffers are identical to the serial ones
+// (tests/test_oracle_parallel.py asserts it).  The parallel forms exist for bench.py's cpu_baseline ("all
+// cores"); every parity test runs the serial forms.
+static int g_oracle_threads = 1;
+static int g_oracle_parallel_alloc = 0;
+static inline void atomic_min_i32(int32_t* p, int32_t v) {
+    int32_t cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v < cur && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+static inline void atomic_max_i32(int32_t* p, int32_t v) {
+    int32_t cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > cur && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+
 using namespace om;
 
 // ---------------------------------------------------------------------------------------------
@@ -225,6 +243,7 @@ struct Ctx {
     Bump* bump;
     View<LineSoup> lines;
     float bbox[4];  // var<private> bbox (flatten.wgsl:807)
+    bool skip_bbox = false, atomic_bbox = false;  // the parallel form: count pass / write pass (see g_oracle_parallel_alloc)
     Ctx(OBuf* b) : cfg((Config*)b[0].p), scene(b[1]), tag_monoids(b[2]), path_bboxes(b[3]), bump((Bump*)b[4].p), lines(b[5]) {}
 };
 
@@ -821,11 +840,18 @@ static void invocation(Ctx& c, uint32_t ix) {
         } else {
             flatten_euler(c, pts, path_ix, transform, 0.0f, pts.p0, pts.p3);
         }
-        if ((c.bbox[2] > c.bbox[0] || c.bbox[3] > c.bbox[1]) && out) {
-            out->x0 = imin_(out->x0, to_i32(floor_(c.bbox[0])));
-            out->y0 = imin_(out->y0, to_i32(floor_(c.bbox[1])));
-            out->x1 = imax_(out->x1, to_i32(ceil_(c.bbox[2])));
-            out->y1 = imax_(out->y1, to_i32(ceil_(c.bbox[3])));
+        if ((c.bbox[2] > c.bbox[0] || c.bbox[3] > c.bbox[1]) && out && !c.skip_bbox) {
+            if (c.atomic_bbox) {  // (integer min / max: the order of the merges does not matter)
+                atomic_min_i32(&out->x0, to_i32(floor_(c.bbox[0])));
+                atomic_min_i32(&out->y0, to_i32(floor_(c.bbox[1])));
+                atomic_max_i32(&out->x1, to_i32(ceil_(c.bbox[2])));
+                atomic_max_i32(&out->y1, to_i32(ceil_(c.bbox[3])));
+            } else {
+                out->x0 = imin_(out->x0, to_i32(floor_(c.bbox[0])));
+                out->y0 = imin_(out->y0, to_i32(floor_(c.bbox[1])));
+                out->x1 = imax_(out->x1, to_i32(ceil_(c.bbox[2])));
+                out->y1 = imax_(out->y1, to_i32(ceil_(c.bbox[3])));
+            }
         }
     }
 }
@@ -833,8 +859,40 @@ static void invocation(Ctx& c, uint32_t ix) {
 
 // [config, scene, tag_monoids, path_bboxes, bump, lines]
 static void flatten(uint32_t n_wg, OBuf* b) {
-    fl::Ctx c(b);
-    for (uint32_t ix = 0; ix < n_wg * WG; ix++) fl::invocation(c, ix);
+    const uint32_t n = n_wg * WG;
+    if (!(g_oracle_parallel_alloc && g_oracle_threads > 1)) {
+        fl::Ctx c(b);
+        for (uint32_t ix = 0; ix < n; ix++) fl::invocation(c, ix);
+        return;
+    }
+    // count -> scan -> write over chunks of consecutive tag bytes
+    const uint32_t n_chunks = (uint32_t)g_oracle_threads * 16u;
+    const uint32_t len = (n + n_chunks - 1u) / n_chunks;
+    std::vector<uint32_t> first(n_chunks + 1u, 0u);
+    Bump* shared = (Bump*)b[4].p;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_oracle_threads)
+    for (uint32_t ch = 0; ch < n_chunks; ch++) {
+        fl::Ctx c(b);
+        Bump local = {};
+        c.bump = &local;
+        c.lines.n = 0;  // nothing is written
+        c.skip_bbox = true;
+        for (uint32_t ix = ch * len; ix < umin_(n, (ch + 1u) * len); ix++) fl::invocation(c, ix);
+        first[ch + 1u] = local.lines;
+    }
+    const uint32_t start = shared->lines;
+    first[0] = start;
+    for (uint32_t ch = 0; ch < n_chunks; ch++) first[ch + 1u] += first[ch];
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_oracle_threads)
+    for (uint32_t ch = 0; ch < n_chunks; ch++) {
+        fl::Ctx c(b);
+        Bump local = {};
+        local.lines = first[ch];
+        c.bump = &local;
+        c.atomic_bbox = true;
+        for (uint32_t ix = ch * len; ix < umin_(n, (ch + 1u) * len); ix++) fl::invocation(c, ix);
+    }
+    shared->lines = first[n_chunks];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1284,8 +1342,10 @@ static void path_count(uint32_t n_wg, OBuf* b) {
     View<Tile> tile(b[4]);
     View<SegmentCount> seg_counts(b[5]);
     uint32_t n_lines = bump->lines;
-    for (uint32_t gid = 0; gid < n_wg * WG; gid++) {
-        if (!(gid < n_lines)) continue;
+    // one line: `cursor` is the segment-count allocator (bump.seg_counts in the serial form); count_only = the first pass of
+    // the parallel form (how many crossings the line allocates, nothing written)
+    auto one_line = [&](uint32_t gid, uint32_t& cursor, bool count_only) {
+        if (!(gid < n_lines)) return;
         LineSoup line = lines.rd(gid);
         V2 lp0 = v2(line.p0[0], line.p0[1]), lp1 = v2(line.p1[0], line.p1[1]);
         bool is_down = lp1.y >= lp0.y;
@@ -1298,8 +1358,8 @@ static void path_count(uint32_t n_wg, OBuf* b) {
         uint32_t line_ix = gid;
         float dx = abs_(s1.x - s0.x);
         float dy = s1.y - s0.y;
-        if (dx + dy == 0.0f) continue;
-        if (dy == 0.0f && floor_(s0.y) == s0.y) continue;
+        if (dx + dy == 0.0f) return;
+        if (dy == 0.0f && floor_(s0.y) == s0.y) return;
         float idxdy = 1.0f / (dx + dy);
         float a = dx * idxdy;
         bool is_positive_slope = s1.x >= s0.x;
@@ -1317,7 +1377,7 @@ static void path_count(uint32_t n_wg, OBuf* b) {
         int32_t bbox[4] = {(int32_t)path.bbox[0], (int32_t)path.bbox[1], (int32_t)path.bbox[2], (int32_t)path.bbox[3]};
         float xmin = fmin_(s0.x, s1.x);
         int32_t stride = bbox[2] - bbox[0];
-        if (s0.y >= (float)bbox[3] || s1.y <= (float)bbox[1] || xmin >= (float)bbox[2] || stride == 0) continue;
+        if (s0.y >= (float)bbox[3] || s1.y <= (float)bbox[1] || xmin >= (float)bbox[2] || stride == 0) return;
         uint32_t imin = 0u;
         if (s0.y < (float)bbox[1]) {
             float iminf = round_(((float)bbox[1] - y0 + bb - a) / (1.0f - a)) - 1.0f;
@@ -1363,6 +1423,7 @@ static void path_count(uint32_t n_wg, OBuf* b) {
             }
         }
         imax = umax_(imin, imax);
+        if (count_only) { cursor += imax - imin; return; }
         ymin = imax_(ymin, bbox[1]);
         ymax = imin_(ymax, bbox[3]);
         for (int32_t y = ymin; y < ymax; y++) {
@@ -1370,8 +1431,8 @@ static void path_count(uint32_t n_wg, OBuf* b) {
             if (Tile* t = tile.at((size_t)(uint32_t)base)) t->backdrop += delta;
         }
         float last_z = floor_(a * ((float)imin - 1.0f) + bb);
-        uint32_t seg_base = bump->seg_counts;
-        bump->seg_counts += imax - imin;
+        uint32_t seg_base = cursor;
+        cursor += imax - imin;
         for (uint32_t i = imin; i < imax; i++) {
             uint32_t subix = i;
             float zf = a * (float)subix + bb;
@@ -1391,8 +1452,42 @@ static void path_count(uint32_t n_wg, OBuf* b) {
             if (seg_ix < cfg.seg_counts_size) seg_counts.wr(seg_ix, SegmentCount{line_ix, counts});
             last_z = z;
         }
+    };
+    const uint32_t n = n_wg * WG;
+    if (!(g_oracle_parallel_alloc && g_oracle_threads > 1)) {
+        for (uint32_t gid = 0; gid < n; gid++) one_line(gid, bump->seg_counts, false);
+        return;
     }
+    // Lines are in path order and the tiles of different paths are disjoint, so chunks of whole paths share nothing but the
+    // allocator: count -> scan -> write over such chunks.
+    const uint32_t nl = umin_(n, n_lines);
+    const uint32_t n_chunks = (uint32_t)g_oracle_threads * 16u;
+    const uint32_t len = (nl + n_chunks - 1u) / n_chunks;
+    std::vector<uint32_t> lo(n_chunks + 1u, nl), first(n_chunks + 1u, 0u);
+    for (uint32_t ch = 0; ch <= n_chunks; ch++) {
+        uint32_t p = umin_(nl, ch * len);
+        while (p > 0u && p < nl && lines.rd(p).path_ix == lines.rd(p - 1u).path_ix) p++;  // to the next path boundary
+        lo[ch] = p;
+    }
+    lo[0] = 0u;
+    for (uint32_t ch = 1; ch <= n_chunks; ch++) lo[ch] = umax_(lo[ch], lo[ch - 1u]);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_oracle_threads)
+    for (uint32_t ch = 0; ch < n_chunks; ch++) {
+        uint32_t cnt = 0u;
+        for (uint32_t gid = lo[ch]; gid < lo[ch + 1u]; gid++) one_line(gid, cnt, true);
+        first[ch + 1u] = cnt;
+    }
+    first[0] = bump->seg_counts;
+    for (uint32_t ch = 0; ch < n_chunks; ch++) first[ch + 1u] += first[ch];
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_oracle_threads)
+    for (uint32_t ch = 0; ch < n_chunks; ch++) {
+        uint32_t cursor = first[ch];
+        for (uint32_t gid = lo[ch]; gid < lo[ch + 1u]; gid++) one_line(gid, cursor, false);
+    }
+    bump->seg_counts = first[n_chunks];
 }
+
+
 
 // backdrop_dyn.wgsl:28-86 -- [config, bump, paths, tiles]
 static void backdrop_dyn(uint32_t n_wg, OBuf* b) {
@@ -1426,6 +1521,7 @@ namespace co {
 struct Ctx {
     const Config* cfg; Bump* bump; View<uint32_t> ptcl; View<Tile> tiles;
     uint32_t cmd_offset, cmd_limit;
+    bool dry = false;  // the counting pass of the parallel form: nothing is written (g_oracle_parallel_alloc)
 };
 static void alloc_cmd(Ctx& c, uint32_t size) {  // coarse.wgsl:70-88
     if (c.cmd_offset + size >= c.cmd_limit) {
@@ -1447,7 +1543,7 @@ static void write_path(Ctx& c, Tile tile, uint32_t tile_ix, uint32_t draw_flags)
     if (n_segs != 0u) {
         uint32_t seg_ix = c.bump->segments;
         c.bump->segments += n_segs;
-        if (Tile* t = c.tiles.at(tile_ix)) t->segment_count_or_ix = ~seg_ix;
+        if (!c.dry) if (Tile* t = c.tiles.at(tile_ix)) t->segment_count_or_ix = ~seg_ix;
         alloc_cmd(c, 4u);
         c.ptcl.wr(c.cmd_offset, 1u);
         bool even_odd = (draw_flags & 1u) != 0u;
@@ -1481,9 +1577,9 @@ static void coarse(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b) {
     const uint32_t BLEND_CLIP = (128u << 8) | 0u;  // MIX_CLIP<<8 | COMPOSE_SRC_OVER(=0 in Jello)
     uint32_t width_in_bins = (cfg.width_in_tiles + 15u) / 16u;
     uint32_t n_partitions = (cfg.n_drawobj + 255u) / 256u;
-    std::vector<uint32_t> drawobjs;
-    for (uint32_t wy = 0; wy < n_wg_y; wy++)
-        for (uint32_t wx = 0; wx < n_wg_x; wx++) {
+    // one bin (= one WGSL workgroup) with the allocator `bump` (the shared one in the serial form); dry = count only
+    auto one_bin = [&](uint32_t wx, uint32_t wy, Bump* bump, View<uint32_t> ptcl, bool dry) {
+            std::vector<uint32_t> drawobjs;
             uint32_t bin_ix = width_in_bins * wy + wx;
             uint32_t bin_tile_x = 16u * wx, bin_tile_y = 16u * wy;
             // merged, draw-ordered element list of this bin
@@ -1497,6 +1593,7 @@ static void coarse(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b) {
                 uint32_t tile_x = local % 16u, tile_y = local / 16u;
                 uint32_t this_tile_ix = (bin_tile_y + tile_y) * cfg.width_in_tiles + bin_tile_x + tile_x;
                 co::Ctx c{&cfg, bump, ptcl, tiles, 0, 0};
+                c.dry = dry;
                 c.cmd_offset = this_tile_ix * 64u;
                 c.cmd_limit = c.cmd_offset + (64u - 2u);
                 uint32_t clip_zero_depth = 0u, clip_depth = 0u, render_blend_depth = 0u, max_blend_depth = 0u;
@@ -1612,7 +1709,41 @@ static void coarse(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b) {
                     ptcl.wr(blend_offset, blend_ix);
                 }
             }
-        }
+    };
+    if (!(g_oracle_parallel_alloc && g_oracle_threads > 1)) {
+        for (uint32_t wy = 0; wy < n_wg_y; wy++)
+            for (uint32_t wx = 0; wx < n_wg_x; wx++) one_bin(wx, wy, bump, ptcl, false);
+        return;
+    }
+    // count -> scan -> write over the bins in their canonical (row-major) order: PTCL chunks, segments and blend space
+    const uint32_t n_bins = n_wg_x * n_wg_y;
+    std::vector<Bump> need(n_bins + 1u);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_oracle_threads)
+    for (uint32_t bi = 0; bi < n_bins; bi++) {
+        Bump local = {};
+        View<uint32_t> none = ptcl;
+        none.n = 0;  // nothing is written
+        one_bin(bi % n_wg_x, bi / n_wg_x, &local, none, true);
+        need[bi + 1u] = local;
+    }
+    need[0] = *bump;
+    for (uint32_t bi = 0; bi < n_bins; bi++) {
+        need[bi + 1u].ptcl += need[bi].ptcl;
+        need[bi + 1u].segments += need[bi].segments;
+        need[bi + 1u].blend += need[bi].blend;
+    }
+    uint32_t failed = 0u;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_oracle_threads) reduction(| : failed)
+    for (uint32_t bi = 0; bi < n_bins; bi++) {
+        Bump local = {};
+        local.ptcl = need[bi].ptcl; local.segments = need[bi].segments; local.blend = need[bi].blend;
+        one_bin(bi % n_wg_x, bi / n_wg_x, &local, ptcl, false);
+        failed |= local.failed;
+    }
+    bump->ptcl = need[n_bins].ptcl;
+    bump->segments = need[n_bins].segments;
+    bump->blend = need[n_bins].blend;
+    bump->failed |= failed;
 }
 
 // path_tiling_setup.wgsl:20-32 -- [bump, indirect, ptcl]
@@ -1625,9 +1756,6 @@ static void path_tiling_setup(OBuf* b) {
     ind->y = 1u; ind->z = 1u;
 }
 
-// Host threads for the stages whose invocations are independent (path_tiling: one segment record per crossing;
-// fine: disjoint pixels per tile).  Default 1; bench.py's cpu_baseline raises it.  Results do not depend on it.
-static int g_oracle_threads = 1;
 
 // path_tiling.wgsl:39-173 -- [bump, seg_counts, lines, paths, tiles, segments]
 static void path_tiling(uint32_t n_wg, OBuf* b) {
@@ -2090,6 +2218,7 @@ static void fill_path_ms_tile(int SAMPLES, uint32_t size_and_rule, uint32_t seg_
 }
 
 extern "C" void oracle_set_threads(int n) { g_oracle_threads = n < 1 ? 1 : n; }
+extern "C" void oracle_set_parallel_alloc(int on) { g_oracle_parallel_alloc = on != 0; }
 
 // aa = 0: analytic area (fine_area); 8 / 16: fine_msaa8 / fine_msaa16 with the mask LUT as last binding
 static void fine_area(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b, int nb, int aa = 0) {

@@ -603,7 +603,7 @@ static void flatten_euler(Ctx& c, const CubicPoints& cubic, uint32_t path_ix, co
             }
             st_pieces++;
             { uint32_t d = 0u; float q = dt; while (q < 1.0f && d < 19u) { q *= 2.0f; d++; } if (d > st_depth) st_depth = d; }
-            g_flatten_stats[2] += n_u;
+            if (!g_oracle_parallel_alloc) g_flatten_stats[2] += n_u;
             last_p = this_pq1.point;
             last_q = this_pq1.deriv;
             last_t = t1;
@@ -616,6 +616,7 @@ static void flatten_euler(Ctx& c, const CubicPoints& cubic, uint32_t path_ix, co
             dt *= 0.5f;
         }
     }
+    if (g_oracle_parallel_alloc) return;  // (the statistics below are for the serial form: shared counters)
     g_flatten_stats[0] += 1u;
     g_flatten_depth[st_depth] += 1u;
     g_flatten_stats[1] += st_attempts;

@@ -17,6 +17,8 @@ timeout -k 10 300 python3 bench.py --aa msaa8 --no-cpu-baseline > "$O/c3_msaa8_b
 timeout -k 10 300 python3 bench.py --aa msaa16 --no-cpu-baseline > "$O/c3_msaa16_bench.json" 2>/dev/null
 bash tools/pmc_fine.sh "$COMMIT" > "$O/pmc_c3.log" 2>&1 && echo "pmc c3 done"
 bash tools/pmc_fine.sh "$COMMIT" --scene c4 > "$O/pmc_c4.log" 2>&1 && echo "pmc c4 done"
+bash tools/pmc_fine.sh "$COMMIT" --scene c4n > "$O/pmc_c4n.log" 2>&1 && echo "pmc c4n done"
+bash tools/fine_split.sh "$COMMIT" > "$O/fine_split.log" 2>&1 && cp gpurun_out/fine_split.json "$O/" && echo "fine split done"
 cp gpurun_out/fine_counters*.json "$O/" 2>/dev/null
 for S in c3 c4 c4n; do timeout -k 10 300 python3 tools/ptcl_stats.py $S > "$O/ptcl_stats_$S.json" 2>/dev/null; done
 echo "ptcl stats done"

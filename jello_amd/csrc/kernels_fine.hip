@@ -3,22 +3,24 @@
 // the tile's segments, composite colours / gradients / images / clip-blend groups, and store
 // un-premultiplied RGBA16F.
 //
-// MI355X design: one wave64 per tile (64 lanes x 4 horizontally adjacent pixels, exactly the
-// WGSL's (4,16) workgroup), two independent tile-waves per workgroup (a CU holds at most 16 workgroups).
-// The PTCL stream and the segment records are the same for all 64 lanes, so each datum is fetched ONCE
-// per tile with wide coalesced loads (the algorithmic-bytes model of the roofline) and then shared on-chip:
-//   * PTCL: the 64-word head, then each 256-word chunk (one dwordx4 per lane = 1 KiB per wave
-//     instruction) is staged in a wave-private 1 KiB LDS window; the interpreter reads a command and
-//     its arguments (and the CMD_COLOR that usually follows a CMD_FILL) in one LDS round trip;
-//   * segments: coarse allocates a tile's segment slices back to back; they are evaluated in batches of
-//     up to 64 (segment,row) pairs by the wave-level pipeline described above fill_path below, with the
-//     next batch's 64-segment window prefetched into registers.
+// MI355X design (round 3): one wave64 per tile (64 lanes x 4 horizontally adjacent pixels, exactly the WGSL's (4,16)
+// workgroup), ONE tile-wave per workgroup (the CU takes 24 of them: 6 per SIMD for the lean instantiation; two or four waves
+// per workgroup measured 4 % / 6 % slower).  The PTCL stream and the segment records are the same for all 64 lanes, so each
+// datum is fetched ONCE per tile with wide coalesced loads (the algorithmic-bytes model of the roofline) and shared on-chip:
+//   * PTCL: a REGISTER window -- lane k of a VGPR holds word k of the stream (one 256-byte load per 64 words, the next
+//     window requested one ahead, re-based with ds_bpermute); a command's words are read off the lanes with v_readlane;
+//   * segments: coarse allocates a tile's segment slices back to back; they are evaluated in batches of up to 63
+//     (segment,row) pairs by the wave-level pipeline described above fill_path below; the next batch's segment window is
+//     requested straight into LDS (global_load_lds) while the current batch is evaluated, and EVERYTHING a batch leaves
+//     behind lives in LDS (struct FillLds), so the command loop carries no per-lane batch state around its back edge.
 // Pixels leave as two 16-byte stores per lane (4 px x RGBA16F = 32 B; 4 lanes cover one 128-B row).
-// The 4-deep clip/blend stack lives in registers (statically indexed), deeper levels spill to
-// blend_spill exactly like the WGSL.  Four instantiations: with/without the clip stack (64 VGPRs) and
-// with/without gradient+image code (25 VGPRs); the launcher picks by ConfigUniform.n_clip and by whether
-// any ramp/image is bound.  The kernel is latency-bound (LDS round trips, short dependent loops), so
-// occupancy matters: 88 VGPRs and 6.5 KB LDS per wave give 5 waves per SIMD for the common variant.
+// Clip / blend stack: level 0 in wave-private LDS, levels 1-3 in a per-tile slice of a global scratch array, deeper levels in
+// blend_spill exactly like the WGSL; layers are lazy (see pushed_depth).  Instantiations: coverage mode (area / msaa8 /
+// msaa16) x with/without the clip stack x with/without gradient+image code; the launcher picks by ConfigUniform.n_clip
+// and by whether any ramp/image is bound.  Lean area variant: 80 VGPRs, no scratch, 6.6 KB of LDS per tile-wave.
+// What bounds it (profiles/r03_fine_experiments.md, r03_fine_split.json): neither HBM nor the VALU pipes alone -- a tile is
+// ~5000 dependent wave-instructions (2800 VALU, 1900 SALU, 300 LDS) with LDS round trips between them; with 6 waves per SIMD
+// the kernel sits between the latency of one wave (24 us per tile) and the pipes' floor (~0.235 ms for the frame).
 #include <cstring>
 
 #include "kcommon.h"
@@ -210,24 +212,29 @@ JD V4 over(V4 bg, V4 fg, float area) {
 //   a == 1 exactly  when the pixel lies to the right of the segment's x-span in that row (xmax <= 0),
 //   a == +0 exactly when it lies to the left (xmin0 - i >= 1; the constant numerator is exactly 0),
 // and only the few pixels the span actually crosses need the full formula.  So, per BATCH of segments
-// (as many consecutive segments of the tile's slice as give <= 64 (segment,row) pairs):
-//   stage 1  lane = segment : the rows it can cross (conservative superset), 1/dy, sign(dx)  -> prefix sum
-//   stage 2  lane = (segment,row) pair : the WGSL's y-part and x-part, exact per-pixel classification,
-//            writes the row's 16 contributions (dy / +0) and the list of crossing pixels
-//   stage 3  lane = crossing pixel : the WGSL's trapezoid formula incl. the division, writes a*dy
-//   stage 4  lane = pixel quad : for every segment of the current CMD_FILL, IN ORDER, adds the contribution
-//            of the segment's pair for its row (if any) and then the y_edge term (f32 addition is not
-//            associative: the order of the WGSL's loop is kept; skipped terms are +-0, which cannot change
-//            a sum that is never -0).
+// (as many consecutive segments of the tile's slice as give <= 63 (segment,row) pairs):
+//   stage 1  lane = segment : the rows it can cross (conservative superset), sign(dx), y_edge  -> prefix sum
+//   stage 2  lane = (segment,row) pair : the WGSL's y-part; the row's 16 pixels are classified ONCE from the x-span as
+//            group 0 computes it, with a margin of 1e-3 that covers the per-group roundings (everything uncertain counts
+//            as crossing); the pair's 16 contributions (dy right of the span, +-0 left of it) go to its ENTRY, and the
+//            entries are SORTED BY PIXEL ROW (segment order inside a row): a per-row bit mask of the batch's pairs, built
+//            with LDS atomics (commutative), gives every pair its rank in its row
+//   stage 3  lane = crossing pixel : the WGSL's trapezoid formula incl. the division, written into the entry.  The
+//            pixel's owner pair = running maximum over marks the pairs leave at their first crossing pixel
+//   stage 4  lane = pixel quad of row r : walks the entries of ITS row only, in order, two per trip (EXEC-masked, in
+//            assembly): the terms of the WGSL's loop that are not +-0 for this row, in the WGSL's order (f32 addition is
+//            not associative; skipped terms are +-0, which cannot change a sum that is never -0).  A segment with a y_edge
+//            term (it touches the tile's left edge; uniform) ends a run for all rows: the term is added, the walk goes on.
+//            C3: 3.5 trips per fill instead of one per segment (5.2) with all 64 lanes.
 // Batches run ahead of the command stream (a tile's segment slices are contiguous), so the per-batch
-// stages run on full waves although a single CMD_FILL has ~3 segments.
+// stages run on full waves although a single CMD_FILL has ~5 segments.
 // ------------------------------------------------------------------------------------------------
 #define FB_SPEC 128u
 #ifndef FINE_LEAN_WAVES_PER_EU
 #define FINE_LEAN_WAVES_PER_EU 6
 #endif
 #ifndef FINE_CLIP_WAVES_PER_EU
-#define FINE_CLIP_WAVES_PER_EU 3  // ~133 VGPRs; LDS (8 KiB of stack + 5.4 KiB per tile-wave) allows 11 waves per CU
+#define FINE_CLIP_WAVES_PER_EU 3  // ~136 VGPRs; LDS (4 KiB of stack + 6.6 KiB per tile-wave) allows 15 waves per CU, the registers 12
 #endif
 #ifndef FINE_CLIP_MS_WAVES_PER_EU
 #define FINE_CLIP_MS_WAVES_PER_EU 3

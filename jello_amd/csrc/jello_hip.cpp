@@ -692,14 +692,30 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
             return fail(ctx, JH_ERR_INVALID, std::string("bad bindings for stage ") + jh_stage_name(stage) + ": config / bump / indirect buffer too small");
     }
     // Hold back the small stages a following stage can absorb (see Deferred); absorb or launch what is being held.
-    const bool deferrable = stage == JH_BBOX_CLEAR || stage == JH_PATH_COUNT_SETUP || stage == JH_PATH_TILING_SETUP;
+    // (pathtag_reduce is held back for a possible three-level scan: reduce + reduce2 + scan1 become one launch; when
+    // pathtag_scan_small follows instead it is launched as recorded)
+    const bool pt2 = stage == JH_PATHTAG_REDUCE2 && ctx->deferred.size() == 1 && !ctx->deferred[0].is_clear &&
+                     ctx->deferred[0].stage == JH_PATHTAG_REDUCE && b.size() >= 2 && ctx->deferred[0].b[2].ptr == b[0].ptr;
+    const bool deferrable = stage == JH_BBOX_CLEAR || stage == JH_PATH_COUNT_SETUP || stage == JH_PATH_TILING_SETUP ||
+                            stage == JH_PATHTAG_REDUCE || pt2;
     uint32_t absorb = 0u;
-    JhBound extra;
+    JhBound extra, extra2;
+    uint32_t fused_grid = 0u;
     std::memset(&extra, 0, sizeof extra);
+    std::memset(&extra2, 0, sizeof extra2);
     if (deferrable) {
-        // (only one kind of thing waits at a time, except bbox_clear + Clear(bump) in front of flatten)
+        // (only one kind of thing waits at a time, except bbox_clear + Clear(bump) in front of flatten and the two pathtag stages)
         for (const Deferred& d : ctx->deferred)
-            if (!(stage == JH_BBOX_CLEAR && d.is_clear)) { JH_FLUSH(ctx); break; }
+            if (!(stage == JH_BBOX_CLEAR && d.is_clear) && !pt2) { JH_FLUSH(ctx); break; }
+    } else if (stage == JH_PATHTAG_SCAN1 && ctx->deferred.size() == 2 && !ctx->deferred[0].is_clear && !ctx->deferred[1].is_clear &&
+               ctx->deferred[0].stage == JH_PATHTAG_REDUCE && ctx->deferred[1].stage == JH_PATHTAG_REDUCE2 && b.size() >= 3 &&
+               ctx->deferred[0].b[2].ptr == b[0].ptr && ctx->deferred[1].b[0].ptr == b[0].ptr && ctx->deferred[1].b[1].ptr == b[1].ptr &&
+               ctx->deferred[1].gx == gx && gx <= 256u) {
+        absorb = JH_ABSORB_PATHTAG;
+        extra = ctx->deferred[0].b[0];
+        extra2 = ctx->deferred[0].b[1];
+        fused_grid = ctx->deferred[0].gx;
+        ctx->deferred.clear();
     } else if (!ctx->deferred.empty()) {
         bool all = true;
         for (const Deferred& d : ctx->deferred) {
@@ -731,6 +747,8 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
     L.gx = gx; L.gy = gy; L.gz = gz;
     L.absorb = absorb;
     L.extra = extra;
+    L.extra2 = extra2;
+    L.fused_grid = fused_grid;
     L.b = b.data();
     L.nb = (int)b.size();
     L.images = images.data();

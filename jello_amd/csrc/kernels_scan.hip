@@ -307,6 +307,69 @@ __global__ __launch_bounds__(JL_WG) void k_pathtag_scan1(Buf<JlTagMonoid> reduce
     MonoidK<5> ex = block_excl_scan_monoid<5>(load_tm(reduced, ix), sh, &tot);
     if (out.ok(ix)) store_tm(&out.p[ix], monoid_add(prefix, ex));
 }
+// pathtag_reduce + pathtag_reduce2 + pathtag_scan1 in ONE launch (the three-level path of scenes with more than 256 tag
+// workgroups; render.go:171-200).  The engine holds the first two dispatches back (jello_hip.cpp, Deferred) and this kernel
+// runs when pathtag_scan1 arrives with all three buffers known: every workgroup reduces its 256 tag words as
+// pathtag_reduce does; the LAST one to finish then does the work of the two small stages (n2 <= 256 workgroups' worth)
+// and leaves `reduced`, `reduced2` and `reduced_scan` exactly as the three dispatches would have.  Cross-workgroup data
+// travel as device-scope (write-through / L2-bypassing) stores and loads, ordered by a completed-stores wait in front of
+// the relaxed counter increment -- no fence (a fence writes back / invalidates a whole L2 on this 8-XCD part).
+JD void store_tm_dev(JlTagMonoid* dst, const MonoidK<5>& m) {
+    uint32_t* w = (uint32_t*)dst;
+#pragma unroll
+    for (int i = 0; i < 5; i++) __hip_atomic_store(&w[i], m.v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+JD MonoidK<5> load_tm_dev(const Buf<JlTagMonoid>& b, uint32_t i) {
+    MonoidK<5> m;
+#pragma unroll
+    for (int k = 0; k < 5; k++) m.v[k] = 0u;
+    if (i < b.n) {
+        const uint32_t* w = (const uint32_t*)&b.p[i];
+#pragma unroll
+        for (int k = 0; k < 5; k++) m.v[k] = __hip_atomic_load(&w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return m;
+}
+__global__ __launch_bounds__(JL_WG) void k_pathtag_reduce_fused(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> reduced,
+                                                                Buf<JlTagMonoid> reduced2, Buf<JlTagMonoid> reduced_scan, uint32_t n2,
+                                                                uint32_t* __restrict__ counter) {
+    __shared__ uint32_t sh[20];
+    __shared__ uint32_t s_last;
+    uint32_t ix = blockIdx.x * JL_WG + threadIdx.x;
+    MonoidK<5> agg = reduce_tag(scene.rd(cfg->layout.pathtag_base + ix));
+    MonoidK<5> t = block_reduce_monoid<5>(agg, sh);
+    if (threadIdx.x == 0) {
+        if (reduced.ok(blockIdx.x)) store_tm_dev(&reduced.p[blockIdx.x], t);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the stores above have completed
+        const uint32_t done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = done + 1u == gridDim.x ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last == 0u) return;  // uniform per workgroup
+    // pathtag_reduce2.wgsl:23-41 for its n2 workgroups
+    for (uint32_t b = 0u; b < n2; b++) {
+        MonoidK<5> r = block_reduce_monoid<5>(load_tm_dev(reduced, b * JL_WG + threadIdx.x), sh);
+        if (threadIdx.x == 0 && reduced2.ok(b)) store_tm(&reduced2.p[b], r);
+        __syncthreads();
+    }
+    __syncthreads();
+    // pathtag_scan1.wgsl:26-67 for its n2 workgroups (reduced2 was written by this workgroup: block-level visibility)
+    for (uint32_t b = 0u; b < n2; b++) {
+        MonoidK<5> pre;
+#pragma unroll
+        for (int i = 0; i < 5; i++) pre.v[i] = 0u;
+        if (threadIdx.x < b) pre = load_tm(reduced2, threadIdx.x);
+        MonoidK<5> prefix = block_reduce_monoid<5>(pre, sh);
+        __syncthreads();
+        MonoidK<5> tot;
+        const uint32_t jx = b * JL_WG + threadIdx.x;
+        MonoidK<5> ex = block_excl_scan_monoid<5>(load_tm_dev(reduced, jx), sh, &tot);
+        if (reduced_scan.ok(jx)) store_tm(&reduced_scan.p[jx], monoid_add(prefix, ex));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+}
+
 // pathtag_scan.wgsl:28-76
 template <bool SMALL>
 __global__ __launch_bounds__(JL_WG) void k_pathtag_scan(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> reduced,
@@ -336,6 +399,18 @@ int jh_launch_pathtag(const JhLaunch& L, int stage) {
             break;
         case 2:
             if (L.nb < 3) return -1;
+            if (L.absorb & JH_ABSORB_PATHTAG) {  // pathtag_reduce and pathtag_reduce2 were held back: one launch does all three
+                // L.extra / L.extra2: [config, scene] of pathtag_reduce; L.gz_fused = its grid; this stage's grid = reduce2's
+                uint32_t* ctr = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_PT_CTR, 64);
+                if (!ctr) return -5;
+                uint32_t* clean = jh_scratch_flags(L.scratch);
+                if ((*clean & JH_CLEAN_PT_CTR) == 0u) (void)hipMemsetAsync(ctr, 0, 64, L.stream);
+                *clean |= JH_CLEAN_PT_CTR;
+                hipLaunchKernelGGL(k_pathtag_reduce_fused, dim3(L.fused_grid), blk, 0, L.stream, (const JlConfig*)L.extra.ptr,
+                                   mkbuf<uint32_t>(L.extra2.ptr, L.extra2.size), mkbuf<JlTagMonoid>(L.b[0].ptr, L.b[0].size),
+                                   mkbuf<JlTagMonoid>(L.b[1].ptr, L.b[1].size), mkbuf<JlTagMonoid>(L.b[2].ptr, L.b[2].size), L.gx, ctr);
+                break;
+            }
             hipLaunchKernelGGL(k_pathtag_scan1, g, blk, 0, L.stream, mkbuf<JlTagMonoid>(L.b[0].ptr, L.b[0].size),
                                mkbuf<JlTagMonoid>(L.b[1].ptr, L.b[1].size), mkbuf<JlTagMonoid>(L.b[2].ptr, L.b[2].size));
             break;

@@ -151,6 +151,25 @@ def check_bevel(bump):
     assert bump["lines"] == KAT["bevel_join_collinear"]["lines"] and bump["failed"] == 0
 
 
+def lines_overflow_guard():
+    s = Scene()
+    s.fill(Fill.NonZero, None, Brush.solid(RGBA), None, Path.rect(2, 3, 9, 7))
+    p = RenderParams(16, 16)
+    return s, p, jello_amd.BumpSizes(lines=2)
+
+
+def check_lines_overflow_guard(get, bump):
+    """flatten.wgsl:508,750-755 + binning.wgsl:67-77: the count keeps running, the store is guarded, binning raises the flag."""
+    k = KAT["lines_overflow_guard"]
+    for name, v in k["bump"].items():
+        assert bump[name] == v, name
+    lines = get("linesBuf", np.uint32)
+    assert lines.size == 2 * 6  # the buffer really is two LineSoup records long
+    want = {tuple([0, 0] + f32_words([e])) for e in k["edges_f32"]}  # LineSoup: path_ix, pad, p0, p1
+    got = [tuple(int(w) for w in lines[6 * i:6 * i + 6]) for i in range(2)]
+    assert all(g in want for g in got) and got[0] != got[1], got
+
+
 # ---- pixel-level known answers (tests/golden/kat_pixels.json, derived by tests/fine_by_hand.py) -----------------------
 PIX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_pixels.json")))
 

@@ -13,8 +13,8 @@ BUMP = ["failed", "binning", "ptcl", "tile", "seg_counts", "segments", "blend", 
 
 
 def run_gpu(engine, scene_params):
-    s, p = scene_params
-    p.bump = jello_amd.BumpSizes(blend_spill=1 << 14)
+    s, p = scene_params[:2]
+    p.bump = scene_params[2] if len(scene_params) > 2 else jello_amd.BumpSizes(blend_spill=1 << 14)
     rec = jello_amd.Host().record(s, p)
     engine.run(rec, RUN_UPLOADS | RUN_DISPATCHES)
     engine.sync()
@@ -83,6 +83,14 @@ def test_bevel_join_between_collinear_segments(engine):
     get, rec, bump = run_gpu(engine, K.bevel_join_collinear())
     try:
         K.check_bevel(bump)
+    finally:
+        engine.release(rec)
+
+
+def test_lines_overflow_guard(engine):
+    get, rec, bump = run_gpu(engine, K.lines_overflow_guard())
+    try:
+        K.check_lines_overflow_guard(get, bump)
     finally:
         engine.release(rec)
 

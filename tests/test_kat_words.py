@@ -13,8 +13,8 @@ BUMP = ["failed", "binning", "ptcl", "tile", "seg_counts", "segments", "blend", 
 
 
 def run_oracle(scene_params):
-    s, p = scene_params
-    p.bump = jello_amd.BumpSizes(blend_spill=1 << 14)
+    s, p = scene_params[:2]
+    p.bump = scene_params[2] if len(scene_params) > 2 else jello_amd.BumpSizes(blend_spill=1 << 14)
     rec = jello_amd.Host().record(s, p)
     o = OracleEngine()
     o.run(rec)
@@ -47,6 +47,11 @@ def test_bbox_extent_rule(built):
     get, cfg, bump = run_oracle(K.bbox_extent_rule())
     assert bump["failed"] == 0
     K.check_bbox_extent_rule(get, cfg)
+
+
+def test_lines_overflow_guard(built):
+    get, cfg, bump = run_oracle(K.lines_overflow_guard())
+    K.check_lines_overflow_guard(get, bump)
 
 
 def test_rect_on_tile_boundaries(built):

@@ -619,29 +619,55 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restr
     const uint32_t lane = lane_id();
     const uint32_t waves = (rank_blocks * JL_WG) >> 6;
     uint32_t P = (blockIdx.x * JL_WG + threadIdx.x) >> 6;
-    uint32_t nps = 0u, npe = 0u;  // range of the path after this one (prefetched: the loop is a chain of dependent loads)
-    if (P < n_paths) path_range(P, pfirst, plast, counts, seg_bases, nps, npe);
+    // The loop is a chain of dependent loads (range -> keys -> rank -> counts word), ~1 us of latency per path when taken one
+    // after the other: it runs two paths ahead instead -- the range of path P + 2 * waves, the keys and counts words of path
+    // P + waves are requested before path P is ranked.
+    auto usable = [&](uint32_t ps, uint32_t pe_all) -> bool { return umin_(pe_all, n) > ps && !npe_big(pe_all - ps); };  // (the same test as in k_pc_emit)
+    auto fetch = [&](uint32_t ps, uint32_t pe_all, uint32_t& key, uint32_t& cw) {
+        key = 0xffffffffu; cw = 0u;
+        const uint32_t k = ps + lane;
+        if (usable(ps, pe_all) && k < umin_(pe_all, n)) {
+            key = keys[k];
+            if (seg_counts.ok(k)) cw = seg_counts.p[k].counts;
+        }
+    };
+    uint32_t ps1 = 0u, pe1 = 0u, ps2 = 0u, pe2 = 0u;  // ranges of paths P and P + waves
+    uint32_t key1 = 0xffffffffu, cw1 = 0u;          // keys / counts words of path P
+    if (P < n_paths) path_range(P, pfirst, plast, counts, seg_bases, ps1, pe1);
+    if (P + waves < n_paths) path_range(P + waves, pfirst, plast, counts, seg_bases, ps2, pe2);
+    ps1 = uni32(ps1); pe1 = uni32(pe1);
+    fetch(ps1, pe1, key1, cw1);
     for (; P < n_paths; P += waves) {
-        const uint32_t ps = uni32(nps), pe_all = uni32(npe), pe = umin_(pe_all, n);  // uniform: scalar registers
-        if (P + waves < n_paths) path_range(P + waves, pfirst, plast, counts, seg_bases, nps, npe);
-        if (pe <= ps || npe_big(pe_all - ps)) continue;  // (the same test as in k_pc_emit)
+        const uint32_t ps = ps1, pe_all = pe1, pe = umin_(pe_all, n);  // uniform: scalar registers
+        const uint32_t my_key = key1, my_cw = cw1;
+        ps1 = uni32(ps2); pe1 = uni32(pe2);
+        ps2 = 0u; pe2 = 0u;
+        if (P + 2u * waves < n_paths) path_range(P + 2u * waves, pfirst, plast, counts, seg_bases, ps2, pe2);
+        if (P + waves < n_paths) fetch(ps1, pe1, key1, cw1);
+        if (!usable(ps, pe_all)) continue;
         {
             const uint32_t k = ps + lane;
             const bool valid = k < pe;
-            uint32_t my_t = valid ? keys[k] : 0xffffffffu;
+            uint32_t my_t = valid ? my_key : 0xffffffffu;
             const bool mine = valid && my_t != 0xffffffffu;  // 0xffffffff: crossing outside the tile buffer
             uint32_t before = 0u, after = 0u;
             uint64_t rem = __builtin_amdgcn_ballot_w64(mine);
+            // One trip per DISTINCT tile: the lanes of that tile keep the trip's ballot (lanes that are not `mine` hold the key
+            // 0xffffffff, which no trip asks for); the ranks come out of the kept masks once, after the loop -- the loop itself is
+            // a scalar find-first, a lane read, a compare and two selects (it was 6 + 7 instructions per trip with the counts
+            // inside: the kernel is bound by instruction issue, 92 scalar + 81 vector instructions per path).
+            uint32_t grp_lo = 0u, grp_hi = 0u;
             for (uint32_t it = 0u; it < 16u && rem != 0ull; it++) {
                 const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, (int)__builtin_ctzll(rem));
-                const uint64_t m = __builtin_amdgcn_ballot_w64(mine && my_t == t);
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                const uint32_t all = (uint32_t)__builtin_popcountll(m);  // scalar
-                if (mine && my_t == t) {
-                    before = below;
-                    after = all - 1u - below;
-                }
+                const bool eq = my_t == t;
+                const uint64_t m = __builtin_amdgcn_ballot_w64(eq);
+                grp_lo = eq ? (uint32_t)m : grp_lo;
+                grp_hi = eq ? (uint32_t)(m >> 32) : grp_hi;
                 rem &= ~m;
+            }
+            if (mine) {
+                before = __builtin_amdgcn_mbcnt_hi(grp_hi, __builtin_amdgcn_mbcnt_lo(grp_lo, 0u));
+                after = (uint32_t)__builtin_popcount(grp_lo) + (uint32_t)__builtin_popcount(grp_hi) - 1u - before;
             }
             // more than 16 distinct tiles (long lines: every crossing in another tile): the remaining lanes compare
             // against all 64 keys instead (4 instructions per key, not 16 per distinct tile)
@@ -656,7 +682,7 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restr
                 if (todo) { before = b; after = a; }
             }
             if (mine && seg_counts.ok(k)) {
-                seg_counts.p[k].counts |= before << 16;
+                seg_counts.p[k].counts = my_cw | (before << 16);
                 if (after == 0u && tile.ok(my_t)) tile.p[my_t].segment_count_or_ix = before + 1u;
             }
         }

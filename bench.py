@@ -375,13 +375,21 @@ def committed_counters(args, fine_ms):
     out["traffic"] = c.get("hbm_bytes_per_launch")
     out["traffic_source"] = "profiles/%s: rocprofv3 --pmc passes at commit %s on these kernel sources (not re-measured in this run)" % (
         os.path.basename(pm), c.get("commit", "?"))
-    # VALU pipe bound: gfx950's SIMDs are 32 lanes wide, a wave64 VALU instruction takes 2 cycles of its SIMD (4 for packed-f32
-    # and 64-bit operations; MI355X_MICROARCH.md) -- a floor no schedule can beat, not what one wave's dependent stream reaches
+    # Pipe bounds from MEASURED issue costs (tools/ubench, profiles/r03_ubench_issue_rates.txt): a SIMD of gfx950 issues a wave64
+    # v_add/mul/sub_f32, v_and/or/xor, v_add_u32 or v_mov in 2.2 cycles, almost everything else (min/max, fma, compares, selects,
+    # conversions, DPP, packed f32, anything with an SGPR source) in 4.2, lane reads with a scalar lane select and transcendentals in
+    # 8.1, and one scalar instruction per 4.08 cycles whatever the number of waves.  The vector figure prices the kernel's STATIC
+    # instruction mix (tools/isa_price.py; dynamic trip counts are not known to the counters).
     if c.get("valu_insts_per_launch") and c.get("simds") and c.get("clock_ghz"):
-        ib = c["valu_insts_per_launch"] * 2.0 / (c["simds"] * c["clock_ghz"] * 1e9) * 1e3
+        per = c.get("valu_cycles_per_inst_static_mix") or 4.2
+        ib = c["valu_insts_per_launch"] * per / (c["simds"] * c["clock_ghz"] * 1e9) * 1e3
         out["valu_pipe_bound_ms"] = round(ib, 4)
-        out["valu_pipe_bound_note"] = ("%.3g VALU wave-instructions per launch x 2 cycles / (%d SIMD-32s x %.2f GHz); measured kernel time / bound = %.2f"
-                                       % (c["valu_insts_per_launch"], c["simds"], c["clock_ghz"], fine_ms / ib if ib > 0 else float("nan")))
+        out["valu_pipe_bound_note"] = ("%.3g VALU wave-instructions per launch x %.2f cycles (static mix, measured issue costs) / (%d SIMDs x %.2f GHz); "
+                                       "bound / measured kernel time = %.2f" % (c["valu_insts_per_launch"], per, c["simds"], c["clock_ghz"],
+                                                                                  ib / fine_ms if fine_ms > 0 else float("nan")))
+        if c.get("salu_insts_per_launch"):
+            sb = c["salu_insts_per_launch"] * 4.08 / (c["simds"] * c["clock_ghz"] * 1e9) * 1e3
+            out["salu_pipe_bound_ms"] = round(sb, 4)
         out["insts_per_tile"] = {k: round(c[v] / c["tiles"], 1) for k, v in (("valu", "valu_insts_per_launch"), ("salu", "salu_insts_per_launch"),
                                                                              ("lds", "lds_insts_per_launch")) if c.get(v) and c.get("tiles")}
     return out

@@ -1187,6 +1187,8 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
                                                          const uint4* __restrict__ ends, uint32_t tcap, const JlLineSoup* __restrict__ tlines, const uint2* __restrict__ tkeys,
                                                          const uint32_t* __restrict__ chunk_used, uint32_t n_chunks, uint32_t FL_CHUNK,
                                                          const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines) {
+    __shared__ uint2 sh_wdat[JL_WG / 64][192];    // per wave: the words it stores this step, in lane order ...
+    __shared__ uint32_t sh_widx[JL_WG / 64][192];  // ... and their 8-byte word indices in the line buffer (~0: none)
     const uint32_t n_t = umin_(counters[2], tcap);
     const uint32_t lines_lim = umin_(cfg->lines_size, lines.n);
     const uint32_t lane = lane_id();
@@ -1212,111 +1214,187 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
     };
     // The markers of the NEXT unit are fetched before this one is worked on: a unit is a chain of dependent round
     // trips (chunk fill -> markers -> piece record -> line base), and the first two now overlap the previous unit.
-    uint32_t lim_next;
-    uint32_t t0_next = unit_slot(blockIdx.x, lim_next);
-    uint32_t v_next = (t0_next != FL_INVALID && t0_next + threadIdx.x < n_t) ? tinfo[t0_next + threadIdx.x] : 0u;
-    for (uint32_t u = blockIdx.x; u < units; u += gridDim.x) {  // uniform per workgroup
-        const uint32_t t0 = t0_next, lim = lim_next;
-        uint32_t v = v_next;
-        t0_next = unit_slot(u + gridDim.x, lim_next);
-        v_next = (t0_next != FL_INVALID && t0_next + threadIdx.x < n_t) ? tinfo[t0_next + threadIdx.x] : 0u;
-        if (t0 == FL_INVALID) continue;
+    // (the markers of the 64 slots in front of the wave's come with them: a piece that began in the previous wave's slots --
+    // four waves in ten -- is then found without a walk back through memory, one dependent round trip per step)
+    auto fetch_markers = [&](uint32_t t0, uint32_t& v, uint32_t& vp) {
+        v = 0u; vp = 0u;
+        if (t0 == FL_INVALID) return;
+        const uint32_t t = t0 + threadIdx.x;
+        if (t < n_t) v = tinfo[t];
+        if (t >= 64u && t - 64u < n_t) vp = tinfo[t - 64u];
+    };
+    // Software pipeline over the work units of a workgroup, two deep: while unit u is evaluated, the piece records of unit
+    // u + G (G = gridDim.x) are on their way and so are the markers of unit u + 2 G.  A unit used to be a chain of three
+    // dependent round trips (markers -> piece record -> transform / line base); one per unit is left.
+    // state of a slot: 0 nothing to do, 1 complete line (copied), 2 line k of a piece
+    auto resolve = [&](uint32_t t0, uint32_t lim, uint32_t v, uint32_t vp, uint32_t& tp, uint32_t& vout) -> uint32_t {
+        tp = 0u; vout = 0u;
+        if (t0 == FL_INVALID) return 0u;  // uniform
         const uint32_t t = t0 + threadIdx.x;
         // which piece covers slot t?  Its first slot carries the marker (pieces have at most 100 lines).  The wave looks
-        // at its 64 markers together: the nearest marker at or before a lane (DPP running maximum); only lanes before
-        // the wave's first marker walk back through memory.
+        // at its 64 markers together: the nearest marker at or before a lane (DPP running maximum); lanes before the
+        // wave's first marker take the last marker of the 64 slots in front of the wave, and only if there is none
+        // either (a piece of more than 64 lines) walk back through memory.
         const uint32_t mark = wave_incl_max_u32(v != 0u ? lane + 1u : 0u);  // 1 + lane of the nearest marker, 0 = none
-        uint32_t tp = t;
+        tp = t;
+        uint32_t walk_from = lane + 1u;  // first distance the memory walk would have to look at
         if (mark != 0u) {
             v = (uint32_t)__shfl((int)v, (int)(mark - 1u), 64);
             tp = t - (lane - (mark - 1u));
         }
+        if (__builtin_amdgcn_ballot_w64(mark == 0u) != 0ull) {  // uniform
+            const uint32_t plast = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max_u32(vp != 0u ? lane + 1u : 0u), 63);
+            if (plast != 0u) {  // uniform
+                const uint32_t pv = (uint32_t)__builtin_amdgcn_readlane((int)vp, (int)(plast - 1u));
+                if (mark == 0u) {
+                    v = pv;
+                    tp = t - lane - 64u + (plast - 1u);
+                }
+            } else {
+                walk_from = lane + 65u;
+            }
+        }
         // the workgroups' reserved chunks are the first n_chunks * FL_CHUNK slots; their unused tails hold nothing
-        if (t >= n_t || threadIdx.x >= lim) continue;
-        if (mark == 0u) {
-            for (uint32_t back = lane + 1u; back <= 100u && back <= t; back++) {
+        if (t >= n_t || threadIdx.x >= lim) return 0u;
+        if (mark == 0u && v == 0u) {
+            for (uint32_t back = walk_from; back <= 100u && back <= t; back++) {
                 v = tinfo[t - back];
                 if (v != 0u) { tp = t - back; break; }
             }
         }
-        if ((v & FL_INFO_DIRECT) != 0u && tp == t) {  // complete line: copy
+        vout = v;
+        if ((v & FL_INFO_DIRECT) != 0u && tp == t) return 1u;
+        if ((v & FL_INFO_PIECE) == 0u) return 0u;
+        if (t - tp >= (v & 0xffffu)) return 0u;
+        return 2u;
+    };
+    auto fetch_rec = [&](uint32_t state, uint32_t tp, uint4& r0, uint4& r1, uint4& r2, uint4& r3) {
+        r0 = r1 = r2 = r3 = make_uint4(0u, 0u, 0u, 0u);
+        if (state == 2u) {
+            const uint4* rec = pieces + (size_t)tp * 4u;
+            r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
+        }
+    };
+    const uint32_t G = gridDim.x;
+    uint32_t lim_a, lim_b;
+    uint32_t t0_a = unit_slot(blockIdx.x, lim_a), t0_b = unit_slot(blockIdx.x + G, lim_b);
+    uint32_t mv_a, mp_a, mv_b, mp_b;
+    fetch_markers(t0_a, mv_a, mp_a);
+    fetch_markers(t0_b, mv_b, mp_b);
+    uint32_t tp_a, v_a;
+    uint32_t st_a = resolve(t0_a, lim_a, mv_a, mp_a, tp_a, v_a);
+    uint4 a0, a1, a2, a3;
+    fetch_rec(st_a, tp_a, a0, a1, a2, a3);
+    for (uint32_t u = blockIdx.x; u < units; u += G) {  // uniform per workgroup
+        // the current unit: resolved, its records requested one trip ago
+        const uint32_t t0 = t0_a, st = st_a, tp = tp_a, v = v_a;
+        const uint4 r0 = a0, r1 = a1, r2 = a2, r3 = a3;
+        // the next unit: its markers were requested one trip ago; resolve them and request its records
+        t0_a = t0_b; lim_a = lim_b;
+        st_a = resolve(t0_b, lim_b, mv_b, mp_b, tp_a, v_a);
+        fetch_rec(st_a, tp_a, a0, a1, a2, a3);
+        // the unit after that: markers
+        t0_b = unit_slot(u + 2u * G, lim_b);
+        fetch_markers(t0_b, mv_b, mp_b);
+        if (t0 == FL_INVALID) continue;  // uniform
+        const uint32_t t = t0 + threadIdx.x;
+        // What a slot writes: up to three 8-byte words of the line buffer (a LineSoup is {path, pad | p0 | p1} = 3 words).
+        // A piece line stores its end point as p1 of its own record and, with the header, as p0 of the next one: the words
+        // 3 dst + 2 ... 3 dst + 4, 24 contiguous bytes.  Stored straight from the lanes, each of the three store instructions
+        // of a wave touches every 64-byte segment of the wave's 1.5 KB -- 72 write requests where 24 carry the bytes, and the
+        // kernel is bound by exactly that (issuing every store twice took it from 117 to 207 us).  So the words go through
+        // LDS in lane order and leave as three stores of 64 CONSECUTIVE words each.
+        uint32_t widx[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+        uint2 wdat[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
+        if (st == 1u) {  // complete line: copy
             const uint2 key = tkeys[t];
             if (key.x < n_slots) {
                 const uint32_t dst = bases[key.x] + key.y;
-                if (dst < lines_lim) lines.p[dst] = tlines[t];
-            }
-            continue;
-        }
-        if ((v & FL_INFO_PIECE) == 0u) continue;
-        const uint32_t n_u = v & 0xffffu, i = t - tp;
-        if (i >= n_u) continue;
-        const uint4* rec = pieces + (size_t)tp * 4u;
-        const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-        const uint32_t flags = r3.y & 63u;
-        const bool last_of_item = i + 1u == n_u && (flags & 4u) != 0u;
-        const uint32_t slot = r2.z, k = r2.w + i;
-        uint4 en = make_uint4(0u, 0u, 0u, 0u);
-        if (last_of_item || k == 0u) en = ends[tp];
-        V2 lp1;
-        if (last_of_item) {
-            lp1 = v2(u2f(en.z), u2f(en.w));
-        } else {  // flatten.wgsl:404-461
-            EulerParams ep;
-            ep.th0 = u2f(r1.x); ep.th1 = 0.0f; ep.k0 = u2f(r1.y); ep.k1 = u2f(r1.z); ep.ch = u2f(r1.w);
-            const float noff = u2f(r2.x), n = u2f(r2.y);
-            const float tt = (float)(i + 1u) / n;
-            float sarg = tt;
-            const uint32_t robust = flags & 3u;
-            if (robust != 1u) {
-                const float k0 = ep.k0 - 0.5f * ep.k1, k1 = ep.k1;
-                const float dist_scaled = noff * ep.ch;
-                const float int0 = u2f(r3.z), integral = u2f(r3.w);  // as k_flatten_items computed them
-                float a, b;
-                if (robust == 2u) {
-                    a = k1;
-                    b = k0;
-                } else {
-                    a = -2.0f * dist_scaled * k1;
-                    b = -1.0f - 2.0f * dist_scaled * k0;
+                if (dst < lines_lim) {
+                    const uint2* src = (const uint2*)(tlines + t);
+#pragma unroll
+                    for (int j = 0; j < 3; j++) { widx[j] = dst * 3u + (uint32_t)j; wdat[j] = src[j]; }
                 }
-                float u = integral * tt + int0;
-                float inv;
-                if (robust == 2u) inv = pow23_abs_(u) * sign_(u); else inv = espc_int_inv_approx(u);
-                sarg = (inv - b) / a;
             }
-            lp1 = es_seg_eval_with_offset(v2(u2f(r0.x), u2f(r0.y)), v2(u2f(r0.z), u2f(r0.w)), ep, sarg, noff);
-        }
-        Xf tr;
-        if ((flags & 16u) != 0u) {
-            tr = xf_identity();
-        } else {
-            uint32_t tb = cfg->layout.transform_base + (r3.y >> 6) * 6u;
-            tr.m0 = u2f(scene.rd(tb)); tr.m1 = u2f(scene.rd(tb + 1u)); tr.m2 = u2f(scene.rd(tb + 2u));
-            tr.m3 = u2f(scene.rd(tb + 3u)); tr.t0 = u2f(scene.rd(tb + 4u)); tr.t1 = u2f(scene.rd(tb + 5u));
-        }
-        const V2 q = xf_apply(tr, lp1);
-        if (slot >= n_slots) continue;
-        const uint32_t dst = bases[slot] + k;
-        const bool fwd = (flags & 8u) != 0u;  // offset >= 0: (start, end); else the line runs (end, start)
-        const bool has_next = !last_of_item && dst + 1u < lines_lim;
-        // Stores are grouped into contiguous byte ranges (a LineSoup is {path, pad, p0, p1} = 3 x 8 bytes): partial
-        // 8-byte stores to three different cache lines per thread tripled the write traffic.
-        uint2* w = (uint2*)lines.p;  // 8-byte words: 3 per line
-        const uint2 hdr = make_uint2(r3.x, 0u), pt = make_uint2(f2u(q.x), f2u(q.y));
-        if (dst < lines_lim) {
-            if (k == 0u) {  // the item's first line: header and start point (the job's start point)
-                const V2 qs = xf_apply(tr, v2(u2f(en.x), u2f(en.y)));
-                w[(size_t)dst * 3u] = hdr;
-                w[(size_t)dst * 3u + (fwd ? 1u : 2u)] = make_uint2(f2u(qs.x), f2u(qs.y));
+        } else if (st == 2u) {
+            const uint32_t n_u = v & 0xffffu, i = t - tp;
+            const uint32_t flags = r3.y & 63u;
+            const bool last_of_item = i + 1u == n_u && (flags & 4u) != 0u;
+            const uint32_t slot = r2.z, k = r2.w + i;
+            uint4 en = make_uint4(0u, 0u, 0u, 0u);
+            if (last_of_item || k == 0u) en = ends[tp];
+            V2 lp1;
+            if (last_of_item) {
+                lp1 = v2(u2f(en.z), u2f(en.w));
+            } else {  // flatten.wgsl:404-461
+                EulerParams ep;
+                ep.th0 = u2f(r1.x); ep.th1 = 0.0f; ep.k0 = u2f(r1.y); ep.k1 = u2f(r1.z); ep.ch = u2f(r1.w);
+                const float noff = u2f(r2.x), n = u2f(r2.y);
+                const float tt = (float)(i + 1u) / n;
+                float sarg = tt;
+                const uint32_t robust = flags & 3u;
+                if (robust != 1u) {
+                    const float k0 = ep.k0 - 0.5f * ep.k1, k1 = ep.k1;
+                    const float dist_scaled = noff * ep.ch;
+                    const float int0 = u2f(r3.z), integral = u2f(r3.w);  // as k_flatten_items computed them
+                    float a, b;
+                    if (robust == 2u) {
+                        a = k1;
+                        b = k0;
+                    } else {
+                        a = -2.0f * dist_scaled * k1;
+                        b = -1.0f - 2.0f * dist_scaled * k0;
+                    }
+                    float uu = integral * tt + int0;
+                    float inv;
+                    if (robust == 2u) inv = pow23_abs_(uu) * sign_(uu); else inv = espc_int_inv_approx(uu);
+                    sarg = (inv - b) / a;
+                }
+                lp1 = es_seg_eval_with_offset(v2(u2f(r0.x), u2f(r0.y)), v2(u2f(r0.z), u2f(r0.w)), ep, sarg, noff);
             }
-            if (fwd) {
-                // [p1 of this line | header of the next | p0 of the next]: 24 contiguous bytes
-                w[(size_t)dst * 3u + 2u] = pt;
-                if (has_next) { w[(size_t)dst * 3u + 3u] = hdr; w[(size_t)dst * 3u + 4u] = pt; }
+            Xf tr;
+            if ((flags & 16u) != 0u) {
+                tr = xf_identity();
             } else {
-                // the line runs (end, start): p0 of this line, header and p1 of the next
-                w[(size_t)dst * 3u + 1u] = pt;
-                if (has_next) { w[(size_t)dst * 3u + 3u] = hdr; w[(size_t)dst * 3u + 5u] = pt; }
+                uint32_t tb = cfg->layout.transform_base + (r3.y >> 6) * 6u;
+                tr.m0 = u2f(scene.rd(tb)); tr.m1 = u2f(scene.rd(tb + 1u)); tr.m2 = u2f(scene.rd(tb + 2u));
+                tr.m3 = u2f(scene.rd(tb + 3u)); tr.t0 = u2f(scene.rd(tb + 4u)); tr.t1 = u2f(scene.rd(tb + 5u));
+            }
+            const V2 q = xf_apply(tr, lp1);
+            if (slot < n_slots) {
+                const uint32_t dst = bases[slot] + k;
+                const bool fwd = (flags & 8u) != 0u;  // offset >= 0: (start, end); else the line runs (end, start)
+                const bool has_next = !last_of_item && dst + 1u < lines_lim;
+                const uint2 hdr = make_uint2(r3.x, 0u), pt = make_uint2(f2u(q.x), f2u(q.y));
+                if (dst < lines_lim) {
+                    if (k == 0u) {  // the item's first line: header and start point (the job's start point), once per item
+                        uint2* w = (uint2*)lines.p;
+                        const V2 qs = xf_apply(tr, v2(u2f(en.x), u2f(en.y)));
+                        w[(size_t)dst * 3u] = hdr;
+                        w[(size_t)dst * 3u + (fwd ? 1u : 2u)] = make_uint2(f2u(qs.x), f2u(qs.y));
+                    }
+                    // fwd: [p1 of this line | header of the next | p0 of the next]; else p0 of this line, header and p1 of the next
+                    widx[0] = dst * 3u + (fwd ? 2u : 1u); wdat[0] = pt;
+                    if (has_next) {
+                        widx[1] = dst * 3u + 3u; wdat[1] = hdr;
+                        widx[2] = dst * 3u + (fwd ? 4u : 5u); wdat[2] = pt;
+                    }
+                }
+            }
+        }
+        {
+            uint2* sd = sh_wdat[threadIdx.x >> 6];
+            uint32_t* si = sh_widx[threadIdx.x >> 6];
+            wave_fence();  // the previous unit's reads of the staging area are done
+#pragma unroll
+            for (int j = 0; j < 3; j++) { sd[3u * lane + (uint32_t)j] = wdat[j]; si[3u * lane + (uint32_t)j] = widx[j]; }
+            wave_fence();
+            uint2* w = (uint2*)lines.p;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const uint32_t ix = si[64u * (uint32_t)j + lane];
+                const uint2 d = sd[64u * (uint32_t)j + lane];
+                if (ix != 0xffffffffu) w[ix] = d;
             }
         }
     }

@@ -15,6 +15,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/g$i" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-graph "$@" > "$OUT/g$i.log" 2>&1 || tail -3 "$OUT/g$i.log"
 done
+# static instruction mix of the kernel, priced with the measured issue costs (tools/isa_price.py)
+"$R/tools/fine_isa.sh" > "$OUT/isa.txt" 2>&1 || tail -3 "$OUT/isa.txt"
 python3 - "$OUT" "$COMMIT" "$R" "$@" <<'PY'
 import csv, glob, hashlib, json, os, sys, collections
 out, commit, root = sys.argv[1], sys.argv[2], sys.argv[3]
@@ -43,6 +45,16 @@ j = {"kernel": "k_fine_area", "scene": scene, "paths": int(opt("--paths", 100000
      "valu_insts_per_launch": avg.get("SQ_INSTS_VALU"), "salu_insts_per_launch": avg.get("SQ_INSTS_SALU"),
      "lds_insts_per_launch": avg.get("SQ_INSTS_LDS"), "simds": 1024, "clock_ghz": 2.4,
      "tiles": (int(opt("--size", 4096 if scene == "c3" else 2048)) // 16) ** 2}
+try:
+    import subprocess
+    inst = "ILi%dELb%dELb%dE" % ({"area": 0, "msaa8": 8, "msaa16": 16}[opt("--aa", "area")], 0 if scene in ("c3", "c1", "c2") else 1,
+                                 0 if scene in ("c3", "c1", "c2") else 1)
+    pr = json.loads(subprocess.check_output([sys.executable, root + "/tools/isa_price.py", "/tmp/asm/fine.s", "k_fine_area" + inst]).decode())
+    j["isa_static_mix"] = pr
+    j["valu_cycles_per_inst_static_mix"] = pr["valu_cycles_per_inst_static_mix"]
+    j["issue_rates_source"] = "profiles/r03_ubench_issue_rates.txt (tools/ubench/valu3.hip on an MI355X): 2.2 / 4.2 / 8.1 cycles of a SIMD per wave64 instruction by class; SALU 4.08"
+except Exception as e:  # noqa: BLE001
+    j["isa_static_mix_error"] = str(e)
 name = "fine_counters.json" if scene == "c3" else "fine_counters_%s.json" % scene
 json.dump(j, open(root + "/gpurun_out/" + name, "w"), indent=1)
 print(json.dumps(j, indent=1))

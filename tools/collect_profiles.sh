@@ -7,6 +7,12 @@ COMMIT=${1:-unknown}
 O=$R/gpurun_out/collect
 rm -rf "$O"; mkdir -p "$O"
 cd "$R"
+# counters first: the bench lines below report roofline.traffic from profiles/fine_counters*.json only if those were measured on
+# the kernel sources being run (here: on the box's copy of profiles/; copy gpurun_out/collect/fine_counters*.json home afterwards)
+bash tools/pmc_fine.sh "$COMMIT" > "$O/pmc_c3.log" 2>&1 && echo "pmc c3 done"
+bash tools/pmc_fine.sh "$COMMIT" --scene c4 > "$O/pmc_c4.log" 2>&1 && echo "pmc c4 done"
+bash tools/pmc_fine.sh "$COMMIT" --scene c4n > "$O/pmc_c4n.log" 2>&1 && echo "pmc c4n done"
+cp gpurun_out/fine_counters*.json profiles/ 2>/dev/null
 for S in c3 c4 c4n; do
   bash tools/kprof.sh col_$S --scene $S > "$O/${S}_summary.txt" 2>&1 || exit 1
   cp gpurun_out/kprof_col_$S/kernel_stats.csv "$O/${S}_kernel_stats.csv"
@@ -15,9 +21,6 @@ for S in c3 c4 c4n; do
 done
 timeout -k 10 300 python3 bench.py --aa msaa8 --no-cpu-baseline > "$O/c3_msaa8_bench.json" 2>/dev/null
 timeout -k 10 300 python3 bench.py --aa msaa16 --no-cpu-baseline > "$O/c3_msaa16_bench.json" 2>/dev/null
-bash tools/pmc_fine.sh "$COMMIT" > "$O/pmc_c3.log" 2>&1 && echo "pmc c3 done"
-bash tools/pmc_fine.sh "$COMMIT" --scene c4 > "$O/pmc_c4.log" 2>&1 && echo "pmc c4 done"
-bash tools/pmc_fine.sh "$COMMIT" --scene c4n > "$O/pmc_c4n.log" 2>&1 && echo "pmc c4n done"
 bash tools/fine_split.sh "$COMMIT" > "$O/fine_split.log" 2>&1 && cp gpurun_out/fine_split.json "$O/" && echo "fine split done"
 cp gpurun_out/fine_counters*.json "$O/" 2>/dev/null
 for S in c3 c4 c4n; do timeout -k 10 300 python3 tools/ptcl_stats.py $S > "$O/ptcl_stats_$S.json" 2>/dev/null; done

@@ -300,6 +300,7 @@ def run_rank(args, world):
             "paths_per_s": round(args.paths * units / per, 1),
             "fine_mpixels_per_s": round(W * H / (fine_ms * 1e-3) / 1e6, 2),
             "launch": "hipGraph replay" if use_graph else "eager",
+            "launches_per_frame": None if not use_graph else dict(zip(("kernels", "fills_and_copies"), eng.graph_node_counts(graphs[0]))),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_source": "eager replay of the same %d steps with a hipEvent pair per stage" % args.steps,
             "bump": bump_now, "sizing_attempts": attempts,

@@ -166,6 +166,8 @@ int jh_dispatch_indirect(jh_ctx* ctx, int stage, uint64_t indirect_buffer_id, ui
 int jh_graph_begin(jh_ctx* ctx);
 int jh_graph_end(jh_ctx* ctx, void** graph_exec);
 int jh_graph_launch(jh_ctx* ctx, void* graph_exec);
+/* What the capture recorded: kernel launches and other nodes (fills, copies) of one replay -- the launches per frame. */
+int jh_graph_node_counts(jh_ctx* ctx, void* graph_exec, uint32_t* kernel_nodes, uint32_t* other_nodes);
 int jh_graph_destroy(jh_ctx* ctx, void* graph_exec);
 
 /* ---- profiling ---- */

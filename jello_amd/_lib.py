@@ -191,6 +191,7 @@ def _declare(L):
     hip.jh_graph_begin.argtypes = [vp]
     hip.jh_graph_end.argtypes = [vp, ctypes.POINTER(vp)]
     hip.jh_graph_launch.argtypes = [vp, vp]
+    hip.jh_graph_node_counts.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     hip.jh_graph_destroy.argtypes = [vp, vp]
     hip.jh_free.argtypes = [vp, ctypes.c_uint64]
     hip.jh_clear.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64]

@@ -69,6 +69,7 @@ struct Deferred {
 struct JhGraph {  // a captured frame plus the resource generation it was captured against
     hipGraphExec_t exec;
     uint64_t generation;
+    uint32_t kernel_nodes, other_nodes;  // what the capture recorded (jh_graph_node_counts)
 };
 
 struct Staging {  // pinned host arena for uploads: the caller's slice is copied once, the DMA runs asynchronously
@@ -171,7 +172,16 @@ void* jh_scratch_get(JhScratch* s, int slot, uint64_t bytes) {
         s->ctx->generation++;  // a captured graph may hold the old pointer
     }
     s->base[slot] = p;
-    s->clean_flags = 0u;  // (new memory holds anything)
+    // new memory holds anything: the slot's "left clean by its kernels" flag goes down (the other slots keep theirs -- with one
+    // flag word for all, a frame that grew ANY array late made the next frame fill every counter again, and a graph captured
+    // from that frame kept the fills)
+    switch (slot) {
+        case JH_SCR_SCAN_TMP: s->clean_flags &= ~(uint32_t)JH_CLEAN_SCAN; break;
+        case JH_SCR_FL_CTR: s->clean_flags &= ~(uint32_t)JH_CLEAN_FL_CTR; break;
+        case JH_SCR_BD_CTR: s->clean_flags &= ~(uint32_t)JH_CLEAN_BD_CTR; break;
+        case JH_SCR_PT_CTR: s->clean_flags &= ~(uint32_t)JH_CLEAN_PT_CTR; break;
+        default: break;  // (the other arrays are written before they are read in every frame)
+    }
     p = (char*)p + (uint64_t)slot * JH_SCR_SKEW;
     s->ptr[slot] = p;
     s->cap[slot] = cap;
@@ -710,7 +720,7 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
     } else if (stage == JH_PATHTAG_SCAN1 && ctx->deferred.size() == 2 && !ctx->deferred[0].is_clear && !ctx->deferred[1].is_clear &&
                ctx->deferred[0].stage == JH_PATHTAG_REDUCE && ctx->deferred[1].stage == JH_PATHTAG_REDUCE2 && b.size() >= 3 &&
                ctx->deferred[0].b[2].ptr == b[0].ptr && ctx->deferred[1].b[0].ptr == b[0].ptr && ctx->deferred[1].b[1].ptr == b[1].ptr &&
-               ctx->deferred[1].gx == gx && gx <= 256u) {
+               ctx->deferred[1].gx >= gx && gx <= 256u) {  // (reduce2 is recorded with 256 workgroups; scan1 reads the first gx of its results)
         absorb = JH_ABSORB_PATHTAG;
         extra = ctx->deferred[0].b[0];
         extra2 = ctx->deferred[0].b[1];
@@ -860,11 +870,32 @@ int jh_graph_end(jh_ctx* ctx, void** graph_exec) {
     ctx->capturing = false;
     HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &graph));
     if (frc != JH_OK) { if (graph) (void)hipGraphDestroy(graph); return frc; }
+    // the launches of the frame, counted on the captured graph itself
+    uint32_t n_kernel = 0u, n_other = 0u;
+    {
+        size_t n = 0;
+        if (hipGraphGetNodes(graph, nullptr, &n) == hipSuccess && n > 0) {
+            std::vector<hipGraphNode_t> nodes(n);
+            if (hipGraphGetNodes(graph, nodes.data(), &n) == hipSuccess)
+                for (size_t i = 0; i < n; i++) {
+                    hipGraphNodeType ty = hipGraphNodeTypeEmpty;
+                    if (hipGraphNodeGetType(nodes[i], &ty) != hipSuccess) continue;
+                    if (ty == hipGraphNodeTypeKernel) n_kernel++; else if (ty != hipGraphNodeTypeEmpty) n_other++;
+                }
+        }
+    }
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (e != hipSuccess) return hip_fail(ctx, e, "hipGraphInstantiate");
-    *graph_exec = (void*)new JhGraph{exec, ctx->generation};
+    *graph_exec = (void*)new JhGraph{exec, ctx->generation, n_kernel, n_other};
+    return JH_OK;
+}
+int jh_graph_node_counts(jh_ctx* ctx, void* graph_exec, uint32_t* kernel_nodes, uint32_t* other_nodes) {
+    if (!ctx || !graph_exec) return JH_ERR_INVALID;
+    const JhGraph* g = (const JhGraph*)graph_exec;
+    if (kernel_nodes) *kernel_nodes = g->kernel_nodes;
+    if (other_nodes) *other_nodes = g->other_nodes;
     return JH_OK;
 }
 int jh_graph_launch(jh_ctx* ctx, void* graph_exec) {

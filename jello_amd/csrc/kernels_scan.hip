@@ -341,31 +341,60 @@ __global__ __launch_bounds__(JL_WG) void k_pathtag_reduce_fused(const JlConfig* 
     if (threadIdx.x == 0) {
         if (reduced.ok(blockIdx.x)) store_tm_dev(&reduced.p[blockIdx.x], t);
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the stores above have completed
-        const uint32_t done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = done + 1u == gridDim.x ? 1u : 0u;
+        // "who is last" over two levels: a device-scope atomic is performed behind the eight L2s, ~20 ns apiece when they all
+        // hit ONE word (782 workgroups: 15 us) -- so the workgroups count in up to 32 groups, each on a cache line of its
+        // own, and only the last of each group counts on the common word.
+        const uint32_t n1 = umin_(32u, gridDim.x), g = blockIdx.x % n1;
+        const uint32_t gsize = gridDim.x / n1 + (g < gridDim.x % n1 ? 1u : 0u);
+        uint32_t* c1 = counter + 32u * (g + 1u);
+        uint32_t last = 0u;
+        if (__hip_atomic_fetch_add(c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gsize) {
+            __hip_atomic_store(c1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+            last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == n1 ? 1u : 0u;
+        }
+        s_last = last;
     }
     __syncthreads();
     if (s_last == 0u) return;  // uniform per workgroup
-    // pathtag_reduce2.wgsl:23-41 for its n2 workgroups
-    for (uint32_t b = 0u; b < n2; b++) {
-        MonoidK<5> r = block_reduce_monoid<5>(load_tm_dev(reduced, b * JL_WG + threadIdx.x), sh);
-        if (threadIdx.x == 0 && reduced2.ok(b)) store_tm(&reduced2.p[b], r);
-        __syncthreads();
-    }
-    __syncthreads();
-    // pathtag_scan1.wgsl:26-67 for its n2 workgroups (reduced2 was written by this workgroup: block-level visibility)
-    for (uint32_t b = 0u; b < n2; b++) {
-        MonoidK<5> pre;
+    // pathtag_reduce2.wgsl:23-41 for its first n2 workgroups: the ones whose results pathtag_scan1 (n2 workgroups) reads.  The
+    // recording dispatches 256 of them whatever the scene; the others reduce entries of `reduced` that pathtag_reduce never wrote
+    // into entries of `reduced2` that no command reads, and are left out.
+    // Then pathtag_scan1.wgsl:26-67 for its n2 workgroups.  Both stages read the same entries of `reduced`: they are fetched
+    // ONCE, four workgroups' worth per round with all loads in flight together (a device-scope load is a ~2 us round trip; taken
+    // one after the other, eight of them made this launch slower than the three it replaces), and the partial sums of
+    // `reduced2` stay in LDS (they are also stored: the buffer holds what the recording says).
+    __shared__ uint32_t s_r2[256][5];  // reduced2[b] of this launch
+    for (uint32_t b0 = 0u; b0 < n2; b0 += 4u) {  // (n2 <= 256; 4 for the 100 k-path frame)
+        MonoidK<5> v[4];
 #pragma unroll
-        for (int i = 0; i < 5; i++) pre.v[i] = 0u;
-        if (threadIdx.x < b) pre = load_tm(reduced2, threadIdx.x);
-        MonoidK<5> prefix = block_reduce_monoid<5>(pre, sh);
-        __syncthreads();
-        MonoidK<5> tot;
-        const uint32_t jx = b * JL_WG + threadIdx.x;
-        MonoidK<5> ex = block_excl_scan_monoid<5>(load_tm_dev(reduced, jx), sh, &tot);
-        if (reduced_scan.ok(jx)) store_tm(&reduced_scan.p[jx], monoid_add(prefix, ex));
-        __syncthreads();
+        for (uint32_t q = 0u; q < 4u; q++) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) v[q].v[i] = 0u;
+            if (b0 + q < n2) v[q] = load_tm_dev(reduced, (b0 + q) * JL_WG + threadIdx.x);
+        }
+#pragma unroll
+        for (uint32_t q = 0u; q < 4u; q++) {
+            const uint32_t b = b0 + q;
+            if (b >= n2) break;  // uniform
+            MonoidK<5> r = block_reduce_monoid<5>(v[q], sh);
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int i = 0; i < 5; i++) s_r2[b][i] = r.v[i];
+                if (reduced2.ok(b)) store_tm(&reduced2.p[b], r);
+            }
+            __syncthreads();
+            // scan1 of workgroup b: prefix = sum of reduced2[l] for l < b (all of them are in LDS by now), then the exclusive scan
+            MonoidK<5> pre;
+#pragma unroll
+            for (int i = 0; i < 5; i++) pre.v[i] = (threadIdx.x < b) ? s_r2[threadIdx.x][i] : 0u;
+            MonoidK<5> prefix = block_reduce_monoid<5>(pre, sh);
+            __syncthreads();
+            MonoidK<5> tot;
+            const uint32_t jx = b * JL_WG + threadIdx.x;
+            MonoidK<5> ex = block_excl_scan_monoid<5>(v[q], sh, &tot);
+            if (reduced_scan.ok(jx)) store_tm(&reduced_scan.p[jx], monoid_add(prefix, ex));
+            __syncthreads();
+        }
     }
     if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
 }
@@ -401,10 +430,11 @@ int jh_launch_pathtag(const JhLaunch& L, int stage) {
             if (L.nb < 3) return -1;
             if (L.absorb & JH_ABSORB_PATHTAG) {  // pathtag_reduce and pathtag_reduce2 were held back: one launch does all three
                 // L.extra / L.extra2: [config, scene] of pathtag_reduce; L.gz_fused = its grid; this stage's grid = reduce2's
-                uint32_t* ctr = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_PT_CTR, 64);
+                const uint64_t ctr_bytes = 33u * 128u;  // the common word + 32 group words, a cache line each
+                uint32_t* ctr = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_PT_CTR, ctr_bytes);
                 if (!ctr) return -5;
                 uint32_t* clean = jh_scratch_flags(L.scratch);
-                if ((*clean & JH_CLEAN_PT_CTR) == 0u) (void)hipMemsetAsync(ctr, 0, 64, L.stream);
+                if ((*clean & JH_CLEAN_PT_CTR) == 0u) (void)hipMemsetAsync(ctr, 0, jh_scratch_cap(L.scratch, JH_SCR_PT_CTR), L.stream);
                 *clean |= JH_CLEAN_PT_CTR;
                 hipLaunchKernelGGL(k_pathtag_reduce_fused, dim3(L.fused_grid), blk, 0, L.stream, (const JlConfig*)L.extra.ptr,
                                    mkbuf<uint32_t>(L.extra2.ptr, L.extra2.size), mkbuf<JlTagMonoid>(L.b[0].ptr, L.b[0].size),

@@ -168,6 +168,12 @@ class Engine:
     def replay(self, graph):
         self._check(self.hip.jh_graph_launch(self.ctx, graph), "graph_launch")
 
+    def graph_node_counts(self, graph):
+        """(kernel launches, other nodes) of one replay of a captured frame."""
+        k, o = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        self._check(self.hip.jh_graph_node_counts(self.ctx, graph, ctypes.byref(k), ctypes.byref(o)), "graph_node_counts")
+        return k.value, o.value
+
     def graph_destroy(self, graph):
         self.hip.jh_graph_destroy(self.ctx, graph)
 

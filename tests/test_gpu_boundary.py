@@ -187,6 +187,33 @@ def test_graph_replays_and_eager_frames_interleave(engine):
     engine.release(rb)
 
 
+def test_launches_per_frame_of_a_large_scene(engine):
+    """The launch diet, counted on the captured graph: a scene on the three-level pathtag path (more than 256 tag workgroups)
+    is 26 kernel launches and no fill -- the held-back commands (bbox_clear, Clear(bump), both setup dispatches, pathtag_reduce
+    + pathtag_reduce2 inside pathtag_scan1's launch) and the single-launch scans are all in effect -- and the replay
+    reproduces the eager frame."""
+    s, p = scenes.scene_c3(40000, 1024)
+    p.bump = s.bump_sizes(1024, 1024)
+    rec = jello_amd.Host().record(s, p)
+    assert rec.config["pathdata_base"] - rec.config["pathtag_base"] > 256 * 256  # tag words: the large scan path
+    engine.run(rec, RUN_UPLOADS | RUN_DISPATCHES)
+    engine.sync()
+    t = rec.target
+    img = engine.download_image(t["id"], t["width"], t["height"]).copy()
+    bump = engine.download(rec.buffer("bumpBuf")[0], dtype=np.uint32)[:8].copy()
+    assert bump[0] == 0
+    g = engine.capture(rec)
+    kernels, others = engine.graph_node_counts(g)
+    assert kernels == 26 and others == 0, (kernels, others)
+    for _ in range(3):
+        engine.replay(g)
+        engine.sync()
+        assert np.array_equal(engine.download_image(t["id"], t["width"], t["height"]), img)
+        assert np.array_equal(engine.download(rec.buffer("bumpBuf")[0], dtype=np.uint32)[:8], bump)
+    engine.graph_destroy(g)
+    engine.release(rec)
+
+
 def test_two_graphs_for_two_output_buffers(engine):
     """bench.py's N > 1 path renders into two caller-owned images in turn (the RCCL gather of frame i reads one while
     frame i + 1 is rendered into the other): one captured graph per output, replayed alternately.  Re-importing the

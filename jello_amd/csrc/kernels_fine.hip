@@ -809,22 +809,144 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             }
         }
     };
+    // One FILL command (fill_path, fine.wgsl:824-878): leaves the finished coverage of the lane's four pixels in area[].
+    auto do_fill = [&](uint32_t size_and_rule, uint32_t seg_data, int32_t backdrop) {
+        uint32_t n_segs = size_and_rule >> 1;
+        // segments behind the end of the buffer read as zero and contribute nothing (robust access), so a corrupt
+        // count is cut to the buffer: the loops below are bounded by the buffer size, not by a stream word
+        // (area coverage only: in the multisampled fill a zero segment touches the tile corner and does count)
+        if constexpr (AA == 0) n_segs = umin_(n_segs, seg_data < segments_n ? segments_n - seg_data : 0u);
+        bool even_odd = (size_and_rule & 1u) != 0u;
+      if constexpr (AA == 0) {
+        float backdrop_f = (float)backdrop;
+#pragma unroll
+        for (int k = 0; k < 4; k++) area[k] = backdrop_f;
+        uint32_t sa = seg_data, remaining = n_segs;
+        while (remaining != 0u) {  // uniform
+#if FINE_SKIP == 4
+            batch_hi = sa + remaining;
+            cur_base = sa;
+#else
+            if (sa - cur_base >= batch_hi - cur_base) build_batch(sa);
+#endif
+            const uint32_t take = umin_(remaining, batch_hi - sa);
+            const uint32_t r0 = sa - cur_base;  // window-relative segments [r0, r0 + take)
+            auto below = [](uint32_t P) -> uint64_t { return (1ull << (P & 63u)) - 1ull; };  // P <= 63
+            // stage 4, lane = pixel quad of row ly: the entries of my row are in segment order, so the terms of the WGSL's
+            // loop that can change my sum -- a*dy of the segments with a pair in my row -- are added in its order by
+            // walking my row's list; a segment with a y_edge term (uniform: a bit of edge_mask) ends a run of such
+            // additions for all rows, the term is added, and the walk goes on behind it.
+            const uint64_t my_rowmask = F.rowmask[ly];
+            const uint32_t st = F.lanest[lane];
+            const uint32_t my_first = F.first[lane];  // lane = window segment: read off with v_readlane below
+            auto first_of = [&](uint32_t sl) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)my_first, (int)(sl & 63u)); };
+            const uint32_t row_addr = st & 0xffffu;
+            uint32_t done = st >> 16;  // entries of my row consumed so far
+            if (sa != next_seg) done = (uint32_t)__builtin_popcountll(my_rowmask & below(first_of(r0)));  // (a fill that does not continue the previous one)
+            uint32_t cur = row_addr + done * 16u;
+            uint64_t em = edge_mask & (below(r0 + take) & ~below(r0));
+            for (; FINE_SKIP != 2 && FINE_SKIP != 4;) {  // uniform
+                const uint32_t e_sl = em != 0ull ? (uint32_t)__builtin_ctzll(em) : 0u;
+                const uint32_t seg_end = em != 0ull ? e_sl + 1u : r0 + take;  // the run covers window segments < seg_end
+                done = (uint32_t)__builtin_popcountll(my_rowmask & below(first_of(seg_end)));
+                const uint32_t hi = row_addr + done * 16u;
+                // Walk my row's entries [cur, hi), two per trip (both loads in flight before the ordered adds): lanes drop
+                // out of EXEC as their rows run out (no lane comes back inside a run), the loop ends when none is left.
+                // Written in assembly: as C++ the compiler keeps two copies of the area registers around this loop (four
+                // moves per trip) and cannot mask the loads (lanes reading a dummy entry collide with the live ones).
+                {
+                    jk_v2f a01 = {area[0], area[1]}, a23 = {area[2], area[3]};
+                    uint64_t sv, s1;
+                    uint32_t t;
+                    asm volatile(
+                        "s_mov_b64 %[sv], exec\n"
+                        "1:\n"
+                        "v_cmpx_lt_u32_e32 vcc, %[cur], %[hi]\n"
+                        "s_cbranch_execz 3f\n"
+                        "ds_read_b128 v[72:75], %[cur]\n"
+                        "v_add_u32_e32 %[t], 16, %[cur]\n"
+                        "v_cmp_lt_u32_e32 vcc, %[t], %[hi]\n"
+                        "s_mov_b64 %[s1], exec\n"
+                        "s_and_b64 exec, exec, vcc\n"
+                        "ds_read_b128 v[76:79], %[cur] offset:16\n"
+                        "s_mov_b64 exec, %[s1]\n"
+                        "v_add_u32_e32 %[cur], 32, %[cur]\n"
+                        "s_waitcnt lgkmcnt(1)\n"
+                        "v_pk_add_f32 %[a01], %[a01], v[72:73]\n"
+                        "v_pk_add_f32 %[a23], %[a23], v[74:75]\n"
+                        "s_and_b64 exec, exec, vcc\n"
+                        "s_waitcnt lgkmcnt(0)\n"
+                        "v_pk_add_f32 %[a01], %[a01], v[76:77]\n"
+                        "v_pk_add_f32 %[a23], %[a23], v[78:79]\n"
+                        "s_mov_b64 exec, %[s1]\n"
+                        "s_branch 1b\n"
+                        "3:\n"
+                        "s_mov_b64 exec, %[sv]\n"
+                        : [cur] "+v"(cur), [a01] "+v"(a01), [a23] "+v"(a23), [sv] "=&s"(sv), [s1] "=&s"(s1), [t] "=&v"(t)
+                        : [hi] "v"(hi)
+                        : "vcc", "memory", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79");
+                    area[0] = a01.x; area[1] = a01.y; area[2] = a23.x; area[3] = a23.y;
+                }
+                cur = hi;
+                if (em == 0ull) break;
+                {
+                    const float2 ed = F.edge[e_sl];
+                    const float y_edge = ed.y * clamp_(lyf - ed.x + 1.0f, 0.0f, 1.0f);
+                    area[0] += y_edge; area[1] += y_edge; area[2] += y_edge; area[3] += y_edge;
+                }
+                em &= em - 1ull;
+            }
+            lds_st_u16(lds_addr(&F.lanest[lane]) + 2u, (uint16_t)done);
+            next_seg = sa + take;
+            sa += take;
+            remaining -= take;
+        }
+        if (even_odd) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { float a = area[k]; area[k] = abs_(a - 2.0f * round_(0.5f * a)); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) area[k] = fmin_(abs_(area[k]), 1.0f);
+        }
+      } else {
+        (void)n_segs; (void)even_odd;
+        fill_path_ms<AA>(F, lane, size_and_rule, seg_data, backdrop, segments, segments_n, mask_lut, mask_lut_n, area);
+      }
+    };
+    auto ensure_window = [&]() {
+    if (pc - wbase > 64u - FINE_TRIP_WORDS) {  // uniform: fewer words than a trip may need are in `wcur`
+        // Re-base the window at pc: lane k takes word pc + k from the two windows (ds_bpermute: a lane shuffle through
+        // the LDS crossbar, no LDS storage), and the window behind the new one is requested.
+        const uint32_t sh = pc - wbase;  // <= 64: a trip advances pc by at most FINE_TRIP_WORDS words (jumps reload)
+        const uint32_t src = lane + sh;
+        const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src & 63u) << 2), (int)wcur);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src & 63u) << 2), (int)wnext);
+        wcur = src < 64u ? a : b;      // src <= 127
+        wbase = pc;
+        wnext = load_win(wbase + 64u);
+    }
+    };
     for (uint32_t guard = 0; guard < (1u << 24); guard++) {
         // (a trip consumes at most FINE_TRIP_WORDS words: up to three BEGIN_CLIPs and a SOLID in front of a command of up to nine)
-        if (pc - wbase > 64u - FINE_TRIP_WORDS) {  // uniform: fewer words than a trip may need are in `wcur`
-            // Re-base the window at pc: lane k takes word pc + k from the two windows (ds_bpermute: a lane shuffle through
-            // the LDS crossbar, no LDS storage), and the window behind the new one is requested.
-            const uint32_t sh = pc - wbase;  // <= 64: a trip advances pc by at most FINE_TRIP_WORDS words (jumps reload)
-            const uint32_t src = lane + sh;
-            const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src & 63u) << 2), (int)wcur);
-            const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src & 63u) << 2), (int)wnext);
-            wcur = src < 64u ? a : b;      // src <= 127
-            wbase = pc;
-            wnext = load_win(wbase + 64u);
-        }
+        ensure_window();
         uint32_t woff = pc - wbase;  // <= 64 - FINE_TRIP_WORDS: the words this trip may consume are all in wcur
         auto W = [&](uint32_t k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)wcur, (int)(woff + k)); };
         uint32_t tag = W(0);
+        if constexpr (!CLIPS) {
+            // FILL followed by COLOR, the usual pair, in a loop of its own: ONE definition of the colour registers around ONE back edge
+            // (as an arm of the general decoder below the pair carried that decoder's flag variables, state copies and branch chain).
+            for (uint32_t hot = 0; hot < (1u << 24) && tag == JL_CMD_FILL && W(4) == JL_CMD_COLOR; hot++) {  // uniform
+                do_fill(W(1), W(2), (int32_t)W(3));
+                const V4 fgc = v4(u2f(W(5)), u2f(W(6)), u2f(W(7)), u2f(W(8)));
+                pc += 9u;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    rgba[k] = FINE_SKIP == 5 ? v4(rgba[k].x + area[k], rgba[k].y + fgc.x, rgba[k].z + fgc.y, rgba[k].w + fgc.z * fgc.w) : over(rgba[k], fgc, area[k]);
+                ensure_window();
+                woff = pc - wbase;
+                tag = W(0);
+            }
+        }
         if constexpr (CLIPS) {
             // BEGIN_CLIP only counts (the save is deferred, see pushed_depth) and SOLID only sets the area: both are
             // consumed in front of the command that follows instead of in trips of their own -- a trip of this loop
@@ -849,110 +971,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         bool have_fg = false;
         V4 fg = v4(0, 0, 0, 0);
         if (tag == JL_CMD_FILL) {  // fill_path, fine.wgsl:824-878
-            uint32_t size_and_rule = W(1);
-            uint32_t seg_data = W(2);
-            int32_t backdrop = (int32_t)W(3);
-            uint32_t n_segs = size_and_rule >> 1;
-            // segments behind the end of the buffer read as zero and contribute nothing (robust access), so a corrupt
-            // count is cut to the buffer: the loops below are bounded by the buffer size, not by a stream word
-            // (area coverage only: in the multisampled fill a zero segment touches the tile corner and does count)
-            if constexpr (AA == 0) n_segs = umin_(n_segs, seg_data < segments_n ? segments_n - seg_data : 0u);
-            bool even_odd = (size_and_rule & 1u) != 0u;
-          if constexpr (AA == 0) {
-            float backdrop_f = (float)backdrop;
-#pragma unroll
-            for (int k = 0; k < 4; k++) area[k] = backdrop_f;
-            uint32_t sa = seg_data, remaining = n_segs;
-            while (remaining != 0u) {  // uniform
-#if FINE_SKIP == 4
-                batch_hi = sa + remaining;
-                cur_base = sa;
-#else
-                if (sa - cur_base >= batch_hi - cur_base) build_batch(sa);
-#endif
-                const uint32_t take = umin_(remaining, batch_hi - sa);
-                const uint32_t r0 = sa - cur_base;  // window-relative segments [r0, r0 + take)
-                auto below = [](uint32_t P) -> uint64_t { return (1ull << (P & 63u)) - 1ull; };  // P <= 63
-                // stage 4, lane = pixel quad of row ly: the entries of my row are in segment order, so the terms of the WGSL's
-                // loop that can change my sum -- a*dy of the segments with a pair in my row -- are added in its order by
-                // walking my row's list; a segment with a y_edge term (uniform: a bit of edge_mask) ends a run of such
-                // additions for all rows, the term is added, and the walk goes on behind it.
-                const uint64_t my_rowmask = F.rowmask[ly];
-                const uint32_t st = F.lanest[lane];
-                const uint32_t my_first = F.first[lane];  // lane = window segment: read off with v_readlane below
-                auto first_of = [&](uint32_t sl) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)my_first, (int)(sl & 63u)); };
-                const uint32_t row_addr = st & 0xffffu;
-                uint32_t done = st >> 16;  // entries of my row consumed so far
-                if (sa != next_seg) done = (uint32_t)__builtin_popcountll(my_rowmask & below(first_of(r0)));  // (a fill that does not continue the previous one)
-                uint32_t cur = row_addr + done * 16u;
-                uint64_t em = edge_mask & (below(r0 + take) & ~below(r0));
-                for (; FINE_SKIP != 2 && FINE_SKIP != 4;) {  // uniform
-                    const uint32_t e_sl = em != 0ull ? (uint32_t)__builtin_ctzll(em) : 0u;
-                    const uint32_t seg_end = em != 0ull ? e_sl + 1u : r0 + take;  // the run covers window segments < seg_end
-                    done = (uint32_t)__builtin_popcountll(my_rowmask & below(first_of(seg_end)));
-                    const uint32_t hi = row_addr + done * 16u;
-                    // Walk my row's entries [cur, hi), two per trip (both loads in flight before the ordered adds): lanes drop
-                    // out of EXEC as their rows run out (no lane comes back inside a run), the loop ends when none is left.
-                    // Written in assembly: as C++ the compiler keeps two copies of the area registers around this loop (four
-                    // moves per trip) and cannot mask the loads (lanes reading a dummy entry collide with the live ones).
-                    {
-                        jk_v2f a01 = {area[0], area[1]}, a23 = {area[2], area[3]};
-                        uint64_t sv, s1;
-                        uint32_t t;
-                        asm volatile(
-                            "s_mov_b64 %[sv], exec\n"
-                            "1:\n"
-                            "v_cmpx_lt_u32_e32 vcc, %[cur], %[hi]\n"
-                            "s_cbranch_execz 3f\n"
-                            "ds_read_b128 v[72:75], %[cur]\n"
-                            "v_add_u32_e32 %[t], 16, %[cur]\n"
-                            "v_cmp_lt_u32_e32 vcc, %[t], %[hi]\n"
-                            "s_mov_b64 %[s1], exec\n"
-                            "s_and_b64 exec, exec, vcc\n"
-                            "ds_read_b128 v[76:79], %[cur] offset:16\n"
-                            "s_mov_b64 exec, %[s1]\n"
-                            "v_add_u32_e32 %[cur], 32, %[cur]\n"
-                            "s_waitcnt lgkmcnt(1)\n"
-                            "v_pk_add_f32 %[a01], %[a01], v[72:73]\n"
-                            "v_pk_add_f32 %[a23], %[a23], v[74:75]\n"
-                            "s_and_b64 exec, exec, vcc\n"
-                            "s_waitcnt lgkmcnt(0)\n"
-                            "v_pk_add_f32 %[a01], %[a01], v[76:77]\n"
-                            "v_pk_add_f32 %[a23], %[a23], v[78:79]\n"
-                            "s_mov_b64 exec, %[s1]\n"
-                            "s_branch 1b\n"
-                            "3:\n"
-                            "s_mov_b64 exec, %[sv]\n"
-                            : [cur] "+v"(cur), [a01] "+v"(a01), [a23] "+v"(a23), [sv] "=&s"(sv), [s1] "=&s"(s1), [t] "=&v"(t)
-                            : [hi] "v"(hi)
-                            : "vcc", "memory", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79");
-                        area[0] = a01.x; area[1] = a01.y; area[2] = a23.x; area[3] = a23.y;
-                    }
-                    cur = hi;
-                    if (em == 0ull) break;
-                    {
-                        const float2 ed = F.edge[e_sl];
-                        const float y_edge = ed.y * clamp_(lyf - ed.x + 1.0f, 0.0f, 1.0f);
-                        area[0] += y_edge; area[1] += y_edge; area[2] += y_edge; area[3] += y_edge;
-                    }
-                    em &= em - 1ull;
-                }
-                lds_st_u16(lds_addr(&F.lanest[lane]) + 2u, (uint16_t)done);
-                next_seg = sa + take;
-                sa += take;
-                remaining -= take;
-            }
-            if (even_odd) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) { float a = area[k]; area[k] = abs_(a - 2.0f * round_(0.5f * a)); }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) area[k] = fmin_(abs_(area[k]), 1.0f);
-            }
-          } else {
-            (void)n_segs; (void)even_odd;
-            fill_path_ms<AA>(F, lane, size_and_rule, seg_data, backdrop, segments, segments_n, mask_lut, mask_lut_n, area);
-          }
+            do_fill(W(1), W(2), (int32_t)W(3));
             pc += 4u;
             if (W(4) == JL_CMD_COLOR) {  // the usual pair: no second trip through the decoder
                 fg = v4(u2f(W(5)), u2f(W(6)), u2f(W(7)), u2f(W(8)));

@@ -809,6 +809,45 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             }
         }
     };
+    // END_CLIP of a layer that is still pending (see the END_CLIP command below for why these are exact): true if the layer
+    // was closed here -- rgba is then what the full formula gives --, false if the full formula has to be taken.
+    auto end_clip_fast = [&](uint32_t blend, float alpha, uint32_t level) -> bool {
+        bool fast = false;
+        if (clip_depth != 0u && pushed_depth <= level && alpha >= 0.0f && alpha < __builtin_inff()) {  // uniform
+            const bool plain = (blend & 0x7fffu) == 0u;
+            const uint32_t mixm = blend >> 8;
+            const bool separable = (blend & 0xffu) == 0u && mixm >= 1u && mixm <= 14u;
+            const bool needs_lum = mixm >= 12u;
+            if (plain || separable) {
+                // (the range tests are unsigned comparisons of bit patterns: one comparison of the MAXIMUM pattern per
+                // group of values -- v_max3_u32 -- instead of one comparison and one mask operation per value)
+                auto umax3 = [](uint32_t a, uint32_t b, uint32_t c) -> uint32_t { return umax_(umax_(a, b), c); };
+                bool ok = umax_(umax3(f2u(area[0]), f2u(area[1]), f2u(area[2])), f2u(area[3])) <= 0x3f800000u;
+                if (!plain) {
+                    uint32_t m[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) m[k] = umax_(umax3(f2u(rgba[k].x), f2u(rgba[k].y), f2u(rgba[k].z)), f2u(rgba[k].w));
+                    ok = ok && umax_(umax3(m[0], m[1], m[2]), m[3]) <= 0x41800000u;
+                    if (needs_lum) {  // uniform
+                        uint32_t lm = 0u;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const float inv_backdrop_a = 1.0f / fmax_(rgba[k].w, 1e-15f);  // blend.wgsl:293-294
+                            const float l = lum(v3(rgba[k].x * inv_backdrop_a, rgba[k].y * inv_backdrop_a, rgba[k].z * inv_backdrop_a));
+                            lm = umax_(lm, f2u(l));
+                        }
+                        ok = ok && lm <= 0x3f800000u;
+                    }
+                }
+                fast = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+                if (fast && plain) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) rgba[k] = v4(rgba[k].x + 0.0f, rgba[k].y + 0.0f, rgba[k].z + 0.0f, rgba[k].w + 0.0f);
+                }
+            }
+        }
+        return fast;
+    };
     // One FILL command (fill_path, fine.wgsl:824-878): leaves the finished coverage of the lane's four pixels in area[].
     auto do_fill = [&](uint32_t size_and_rule, uint32_t seg_data, int32_t backdrop) {
         uint32_t n_segs = size_and_rule >> 1;
@@ -932,16 +971,45 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         uint32_t woff = pc - wbase;  // <= 64 - FINE_TRIP_WORDS: the words this trip may consume are all in wcur
         auto W = [&](uint32_t k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)wcur, (int)(woff + k)); };
         uint32_t tag = W(0);
-        if constexpr (!CLIPS) {
+        {
             // FILL followed by COLOR, the usual pair, in a loop of its own: ONE definition of the colour registers around ONE back edge
             // (as an arm of the general decoder below the pair carried that decoder's flag variables, state copies and branch chain).
             for (uint32_t hot = 0; hot < (1u << 24) && tag == JL_CMD_FILL && W(4) == JL_CMD_COLOR; hot++) {  // uniform
                 do_fill(W(1), W(2), (int32_t)W(3));
                 const V4 fgc = v4(u2f(W(5)), u2f(W(6)), u2f(W(7)), u2f(W(8)));
                 pc += 9u;
+                materialize();
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                     rgba[k] = FINE_SKIP == 5 ? v4(rgba[k].x + area[k], rgba[k].y + fgc.x, rgba[k].z + fgc.y, rgba[k].w + fgc.z * fgc.w) : over(rgba[k], fgc, area[k]);
+                ensure_window();
+                woff = pc - wbase;
+                tag = W(0);
+            }
+        }
+        if constexpr (CLIPS) {
+            // Empty layers -- BEGIN_CLIP ... [SOLID] END_CLIP with nothing drawn in between, 213 per tile in the C4 scene -- likewise in a
+            // loop of their own: the BEGIN_CLIPs only count, SOLID sets the area, and an END_CLIP that the shortcut can close leaves
+            // the loop's state as the general decoder would.  Anything else falls through to the decoder with the words consumed so
+            // far accounted for (exactly what its own folding of BEGIN_CLIP / SOLID does).
+            for (uint32_t hot = 0; hot < (1u << 24); hot++) {  // uniform
+                uint32_t k = 0u, nb = 0u;
+                while (nb < 3u && W(k) == JL_CMD_BEGIN_CLIP) { nb++; k++; }
+                const bool solid = W(k) == JL_CMD_SOLID;
+                if (solid) k++;
+                if (W(k) != JL_CMD_END_CLIP) break;
+                // (the decoder's order: BEGIN_CLIPs, then SOLID, then the command)
+                clip_depth += nb;
+                if (solid) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) area[q] = 1.0f;
+                }
+                pc += k; woff += k;
+                tag = JL_CMD_END_CLIP;
+                if (clip_depth == 0u) break;  // (a stray END_CLIP: the decoder's business)
+                if (!end_clip_fast(W(1), u2f(W(2)), clip_depth - 1u)) break;
+                clip_depth -= 1u;
+                pc += 3u;
                 ensure_window();
                 woff = pc - wbase;
                 tag = W(0);
@@ -1010,40 +1078,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             //                      backdrops: no shortcut.)
             // Anything else (other compose operators, a backdrop outside [+0, 16], NaNs) performs the pending saves and takes
             // the full formula.  The unsigned comparison of the bit patterns tests "+0 <= v <= limit".
-            bool fast = false;
-            if (clip_depth != 0u && pushed_depth <= level && alpha >= 0.0f && alpha < __builtin_inff()) {  // uniform
-                const bool plain = (blend & 0x7fffu) == 0u;
-                const uint32_t mixm = blend >> 8;
-                const bool separable = (blend & 0xffu) == 0u && mixm >= 1u && mixm <= 14u;
-                const bool needs_lum = mixm >= 12u;
-                if (plain || separable) {
-                    // (the range tests are unsigned comparisons of bit patterns: one comparison of the MAXIMUM pattern per
-                    // group of values -- v_max3_u32 -- instead of one comparison and one mask operation per value)
-                    auto umax3 = [](uint32_t a, uint32_t b, uint32_t c) -> uint32_t { return umax_(umax_(a, b), c); };
-                    bool ok = umax_(umax3(f2u(area[0]), f2u(area[1]), f2u(area[2])), f2u(area[3])) <= 0x3f800000u;
-                    if (!plain) {
-                        uint32_t m[4];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) m[k] = umax_(umax3(f2u(rgba[k].x), f2u(rgba[k].y), f2u(rgba[k].z)), f2u(rgba[k].w));
-                        ok = ok && umax_(umax3(m[0], m[1], m[2]), m[3]) <= 0x41800000u;
-                        if (needs_lum) {  // uniform
-                            uint32_t lm = 0u;
-#pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                const float inv_backdrop_a = 1.0f / fmax_(rgba[k].w, 1e-15f);  // blend.wgsl:293-294
-                                const float l = lum(v3(rgba[k].x * inv_backdrop_a, rgba[k].y * inv_backdrop_a, rgba[k].z * inv_backdrop_a));
-                                lm = umax_(lm, f2u(l));
-                            }
-                            ok = ok && lm <= 0x3f800000u;
-                        }
-                    }
-                    fast = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
-                    if (fast && plain) {
-#pragma unroll
-                        for (int k = 0; k < 4; k++) rgba[k] = v4(rgba[k].x + 0.0f, rgba[k].y + 0.0f, rgba[k].z + 0.0f, rgba[k].w + 0.0f);
-                    }
-                }
-            }
+            const bool fast = end_clip_fast(blend, alpha, level);
             if (!fast) {
                 materialize();
 #pragma unroll

@@ -18,9 +18,13 @@
 // blend_spill exactly like the WGSL; layers are lazy (see pushed_depth).  Instantiations: coverage mode (area / msaa8 /
 // msaa16) x with/without the clip stack x with/without gradient+image code; the launcher picks by ConfigUniform.n_clip
 // and by whether any ramp/image is bound.  Lean area variant: 80 VGPRs, no scratch, 6.6 KB of LDS per tile-wave.
-// What bounds it (profiles/r03_fine_experiments.md, r03_fine_split.json): neither HBM nor the VALU pipes alone -- a tile is
-// ~5000 dependent wave-instructions (2800 VALU, 1900 SALU, 300 LDS) with LDS round trips between them; with 6 waves per SIMD
-// the kernel sits between the latency of one wave (24 us per tile) and the pipes' floor (~0.235 ms for the frame).
+// Command loop: loops per PATTERN in front of a general decoder.  FILL followed by COLOR (the pair a plain scene consists of) runs in a
+// loop of its own, and so do the empty layers of clip scenes (BEGIN_CLIP ... [SOLID] END_CLIP closed by the shortcut): one definition of the
+// sixteen colour registers around one back edge each.  As arms of one decoder loop with many exits they carried its flag variables, state
+// copies and branch chain (C3: 0.402 -> 0.369 ms; C4: 31 k -> 19 k vector instructions per tile).
+// What bounds it (profiles/r03_fine_experiments.md, r03_fine_split.json, r03_ubench_issue_rates.txt): vector issue.  A C3 tile is 2710 VALU +
+// 1550 SALU + 300 LDS wave-instructions; priced with the measured issue costs (3.8 cycles per vector instruction of this mix, 4.1 per scalar
+// one) the vector pipe of a SIMD is busy 74 % of the kernel's time, the scalar pipe 46 %, the LDS ~40 %.
 #include <cstring>
 
 #include "kcommon.h"

@@ -624,6 +624,11 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
     uint32_t next_seg = 0xffffffffu;                 // the segment the rows' consumed counts stand in front of
     const float lyf = (float)ly;
     uint32_t ent_lds = 0u;  // LDS byte address of my quad's plane of entries (stage 4 walks addresses)
+    // per-lane walk state of the batch, carried in registers from fill to fill where there are registers (!CLIPS; as LDS words they cost
+    // every fill a round trip before its walk could start: C3 fine 362 -> 358 us): my row's mask of pairs, the first pair of the window segment in this lane, my row's entries and how many of
+    // them the fills so far have consumed
+    uint64_t s4_rowmask = 0ull;
+    uint32_t s4_first = 0u, s4_row_addr = 0u, s4_done = 0u;
     if constexpr (AA == 0) ent_lds = lds_addr(&F.ent[lx][0]);
 
     // Evaluate the batch that starts at segment `so` (uniform).
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         const uint32_t e_rel = (uint32_t)__builtin_popcountll(fit);       // > 0: one segment has at most 16 pairs
         n_pairs = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(e_rel - 1u));
         const uint32_t first = incl - my_cnt;
-        F.first[lane] = (uint8_t)(lane < e_rel ? first : n_pairs);
+        if constexpr (CLIPS) F.first[lane] = (uint8_t)(lane < e_rel ? first : n_pairs); else s4_first = lane < e_rel ? first : n_pairs;
         // y_edge >= 16 (path_tiling's "no edge" value is 1e9) clamps to 0 for every row of the tile
         edge_mask = __builtin_amdgcn_ballot_w64(c_ye < 16.0f) & fit;
         const uint32_t meta = first | ((uint32_t)ra << 8) | (sane ? (1u << 16) : 0u);
@@ -725,7 +730,13 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         inc16 += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc16, JK_DPP_ROW_SHR(8), 0xf, 0xf, false);
         const uint32_t excl16 = inc16 - c16;
         const uint32_t pos = (__shfl(excl16, (int)row, 64) + rank) & 63u;
-        F.lanest[lane] = ent_lds + __shfl(excl16, (int)ly, 64) * 16u;  // nothing consumed yet
+        if constexpr (CLIPS) {
+            F.lanest[lane] = ent_lds + __shfl(excl16, (int)ly, 64) * 16u;  // nothing consumed yet
+        } else {
+            s4_row_addr = ent_lds + __shfl(excl16, (int)ly, 64) * 16u;
+            s4_done = 0u;  // nothing consumed yet
+            s4_rowmask = F.rowmask[ly];
+        }
         next_seg = so;
         if (is_pair) {
             // pixel q contributes dy from column c1 on: clamp(q + 1 - c1, 0, 1) is exactly 1 or 0, and dy * 0 = +-0 is what the
@@ -880,12 +891,18 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             // loop that can change my sum -- a*dy of the segments with a pair in my row -- are added in its order by
             // walking my row's list; a segment with a y_edge term (uniform: a bit of edge_mask) ends a run of such
             // additions for all rows, the term is added, and the walk goes on behind it.
-            const uint64_t my_rowmask = F.rowmask[ly];
-            const uint32_t st = F.lanest[lane];
-            const uint32_t my_first = F.first[lane];  // lane = window segment: read off with v_readlane below
-            auto first_of = [&](uint32_t sl) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)my_first, (int)(sl & 63u)); };
-            const uint32_t row_addr = st & 0xffffu;
-            uint32_t done = st >> 16;  // entries of my row consumed so far
+            uint64_t my_rowmask;
+            uint32_t my_first, row_addr, done;  // (first pair of the window segment in this lane; my row's entries; how many are consumed)
+            if constexpr (CLIPS) {  // (the clip instantiations have no registers to spare: the state stays in LDS)
+                my_rowmask = F.rowmask[ly];
+                const uint32_t st = F.lanest[lane];
+                my_first = F.first[lane];
+                row_addr = st & 0xffffu;
+                done = st >> 16;
+            } else {
+                my_rowmask = s4_rowmask; my_first = s4_first; row_addr = s4_row_addr; done = s4_done;
+            }
+            auto first_of = [&](uint32_t sl) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)my_first, (int)(sl & 63u)); };  // lane = window segment
             if (sa != next_seg) done = (uint32_t)__builtin_popcountll(my_rowmask & below(first_of(r0)));  // (a fill that does not continue the previous one)
             uint32_t cur = row_addr + done * 16u;
             uint64_t em = edge_mask & (below(r0 + take) & ~below(r0));
@@ -940,7 +957,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                 }
                 em &= em - 1ull;
             }
-            lds_st_u16(lds_addr(&F.lanest[lane]) + 2u, (uint16_t)done);
+            if constexpr (CLIPS) lds_st_u16(lds_addr(&F.lanest[lane]) + 2u, (uint16_t)done); else s4_done = done;
             next_seg = sa + take;
             sa += take;
             remaining -= take;

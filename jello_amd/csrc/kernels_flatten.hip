@@ -991,7 +991,8 @@ JD PieceParams piece_params(const CubicParams& cp, float scale, float offset) {
 }
 
 #ifndef FL_WAVES_PER_EU
-#define FL_WAVES_PER_EU 3  // 149 VGPRs, no spills (4: 128 VGPRs with spills measured slower)
+#define FL_WAVES_PER_EU 4  // 128 VGPRs with 8 spilled, reloaded in the batch set-up and the fallback (marked unlikely): 190.7 us against 194.0 with 3 waves
+                           // and 149 VGPRs (same box); without the inlined fallback the loop needs 131 and runs in 182 us at 4 waves
 #endif
 #ifndef FL_BLOCKS_PER_CU
 #define FL_BLOCKS_PER_CU 5  // more workgroups than fit at once: the dynamic batch queue evens out the tail
@@ -1153,7 +1154,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
             counts[slot] = total;
         }
         wave_fence();
-        if (bail) {  // uniform, rare: the sequential walk for the jobs that did not finish
+        if (__builtin_expect(bail, 0)) {  // uniform, rare: the sequential walk for the jobs that did not finish
             o.slot = slot; o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
             if (!redo) e.done = true;
             bool have = redo;

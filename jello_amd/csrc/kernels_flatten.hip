@@ -1274,6 +1274,13 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
         if (state == 2u) {
             const uint4* rec = pieces + (size_t)tp * 4u;
             r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
+        } else if (state == 1u) {  // a complete line (tp == its own slot): its key and its 24 bytes come the same way, one step ahead
+            const uint2 key = tkeys[tp];
+            const uint2* src = (const uint2*)(tlines + tp);
+            const uint2 w0 = src[0], w1 = src[1], w2 = src[2];
+            r0 = make_uint4(key.x, key.y, 0u, 0u);
+            r1 = make_uint4(w0.x, w0.y, w1.x, w1.y);
+            r2 = make_uint4(w2.x, w2.y, 0u, 0u);
         }
     };
     const uint32_t G = gridDim.x;
@@ -1307,14 +1314,14 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
         // LDS in lane order and leave as three stores of 64 CONSECUTIVE words each.
         uint32_t widx[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
         uint2 wdat[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
-        if (st == 1u) {  // complete line: copy
-            const uint2 key = tkeys[t];
+        if (st == 1u) {  // complete line: copy (key and line fetched with the records)
+            const uint2 key = make_uint2(r0.x, r0.y);
             if (key.x < n_slots) {
                 const uint32_t dst = bases[key.x] + key.y;
                 if (dst < lines_lim) {
-                    const uint2* src = (const uint2*)(tlines + t);
-#pragma unroll
-                    for (int j = 0; j < 3; j++) { widx[j] = dst * 3u + (uint32_t)j; wdat[j] = src[j]; }
+                    widx[0] = dst * 3u; wdat[0] = make_uint2(r1.x, r1.y);
+                    widx[1] = dst * 3u + 1u; wdat[1] = make_uint2(r1.z, r1.w);
+                    widx[2] = dst * 3u + 2u; wdat[2] = make_uint2(r2.x, r2.y);
                 }
             }
         } else if (st == 2u) {
@@ -1324,6 +1331,17 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
             const uint32_t slot = r2.z, k = r2.w + i;
             uint4 en = make_uint4(0u, 0u, 0u, 0u);
             if (last_of_item || k == 0u) en = ends[tp];
+            // (the transform and the line base only depend on the record: requested here, in front of the Euler evaluation, their
+            // round trips pass under its ~500 instructions instead of following them)
+            Xf tr;
+            if ((flags & 16u) != 0u) {
+                tr = xf_identity();
+            } else {
+                uint32_t tb = cfg->layout.transform_base + (r3.y >> 6) * 6u;
+                tr.m0 = u2f(scene.rd(tb)); tr.m1 = u2f(scene.rd(tb + 1u)); tr.m2 = u2f(scene.rd(tb + 2u));
+                tr.m3 = u2f(scene.rd(tb + 3u)); tr.t0 = u2f(scene.rd(tb + 4u)); tr.t1 = u2f(scene.rd(tb + 5u));
+            }
+            const uint32_t slot_base = slot < n_slots ? bases[slot] : 0u;
             V2 lp1;
             if (last_of_item) {
                 lp1 = v2(u2f(en.z), u2f(en.w));
@@ -1353,17 +1371,9 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
                 }
                 lp1 = es_seg_eval_with_offset(v2(u2f(r0.x), u2f(r0.y)), v2(u2f(r0.z), u2f(r0.w)), ep, sarg, noff);
             }
-            Xf tr;
-            if ((flags & 16u) != 0u) {
-                tr = xf_identity();
-            } else {
-                uint32_t tb = cfg->layout.transform_base + (r3.y >> 6) * 6u;
-                tr.m0 = u2f(scene.rd(tb)); tr.m1 = u2f(scene.rd(tb + 1u)); tr.m2 = u2f(scene.rd(tb + 2u));
-                tr.m3 = u2f(scene.rd(tb + 3u)); tr.t0 = u2f(scene.rd(tb + 4u)); tr.t1 = u2f(scene.rd(tb + 5u));
-            }
             const V2 q = xf_apply(tr, lp1);
             if (slot < n_slots) {
-                const uint32_t dst = bases[slot] + k;
+                const uint32_t dst = slot_base + k;
                 const bool fwd = (flags & 8u) != 0u;  // offset >= 0: (start, end); else the line runs (end, start)
                 const bool has_next = !last_of_item && dst + 1u < lines_lim;
                 const uint2 hdr = make_uint2(r3.x, 0u), pt = make_uint2(f2u(q.x), f2u(q.y));

@@ -20,7 +20,8 @@ def lib_paths():
     # bench.py's default run never set it)
     return {
         "hip": os.environ.get("JELLO_HIP_LIB") or os.path.join(_HERE, "libjello_hip.so"),
-        "host": os.path.join(_HERE, "libjello_host.so"),
+        # JELLO_HOST_LIB: the sanitizer build of tools/sanitize_cpu.sh (CPU suite under ASan / UBSan)
+        "host": os.environ.get("JELLO_HOST_LIB") or os.path.join(_HERE, "libjello_host.so"),
     }
 
 

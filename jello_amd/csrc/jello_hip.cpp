@@ -720,7 +720,7 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
     } else if (stage == JH_PATHTAG_SCAN1 && ctx->deferred.size() == 2 && !ctx->deferred[0].is_clear && !ctx->deferred[1].is_clear &&
                ctx->deferred[0].stage == JH_PATHTAG_REDUCE && ctx->deferred[1].stage == JH_PATHTAG_REDUCE2 && b.size() >= 3 &&
                ctx->deferred[0].b[2].ptr == b[0].ptr && ctx->deferred[1].b[0].ptr == b[0].ptr && ctx->deferred[1].b[1].ptr == b[1].ptr &&
-               ctx->deferred[1].gx >= gx && gx <= 256u) {  // (reduce2 is recorded with 256 workgroups; scan1 reads the first gx of its results)
+               ctx->deferred[1].gx >= gx && gx > 0u && gx <= 256u) {  // (reduce2 is recorded with 256 workgroups; scan1 reads the first gx of its results)
         absorb = JH_ABSORB_PATHTAG;
         extra = ctx->deferred[0].b[0];
         extra2 = ctx->deferred[0].b[1];
@@ -730,7 +730,9 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
         bool all = true;
         for (const Deferred& d : ctx->deferred) {
             bool ok = false;
-            if (stage == JH_FLATTEN && b.size() >= 6) {
+            // (a dispatch with no workgroups launches nothing that could do the held-back work in passing -- an empty scene's
+            // flatten, renderer.cpp: flatten_wgs = 0 -- so bbox_clear and Clear(bump) run as recorded: ADVICE r03)
+            if (stage == JH_FLATTEN && b.size() >= 6 && gx > 0u) {
                 if (d.is_clear) ok = d.clear_ptr == b[4].ptr && d.clear_bytes == b[4].size && b[4].size == sizeof(JlBump);
                 else ok = d.stage == JH_BBOX_CLEAR && d.b[0].ptr == b[0].ptr && d.b[1].ptr == b[3].ptr && d.b[1].size == b[3].size;
             } else if (stage == JH_PATH_COUNT && indirect && b.size() >= 6) {

@@ -84,7 +84,7 @@ static Affine to_affine(const double* c) {
     if (c) std::memcpy(a.c, c, sizeof a.c);
     return a;
 }
-static Brush to_brush(const jl_brush* b) {
+static Brush to_brush(Scene* scene, const jl_brush* b) {
     Brush r;
     r.kind = (Brush::Kind)b->kind;
     r.extend = (Extend)b->extend;
@@ -97,7 +97,13 @@ static Brush to_brush(const jl_brush* b) {
         cs.color = Color{b->stops[i].rgba[0], b->stops[i].rgba[1], b->stops[i].rgba[2], b->stops[i].rgba[3]};
         r.stops.push_back(cs);
     }
-    r.image.width = b->image_width; r.image.height = b->image_height; r.image.pixels = b->image_pixels; r.image.key = b->image_key;
+    r.image.width = b->image_width; r.image.height = b->image_height; r.image.key = b->image_key;
+    if (b->image_pixels && b->image_width && b->image_height) {
+        // the caller's array is only borrowed for the duration of this call (it used to be kept as a raw pointer and read
+        // at render time: a use-after-free for every caller that dropped its array)
+        r.image.owned = scene->own_pixels(b->image_key, b->image_pixels, (size_t)b->image_width * b->image_height * 4);
+        r.image.pixels = r.image.owned->data();
+    }
     return r;
 }
 
@@ -106,14 +112,14 @@ void* jl_scene_new() { return new Scene(); }
 void jl_scene_free(void* s) { delete (Scene*)s; }
 void jl_scene_reset(void* s) { ((Scene*)s)->reset(); }
 int jl_scene_fill(void* s, int fill_rule, const double* transform, const jl_brush* brush, const double* brush_transform, const jl_path_el* els, int n) {
-    GUARD(((Scene*)s)->fill((Fill)fill_rule, to_affine(transform), to_brush(brush), to_affine(brush_transform), to_path(els, n)), -1);
+    GUARD(((Scene*)s)->fill((Fill)fill_rule, to_affine(transform), to_brush((Scene*)s, brush), to_affine(brush_transform), to_path(els, n)), -1);
     return 0;
 }
 int jl_scene_stroke(void* s, const jl_stroke* st, const double* transform, const jl_brush* brush, const double* brush_transform,
                     const jl_path_el* els, int n) {
     Stroke k;
     k.width = st->width; k.join = (Join)st->join; k.start_cap = (Cap)st->start_cap; k.end_cap = (Cap)st->end_cap; k.miter_limit = st->miter_limit;
-    GUARD(((Scene*)s)->stroke(k, to_affine(transform), to_brush(brush), to_affine(brush_transform), to_path(els, n)), -1);
+    GUARD(((Scene*)s)->stroke(k, to_affine(transform), to_brush((Scene*)s, brush), to_affine(brush_transform), to_path(els, n)), -1);
     return 0;
 }
 int jl_scene_push_layer(void* s, int mix, int compose, float alpha, const double* transform, const jl_path_el* els, int n) {

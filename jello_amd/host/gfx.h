@@ -5,6 +5,7 @@
 // dependency, so this API takes colours already in linear sRGB, un-premultiplied.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "jmath.h"
@@ -42,6 +43,10 @@ struct Image {  // gfx/image.go -- RGBA8 pixels, row-major
     uint32_t width = 0, height = 0;
     const uint8_t* pixels = nullptr;
     uint64_t key = 0;  // identity for de-duplication (the Go code keys on the image.Image pointer)
+    // In Go the garbage collector keeps the image.Image alive for as long as an encoding points at it.  Here the brush
+    // OWNS its pixels when it came through the C API (`pixels` points into `owned`): a caller may free its array as
+    // soon as Scene.fill / stroke returns, the patch is read at render time (renderer.cpp, upload_image).
+    std::shared_ptr<const std::vector<uint8_t>> owned;
 };
 
 struct Brush {

@@ -5,6 +5,9 @@
 // element counts the renderer allocates, so that the first attempt normally fits
 // and the engine's regrow loop is only the safety net.
 #pragma once
+#include <cstring>
+#include <unordered_map>
+
 #include "encoding.h"
 #include "estimate.h"
 
@@ -12,7 +15,7 @@ namespace jello {
 
 class Scene {
    public:
-    void reset() { encoding_.reset(); estimator_.reset(); footprint_.reset(); }
+    void reset() { encoding_.reset(); estimator_.reset(); footprint_.reset(); image_store_.clear(); }
     Encoding& encoding() { return encoding_; }
     const Encoding& encoding() const { return encoding_; }
 
@@ -41,7 +44,18 @@ class Scene {
     // BumpEstimator, tiles / bin_data / ptcl / blend_spill from the draw objects' bounding boxes; never below `floor`.
     BumpSizes bump_sizes(uint32_t width, uint32_t height) const;
 
+    // Pixel copies of the image brushes that entered through the C API, one per (key, contents): thousands of fills
+    // with one image share one copy.  Entries live as long as the Scene; the patches hold references of their own.
+    std::shared_ptr<const std::vector<uint8_t>> own_pixels(uint64_t key, const uint8_t* px, size_t n) {
+        auto it = image_store_.find(key);
+        if (it != image_store_.end() && it->second->size() == n && std::memcmp(it->second->data(), px, n) == 0) return it->second;
+        auto copy = std::make_shared<const std::vector<uint8_t>>(px, px + n);
+        image_store_[key] = copy;
+        return copy;
+    }
+
    private:
+    std::unordered_map<uint64_t, std::shared_ptr<const std::vector<uint8_t>>> image_store_;
     Encoding encoding_;
     BumpEstimator estimator_;
     FootprintEstimator footprint_;

@@ -32,7 +32,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        p = os.path.join(_HERE, "liboracle.so")
+        # JELLO_ORACLE_LIB: the sanitizer build of tools/sanitize_cpu.sh
+        p = os.environ.get("JELLO_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(p):
             build()
         _lib = ctypes.CDLL(p)

@@ -214,6 +214,24 @@ def test_empty_scene(engine):
     assert np.allclose(img[..., 0], 0.5) and np.allclose(img[..., 3], 1.0)
 
 
+def test_empty_scene_after_a_failed_frame_sees_a_cleared_bump(engine):
+    """the recording's bbox_clear and Clear(bump) are held back for flatten to absorb; an empty scene dispatches
+    flatten with zero workgroups, which launches nothing -- the clear must then run as recorded.  The pooled 32-byte bump
+    allocation is poisoned by a frame that fails (failed != 0, counters != 0) and is handed to the empty frame next."""
+    s, p = scenes.scene_c3(400, 256)
+    p.bump = BumpSizes(bin_data=256, tiles=512, lines=64, seg_counts=64, segments=64, blend_spill=256, ptcl=1 << 14)
+    rec, bump, attempts = engine.render(s, p, robust=False)
+    assert bump["failed"] != 0 and bump["lines"] != 0 and attempts == 1
+    for _ in range(2):
+        e = jello_amd.Scene()
+        rec, bump, attempts = engine.render(e, jello_amd.RenderParams(64, 64, base_color=(0.5, 0.25, 1.0, 1.0)), robust=True, retain=True)
+        assert attempts == 1 and all(v == 0 for v in bump.values()), bump
+        t = rec.target
+        img = engine.download_image(t["id"], t["width"], t["height"]).view(np.float16).astype(np.float32)
+        engine.release(rec)
+        assert np.all(img[..., 0] == 0.5) and np.all(img[..., 1] == 0.25) and np.all(img[..., 3] == 1.0)
+
+
 def test_regrow_loop_recovers_from_undersized_buffers(engine):
     """renderer/render.go:458-460 reads bump back; with every bump buffer far too small the first attempt must fail
     cleanly (no hang, no fault), the regrow loop must converge, and the final image must be the one the oracle gives

@@ -12,9 +12,11 @@ driver's own `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --ma
 and exits with the launcher's code.  Under torchrun it is one rank: every rank renders its own
 independent scene (C5: weak scaling, no data-path collective) and, as C5 is written, the finished
 RGBA16F images are gathered on rank 0 over RCCL, double-buffered so that the transfer of frame i
-overlaps the render of frame i+1.  For N > 1 both figures are timed (K steps each, each bracketed by
-barrier + synchronize): `value` is the one WITH the gather, `value_no_gather` the renderer alone
-(`--no-gather` makes that one the `value`).
+overlaps the render of frame i+1.  For N > 1 ONE run times three modes (K steps each, each bracketed by barrier +
+synchronize): no gather (frames stay where they were rendered), gather to rank 0 (C5 as written: this is `value`), and
+gather to rank (step mod N) -- all three are printed under `modes` with the wire's ceiling for each
+(`sharding.gather_model`) and the speed-up over one of this run's own ranks that each implies.  `--no-gather` /
+`--gather-dst 0|rotate` restrict the run to one mode.
 
 Prints ONE JSON line on rank 0.
 """
@@ -48,10 +50,11 @@ def parse_args(argv=None):
     ap.add_argument("--aa", choices=["area", "msaa8", "msaa16"], default="area", help="coverage mode of the fine stage (the headline is area)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: time only the independent renders, no image gather")
-    ap.add_argument("--gather-dst", choices=["0", "rotate"], default="0",
+    ap.add_argument("--gather-dst", choices=["all", "0", "rotate"], default="all",
                     help="N > 1: where the finished frames are collected: on rank 0 (C5 as written: one compositor GPU; its inbound "
                          "links bound the job) or on rank (step mod N) -- consecutive gathers then use disjoint inbound links and, "
-                         "being double-buffered on two communicators, overlap each other as well as the next render")
+                         "being double-buffered on two communicators, overlap each other as well as the next render; "
+                         "all (default) = time both, after the gather-free loop, in one run")
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; the line reports the median block")
     ap.add_argument("--bands", action="store_true",
                     help="N > 1: ONE scene, every rank runs the element stages on it and coarse+fine for its band of bin rows "
@@ -146,8 +149,10 @@ def run_rank(args, world):
     rec = host.record(scene, params)
     cfg = rec.config
 
-    gather = world > 1 and not args.no_gather and not args.bands
-    rotate = gather and args.gather_dst == "rotate"
+    gather_modes = []  # which gathers are timed behind the gather-free loop
+    if world > 1 and not args.no_gather and not args.bands:
+        gather_modes = ["0", "rotate"] if args.gather_dst == "all" else [args.gather_dst]
+    gather = bool(gather_modes)
     # output images: torch owns the device memory (double-buffered for the overlapped gather)
     outs = [torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(2 if gather else 1)]
     gathered = None
@@ -155,7 +160,7 @@ def run_rank(args, world):
     if gather:
         # one communicator per buffer of the double buffer: two gathers on ONE communicator run one after the other
         gather_groups = [dist.new_group(ranks=list(range(world))) for _ in range(2)]
-        if rank == 0 or rotate:
+        if rank == 0 or "rotate" in gather_modes:
             gathered = [[torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(world)] for _ in range(2)]
 
     if args.bands:  # (buffers were sized by the unsharded render above; from here on this rank owns its band only)
@@ -180,43 +185,30 @@ def run_rank(args, world):
     # per output buffer and the timed steps replay it.
     use_graph = not args.no_graph
     graphs = [eng.capture(rec, o.data_ptr()) for o in outs] if use_graph else []
-    pending = [None, None]
+    pipe = sharding.GatherPipeline(dist, rank, world, outs, gathered, gather_groups)
 
-    def drain():
-        for j in range(2):
-            if pending[j] is not None:
-                pending[j].wait()
-                pending[j] = None
+    def render(k):
+        if use_graph:
+            eng.replay(graphs[k])
+        else:
+            eng.run(rec, RUN_DISPATCHES, outs[k].data_ptr())
 
-    def timed(with_gather):
+    def timed(mode):
         """W warmup steps, then --blocks blocks of exactly K steps, each between barrier + synchronize on both sides and
-        each the max over ranks; returns the block times (seconds), sorted."""
-        def step(i):
-            k = (i & 1) if with_gather else 0
-            if pending[k] is not None:
-                pending[k].wait()  # the gather that last read outs[k] (stream-ordered: the host does not block)
-                pending[k] = None
-            if use_graph:
-                eng.replay(graphs[k])
-            else:
-                eng.run(rec, RUN_DISPATCHES, outs[k].data_ptr())
-            if with_gather:
-                dst = sharding.gather_dst_for_step(i, world, args.gather_dst)
-                _, pending[k] = sharding.gather_images(dist, outs[k], rank, world, dst=dst, async_op=True,
-                                                       out=gathered[k] if rank == dst else None, group=gather_groups[k])
+        each the max over ranks; returns the block times (seconds), sorted.  mode: None / "0" / "rotate" (GatherPipeline)."""
         for i in range(args.warmup):
-            step(i)
+            pipe.step(i, render, mode)
         blocks = []
         for _ in range(max(1, args.blocks)):
-            drain()
+            pipe.drain()
             torch.cuda.synchronize(dev)
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             for i in range(args.steps):
-                step(i)
-            drain()
+                pipe.step(i, render, mode)
+            pipe.drain()
             torch.cuda.synchronize(dev)
             if world > 1:
                 dist.barrier()
@@ -229,9 +221,10 @@ def run_rank(args, world):
             blocks.append(el)
         return sorted(blocks)
 
-    blocks_plain = timed(False)
-    blocks_gather = timed(True) if gather else None
-    blocks = blocks_gather if gather else blocks_plain
+    blocks_plain = timed(None)
+    blocks_by_mode = {m: timed(m) for m in gather_modes}
+    head_mode = ("0" if "0" in gather_modes else gather_modes[0]) if gather else None  # C5 as written gathers on rank 0
+    blocks = blocks_by_mode[head_mode] if gather else blocks_plain
     elapsed_plain = blocks_plain[len(blocks_plain) // 2]
     elapsed = blocks[len(blocks) // 2]  # the median block
     # The frames that were timed are the frame that was checked: replayed (or re-run) frames must be bit-identical to the
@@ -283,7 +276,8 @@ def run_rank(args, world):
         units = 1 if args.bands else world  # frames finished per step by the whole job
         per = elapsed / args.steps
         mode = ("bin-row bands of one scene x%d" % world) if args.bands else \
-            "scene-per-gpu x%d%s" % (world, " + RCCL image gather to rank 0 (overlapped, double-buffered)" if gather else "")
+            "scene-per-gpu x%d%s" % (world, (" + RCCL image gather to %s (overlapped, double-buffered)" %
+                                             ("rank 0" if head_mode == "0" else "rank (step mod N)")) if gather else "")
         headline = args.scene == "c3" and args.paths == 100_000 and args.size == 4096
         metric = "Mpixels/sec fine-raster + paths/sec, 100k-path 4096^2 scene" if headline else \
             "Mpixels/sec fine-raster + paths/sec, %s scene, %d paths, %d^2 (NOT the headline configuration)" % (args.scene, args.paths, args.size)
@@ -310,12 +304,32 @@ def run_rank(args, world):
             "device": eng.device_info()["name"],
         }
         if world > 1 and not args.bands:
+            # Every mode of this run side by side.  `render` = the gather-free step of THIS run (every rank finishes one frame
+            # per step), so N * render / step is the speed-up over one of this run's own ranks that a mode delivers.
             pp = elapsed_plain / args.steps
-            result["value_no_gather"] = round(W * H * world / pp / 1e6, 2)
+            frame_bytes = W * H * 8
+
+            def mode_entry(name, blk, model):
+                per_m = blk[len(blk) // 2] / args.steps
+                e = {"value": round(W * H * world / per_m / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(per_m * 1e3, 4),
+                     "block_ms_per_step": [round(b / args.steps * 1e3, 4) for b in blk],
+                     "speedup_over_one_rank_of_this_run": round(world * pp / per_m, 2)}
+                if model is not None:
+                    e["wire_model"] = model
+                    e["ceiling_speedup"] = model["ceiling_speedup"]
+                else:
+                    e["ceiling_speedup"] = float(world)
+                return e
+            result["modes"] = {"no_gather": mode_entry("no_gather", blocks_plain, None)}
+            for m in gather_modes:
+                result["modes"]["gather_to_rank0" if m == "0" else "gather_to_rank_step_mod_n"] = mode_entry(
+                    m, blocks_by_mode[m], sharding.gather_model(world, pp * 1e3, frame_bytes, m))
+            result["value_mode"] = "no_gather" if not gather else ("gather_to_rank0" if head_mode == "0" else "gather_to_rank_step_mod_n")
+            result["value_no_gather"] = result["modes"]["no_gather"]["value"]
             result["ms_per_step_no_gather"] = round(pp * 1e3, 4)
             if gather:
                 result["value_with_gather"] = result["value"]
-                result["gather"] = sharding.gather_model(world, pp * 1e3, W * H * 8, args.gather_dst)
+                result["gather"] = sharding.gather_model(world, pp * 1e3, frame_bytes, head_mode)
     for g in graphs:
         eng.graph_destroy(g)
     eng.release(rec)

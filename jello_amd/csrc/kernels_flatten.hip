@@ -20,6 +20,8 @@
 // Algorithmic traffic: scene bytes + 20 B / tag word in, 24 B / line out (+ 64-80 B / piece through the temp).
 // k_flatten_items is VALU/latency-bound (f64 transcendentals, 1...30 subdivision attempts per job).
 #include "kcommon.h"
+#define FF_INLINE __device__ __forceinline__
+#include "flatten_fast.h"
 
 using namespace jk;
 using namespace jd;
@@ -879,10 +881,11 @@ struct FlBatch {
     uint32_t jhead[64];                // newest piece of the job + 1 (0 = none), lane = job
     uint32_t jpend[64];                // nodes of the job that are still unresolved
     uint32_t stack[FLQ_STACK];         // job | level << 6 | t0_u << 11
-    uint32_t l_tpos[FLQ_LEAVES];
+    uint32_t l_tpos[FLQ_LEAVES];       // phase A: the accepted node (same packing as the stack); phase B: its first temp slot
     uint16_t l_key[FLQ_LEAVES];        // t0 in units of 2^-9 << 7 | n
     uint16_t l_link[FLQ_LEAVES];       // job << 10 | next piece of the job + 1
-    uint32_t n_stack, n_leaves, bail;
+    uint32_t unsure[128];              // nodes the transcendental-free test could not decide (flatten_fast.h): < 64 waiting + 64 new
+    uint32_t n_stack, n_leaves, bail, n_unsure;
 };
 // The job state (control points, scale, offset, ids) stays in the registers of the lane that set the job up; the lane
 // that evaluates one of its nodes fetches it with ds_bpermute (no LDS storage: occupancy is bound by registers only).
@@ -895,30 +898,34 @@ struct NodeResult {
     V2 es_p0, es_p1;
     bool ends_at_one;
 };
-// One attempt of flatten.wgsl:362-403 for the interval [t0_u, t0_u + 1] * 2^-level of the cubic (p0..p3).
-JD NodeResult node_test(V2 p0, V2 p1, V2 p2, V2 p3, float scale, uint32_t level, uint32_t t0_u) {
-    const float tol = 0.25f;
-    const float dt = u2f((127u - level) << 23);  // 2^-level
-    const float t0 = (float)t0_u * dt;
-    // the state the sequential walk carries into this interval: the end of the piece that ended at t0
+// The two ends of the interval [t0_u, t0_u + 1] * 2^-level as the sequential walk of flatten.wgsl:362-383 sees them: the
+// state it carries into the interval (the end of the piece that ended at t0) and the point / derivative at t1.
+struct NodeEnds {
     V2 last_p, last_q;
     float last_t;
+    V2 point, deriv;
+    float t1;
+};
+JD NodeEnds node_ends(V2 p0, V2 p1, V2 p2, V2 p3, uint32_t level, uint32_t t0_u) {
+    const float dt = u2f((127u - level) << 23);  // 2^-level
+    const float t0 = (float)t0_u * dt;
+    NodeEnds r;
     if (t0_u == 0u) {
-        last_p = p0;
-        last_q = p1 - p0;
-        if (dot(last_q, last_q) < DERIV_THRESH_SQUARED) last_q = eval_cubic_and_deriv(p0, p1, p2, p3, DERIV_EPS).deriv;
-        last_t = 0.0f;
+        r.last_p = p0;
+        r.last_q = p1 - p0;
+        if (dot(r.last_q, r.last_q) < DERIV_THRESH_SQUARED) r.last_q = eval_cubic_and_deriv(p0, p1, p2, p3, DERIV_EPS).deriv;
+        r.last_t = 0.0f;
     } else {
         PointDeriv pq0 = eval_cubic_and_deriv(p0, p1, p2, p3, t0);
-        last_t = t0;
+        r.last_t = t0;
         if (dot(pq0.deriv, pq0.deriv) < DERIV_THRESH_SQUARED) {  // (t0 < 1 here: the piece before took the adjusted end)
             PointDeriv n0 = eval_cubic_and_deriv(p0, p1, p2, p3, t0 - DERIV_EPS);
             pq0.deriv = n0.deriv;
             pq0.point = n0.point;
-            last_t = t0 - DERIV_EPS;
+            r.last_t = t0 - DERIV_EPS;
         }
-        last_p = pq0.point;
-        last_q = pq0.deriv;
+        r.last_p = pq0.point;
+        r.last_q = pq0.deriv;
     }
     float t1 = t0 + dt;
     PointDeriv this_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1);
@@ -930,13 +937,64 @@ JD NodeResult node_test(V2 p0, V2 p1, V2 p2, V2 p3, float scale, uint32_t level,
             t1 = t1 - DERIV_EPS;
         }
     }
-    const float actual_dt = t1 - last_t;
+    r.point = this_pq1.point;
+    r.deriv = this_pq1.deriv;
+    r.t1 = t1;
+    return r;
+}
+// One attempt of flatten.wgsl:362-403 for the interval [t0_u, t0_u + 1] * 2^-level of the cubic (p0..p3): the pinned sequence.
+JD NodeResult node_test(V2 p0, V2 p1, V2 p2, V2 p3, float scale, uint32_t level, uint32_t t0_u) {
+    const float tol = 0.25f;
+    const float dt = u2f((127u - level) << 23);
+    const NodeEnds ne = node_ends(p0, p1, p2, p3, level, t0_u);
+    const float actual_dt = ne.t1 - ne.last_t;
     NodeResult r;
-    r.cp = cubic_from_points_derivs(last_p, this_pq1.point, last_q, this_pq1.deriv, actual_dt);
+    r.cp = cubic_from_points_derivs(ne.last_p, ne.point, ne.last_q, ne.deriv, actual_dt);
     r.accept = r.cp.err * scale <= tol || dt <= SUBDIV_LIMIT;
-    r.es_p0 = last_p;
-    r.es_p1 = this_pq1.point;
-    r.ends_at_one = t1 == 1.0f;
+    r.es_p0 = ne.last_p;
+    r.es_p1 = ne.point;
+    r.ends_at_one = ne.t1 == 1.0f;
+    return r;
+}
+// The same attempt, DECIDED without transcendentals where that is provably safe (flatten_fast.h): FF_ACCEPT / FF_REJECT
+// agree with node_test().accept, FF_UNSURE means "run node_test".  (dt > SUBDIV_LIMIT for every level the cooperative
+// subdivision visits, FLQ_MAX_LEVEL < 16, so the test is the error test alone.)
+JD int node_test_fast(V2 p0, V2 p1, V2 p2, V2 p3, float scale, uint32_t level, uint32_t t0_u, float* v_est, float* delta) {
+    const float tol = 0.25f;
+    const NodeEnds ne = node_ends(p0, p1, p2, p3, level, t0_u);
+    const float actual_dt = ne.t1 - ne.last_t;
+    // cubic_from_points_derivs (flatten.wgsl:94-114) up to d0 / d1, the same operations on the same values
+    const V2 chord = ne.point - ne.last_p;
+    const float chord_squared = dot(chord, chord);
+    const float chord_len = sqrt_(chord_squared);
+    const V2 q0 = ne.last_q, q1 = ne.deriv;
+    *v_est = 0.0f; *delta = 0.0f;
+    if (chord_squared < DERIV_THRESH_SQUARED) {  // no transcendentals in this branch: decided exactly
+        const float chord_err = sqrt_((float)(9.0 / 32.0) * (dot(q0, q0) + dot(q1, q1))) * actual_dt;
+        return (chord_err * scale <= tol) ? ffast::FF_ACCEPT : ffast::FF_REJECT;
+    }
+    const float sc = actual_dt / chord_squared;
+    const V2 h0 = v2(q0.x * chord.x + q0.y * chord.y, q0.y * chord.x - q0.x * chord.y);
+    const V2 h1 = v2(q1.x * chord.x + q1.y * chord.y, q1.x * chord.y - q1.y * chord.x);
+    const float len0 = length(h0), len1 = length(h1);
+    return ffast::ff_decide(h0.x, h0.y, len0, h1.x, h1.y, len1, len0 * sc, len1 * sc, chord_len, scale, tol, v_est, delta);
+}
+// th0, th1 and chord_len of an ACCEPTED interval (the pinned atan2; err is not needed any more)
+JD CubicParams piece_angles(const NodeEnds& ne) {
+    const V2 chord = ne.point - ne.last_p;
+    const float chord_squared = dot(chord, chord);
+    CubicParams r;
+    r.err = 0.0f;
+    if (chord_squared < DERIV_THRESH_SQUARED) {
+        r.th0 = 0.0f; r.th1 = 0.0f; r.chord_len = DERIV_THRESH;
+        return r;
+    }
+    const V2 q0 = ne.last_q, q1 = ne.deriv;
+    const V2 h0 = v2(q0.x * chord.x + q0.y * chord.y, q0.y * chord.x - q0.x * chord.y);
+    const V2 h1 = v2(q1.x * chord.x + q1.y * chord.y, q1.x * chord.y - q1.y * chord.x);
+    r.th0 = atan2_(h0.y, h0.x);
+    r.th1 = atan2_(h1.y, h1.x);
+    r.chord_len = sqrt_(chord_squared);
     return r;
 }
 
@@ -990,6 +1048,9 @@ JD PieceParams piece_params(const CubicParams& cp, float scale, float offset) {
     return r;
 }
 
+#ifdef FL_FAST_CHECK
+__device__ uint32_t g_ff_stats[8];  // nodes tested, undecided, contradictions, bound violations
+#endif
 #ifndef FL_WAVES_PER_EU
 #define FL_WAVES_PER_EU 4  // 128 VGPRs with 8 spilled, reloaded in the batch set-up and the fallback (marked unlikely): 190.7 us against 194.0 with 3 waves
                            // and 149 VGPRs (same box); without the inlined fallback the loop needs 131 and runs in 182 us at 4 waves
@@ -1062,55 +1123,102 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
         {
             const uint64_t am = __builtin_amdgcn_ballot_w64(active);
             if (active) B.stack[(uint32_t)__builtin_popcountll(am & ((1ull << lane) - 1ull))] = lane;  // root: level 0, t0_u 0
-            if (lane == 0u) { B.n_stack = (uint32_t)__builtin_popcountll(am); B.n_leaves = 0u; B.bail = 0u; }
+            if (lane == 0u) { B.n_stack = (uint32_t)__builtin_popcountll(am); B.n_leaves = 0u; B.bail = 0u; B.n_unsure = 0u; }
         }
         wave_fence();
-        // ---- drain the stack ----
+        // ---- phase A: drain the stack -- DECISIONS only.  A node is accepted, rejected (its halves are pushed) or left
+        // undecided by the transcendental-free test (flatten_fast.h; ~0.1 % of the nodes); the undecided ones wait in a list of
+        // their own and get the pinned sequence in rounds of up to 64 when the stack has run dry (or 64 are waiting). ----
         for (;;) {
             const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.n_stack);
-            if (ns == 0u) break;
-            const uint32_t take = umin_(ns, 64u);
+            const uint32_t nu = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.n_unsure);
+            if (ns == 0u && nu == 0u) break;
+            const bool exact_round = ns == 0u || nu >= 64u;  // uniform
+            const uint32_t take = umin_(exact_round ? nu : ns, 64u);
             const bool has = lane < take;
-            const uint32_t node = has ? B.stack[ns - 1u - lane] : 0u;
+            const uint32_t node = has ? (exact_round ? B.unsure[nu - 1u - lane] : B.stack[ns - 1u - lane]) : 0u;
             wave_fence();
             const uint32_t j = node & 63u, level = (node >> 6) & 31u, t0_u = node >> 11;
             // the job's state from its owner lane (every lane takes part in the permutes)
             const V2 jp0 = v2(lanef(e.p0.x, j), lanef(e.p0.y, j)), jp1 = v2(lanef(e.p1.x, j), lanef(e.p1.y, j));
             const V2 jp2 = v2(lanef(e.p2.x, j), lanef(e.p2.y, j)), jp3 = v2(lanef(e.p3.x, j), lanef(e.p3.y, j));
-            const float scale = lanef(e.scale, j), offset = lanef(e.offset, j);
-            NodeResult r;
-            r.accept = false;
-            if (has) r = node_test(jp0, jp1, jp2, jp3, scale, level, t0_u);
-            // a piece needs the ids of its job and, if it is the item's first or last, the item's end points
-            const uint32_t j_slot = laneu(slot, j), j_path = laneu(e.path_ix, j), j_trans = laneu(e.trans_ix, j);
-            const float j_tsx = lanef(e.t_start.x, j), j_tsy = lanef(e.t_start.y, j), j_tex = lanef(e.t_end.x, j), j_tey = lanef(e.t_end.y, j);
-            const bool acc = has && r.accept, rej = has && !r.accept;
-            const uint64_t accm = __builtin_amdgcn_ballot_w64(acc), rejm = __builtin_amdgcn_ballot_w64(rej);
+            const float scale = lanef(e.scale, j);
+            int kind = ffast::FF_UNSURE;
+            if (exact_round) {
+                if (has) kind = node_test(jp0, jp1, jp2, jp3, scale, level, t0_u).accept ? ffast::FF_ACCEPT : ffast::FF_REJECT;
+            } else if (has) {
+                float v_est, delta;
+                kind = node_test_fast(jp0, jp1, jp2, jp3, scale, level, t0_u, &v_est, &delta);
+#ifdef FL_FAST_CHECK  // (make VARIANT=ffcheck: both paths on every node; contradictions and bound violations are counted)
+                {
+                    const NodeResult rx = node_test(jp0, jp1, jp2, jp3, scale, level, t0_u);
+                    const float vx = rx.cp.err * scale;
+                    atomicAdd(&g_ff_stats[0], 1u);
+                    if (kind == ffast::FF_UNSURE) atomicAdd(&g_ff_stats[1], 1u);
+                    if ((kind == ffast::FF_ACCEPT && !rx.accept) || (kind == ffast::FF_REJECT && rx.accept)) atomicAdd(&g_ff_stats[2], 1u);
+                    if (delta > 0.0f && !(abs_(v_est - vx) <= delta)) atomicAdd(&g_ff_stats[3], 1u);
+                    if (delta == 0.0f && kind != ffast::FF_UNSURE && v_est != 0.0f && v_est != vx) atomicAdd(&g_ff_stats[3], 1u);
+                }
+#endif
+            }
+            const bool acc = has && kind == ffast::FF_ACCEPT, rej = has && kind == ffast::FF_REJECT, uns = has && kind == ffast::FF_UNSURE;
+            const uint64_t accm = __builtin_amdgcn_ballot_w64(acc), rejm = __builtin_amdgcn_ballot_w64(rej), unsm = __builtin_amdgcn_ballot_w64(uns);
             const uint32_t n_acc = (uint32_t)__builtin_popcountll(accm), n_rej = (uint32_t)__builtin_popcountll(rejm);
+            const uint32_t n_uns = (uint32_t)__builtin_popcountll(unsm);
             const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.n_leaves);
+            const uint32_t ns_left = exact_round ? ns : ns - take, nu_left = exact_round ? nu - take : nu;
             const bool too_deep = __builtin_amdgcn_ballot_w64(rej && level + 1u > FLQ_MAX_LEVEL) != 0ull;
-            if (too_deep || ns - take + 2u * n_rej > FLQ_STACK || nl + n_acc > FLQ_LEAVES) {  // uniform: give up on the unfinished jobs
+            if (too_deep || ns_left + 2u * n_rej > FLQ_STACK || nl + n_acc > FLQ_LEAVES) {  // uniform: give up on the unfinished jobs
                 if (lane == 0u) B.bail = 1u;
                 wave_fence();
                 break;
             }
             const uint64_t below = (1ull << lane) - 1ull;
             if (rej) {
-                const uint32_t pos = ns - take + 2u * (uint32_t)__builtin_popcountll(rejm & below);
+                const uint32_t pos = ns_left + 2u * (uint32_t)__builtin_popcountll(rejm & below);
                 B.stack[pos] = j | ((level + 1u) << 6) | ((2u * t0_u + 1u) << 11);
                 B.stack[pos + 1u] = j | ((level + 1u) << 6) | ((2u * t0_u) << 11);  // the left half on top: popped first
                 atomicAdd(&B.jpend[j], 1u);
             }
-            if (acc) {
-                const PieceParams pp = piece_params(r.cp, scale, offset);
+            if (acc) {  // a piece: its record is written in phase B
+                const uint32_t li = nl + (uint32_t)__builtin_popcountll(accm & below);
+                B.l_tpos[li] = node;
+                B.l_key[li] = (uint16_t)((t0_u << (FLQ_MAX_LEVEL - level)) << 7);
+                const uint32_t prev = atomicExch(&B.jhead[j], li + 1u);
+                B.l_link[li] = (uint16_t)((j << 10) | prev);
+                atomicSub(&B.jpend[j], 1u);
+            }
+            if (uns) B.unsure[nu_left + (uint32_t)__builtin_popcountll(unsm & below)] = node;  // (nu_left < 64 in a fast round)
+            if (lane == 0u) { B.n_stack = ns_left + 2u * n_rej; B.n_leaves = nl + n_acc; B.n_unsure = nu_left + n_uns; }
+            wave_fence();
+        }
+        // ---- phase B: the pieces, 64 at a time whichever jobs they belong to: the pinned angles (two atan2), the Euler
+        // parameters and the line count (flatten.wgsl:404-447), the temp slots, the record ----
+        const bool bail = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.bail) != 0u;
+        const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.n_leaves);
+        for (uint32_t lbase = 0u; lbase < nl; lbase += 64u) {
+            const uint32_t li = lbase + lane;
+            const bool has = li < nl;
+            const uint32_t node = has ? B.l_tpos[li] : 0u;
+            const uint32_t j = node & 63u, level = (node >> 6) & 31u, t0_u = node >> 11;
+            const V2 jp0 = v2(lanef(e.p0.x, j), lanef(e.p0.y, j)), jp1 = v2(lanef(e.p1.x, j), lanef(e.p1.y, j));
+            const V2 jp2 = v2(lanef(e.p2.x, j), lanef(e.p2.y, j)), jp3 = v2(lanef(e.p3.x, j), lanef(e.p3.y, j));
+            const float scale = lanef(e.scale, j), offset = lanef(e.offset, j);
+            // a piece needs the ids of its job and, if it is the item's first or last, the item's end points
+            const uint32_t j_slot = laneu(slot, j), j_path = laneu(e.path_ix, j), j_trans = laneu(e.trans_ix, j);
+            const float j_tsx = lanef(e.t_start.x, j), j_tsy = lanef(e.t_start.y, j), j_tex = lanef(e.t_end.x, j), j_tey = lanef(e.t_end.y, j);
+            if (has && B.jpend[j] == 0u) {  // (an unfinished job -- bail -- is redone below)
+                const NodeEnds ne = node_ends(jp0, jp1, jp2, jp3, level, t0_u);
+                const CubicParams cp = piece_angles(ne);
+                const PieceParams pp = piece_params(cp, scale, offset);
                 const uint32_t n_u = pp.n_u;
                 uint32_t tpos = atomicAdd(o.lds_next, n_u);
                 if (tpos + n_u > o.lds_limit) tpos = atomicAdd(o.g_next, n_u);
-                const uint32_t fl = pp.robust | (r.ends_at_one ? 4u : 0u) | ((offset >= 0.0f) ? 8u : 0u) | ((offset == 0.0f) ? 16u : 0u) |
+                const uint32_t fl = pp.robust | ((ne.t1 == 1.0f) ? 4u : 0u) | ((offset >= 0.0f) ? 8u : 0u) | ((offset == 0.0f) ? 16u : 0u) |
                                     ((t0_u == 0u) ? 32u : 0u);
                 if (tpos < tcap && tpos + n_u <= tcap) {
                     uint4* rec = pieces + (size_t)tpos * 4u;
-                    rec[0] = make_uint4(f2u(r.es_p0.x), f2u(r.es_p0.y), f2u(r.es_p1.x), f2u(r.es_p1.y));
+                    rec[0] = make_uint4(f2u(ne.last_p.x), f2u(ne.last_p.y), f2u(ne.point.x), f2u(ne.point.y));
                     rec[1] = make_uint4(f2u(pp.ep.th0), f2u(pp.ep.k0), f2u(pp.ep.k1), f2u(pp.ep.ch));
                     ((uint2*)rec)[4] = make_uint2(f2u(pp.noff), f2u(pp.n));  // rec[2] = noff, n, slot, first line of the piece --
                     ((uint32_t*)rec)[10] = j_slot;                            // the last word is written once, below
@@ -1120,26 +1228,17 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
                     if (tpos >= o.overflow_start)  // only the chunk area is zeroed up front (rare path)
                         for (uint32_t i = 1u; i < n_u; i++) tinfo[tpos + i] = 0u;
                 }
-                const uint32_t li = nl + (uint32_t)__builtin_popcountll(accm & below);
                 B.l_tpos[li] = tpos;
-                B.l_key[li] = (uint16_t)(((t0_u << (FLQ_MAX_LEVEL - level)) << 7) | n_u);
-                const uint32_t prev = atomicExch(&B.jhead[j], li + 1u);
-                B.l_link[li] = (uint16_t)((j << 10) | prev);
-                atomicSub(&B.jpend[j], 1u);
+                B.l_key[li] = (uint16_t)(B.l_key[li] | n_u);
             }
-            if (lane == 0u) { B.n_stack = ns - take + 2u * n_rej; B.n_leaves = nl + n_acc; }
-            wave_fence();
         }
+        wave_fence();
         // ---- a piece's first line = the lines of its job's pieces before it; a job's line count ----
-        const bool bail = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.bail) != 0u;
-        const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.n_leaves);
         for (uint32_t li = lane; li < nl; li += 64u) {
-            const uint32_t j = B.l_link[li] >> 10, tpos = B.l_tpos[li], key = B.l_key[li];
+            const uint32_t j = B.l_link[li] >> 10, key = B.l_key[li];
+            if (B.jpend[j] != 0u) continue;  // unfinished (bail): the job is redone below, phase B left its pieces out
+            const uint32_t tpos = B.l_tpos[li];
             const bool ok = tpos < tcap && tpos + (key & 127u) <= tcap;
-            if (B.jpend[j] != 0u) {  // unfinished (bail): the job is redone below, its pieces so far are withdrawn
-                if (ok) tinfo[tpos] = 0u;
-                continue;
-            }
             uint32_t first = 0u;
             for (uint32_t q = B.jhead[j]; q != 0u; q = B.l_link[q - 1u] & 1023u) {
                 const uint32_t k2 = B.l_key[q - 1u];
@@ -1567,6 +1666,20 @@ __global__ __launch_bounds__(JL_WG) void k_flatten_bbox(const JlConfig* __restri
 }
 
 }  // namespace
+
+#ifdef FL_FAST_CHECK
+// (check build only: tools/soak_flatten_fast.py) out[0..3] = nodes tested by the fast path, undecided, contradictions with the
+// pinned sequence, violations of the proven bound -- accumulated since the last reset
+extern "C" int jh_debug_flatten_fast_stats(uint32_t* out8, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ff_stats), 8 * sizeof(uint32_t)) != hipSuccess) return -1;
+    if (reset) {
+        const uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ff_stats), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // [config, scene, tag_monoids, path_bboxes, bump, lines]
 int jh_launch_flatten(const JhLaunch& L) {

@@ -150,3 +150,303 @@ def blend_mix_compose_srcover(backdrop, src, mix, log=None):
     out = [log("out.%s = mix(backdrop, cs', src.a)" % n, f32(f32(f32(backdrop[j]) * f32(f32(1.0) - sa)) + f32(cs2[j] * sa))) for j, n in enumerate("rgb")]
     out.append(log("out.a = src.a + backdrop.a * (1 - src.a)", sa + f32(ba * f32(f32(1.0) - sa))))
     return out, log
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the remaining mix modes, gradients, images.  Sources: shared/blend.wgsl:24-195 (mix functions), :288-310;
+# draw_leaf.wgsl:151-247 (radial / sweep / image info words), shared/transform.wgsl, fine.wgsl:988-1087.
+# ---------------------------------------------------------------------------------------------------------------------
+def _screen(cb, cs):  # cb + cs - (cb * cs)
+    return f32(f32(cb + cs) - f32(cb * cs))
+
+
+def _hard_light(cb, cs):  # select(screen(cb, 2 cs - 1), cb * 2 * cs, cs <= 0.5)
+    if cs <= f32(0.5):
+        return f32(f32(cb * f32(2.0)) * cs)
+    return _screen(cb, f32(f32(f32(2.0) * cs) - f32(1.0)))
+
+
+def _color_dodge(cb, cs):
+    if cb == f32(0.0):
+        return f32(0.0)
+    if cs == f32(1.0):
+        return f32(1.0)
+    return f32(min(f32(1.0), f32(cb / f32(f32(1.0) - cs))))
+
+
+def _color_burn(cb, cs):
+    if cb == f32(1.0):
+        return f32(1.0)
+    if cs == f32(0.0):
+        return f32(0.0)
+    return f32(f32(1.0) - f32(min(f32(1.0), f32(f32(f32(1.0) - cb) / cs))))
+
+
+def _soft_light(cb, cs):
+    if cb <= f32(0.25):
+        d = f32(f32(f32(f32(f32(f32(16.0) * cb) - f32(12.0)) * cb) + f32(4.0)) * cb)
+    else:
+        d = f32(np.sqrt(cb))
+    if cs <= f32(0.5):
+        return f32(cb - f32(f32(f32(f32(1.0) - f32(f32(2.0) * cs)) * cb) * f32(f32(1.0) - cb)))
+    return f32(cb + f32(f32(f32(f32(2.0) * cs) - f32(1.0)) * f32(d - cb)))
+
+
+def sat(c):  # max(c.x, max(c.y, c.z)) - min(c.x, min(c.y, c.z))
+    return f32(f32(max(c[0], max(c[1], c[2]))) - f32(min(c[0], min(c[1], c[2]))))
+
+
+def set_sat(c, s):
+    """shared/blend.wgsl:92-141: the smallest channel becomes 0, the largest s, the middle one scales."""
+    c = [f32(v) for v in c]
+    s = f32(s)
+
+    def inner(imin, imid, imax):
+        if c[imax] > c[imin]:
+            c[imid] = f32(f32(f32(c[imid] - c[imin]) * s) / f32(c[imax] - c[imin]))
+            c[imax] = s
+        else:
+            c[imid] = f32(0.0)
+            c[imax] = f32(0.0)
+        c[imin] = f32(0.0)
+    r, g, b = 0, 1, 2
+    if c[r] <= c[g]:
+        if c[g] <= c[b]:
+            inner(r, g, b)
+        elif c[r] <= c[b]:
+            inner(r, b, g)
+        else:
+            inner(b, r, g)
+    else:
+        if c[r] <= c[b]:
+            inner(g, r, b)
+        elif c[g] <= c[b]:
+            inner(g, b, r)
+        else:
+            inner(b, g, r)
+    return c
+
+
+MIX_NAMES = ["normal", "multiply", "screen", "overlay", "darken", "lighten", "color_dodge", "color_burn", "hard_light", "soft_light",
+             "difference", "exclusion", "hue", "saturation", "color", "luminosity"]
+
+
+def blend_mix(cb, cs, mix):
+    """shared/blend.wgsl:142-195, per channel where the mode is separable."""
+    cb, cs = [f32(v) for v in cb], [f32(v) for v in cs]
+    per = {"multiply": lambda b, s: f32(b * s), "screen": _screen, "overlay": lambda b, s: _hard_light(s, b),
+           "darken": lambda b, s: f32(min(b, s)), "lighten": lambda b, s: f32(max(b, s)), "color_dodge": _color_dodge,
+           "color_burn": _color_burn, "hard_light": _hard_light, "soft_light": _soft_light,
+           "difference": lambda b, s: f32(abs(f32(b - s))),
+           "exclusion": lambda b, s: f32(f32(b + s) - f32(f32(f32(2.0) * b) * s))}
+    if mix in per:
+        return [per[mix](b, s) for b, s in zip(cb, cs)]
+    if mix == "hue":
+        return set_lum(set_sat(cs, sat(cb)), lum(cb))
+    if mix == "saturation":
+        return set_lum(set_sat(cb, sat(cs)), lum(cb))
+    if mix == "color":
+        return set_lum(cs, lum(cb))
+    if mix == "luminosity":
+        return set_lum(cb, lum(cs))
+    return cs
+
+
+def blend_mix_compose(backdrop, src, mix, log=None):
+    """shared/blend.wgsl:288-310 with compose = SrcOver and any mix mode ("normal" takes the early return of :291-294)."""
+    log = log or Log()
+    if mix == "normal":
+        k = log("1 - src.a", f32(1.0) - f32(src[3]))
+        return [log("out.%s = backdrop.%s * (1 - src.a) + src.%s" % (n, n, n), f32(f32(f32(backdrop[j]) * k) + f32(src[j]))) for j, n in enumerate("rgba")], log
+    inv_src_a = log("inv_src_a = 1 / max(src.a, 1e-15)", f32(1.0) / f32(max(f32(src[3]), f32(1e-15))))
+    cs = [log("cs.%s = src.%s * inv_src_a" % (n, n), f32(f32(src[j]) * inv_src_a)) for j, n in enumerate("rgb")]
+    inv_b_a = log("inv_backdrop_a = 1 / max(backdrop.a, 1e-15)", f32(1.0) / f32(max(f32(backdrop[3]), f32(1e-15))))
+    cb = [log("cb.%s = backdrop.%s * inv_backdrop_a" % (n, n), f32(f32(backdrop[j]) * inv_b_a)) for j, n in enumerate("rgb")]
+    mixed = [log("mixed.%s (%s)" % (n, mix), v) for n, v in zip("rgb", blend_mix(cb, cs, mix))]
+    ba, sa = f32(backdrop[3]), f32(src[3])
+    cs2 = [log("cs'.%s = mix(cs, mixed, backdrop.a)" % n, f32(f32(cs[j] * f32(f32(1.0) - ba)) + f32(mixed[j] * ba))) for j, n in enumerate("rgb")]
+    out = [log("out.%s = mix(backdrop, cs', src.a)" % n, f32(f32(f32(backdrop[j]) * f32(f32(1.0) - sa)) + f32(cs2[j] * sa))) for j, n in enumerate("rgb")]
+    out.append(log("out.a = src.a + backdrop.a * (1 - src.a)", sa + f32(ba * f32(f32(1.0) - sa))))
+    return out, log
+
+
+# ---- shared/transform.wgsl on (matrx[4], translate[2]) tuples ----
+def xf_inverse(t):
+    m, tr = [f32(v) for v in t[0]], [f32(v) for v in t[1]]
+    inv_det = f32(f32(1.0) / f32(f32(m[0] * m[3]) - f32(m[1] * m[2])))
+    im = [f32(inv_det * m[3]), f32(inv_det * f32(-m[1])), f32(inv_det * f32(-m[2])), f32(inv_det * m[0])]
+    ntx, nty = f32(-tr[0]), f32(-tr[1])  # mat2x2(inv_mat.xy, inv_mat.zw) * -translate = xy * ntx + zw * nty
+    return (im, [f32(f32(im[0] * ntx) + f32(im[2] * nty)), f32(f32(im[1] * ntx) + f32(im[3] * nty))])
+
+
+def xf_mul(a, b):
+    am, at, bm, bt = a[0], a[1], b[0], b[1]
+    m = [f32(f32(am[0] * bm[0]) + f32(am[2] * bm[1])), f32(f32(am[1] * bm[0]) + f32(am[3] * bm[1])),
+         f32(f32(am[0] * bm[2]) + f32(am[2] * bm[3])), f32(f32(am[1] * bm[2]) + f32(am[3] * bm[3]))]
+    t = [f32(f32(f32(am[0] * bt[0]) + f32(am[2] * bt[1])) + at[0]), f32(f32(f32(am[1] * bt[0]) + f32(am[3] * bt[1])) + at[1])]
+    return (m, t)
+
+
+def xf_apply(t, x, y):  # matrx.xy * p.x + matrx.zw * p.y + translate
+    m, tr = t
+    return f32(f32(f32(m[0] * f32(x)) + f32(m[2] * f32(y))) + tr[0]), f32(f32(f32(m[1] * f32(x)) + f32(m[3] * f32(y))) + tr[1])
+
+
+IDENT = ([f32(1.0), f32(0.0), f32(0.0), f32(1.0)], [f32(0.0), f32(0.0)])
+
+
+def _from_poly2(p0, p1):
+    return ([f32(p1[1] - p0[1]), f32(p0[0] - p1[0]), f32(p1[0] - p0[0]), f32(p1[1] - p0[1])], [f32(p0[0]), f32(p0[1])])
+
+
+def _two_point_to_unit_line(p0, p1):
+    return xf_mul(_from_poly2([f32(0.0), f32(0.0)], [f32(1.0), f32(0.0)]), xf_inverse(_from_poly2(p0, p1)))
+
+
+def _distance(a, b):
+    dx, dy = f32(a[0] - b[0]), f32(a[1] - b[1])
+    return f32(np.sqrt(f32(f32(dx * dx) + f32(dy * dy))))
+
+
+def rad_grad_info(p0, p1, r0, r1, log=None):
+    """draw_leaf.wgsl:151-222 under the identity transform: (xform, focal_x, radius, kind, flags).
+    kind (shared/config.wgsl:67-70): 1 circular, 2 strip, 3 focal-on-circle, 4 cone; flags bit 0 = swapped (:73)."""
+    log = log or Log()
+    EPS = f32(1.0) / f32(4096.0)
+    p0, p1, r0, r1 = [f32(v) for v in p0], [f32(v) for v in p1], f32(r0), f32(r1)
+    user_to_gradient = xf_inverse(IDENT)
+    flags = 0
+    if abs(f32(r0 - r1)) <= EPS:
+        scaled = f32(r0 / _distance(p0, p1))
+        return xf_mul(_two_point_to_unit_line(p0, p1), user_to_gradient), f32(0.0), f32(scaled * scaled), 2, 0, log
+    kind = 4
+    if p0[0] == p1[0] and p0[1] == p1[1]:
+        kind = 1
+        p0 = [f32(p0[0] + EPS), f32(p0[1] + EPS)]
+    if r1 == f32(0.0):
+        flags |= 1
+        p0, p1, r0, r1 = p1, p0, r1, r0
+    focal_x = log("focal_x = r0 / (r0 - r1)", f32(r0 / f32(r0 - r1)))
+    omf = f32(f32(1.0) - focal_x)
+    cf = [f32(f32(omf * p0[0]) + f32(focal_x * p1[0])), f32(f32(omf * p0[1]) + f32(focal_x * p1[1]))]
+    radius = log("radius = r1 / distance(cf, p1)", f32(r1 / _distance(cf, p1)))
+    unit = xf_mul(_two_point_to_unit_line(cf, p1), user_to_gradient)
+    if abs(f32(radius - f32(1.0))) <= EPS:
+        kind = 3
+        scale = f32(f32(0.5) * abs(f32(f32(1.0) - focal_x)))
+        xform = xf_mul(([scale, f32(0.0), f32(0.0), scale], [f32(0.0), f32(0.0)]), unit)
+    else:
+        a = f32(f32(radius * radius) - f32(1.0))
+        scale_ratio = f32(abs(f32(f32(1.0) - focal_x)) / a)
+        scale_x = f32(radius * scale_ratio)
+        scale_y = f32(f32(np.sqrt(abs(a))) * scale_ratio)
+        xform = xf_mul(([scale_x, f32(0.0), f32(0.0), scale_y], [f32(0.0), f32(0.0)]), unit)
+    for n, v in zip(("m0", "m1", "m2", "m3"), xform[0]):
+        log("xform." + n, v)
+    log("xform.tx", xform[1][0]); log("xform.ty", xform[1][1])
+    return xform, focal_x, radius, kind, flags, log
+
+
+def rad_grad_ramp_x(xform, focal_x, radius, kind, flags, gx, gy, mode, log=None):
+    """fine.wgsl:991-1036 for the pixel at GLOBAL (gx, gy): the ramp column, or None where the gradient is not valid."""
+    log = log or Log()
+    is_swapped = (flags & 1) != 0
+    r1_recip = f32(0.0) if kind == 1 else f32(f32(1.0) / radius)
+    less_scale = f32(-1.0) if (is_swapped or f32(f32(1.0) - focal_x) < 0) else f32(1.0)
+    omf = f32(f32(1.0) - focal_x)
+    t_sign = f32(1.0) if omf > 0 else (f32(-1.0) if omf < 0 else f32(0.0))
+    x, y = xf_apply(xform, gx, gy)
+    log("local x", x); log("local y", y)
+    xx, yy = f32(x * x), f32(y * y)
+    valid = True
+    if kind == 2:
+        a = f32(radius - yy)
+        with np.errstate(invalid="ignore"):
+            t = f32(f32(np.sqrt(a)) + x)
+        valid = a >= 0
+    elif kind == 3:
+        t = f32(f32(xx + yy) / x)
+        valid = t >= 0 and x != 0
+    elif radius > f32(1.0):
+        t = f32(f32(np.sqrt(f32(xx + yy))) - f32(x * r1_recip))
+    else:
+        a = f32(xx - yy)
+        with np.errstate(invalid="ignore"):
+            t = f32(f32(less_scale * f32(np.sqrt(a))) - f32(x * r1_recip))
+        valid = a >= 0 and t >= 0
+    if not valid:
+        log.steps.append("not valid: the pixel keeps its backdrop")
+        return None, log
+    log("t", t)
+    t = log("extend_mode(focal_x + t_sign * t)", extend_mode(f32(focal_x + f32(t_sign * t)), mode))
+    if is_swapped:
+        t = log("1 - t (swapped)", f32(f32(1.0) - t))
+    xi = int(np.rint(log("t * 511", f32(t * f32(511.0)))))
+    log.steps.append("ramp x = %d" % xi)
+    return xi, log
+
+
+def sweep_info(center, log=None):
+    """draw_leaf.wgsl:223-235 under the identity transform: inverse of translate(center)."""
+    return xf_inverse(xf_mul(IDENT, ([f32(1.0), f32(0.0), f32(0.0), f32(1.0)], [f32(center[0]), f32(center[1])])))
+
+
+def sweep_ramp_x(inv, t0, t1, gx, gy, mode, log=None):
+    """fine.wgsl:1038-1066."""
+    log = log or Log()
+    scale = f32(f32(1.0) / f32(f32(t1) - f32(t0)))
+    x, y = xf_apply(inv, gx, gy)
+    xabs, yabs = f32(abs(x)), f32(abs(y))
+    slope = log("slope = min / max", f32(f32(min(xabs, yabs)) / f32(max(xabs, yabs))))
+    s = f32(slope * slope)
+    c0, c1, c2, c3 = f32(0.15912117063999176025390625), f32(-5.185396969318389892578125e-2), f32(2.476101927459239959716796875e-2), f32(-7.0547382347285747528076171875e-3)
+    phi = f32(slope * f32(c0 + f32(s * f32(c1 + f32(s * f32(c2 + f32(s * c3)))))))
+    log("phi (first octant)", phi)
+    if xabs < yabs:
+        phi = f32(f32(0.25) - phi)
+    if x < 0:
+        phi = f32(f32(0.5) - phi)
+    if y < 0:
+        phi = f32(f32(1.0) - phi)
+    if phi != phi:
+        phi = f32(0.0)
+    log("phi", phi)
+    phi = log("(phi - t0) * scale", f32(f32(phi - f32(t0)) * scale))
+    t = log("extend_mode", extend_mode(phi, mode))
+    xi = int(np.rint(log("t * 511", f32(t * f32(511.0)))))
+    log.steps.append("ramp x = %d" % xi)
+    return xi, log
+
+
+def srgb8_to_linear(v):
+    """IEC 61966-2-1 decoding of one 8-bit channel, evaluated in binary64 and rounded once (an rgba8unorm-srgb texel)."""
+    c = v / 255.0
+    return f32(c / 12.92 if c <= 0.04045 else ((c + 0.055) / 1.055) ** 2.4)
+
+
+def image_pixel(pixels, inv, gx, gy, log=None):
+    """fine.wgsl:1068-1087 for the pixel at GLOBAL (gx, gy) with area 1: the premultiplied bilinear sample, or None outside the
+    image.  pixels: (h, w, 4) uint8, sRGB-encoded colour + linear alpha (render.go:137 uploads scene images as Rgba8Srgb)."""
+    log = log or Log()
+    h, w = pixels.shape[0], pixels.shape[1]
+    u, v = xf_apply(inv, gx, gy)
+    log("uv.x", u); log("uv.y", v)
+    if not (u < f32(w) and v < f32(h)):
+        return None, log
+    x0, y0, x1, y1 = int(np.floor(u)), int(np.floor(v)), int(np.ceil(u)), int(np.ceil(v))
+    fx, fy = log("fract(uv.x)", f32(u - f32(np.floor(u)))), log("fract(uv.y)", f32(v - f32(np.floor(v))))
+
+    def texel(x, y):  # textureLoad is zero outside the texture (robust access); premul_alpha
+        if not (0 <= x < w and 0 <= y < h):
+            return [f32(0.0)] * 4
+        p = pixels[y, x]
+        a = f32(f32(int(p[3])) / f32(255.0))
+        return [f32(srgb8_to_linear(int(p[0])) * a), f32(srgb8_to_linear(int(p[1])) * a), f32(srgb8_to_linear(int(p[2])) * a), a]
+
+    def mix4(p, q, t):
+        return [f32(f32(p[j] * f32(f32(1.0) - t)) + f32(q[j] * t)) for j in range(4)]
+    a, b, c, d = texel(x0, y0), texel(x0, y1), texel(x1, y0), texel(x1, y1)
+    out = mix4(mix4(a, b, fy), mix4(c, d, fy), fx)
+    for n, val in zip("rgba", out):
+        log("fg." + n, val)
+    return out, log

@@ -13,6 +13,16 @@ sys.path.insert(0, os.path.dirname(HERE))
 import fine_by_hand as H  # noqa: E402
 
 
+def kat_image_pixels():
+    """The 4x4 RGBA8 image of the image-brush known answer."""
+    import numpy as np
+    px = np.zeros((4, 4, 4), np.uint8)
+    for y in range(4):
+        for x in range(4):
+            px[y, x] = (60 * x + 15, 50 * y + 30, 255 - 40 * x - 20 * y, 128 if (x + y) & 1 else 255)
+    return px
+
+
 def h16(hs):
     return ["0x%04x" % v for v in hs]
 
@@ -128,6 +138,126 @@ def build():
         "arc_interior_points_approx": [[p1[0], p1[1]], [p2[0], p2[1]]], "lines_when_h_is_1e-7": 8,
         "lines_h_1e-7": [[20, 24, 30, 24], [30, 16, 20, 16], [30, 24, 30, 24], [30, 16, 30, 16], [30, 24, 50, 24], [50, 16, 30, 16],
                          [50, 24, 50, 16], [20, 16, 20, 24]]}
+    # ================================= round 4 =========================================================================
+    import numpy as np
+    # ---- 7. the other mix modes at END_CLIP (shared/blend.wgsl:24-195), translucent source over an opaque backdrop ------
+    backdrop, src_straight = [0.75, 0.5, 0.25, 1.0], [0.5, 0.875, 0.25, 0.5]
+    src = [src_straight[0] * 0.5, src_straight[1] * 0.5, src_straight[2] * 0.5, 0.5]  # premultiplied by the encoder: exact
+    for mix in ("screen", "overlay", "darken", "lighten", "color_dodge", "color_burn", "hard_light", "soft_light", "difference",
+                "exclusion", "hue", "saturation", "color"):
+        o, log = H.blend_mix_compose(backdrop, src, mix)
+        hs, log = H.store_rgba16f(o, log)
+        out["blend2_" + mix] = {
+            "scene": "16x16 target, opaque base colour (.75, .5, .25, 1); PushLayer(%s, SrcOver, alpha 1, clip (0,0)-(16,16)); "
+                     "Fill(solid straight (.5, .875, .25, .5)) of (0,0)-(16,16); PopLayer" % mix,
+            "derivation": ["the fill leaves rgba = (.25, .4375, .125, .5) in the layer; END_CLIP: fg = rgba * 1 * 1; "
+                           "blend_mix_compose(base, fg, %d << 8 | SrcOver): cs = fg.rgb * (1 / 0.5) = (.5, .875, .25), cb = (.75, .5, .25); "
+                           "cs' = mix(cs, mixed, 1) = cs * 0 + mixed; out.rgb = base * 0.5 + cs' * 0.5, out.a = 1 (steps)" % H.MIX_NAMES.index(mix)],
+            "result_premultiplied": [float(v) for v in o], "pixels_rgba16f": {"7,7": h16(hs), "0,15": h16(hs)}, "steps": log.steps}
+    # ---- 8. two-point conical gradients: swapped cone with radius > 1 and with radius < 1 -------------------------------
+    for name, r0 in (("radial_cone_swapped", 16.0), ("radial_cone_swapped_small", 4.0)):
+        xform, focal_x, radius, kind, flags, ilog = H.rad_grad_info((4.0, 8.0), (12.0, 8.0), r0, 0.0)
+        ramp_x, steps = {}, {}
+        for (gx, gy) in [(6, 3), (12, 8), (1, 14), (15, 0), (9, 8), (13, 9)]:
+            x, log = H.rad_grad_ramp_x(xform, focal_x, radius, kind, flags, gx, gy, 0)
+            ramp_x["%d,%d" % (gx, gy)] = x
+            steps["%d,%d" % (gx, gy)] = log.steps
+        out[name] = {
+            "scene": "16x16 target, transparent base; Fill(radial gradient c0 = (4,8) r0 = %g, c1 = (12,8) r1 = 0, red -> blue, Pad) of (0,0)-(16,16)" % r0,
+            "derivation": ["draw_leaf.wgsl:151-222: r1 == 0 swaps points and radii (flags = SWAPPED): p0 = (12,8) r0 = 0, p1 = (4,8) r1 = %g; "
+                           "focal_x = 0 / (0 - r1) = -0; cf = p0; radius = r1 / |cf - p1| = %g -> kind CONE (4, shared/config.wgsl:70); info[9] = flags << 3 | kind = 0xc" % (r0, r0 / 8.0),
+                           "xform = scale(scale_x, scale_y) * two_point_to_unit_line(cf, p1) (steps_info), all from shared/transform.wgsl",
+                           "fine.wgsl:991-1036 per pixel (steps_by_pixel): radius > 1: t = sqrt(xx + yy) - x / radius, always valid; radius < 1: "
+                           "t = less_scale * sqrt(xx - yy) - x / radius with less_scale = -1 (swapped), valid iff xx >= yy and t >= 0 -- an invalid "
+                           "pixel keeps its backdrop (transparent: all four halves 0); then extend(focal_x + t), 1 - t (swapped), round(t * 511)",
+                           "the ramp texels are opaque: a valid pixel's stored value equals texel ramp_x of the recording's ramp upload"],
+            "info_words_1_to_9": ["0x%08x" % int(np.float32(v).view(np.uint32)) for v in list(xform[0]) + list(xform[1]) + [focal_x, radius]] + ["0x%08x" % ((flags << 3) | kind)],
+            "ramp_x": ramp_x, "steps_info": ilog.steps, "steps_by_pixel": steps}
+    # ---- 9. sweep gradient -----------------------------------------------------------------------------------------------
+    inv = H.sweep_info((8.0, 8.0))
+    ramp_x, steps = {}, {}
+    for (gx, gy) in [(12, 8), (12, 10), (5, 12), (3, 4), (13, 2), (8, 3), (9, 15)]:
+        x, log = H.sweep_ramp_x(inv, 0.0, 1.0, gx, gy, 0)
+        ramp_x["%d,%d" % (gx, gy)] = x
+        steps["%d,%d" % (gx, gy)] = log.steps
+    out["sweep_gradient"] = {
+        "scene": "16x16 target; Fill(sweep gradient centre (8,8), angles 0 .. 2 pi, red -> blue, Pad) of (0,0)-(16,16)",
+        "derivation": ["the encoder stores t0 = 0 / 2pi = 0 and t1 = f32(2 pi) / f32(2 pi) = 1 (encoding.go: angles as turn fractions); "
+                       "draw_leaf.wgsl:223-235: info = inverse(translate(8,8)) = identity matrix, translate (-8,-8), then t0, t1",
+                       "fine.wgsl:1038-1066: Skia's xy_to_unit_angle polynomial on slope = min(|x|,|y|) / max(|x|,|y|), octant fix-ups "
+                       "(1/4 - phi, 1/2 - phi, 1 - phi), phi = (phi - t0) * 1 / (t1 - t0), Pad, round(t * 511) (steps_by_pixel)",
+                       "on the +x axis (12,8): slope = 0 -> phi = 0 -> texel 0 (red); straight down (8,3) is y < 0: phi = 1 - 1/4 = 0.75 -> texel 383"],
+        "info_words_1_to_8": ["0x%08x" % int(np.float32(v).view(np.uint32)) for v in list(inv[0]) + list(inv[1]) + [0.0, 1.0]],
+        "ramp_x": ramp_x, "steps_by_pixel": steps}
+    # ---- 10. image brush: bilinear sample of sRGB texels with linear alpha -------------------------------------------------
+    px = kat_image_pixels()
+    inv = H.xf_inverse(([np.float32(1), np.float32(0), np.float32(0), np.float32(1)], [np.float32(2.25), np.float32(3.5)]))
+    pixels, steps = {}, {}
+    for (gx, gy) in [(4, 5), (3, 4), (5, 6), (2, 3)]:
+        fg, log = H.image_pixel(px, inv, gx, gy)
+        rgba, log = H.over([0, 0, 0, 0], fg, 1.0, log)
+        hs, log = H.store_rgba16f(rgba, log)
+        pixels["%d,%d" % (gx, gy)] = h16(hs)
+        steps["%d,%d" % (gx, gy)] = log.steps
+    out["image_bilinear_srgb"] = {
+        "scene": "16x16 target, transparent base; Fill(image brush 4x4 RGBA8, brush transform translate(2.25, 3.5)) of (0,0)-(16,16); texel (x, y) = "
+                 "(60 x + 15, 50 y + 30, 255 - 40 x - 20 y, 255 except 128 where x + y is odd)",
+        "derivation": ["draw_leaf.wgsl:236-247: info = inverse(translate(2.25, 3.5)): uv = (X - 2.25, Y - 3.5); extents (4, 4)",
+                       "fine.wgsl:1068-1087: texels (floor, floor), (floor, ceil), (ceil, floor), (ceil, ceil) -- zero outside the texture (robust "
+                       "access) --, each decoded like an rgba8unorm-srgb texel (IEC 61966-2-1 in binary64, rounded once; alpha = a / 255) and "
+                       "premultiplied, then mix(mix(a, b, fy), mix(c, d, fy), fx) with mix(p, q, t) = p (1 - t) + q t",
+                       "pixel (4,5): uv = (1.75, 1.5): texels (1,1), (1,2), (2,1), (2,2), fx = .75, fy = .5; pixel (2,3): uv = (-0.25, -0.5): "
+                       "floor = -1 on both axes: three of the four texels are outside and read as zero",
+                       "over a transparent base: rgba = fg; stored (rgb / a, a)"],
+        "image_rgba8": [[int(v) for v in row.reshape(-1)] for row in px], "pixels_rgba16f": pixels, "steps_by_pixel": steps}
+    # ---- 11. even-odd fill: a rectangle with a same-direction rectangle inside it ---------------------------------------------
+    segs = [[2, 2, 14, 2, 1e9], [14, 2, 14, 14, 1e9], [14, 14, 2, 14, 1e9], [2, 14, 2, 2, 1e9],
+            [4.5, 5, 10.5, 5, 1e9], [10.5, 5, 10.5, 11.25, 1e9], [10.5, 11.25, 4.5, 11.25, 1e9], [4.5, 11.25, 4.5, 5, 1e9]]
+    fg = [0.25, 0.5, 1.0, 1.0]
+    pixels, areas, steps = {}, {}, {}
+    for (x, y) in [(3, 7), (4, 7), (7, 7), (10, 7), (11, 7), (7, 11), (4, 11), (7, 12), (1, 7)]:
+        a, log = H.fill_area(segs, 0, x, y, even_odd=True)
+        rgba, log = H.over([0, 0, 0, 0], fg, a, log)
+        hs, log = H.store_rgba16f(rgba, log)
+        pixels["%d,%d" % (x, y)] = h16(hs)
+        areas["%d,%d" % (x, y)] = float(a)
+        steps["%d,%d" % (x, y)] = log.steps
+    out["even_odd_fill"] = {
+        "scene": "16x16 target, transparent base; Fill(EvenOdd, solid (.25, .5, 1, 1)) of ONE path: rect (2,2)-(14,14) followed by rect "
+                 "(4.5,5)-(10.5,11.25), both in the same direction",
+        "derivation": ["eight lines, none touches x = 0 or a tile edge: eight segments with their own end points, y_edge = 1e9",
+                       "fine.wgsl:824-870: the signed area sums to the winding number's coverage: 1 between the rectangles, 2 inside the inner "
+                       "one, 1.5 / 1.25 / 1.125 where the inner rectangle's left / bottom edges cut a pixel; even-odd: "
+                       "|area - 2 round(area / 2)| with round = ties to even (:865-870)",
+                       "(3,7): |1 - 2 round(.5)| = |1 - 0| = 1;  (7,7): |2 - 2 round(1)| = 0;  (4,7): |1.5 - 2 round(.75)| = .5;  "
+                       "(7,11): rows 11 .. 11.25 of the inner rectangle: 1.25 -> |1.25 - 2 round(.625)| = .75;  (4,11): 1 + .5 * .25 = 1.125 -> .875"],
+        "areas": areas, "pixels_rgba16f": pixels, "steps_by_pixel": {k: steps[k] for k in ("4,7", "4,11")}}
+    # ---- 12. five nested layers: the fifth level lives in blend_spill (fine.wgsl:938-973) ------------------------------------
+    base = [0.25, 0.5, 0.75, 1.0]
+    layers = [("normal", 1.0, [0.5, 0.25, 0.125, 0.5]), ("normal", 0.75, [0.125, 0.5, 0.25, 0.5]), ("screen", 0.5, [0.25, 0.125, 0.5, 0.5]),
+              ("normal", 0.75, [0.5, 0.5, 0.125, 0.5]), ("multiply", 0.5, [0.125, 0.25, 0.5, 0.5])]  # (mix, layer alpha, premultiplied fill colour)
+    log = H.Log()
+    stack, rgba = [], [np.float32(v) for v in base]
+    for k, (mix, alpha, col) in enumerate(layers):
+        stack.append(rgba)
+        log.steps.append("BEGIN_CLIP %d: save rgba, restart from 0; COLOR %r" % (k + 1, col))
+        rgba, log = H.over([0, 0, 0, 0], col, 1.0, log)
+    for k in range(4, -1, -1):
+        mix, alpha, col = layers[k]
+        bg = stack.pop()
+        fg = [np.float32(np.float32(v * np.float32(1.0)) * np.float32(alpha)) for v in rgba]
+        log.steps.append("END_CLIP %d (%s, alpha %g): fg = rgba * area * alpha = %r%s" % (k + 1, mix, alpha, [float(v) for v in fg],
+                                                                                      " -- bg comes back from blend_spill" if k == 4 else ""))
+        rgba, log = H.blend_mix_compose(bg, fg, mix, log)
+    hs, log = H.store_rgba16f(rgba, log)
+    out["five_layers_blend_spill"] = {
+        "scene": "16x16 target, opaque base (.25, .5, .75, 1); five nested PushLayer(mix_k, SrcOver, alpha_k, clip (0,0)-(16,16)), each followed by "
+                 "Fill(solid, premultiplied c_k) of (0,0)-(16,16); mix / alpha / c_k: " + "; ".join("%s %g %r" % l for l in layers),
+        "derivation": ["fine.wgsl:938-949: BEGIN_CLIP saves rgba into blend_stack[clip_depth] for clip_depth < 4, into blend_spill behind "
+                       "blend_offset for the fifth level, and restarts from 0; :951-972 END_CLIP: fg = rgba * area * alpha, rgba = "
+                       "blend_mix_compose(saved, fg, blend)", "coarse: max_blend_depth = 5 > 4 -> this tile reserves (5 - 4) * 256 entries: bump.blend = 256, "
+                       "ptcl[0] (blend_ix) = 0", "every step in `steps`"],
+        "bump_blend": 256, "result_premultiplied": [float(v) for v in rgba], "pixels_rgba16f": {"7,7": h16(hs), "15,0": h16(hs)}, "steps": log.steps}
     return out
 
 

@@ -215,6 +215,89 @@ def px_eps_tangent(handle_y):
     return s, RenderParams(64, 64)
 
 
+# ---- round 4 ----
+MIX_BY_NAME = {"screen": Mix.Screen, "overlay": Mix.Overlay, "darken": Mix.Darken, "lighten": Mix.Lighten, "color_dodge": Mix.ColorDodge,
+               "color_burn": Mix.ColorBurn, "hard_light": Mix.HardLight, "soft_light": Mix.SoftLight, "difference": Mix.Difference,
+               "exclusion": Mix.Exclusion, "hue": Mix.Hue, "saturation": Mix.Saturation, "color": Mix.Color, "normal": Mix.Normal,
+               "multiply": Mix.Multiply, "luminosity": Mix.Luminosity}
+MIX2 = ["screen", "overlay", "darken", "lighten", "color_dodge", "color_burn", "hard_light", "soft_light", "difference", "exclusion", "hue",
+        "saturation", "color"]
+FULL = (0, 0, 16, 16)
+
+
+def px_blend2(mix_name):
+    s = Scene()
+    s.push_layer(MIX_BY_NAME[mix_name], Compose.SrcOver, 1.0, None, Path.rect(*FULL))
+    s.fill(Fill.NonZero, None, Brush.solid((0.5, 0.875, 0.25, 0.5)), None, Path.rect(*FULL))
+    s.pop_layer()
+    return s, RenderParams(16, 16, base_color=(0.75, 0.5, 0.25, 1.0))
+
+
+def px_radial(r0):
+    s = Scene()
+    stops = [ColorStop(0.0, (1, 0, 0, 1)), ColorStop(1.0, (0, 0, 1, 1))]
+    s.fill(Fill.NonZero, None, Brush.radial((4, 8), r0, (12, 8), 0.0, stops, jello_amd.Extend.Pad), None, Path.rect(*FULL))
+    return s, RenderParams(16, 16)
+
+
+def px_sweep():
+    import math
+    s = Scene()
+    stops = [ColorStop(0.0, (1, 0, 0, 1)), ColorStop(1.0, (0, 0, 1, 1))]
+    s.fill(Fill.NonZero, None, Brush.sweep((8, 8), 0.0, 2.0 * math.pi, stops, jello_amd.Extend.Pad), None, Path.rect(*FULL))
+    return s, RenderParams(16, 16)
+
+
+def px_image():
+    """The pixel array is built in a helper and dropped before the scene is rendered: the Scene owns its copy (the brush used
+    to keep a raw pointer into the freed array -- VERDICT r03)."""
+    s = Scene()
+
+    def add():
+        px = np.array(PIX["image_bilinear_srgb"]["image_rgba8"], np.uint8).reshape(4, 4, 4).copy()
+        s.fill(Fill.NonZero, None, Brush.image(px), (1, 0, 0, 1, 2.25, 3.5), Path.rect(*FULL))
+        px[:] = 0xEE  # what a recycled allocation would hold
+    add()
+    junk = [np.full((4, 4, 4), 0x55, np.uint8) for _ in range(64)]  # churn the allocator's small blocks
+    del junk
+    return s, RenderParams(16, 16)
+
+
+def px_even_odd():
+    s = Scene()
+    p = Path.rect(2, 2, 14, 14)
+    p.els += Path.rect(4.5, 5, 10.5, 11.25).els
+    s.fill(Fill.EvenOdd, None, Brush.solid((0.25, 0.5, 1.0, 1.0)), None, p)
+    return s, RenderParams(16, 16)
+
+
+def px_five_layers():
+    """Fill colours are given straight (the encoder premultiplies): premultiplied c_k = straight rgb * 0.5."""
+    s = Scene()
+    layers = [("normal", 1.0, (1.0, 0.5, 0.25, 0.5)), ("normal", 0.75, (0.25, 1.0, 0.5, 0.5)), ("screen", 0.5, (0.5, 0.25, 1.0, 0.5)),
+              ("normal", 0.75, (1.0, 1.0, 0.25, 0.5)), ("multiply", 0.5, (0.25, 0.5, 1.0, 0.5))]
+    for mix, alpha, col in layers:
+        s.push_layer(MIX_BY_NAME[mix], Compose.SrcOver, alpha, None, Path.rect(*FULL))
+        s.fill(Fill.NonZero, None, Brush.solid(col), None, Path.rect(*FULL))
+    for _ in layers:
+        s.pop_layer()
+    return s, RenderParams(16, 16, base_color=(0.25, 0.5, 0.75, 1.0))
+
+
+def check_px_ramp_gradient(get, img, rec, key, n_info):
+    """Radial / sweep: the info words draw_leaf wrote, and every listed pixel = texel ramp_x of the uploaded ramp (opaque
+    texels over a transparent base), or untouched (all zero) where the gradient is not valid."""
+    k = PIX[key]
+    info = get("infoBinDataBuf", np.uint32)
+    assert ["0x%08x" % int(v) for v in info[1:1 + n_info]] == k["info_words_1_to_%d" % n_info]
+    ramp = ramp_rows(rec)
+    assert [int(v) for v in ramp[0, 0]] == [0x3c00, 0, 0, 0x3c00] and [int(v) for v in ramp[0, 511]] == [0, 0, 0x3c00, 0x3c00]
+    for pos, x in k["ramp_x"].items():
+        gx, gy = [int(v) for v in pos.split(",")]
+        want = [0, 0, 0, 0] if x is None else [int(v) for v in ramp[0, x]]
+        assert [int(v) for v in img[gy, gx]] == want, (key, pos, x)
+
+
 def ramp_rows(rec):
     """The gradient ramps the recording uploads (RGBA16F, 512 texels per row), as f16 bit patterns."""
     ups = [c for c in rec.commands() if c["kind"] == jello_amd.CMD.UPLOAD_IMAGE]

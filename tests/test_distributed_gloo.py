@@ -65,8 +65,10 @@ def test_scene_per_rank_and_gather(built):
 
 
 def _rotate_worker(rank, world, port, q):
-    """bench.py's N > 1 step loop with --gather-dst rotate, on gloo: double-buffered async gathers on two communicators,
-    destination = step mod world; every destination must end up with every rank's frame of ITS steps."""
+    """bench.py's N > 1 step loop (sharding.GatherPipeline, the object bench.py drives) on gloo, the THREE modes one after
+    the other in one process group as `bench.py --gpus N` runs them: no gather, gather to rank 0, gather to rank
+    (step mod world) -- double-buffered async gathers on two communicators.  Every destination must end up with every
+    rank's frame of ITS steps, and a buffer must not be rendered into before its gather is done."""
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -78,26 +80,25 @@ def _rotate_worker(rank, world, port, q):
         groups = [dist.new_group(ranks=list(range(world))) for _ in range(2)]
         outs = [torch.zeros(64, dtype=torch.int32) for _ in range(2)]
         gathered = [[torch.zeros(64, dtype=torch.int32) for _ in range(world)] for _ in range(2)]
-        pending = [None, None]
-        got = {}
+        pipe = sharding.GatherPipeline(dist, rank, world, outs, gathered, groups)
         steps = 6
-        for i in range(steps):
-            k = i & 1
-            if pending[k] is not None:
-                pending[k][0].wait()
-                if pending[k][1] is not None:  # this rank was the destination of that step
-                    got[pending[k][1]] = [int(t[0]) for t in gathered[k]]
-                pending[k] = None
-            outs[k].fill_(100 * i + rank)  # "render" frame i of this rank
-            dst = sharding.gather_dst_for_step(i, world, "rotate")
-            _, work = sharding.gather_images(dist, outs[k], rank, world, dst=dst, async_op=True,
-                                             out=gathered[k] if rank == dst else None, group=groups[k])
-            pending[k] = (work, i if rank == dst else None)
-        for k in range(2):
-            if pending[k] is not None:
-                pending[k][0].wait()
-                if pending[k][1] is not None:
-                    got[pending[k][1]] = [int(t[0]) for t in gathered[k]]
+        got = {}
+        for mode in (None, "0", "rotate"):
+            seen = {}
+            rendered = []
+
+            def render(k, _r=rendered):
+                i = len(_r)
+                _r.append(k)
+                outs[k].fill_(1000 * {None: 1, "0": 2, "rotate": 3}[mode] + 100 * i + rank)  # "render" frame i of this rank
+
+            def on_gathered(step, bufs, _s=seen):
+                _s[step] = [int(t[0]) for t in bufs]
+            for i in range(steps):
+                pipe.step(i, render, mode, on_gathered)
+            pipe.drain(on_gathered)
+            dist.barrier()
+            got[str(mode)] = (seen, rendered)
         q.put((rank, got))
         dist.barrier()
     finally:
@@ -116,9 +117,17 @@ def test_rotating_gather_destination_double_buffered(built):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # rank 0 collected the even steps, rank 1 the odd ones, each with both ranks' frames of that step
-    assert results[0] == {i: [100 * i, 100 * i + 1] for i in (0, 2, 4)}
-    assert results[1] == {i: [100 * i, 100 * i + 1] for i in (1, 3, 5)}
+    for r in (0, 1):
+        # no gather: nothing arrives anywhere, every frame goes to buffer 0
+        assert results[r]["None"] == ({}, [0] * 6)
+        # both gather modes alternate the two buffers
+        assert results[r]["0"][1] == [0, 1, 0, 1, 0, 1] and results[r]["rotate"][1] == [0, 1, 0, 1, 0, 1]
+    # gather to rank 0: rank 0 collected every step with both ranks' frames of that step, rank 1 nothing
+    assert results[0]["0"][0] == {i: [2000 + 100 * i, 2000 + 100 * i + 1] for i in range(6)}
+    assert results[1]["0"][0] == {}
+    # rotating destination: rank 0 collected the even steps, rank 1 the odd ones
+    assert results[0]["rotate"][0] == {i: [3000 + 100 * i, 3000 + 100 * i + 1] for i in (0, 2, 4)}
+    assert results[1]["rotate"][0] == {i: [3000 + 100 * i, 3000 + 100 * i + 1] for i in (1, 3, 5)}
 
 
 def test_gather_model_states_the_ceiling():

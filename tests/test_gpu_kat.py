@@ -159,3 +159,57 @@ def test_px_eps_tangent_rule_at_a_round_join(engine):
         assert [[float(v) for v in r] for r in lines] == [[float(v) for v in r] for r in k["lines_h_1e-7"]]
     finally:
         engine.release(rec)
+
+
+# ---- round 4: the HIP image against the hand-derived pixels of the remaining mix modes, gradients, images, even-odd, blend spill ----
+@pytest.mark.parametrize("mix", K.MIX2)
+def test_px_end_clip_blend_other_modes(engine, mix):
+    get, img, rec, bump = run_gpu_image(engine, K.px_blend2(mix))
+    try:
+        K.check_pixels(img, K.PIX["blend2_" + mix]["pixels_rgba16f"])
+    finally:
+        engine.release(rec)
+
+
+@pytest.mark.parametrize("key,r0", [("radial_cone_swapped", 16.0), ("radial_cone_swapped_small", 4.0)])
+def test_px_radial_cone_swapped(engine, key, r0):
+    get, img, rec, bump = run_gpu_image(engine, K.px_radial(r0))
+    try:
+        K.check_px_ramp_gradient(get, img, rec, key, 9)
+    finally:
+        engine.release(rec)
+
+
+def test_px_sweep_gradient(engine):
+    get, img, rec, bump = run_gpu_image(engine, K.px_sweep())
+    try:
+        K.check_px_ramp_gradient(get, img, rec, "sweep_gradient", 8)
+    finally:
+        engine.release(rec)
+
+
+def test_px_image_bilinear_srgb(engine):
+    """Known texel values (not "two pixels differ"), from a pixel array that is freed before the render."""
+    get, img, rec, bump = run_gpu_image(engine, K.px_image())
+    try:
+        K.check_pixels(img, K.PIX["image_bilinear_srgb"]["pixels_rgba16f"])
+    finally:
+        engine.release(rec)
+
+
+def test_px_even_odd_fill(engine):
+    get, img, rec, bump = run_gpu_image(engine, K.px_even_odd())
+    try:
+        assert bump["lines"] == 8 and bump["segments"] == 8
+        K.check_pixels(img, K.PIX["even_odd_fill"]["pixels_rgba16f"])
+    finally:
+        engine.release(rec)
+
+
+def test_px_five_layers_through_the_blend_spill(engine):
+    get, img, rec, bump = run_gpu_image(engine, K.px_five_layers())
+    try:
+        assert bump["blend"] == K.PIX["five_layers_blend_spill"]["bump_blend"]
+        K.check_pixels(img, K.PIX["five_layers_blend_spill"]["pixels_rgba16f"])
+    finally:
+        engine.release(rec)

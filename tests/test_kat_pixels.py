@@ -78,3 +78,43 @@ def test_eps_tangent_rule_at_a_round_join(built):
     assert bump["lines"] == k["lines_when_h_is_1e-7"]
     lines = get("linesBuf", np.float32)[:8 * 6].reshape(-1, 6)[:, 2:]
     assert [[float(v) for v in r] for r in lines] == [[float(v) for v in r] for r in k["lines_h_1e-7"]]
+
+
+# ---- round 4: the remaining mix modes, conical / sweep gradients, an sRGB image brush, even-odd, the blend spill ----
+@pytest.mark.parametrize("mix", K.MIX2)
+def test_end_clip_blend_other_modes(built, mix):
+    get, img, rec, bump = run_oracle(K.px_blend2(mix))
+    K.check_pixels(img, K.PIX["blend2_" + mix]["pixels_rgba16f"])
+
+
+@pytest.mark.parametrize("key,r0", [("radial_cone_swapped", 16.0), ("radial_cone_swapped_small", 4.0)])
+def test_radial_cone_swapped(built, key, r0):
+    get, img, rec, bump = run_oracle(K.px_radial(r0))
+    K.check_px_ramp_gradient(get, img, rec, key, 9)
+
+
+def test_sweep_gradient(built):
+    get, img, rec, bump = run_oracle(K.px_sweep())
+    K.check_px_ramp_gradient(get, img, rec, "sweep_gradient", 8)
+
+
+def test_image_bilinear_srgb(built):
+    get, img, rec, bump = run_oracle(K.px_image())
+    K.check_pixels(img, K.PIX["image_bilinear_srgb"]["pixels_rgba16f"])
+
+
+def test_even_odd_fill(built):
+    get, img, rec, bump = run_oracle(K.px_even_odd())
+    assert bump["lines"] == 8 and bump["segments"] == 8
+    K.check_pixels(img, K.PIX["even_odd_fill"]["pixels_rgba16f"])
+
+
+def test_five_layers_through_the_blend_spill(built):
+    get, img, rec, bump = run_oracle(K.px_five_layers())
+    assert bump["blend"] == K.PIX["five_layers_blend_spill"]["bump_blend"]
+    K.check_pixels(img, K.PIX["five_layers_blend_spill"]["pixels_rgba16f"])
+
+
+def test_hand_derived_even_odd_areas():
+    a = K.PIX["even_odd_fill"]["areas"]
+    assert a == {"3,7": 1.0, "4,7": 0.5, "7,7": 0.0, "10,7": 0.5, "11,7": 1.0, "7,11": 0.75, "4,11": 0.875, "7,12": 1.0, "1,7": 0.0}

@@ -101,20 +101,29 @@ JD double dcos(double x) {
     double c = (q & 1) ? sin_poly(r) : cos_poly(r);
     return ((q + 1) & 2) ? -c : c;
 }
-JD double atan_tab(int k) {
-    // atan(k/8), k = 0..8; a switch keeps the table in SGPR/inline constants instead of scratch.
-    switch (k) {
-        case 0: return 0.0;
-        case 1: return 0.12435499454676144;
-        case 2: return 0.24497866312686414;
-        case 3: return 0.35877067027057225;
-        case 4: return 0.4636476090008061;
-        case 5: return 0.5585993153435624;
-        case 6: return 0.6435011087932844;
-        case 7: return 0.7188299996216245;
-        default: return 0.7853981633974483;
-    }
+// atan(k/8), k = 0..8.  The index differs per lane, so a `switch` compiles to a tree of divergent branches (~50 scalar
+// instructions and their pipeline bubbles per call) and a chain of selects to ~35 vector instructions (every 32-bit half of
+// every constant needs a move).  Kernels that call atan2_ / acos_ / asin_ in a hot loop therefore keep the nine constants in
+// LDS: define JD_ATAN_TAB_LDS as a `__shared__ double[9]` before including this header and fill it with atan_tab_fill()
+// at the top of the kernel -- one ds_read_b64 per call.  Same constants, same result either way.
+JD double atan_tab_const(int k) {
+    // (a tree over the bits of k; any k outside 0..8 reads as 8, like a switch's default)
+    const bool b0 = (k & 1) != 0, b1 = (k & 2) != 0, b2 = (k & 4) != 0, hi = (unsigned)k >= 8u;
+    const double t01 = b0 ? 0.12435499454676144 : 0.0, t23 = b0 ? 0.35877067027057225 : 0.24497866312686414;
+    const double t45 = b0 ? 0.5585993153435624 : 0.4636476090008061, t67 = b0 ? 0.7188299996216245 : 0.6435011087932844;
+    const double t03 = b1 ? t23 : t01, t47 = b1 ? t67 : t45;
+    const double t07 = b2 ? t47 : t03;
+    return hi ? 0.7853981633974483 : t07;
 }
+#ifdef JD_ATAN_TAB_LDS
+JD void atan_tab_fill() {  // every thread of the workgroup must call it (before its first atan2_ / acos_ / asin_)
+    if (threadIdx.x < 9u) JD_ATAN_TAB_LDS[threadIdx.x] = atan_tab_const((int)threadIdx.x);
+    __syncthreads();
+}
+JD double atan_tab(int k) { return JD_ATAN_TAB_LDS[(unsigned)k > 8u ? 8u : (unsigned)k]; }
+#else
+JD double atan_tab(int k) { return atan_tab_const(k); }
+#endif
 // atan(n/d) for 0 <= n <= d, d > 0: split at k/8, atan(n/d) = atan(k/8) + atan(t), t = (n - c d) / (d + c n), c = k/8.
 // k is picked from the binary32 quotient (any k with |n/d - k/8| <= 1/16 + 2^-24 keeps |t| < 0.07), so the only
 // binary64 division is the one of t.

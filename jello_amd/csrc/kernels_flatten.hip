@@ -19,6 +19,9 @@
 // (shaders/cpu/flatten.go:664-823) -- with the subdivision arithmetic executed exactly once.
 // Algorithmic traffic: scene bytes + 20 B / tag word in, 24 B / line out (+ 64-80 B / piece through the temp).
 // k_flatten_items is VALU/latency-bound (f64 transcendentals, 1...30 subdivision attempts per job).
+#include <hip/hip_runtime.h>
+__shared__ double fl_atan_tab[9];  // dmath.h: atan(k/8) for the table-split arctangent, filled by atan_tab_fill()
+#define JD_ATAN_TAB_LDS fl_atan_tab
 #include "kcommon.h"
 #define FF_INLINE __device__ __forceinline__
 #include "flatten_fast.h"
@@ -1073,6 +1076,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
     uint32_t n_heavy = umin_(counters[0], cap), n_light = umin_(counters[FL_CTR_LIGHT], cap - n_heavy);
     uint32_t n = n_heavy + n_light;
     if (blockIdx.x * 64u >= n) return;  // uniform: this workgroup's share of the list is empty
+    atan_tab_fill();
     if (threadIdx.x == 0) {
         uint32_t cb = blockIdx.x * FL_CHUNK;  // static: the overflow area (counters[2]) starts behind the last chunk
         sh_chunk = cb;
@@ -1126,6 +1130,10 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
             if (lane == 0u) { B.n_stack = (uint32_t)__builtin_popcountll(am); B.n_leaves = 0u; B.bail = 0u; B.n_unsure = 0u; }
         }
         wave_fence();
+#ifdef FL_SPLIT_NO_A  // (measurement builds only, tools/flatten_split.sh: the kernel without its subdivision -- results are wrong)
+        if (lane == 0u) B.n_stack = 0u;
+        wave_fence();
+#endif
         // ---- phase A: drain the stack -- DECISIONS only.  A node is accepted, rejected (its halves are pushed) or left
         // undecided by the transcendental-free test (flatten_fast.h; ~0.1 % of the nodes); the undecided ones wait in a list of
         // their own and get the pinned sequence in rounds of up to 64 when the stack has run dry (or 64 are waiting). ----
@@ -1196,7 +1204,11 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
         // parameters and the line count (flatten.wgsl:404-447), the temp slots, the record ----
         const bool bail = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.bail) != 0u;
         const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.n_leaves);
+#ifdef FL_SPLIT_NO_B  // (measurement builds only: no piece is written)
+        for (uint32_t lbase = nl; lbase < nl; lbase += 64u) {
+#else
         for (uint32_t lbase = 0u; lbase < nl; lbase += 64u) {
+#endif
             const uint32_t li = lbase + lane;
             const bool has = li < nl;
             const uint32_t node = has ? B.l_tpos[li] : 0u;
@@ -1289,6 +1301,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
                                                          const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines) {
     __shared__ uint2 sh_wdat[JL_WG / 64][192];    // per wave: the words it stores this step, in lane order ...
     __shared__ uint32_t sh_widx[JL_WG / 64][192];  // ... and their 8-byte word indices in the line buffer (~0: none)
+    atan_tab_fill();
     const uint32_t n_t = umin_(counters[2], tcap);
     const uint32_t lines_lim = umin_(cfg->lines_size, lines.n);
     const uint32_t lane = lane_id();

@@ -161,8 +161,9 @@ int jh_dispatch_indirect(jh_ctx* ctx, int stage, uint64_t indirect_buffer_id, ui
  * makes a scratch array grow.  jh_graph_launch detects this (a generation counter) and returns JH_ERR_INVALID.
  * Two internal counters (flatten's work lists, backdrop's wide-row list) are zeroed by kernels of the frame itself
  * instead of by fill launches, so a captured frame contains no fill for them: it assumes, like every frame, that the
- * frame before it ran to its end (a stage that fails half-way makes the next EAGER stage fill again; a graph replayed
- * right after such a failure would not -- run one eager frame first). */
+ * frame before it ran to its end.  A stage that fails half-way leaves a host-side flag down: the next eager stage fills
+ * again, and jh_graph_launch zeroes the counters its graph has no fill for before it replays (counted:
+ * jh_debug_graph_self_cleans). */
 int jh_graph_begin(jh_ctx* ctx);
 int jh_graph_end(jh_ctx* ctx, void** graph_exec);
 int jh_graph_launch(jh_ctx* ctx, void* graph_exec);
@@ -191,6 +192,7 @@ int jh_selftest_math(jh_ctx* ctx, int op, const float* a, const float* b, float*
  * with `byte` and forgets that any counter was left clean -- the state of freshly allocated device memory that happens
  * not to be zero.  Tests use it to show that no stage relies on what an earlier frame (or hipMalloc) left behind, the
  * way the reference's pooled buffers hold stale data (engine/wgpu_engine/wgpu.go:772-808). */
+uint64_t jh_debug_graph_self_cleans(jh_ctx* ctx);  /* replays that had to zero an internal counter first (tests) */
 int jh_debug_poison_scratch(jh_ctx* ctx, int byte);
 
 /* ---- introspection ---- */

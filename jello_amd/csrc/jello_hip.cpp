@@ -70,6 +70,10 @@ struct JhGraph {  // a captured frame plus the resource generation it was captur
     hipGraphExec_t exec;
     uint64_t generation;
     uint32_t kernel_nodes, other_nodes;  // what the capture recorded (jh_graph_node_counts)
+    // JH_CLEAN_* flags that were up when the capture began: the graph holds NO fill for those counters and relies on the
+    // frame before it having left them zeroed.  jh_graph_launch zeroes whichever of them is not clean at that moment (a frame
+    // that failed half-way, jh_debug_poison_scratch) before the replay.
+    uint32_t assumes_clean;
 };
 
 struct Staging {  // pinned host arena for uploads: the caller's slice is copied once, the DMA runs asynchronously
@@ -100,6 +104,8 @@ struct jh_ctx {
     // regrow or import, scratch regrow.  jh_graph_launch refuses a graph captured against an older generation.
     uint64_t generation = 0;
     bool capturing = false;
+    uint32_t clean_at_capture_begin = 0u;
+    uint64_t graph_self_cleans = 0;  // replays that had to zero a counter first (jh_debug_graph_self_cleans)
     Staging staging;
     // fine: descriptor table of the bound image array when it has more entries than fit in the kernel arguments
     void* image_table = nullptr;
@@ -179,7 +185,6 @@ void* jh_scratch_get(JhScratch* s, int slot, uint64_t bytes) {
         case JH_SCR_SCAN_TMP: s->clean_flags &= ~(uint32_t)JH_CLEAN_SCAN; break;
         case JH_SCR_FL_CTR: s->clean_flags &= ~(uint32_t)JH_CLEAN_FL_CTR; break;
         case JH_SCR_BD_CTR: s->clean_flags &= ~(uint32_t)JH_CLEAN_BD_CTR; break;
-        case JH_SCR_PT_CTR: s->clean_flags &= ~(uint32_t)JH_CLEAN_PT_CTR; break;
         default: break;  // (the other arrays are written before they are read in every frame)
     }
     p = (char*)p + (uint64_t)slot * JH_SCR_SKEW;
@@ -702,30 +707,14 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
             return fail(ctx, JH_ERR_INVALID, std::string("bad bindings for stage ") + jh_stage_name(stage) + ": config / bump / indirect buffer too small");
     }
     // Hold back the small stages a following stage can absorb (see Deferred); absorb or launch what is being held.
-    // (pathtag_reduce is held back for a possible three-level scan: reduce + reduce2 + scan1 become one launch; when
-    // pathtag_scan_small follows instead it is launched as recorded)
-    const bool pt2 = stage == JH_PATHTAG_REDUCE2 && ctx->deferred.size() == 1 && !ctx->deferred[0].is_clear &&
-                     ctx->deferred[0].stage == JH_PATHTAG_REDUCE && b.size() >= 2 && ctx->deferred[0].b[2].ptr == b[0].ptr;
-    const bool deferrable = stage == JH_BBOX_CLEAR || stage == JH_PATH_COUNT_SETUP || stage == JH_PATH_TILING_SETUP ||
-                            stage == JH_PATHTAG_REDUCE || pt2;
+    const bool deferrable = stage == JH_BBOX_CLEAR || stage == JH_PATH_COUNT_SETUP || stage == JH_PATH_TILING_SETUP;
     uint32_t absorb = 0u;
-    JhBound extra, extra2;
-    uint32_t fused_grid = 0u;
+    JhBound extra;
     std::memset(&extra, 0, sizeof extra);
-    std::memset(&extra2, 0, sizeof extra2);
     if (deferrable) {
-        // (only one kind of thing waits at a time, except bbox_clear + Clear(bump) in front of flatten and the two pathtag stages)
+        // (only one kind of thing waits at a time, except bbox_clear + Clear(bump) in front of flatten)
         for (const Deferred& d : ctx->deferred)
-            if (!(stage == JH_BBOX_CLEAR && d.is_clear) && !pt2) { JH_FLUSH(ctx); break; }
-    } else if (stage == JH_PATHTAG_SCAN1 && ctx->deferred.size() == 2 && !ctx->deferred[0].is_clear && !ctx->deferred[1].is_clear &&
-               ctx->deferred[0].stage == JH_PATHTAG_REDUCE && ctx->deferred[1].stage == JH_PATHTAG_REDUCE2 && b.size() >= 3 &&
-               ctx->deferred[0].b[2].ptr == b[0].ptr && ctx->deferred[1].b[0].ptr == b[0].ptr && ctx->deferred[1].b[1].ptr == b[1].ptr &&
-               ctx->deferred[1].gx >= gx && gx > 0u && gx <= 256u) {  // (reduce2 is recorded with 256 workgroups; scan1 reads the first gx of its results)
-        absorb = JH_ABSORB_PATHTAG;
-        extra = ctx->deferred[0].b[0];
-        extra2 = ctx->deferred[0].b[1];
-        fused_grid = ctx->deferred[0].gx;
-        ctx->deferred.clear();
+            if (!(stage == JH_BBOX_CLEAR && d.is_clear)) { JH_FLUSH(ctx); break; }
     } else if (!ctx->deferred.empty()) {
         bool all = true;
         for (const Deferred& d : ctx->deferred) {
@@ -759,8 +748,6 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
     L.gx = gx; L.gy = gy; L.gz = gz;
     L.absorb = absorb;
     L.extra = extra;
-    L.extra2 = extra2;
-    L.fused_grid = fused_grid;
     L.b = b.data();
     L.nb = (int)b.size();
     L.images = images.data();
@@ -862,6 +849,7 @@ int jh_graph_begin(jh_ctx* ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     ctx->capturing = true;
+    ctx->clean_at_capture_begin = ctx->scratch.clean_flags;
     return JH_OK;
 }
 int jh_graph_end(jh_ctx* ctx, void** graph_exec) {
@@ -870,6 +858,9 @@ int jh_graph_end(jh_ctx* ctx, void** graph_exec) {
     hipGraph_t graph = nullptr;
     const int frc = flush_deferred(ctx);  // held-back commands belong to the captured frame
     ctx->capturing = false;
+    // Nothing ran: the device holds what it held when the capture began, and so must the host's picture of it (a launcher that
+    // found a flag down recorded its fill INTO the graph and raised the flag -- the fill has not happened).
+    ctx->scratch.clean_flags = ctx->clean_at_capture_begin;
     HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &graph));
     if (frc != JH_OK) { if (graph) (void)hipGraphDestroy(graph); return frc; }
     // the launches of the frame, counted on the captured graph itself
@@ -890,7 +881,7 @@ int jh_graph_end(jh_ctx* ctx, void** graph_exec) {
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (e != hipSuccess) return hip_fail(ctx, e, "hipGraphInstantiate");
-    *graph_exec = (void*)new JhGraph{exec, ctx->generation, n_kernel, n_other};
+    *graph_exec = (void*)new JhGraph{exec, ctx->generation, n_kernel, n_other, ctx->clean_at_capture_begin};
     return JH_OK;
 }
 int jh_graph_node_counts(jh_ctx* ctx, void* graph_exec, uint32_t* kernel_nodes, uint32_t* other_nodes) {
@@ -909,6 +900,18 @@ int jh_graph_launch(jh_ctx* ctx, void* graph_exec) {
     if (g->generation != ctx->generation)
         return fail(ctx, JH_ERR_INVALID, "jh_graph_launch: stale graph (a buffer, image or scratch array it refers to was freed, regrown or "
                                          "re-imported after the capture) -- capture again");
+    // Counters the graph expects zeroed (it has no fill for them) and that are not: the frame before did not run to its end
+    // (a stage failed half-way) or the scratch was poisoned.  Zero them here -- the eager path's own remedy -- then replay.
+    const uint32_t dirty = g->assumes_clean & ~ctx->scratch.clean_flags;
+    if (dirty) {
+        static const struct { uint32_t flag; int slot; } kSlots[] = {
+            {JH_CLEAN_FL_CTR, JH_SCR_FL_CTR}, {JH_CLEAN_BD_CTR, JH_SCR_BD_CTR}, {JH_CLEAN_SCAN, JH_SCR_SCAN_TMP}};
+        for (const auto& k : kSlots)
+            if ((dirty & k.flag) && ctx->scratch.ptr[k.slot] && ctx->scratch.cap[k.slot])
+                HIP_TRY(ctx, hipMemsetAsync(ctx->scratch.ptr[k.slot], 0, ctx->scratch.cap[k.slot], ctx->stream));
+        ctx->scratch.clean_flags |= dirty;
+        ctx->graph_self_cleans++;
+    }
     HIP_TRY(ctx, hipGraphLaunch(g->exec, ctx->stream));
     return JH_OK;
 }
@@ -1062,6 +1065,8 @@ int jh_debug_poison_scratch(jh_ctx* ctx, int byte) {
     ctx->scratch.clean_flags = 0u;
     return JH_OK;
 }
+
+uint64_t jh_debug_graph_self_cleans(jh_ctx* ctx) { return ctx ? ctx->graph_self_cleans : 0; }
 
 int jh_device_info(jh_ctx* ctx, char* name, int name_len, int* compute_units, uint64_t* total_mem) {
     if (!ctx) return JH_ERR_INVALID;

@@ -212,12 +212,9 @@ struct JhLaunch {
     uint32_t band_row0, band_row1;  // jh_set_band: bin rows [row0, row1) this context writes PTCL for and rasterises (0, ~0u = all)
     const JhImageDesc* image_table;  // device table of all n_images descriptors when n_images > JH_FINE_INLINE_IMAGES, else nullptr
     uint32_t absorb;  // JH_ABSORB_*: held-back commands this stage performs in passing (jello_hip.cpp, Deferred)
-    JhBound extra;    // JH_ABSORB_SETUP of path_tiling: the ptcl buffer of path_tiling_setup (ptcl[0] = ~0 on failure);
-                      // JH_ABSORB_PATHTAG: the config of pathtag_reduce
-    JhBound extra2;   // JH_ABSORB_PATHTAG: the scene of pathtag_reduce
-    uint32_t fused_grid;  // JH_ABSORB_PATHTAG: the grid of pathtag_reduce
+    JhBound extra;    // JH_ABSORB_SETUP of path_tiling: the ptcl buffer of path_tiling_setup (ptcl[0] = ~0 on failure)
 };
-enum { JH_ABSORB_BBOX_CLEAR = 1u, JH_ABSORB_BUMP_CLEAR = 2u, JH_ABSORB_SETUP = 4u, JH_ABSORB_PATHTAG = 8u };
+enum { JH_ABSORB_BBOX_CLEAR = 1u, JH_ABSORB_BUMP_CLEAR = 2u, JH_ABSORB_SETUP = 4u };
 
 enum {  // scratch slots
     JH_SCR_SCAN_TMP = 0,
@@ -233,14 +230,13 @@ enum {  // scratch slots
     JH_SCR_J = 10,
     JH_SCR_FL_CTR = 11,  // flatten's list counters / chunk fills: NOT shared with other stages (they survive between frames)
     JH_SCR_BD_CTR = 12,  // backdrop's wide-row counter: likewise
-    JH_SCR_PT_CTR = 13,  // the fused pathtag launch's finished-workgroups counter: likewise
-    JH_SCR_COUNT = 14
+    JH_SCR_COUNT = 13
 };
 // Counters a stage needs zeroed when it starts are zeroed by the LAST kernel that runs before without using them (the
 // stage's own last kernel of the frame before, or a kernel of the stage in front) instead of by a fill launch of
 // ~4.4 us; a host-side flag per counter says whether that has happened since the counter was last used.  A stage that
 // finds its flag down (first frame, an aborted frame, a stage run on its own, a scratch reallocation) fills as before.
-enum { JH_CLEAN_FL_CTR = 1u, JH_CLEAN_BD_CTR = 2u, JH_CLEAN_PT_CTR = 4u, JH_CLEAN_SCAN = 8u };
+enum { JH_CLEAN_FL_CTR = 1u, JH_CLEAN_BD_CTR = 2u, JH_CLEAN_SCAN = 8u };
 uint32_t* jh_scratch_flags(JhScratch* s);
 uint64_t jh_scratch_cap(JhScratch* s, int slot);  // bytes the slot holds (>= what was last asked for)
 

@@ -6,6 +6,7 @@
 // All of these are HBM-bound integer work: 16 B / tag word in, 20 B out (K4); wave64 DPP
 // prefix (row_shr + row_bcast) + a 4-entry LDS exchange per 256-thread block replaces the WGSL's 8-round LDS ladder.
 #include "kcommon.h"
+#include <cstring>
 
 using namespace jk;
 using namespace jd;
@@ -13,90 +14,6 @@ using namespace jd;
 // ------------------------------------------------------------------------------------------------
 // generic exclusive scan (u32)
 // ------------------------------------------------------------------------------------------------
-#define SCAN_ITEMS 8
-#define SCAN_TILE (JL_WG * SCAN_ITEMS)
-
-// Two launches: SCAN_G workgroups each own a contiguous range of ceil(n / SCAN_G) elements (rounded to whole tiles).
-// (Measured on MI355X, round 2: the same two phases in ONE launch with a grid barrier in between -- an arrival counter,
-// relaxed device-scope atomics only, all 512 workgroups resident -- took 26.7 us per scan against 15.2 us for the two
-// launches: 512 arrivals on one word plus the polling cost more than the second launch.  Decoupled look-back was
-// built and measured too: one launch, every workgroup publishes its range's sum as ONE 64-bit descriptor (epoch << 32 |
-// sum, relaxed device-scope atomics, no fences; the epoch lives in device memory and is advanced by the last workgroup
-// to leave, so there is no reset launch and hipGraph replay works) and sums the descriptors before its own.  Bit-exact
-// on the whole GPU suite, but 21.1 us per scan with the descriptors packed and 19.6 us with one per 128 bytes, against
-// 15.5 us: all 512 workgroups are resident at once and finish their first phase together, so they poll 512 x 512
-// descriptors through the device-coherent path (the eight L2s are not coherent with each other) while they wait --
-// that costs more than the ~4.5 us a second launch does.)
-// Pass 1 reduces the range to one sum; pass 2 first turns the (at most SCAN_G) sums before its own into its carry-in
-// with one block reduction -- cheaper than a third single-workgroup launch in between -- then scans its range.
-#define SCAN_G 512u
-JD uint32_t scan_range_len(uint32_t n) { return ((n + SCAN_G - 1u) / SCAN_G + SCAN_TILE - 1u) / SCAN_TILE * SCAN_TILE; }
-
-__global__ __launch_bounds__(JL_WG) void k_scan_block_sums(const uint32_t* __restrict__ in, uint32_t stride, uint32_t n_max,
-                                                           const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ block_sums) {
-    __shared__ uint32_t sh[8];
-    uint32_t n = n_dev ? umin_(*n_dev, n_max) : n_max;
-    const uint32_t len = scan_range_len(n);
-    const uint32_t lo = blockIdx.x * len, hi = umin_(lo + len, n);
-    uint32_t s = 0;
-    for (uint32_t base = lo + threadIdx.x * SCAN_ITEMS; base < hi; base += SCAN_TILE) {
-#pragma unroll
-        for (int i = 0; i < SCAN_ITEMS; i++) {
-            uint32_t ix = base + i;
-            if (ix < hi) s += in[(size_t)ix * stride];
-        }
-    }
-    MonoidK<1> m;
-    m.v[0] = s;
-    MonoidK<1> t = block_reduce_monoid<1>(m, sh);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = t.v[0];
-}
-
-__global__ __launch_bounds__(JL_WG) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t stride, uint32_t* __restrict__ out, uint32_t n_max,
-                                                      const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ block_sums,
-                                                      uint32_t* __restrict__ total_dev) {
-    __shared__ uint32_t sh[8];
-    uint32_t n = n_dev ? umin_(*n_dev, n_max) : n_max;
-    const uint32_t len = scan_range_len(n);
-    const uint32_t lo = blockIdx.x * len, hi = umin_(lo + len, n);
-    // carry-in: sum of the ranges before mine (SCAN_G = 2 * JL_WG values); the last workgroup also publishes the total
-    MonoidK<1> m;
-    {
-        const uint32_t a = threadIdx.x, b2 = threadIdx.x + JL_WG;
-        uint32_t va = block_sums[a], vb = block_sums[b2];
-        m.v[0] = (a < blockIdx.x ? va : 0u) + (b2 < blockIdx.x ? vb : 0u);
-        if (blockIdx.x == SCAN_G - 1u && total_dev) {
-            MonoidK<1> all;
-            all.v[0] = va + vb;
-            MonoidK<1> t = block_reduce_monoid<1>(all, sh);
-            if (threadIdx.x == 0) *total_dev = t.v[0];
-            __syncthreads();
-        }
-    }
-    uint32_t carry = block_reduce_monoid<1>(m, sh).v[0];
-    for (uint32_t base0 = lo; base0 < hi; base0 += SCAN_TILE) {
-        const uint32_t base = base0 + threadIdx.x * SCAN_ITEMS;
-        uint32_t v[SCAN_ITEMS];
-        uint32_t s = 0;
-#pragma unroll
-        for (int i = 0; i < SCAN_ITEMS; i++) {
-            uint32_t ix = base + i;
-            v[i] = ix < hi ? in[(size_t)ix * stride] : 0u;
-            s += v[i];
-        }
-        uint32_t tot;
-        uint32_t excl = block_excl_scan_u32(s, sh, &tot) + carry;
-#pragma unroll
-        for (int i = 0; i < SCAN_ITEMS; i++) {
-            uint32_t ix = base + i;
-            if (ix < hi) out[ix] = excl;
-            excl += v[i];
-        }
-        carry += tot;
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Single-pass scan with decoupled look-back (Merrill & Garland 2016), the form the north star asks for: ONE launch, every
 // workgroup scans a tile of LB_TILE elements and gets the sum of everything before it from the tiles in front of it.
@@ -110,11 +27,13 @@ __global__ __launch_bounds__(JL_WG) void k_scan_apply(const uint32_t* __restrict
 //   * only the tiles that hold elements take part (the element count may live on the device); the last of them to finish
 //     puts the descriptors and both counters back to zero, so the next launch (or hipGraph replay) needs no reset.
 // Round 3, C3 on MI355X (profiles/r03_scan.md): 12.8 us (2.4 M slots) and 16.6 us (3.3 M lines) per scan against 19.6 us
-// for the two launches above (kept: JH_SCAN_LOOKBACK=0); with 4 K-element tiles it LOST (20.6 / 25.8 us), and reading four
-// or eight descriptors per lane and round made it slower still.
-#ifndef JH_SCAN_LOOKBACK
-#define JH_SCAN_LOOKBACK 1
-#endif
+// for the two-launch scan of round 2 (512 ranges reduced, then carry-in + scan; deleted in round 4 together with its
+// JH_SCAN_LOOKBACK=0 switch -- an alternate nothing tested); with 4 K-element tiles it LOST (20.6 / 25.8 us), and reading
+// four or eight descriptors per lane and round made it slower still.  Round 2's other single-launch attempts (a grid
+// barrier on an arrival counter: 26.7 us; every workgroup summing ALL descriptors before its own: 19.6-21.1 us) are in DESIGN 3.
+// Memory model (round 4): the descriptor carries value AND validity in one 64-bit word, so publishing and reading it are
+// relaxed agent-scope atomics by right -- nothing else travels through it.  The one hand-off that orders DIFFERENT
+// addresses is the reset by the last tile, and that is a release / acquire read-modify-write (below).
 #ifndef LB_ITEMS
 #define LB_ITEMS 64  // elements per thread: 16 K elements per tile (fewer, larger tiles: every look-back round is a device-coherent
 #endif               // round trip of ~2 us on this 8-XCD part, and tile i needs ~i/64 of them until prefixes have spread)
@@ -130,7 +49,7 @@ __global__ __launch_bounds__(JL_WG) void k_scan_lookback(const uint32_t* __restr
                                                          uint32_t* __restrict__ ctrl,            // [0] next tile id, [1] tiles finished
                                                          unsigned long long* __restrict__ desc) {
     __shared__ uint32_t sh[8];
-    __shared__ uint32_t s_tile, s_prefix;
+    __shared__ uint32_t s_tile, s_prefix, s_last;
     const uint32_t n = n_dev ? umin_(*n_dev, n_max) : n_max;
     const uint32_t n_tiles = (n + LB_TILE - 1u) / LB_TILE;
     if (n_tiles == 0u) {
@@ -199,6 +118,16 @@ __global__ __launch_bounds__(JL_WG) void k_scan_lookback(const uint32_t* __restr
     __syncthreads();
     const uint32_t prefix = tile != 0u ? s_prefix : 0u;
     excl += prefix;
+    // Every tile counts itself out as soon as it has published its inclusive prefix and reads no descriptor any more -- BEFORE
+    // it writes its share of `out`, which the release would otherwise have to wait for (and flush): 15.6 us per scan with the
+    // count-out at the end of the kernel against 11.3 us with relaxed atomics.  The last one to count out resets the state.
+    // Release: this tile's descriptor accesses are done before it counts out; acquire: the last tile's resets come after every
+    // other tile's count -- the hand-off does not rest on instruction order.
+    if (threadIdx.x == 0u) {
+        if (tile == n_tiles - 1u && total_dev) *total_dev = prefix + tot;
+        const uint32_t gone = __hip_atomic_fetch_add(&ctrl[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = gone + 1u == n_tiles ? 1u : 0u;
+    }
     if (base + LB_ITEMS <= n) {
         uint4* q = (uint4*)(out + base);
 #pragma unroll
@@ -217,14 +146,8 @@ __global__ __launch_bounds__(JL_WG) void k_scan_lookback(const uint32_t* __restr
             excl += v[i];
         }
     }
-    if (threadIdx.x == 0u) {
-        if (tile == n_tiles - 1u && total_dev) *total_dev = prefix + tot;
-        // every tile counts itself out when nothing of it reads descriptors any more; the last one resets the state
-        const uint32_t gone = __hip_atomic_fetch_add(&ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_tile = gone + 1u == n_tiles ? 1u : 0u;
-    }
     __syncthreads();
-    if (s_tile != 0u) {  // (uniform) the last tile to finish
+    if (s_last != 0u) {  // (uniform) the last tile to count out: nobody reads a descriptor any more
         for (uint32_t i = threadIdx.x; i < n_tiles; i += JL_WG) lb_store(&desc[i], 0ull);
         if (threadIdx.x == 0u) {
             __hip_atomic_store(&ctrl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -235,7 +158,6 @@ __global__ __launch_bounds__(JL_WG) void k_scan_lookback(const uint32_t* __restr
 
 int jh_scan_u32(const JhLaunch& L, const uint32_t* in, uint32_t in_stride, uint32_t* out, uint32_t n_max, const uint32_t* n_dev,
                 uint32_t* total_dev) {
-#if JH_SCAN_LOOKBACK
     const uint64_t max_tiles = ((uint64_t)n_max + LB_TILE - 1u) / LB_TILE;
     // [ctrl: 256 bytes][one descriptor per tile]: zero between launches (the kernel cleans up after itself; the flag says
     // whether that has happened since the slot was allocated)
@@ -252,14 +174,6 @@ int jh_scan_u32(const JhLaunch& L, const uint32_t* in, uint32_t in_stride, uint3
     hipLaunchKernelGGL(k_scan_lookback, dim3((uint32_t)max_tiles), dim3(JL_WG), 0, L.stream, in, in_stride, out, n_max, n_dev, total_dev,
                        (uint32_t*)st, (unsigned long long*)(st + 256));
     return 0;
-#else
-    uint32_t* block_sums = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_SCAN_TMP, (uint64_t)SCAN_G * 12);
-    if (!block_sums) return -5;
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(SCAN_G), dim3(JL_WG), 0, L.stream, in, in_stride, n_max, n_dev, block_sums);
-    hipLaunchKernelGGL(k_scan_apply, dim3(SCAN_G), dim3(JL_WG), 0, L.stream, in, in_stride, out, n_max, n_dev, (const uint32_t*)block_sums,
-                       total_dev);
-    return 0;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -307,98 +221,10 @@ __global__ __launch_bounds__(JL_WG) void k_pathtag_scan1(Buf<JlTagMonoid> reduce
     MonoidK<5> ex = block_excl_scan_monoid<5>(load_tm(reduced, ix), sh, &tot);
     if (out.ok(ix)) store_tm(&out.p[ix], monoid_add(prefix, ex));
 }
-// pathtag_reduce + pathtag_reduce2 + pathtag_scan1 in ONE launch (the three-level path of scenes with more than 256 tag
-// workgroups; render.go:171-200).  The engine holds the first two dispatches back (jello_hip.cpp, Deferred) and this kernel
-// runs when pathtag_scan1 arrives with all three buffers known: every workgroup reduces its 256 tag words as
-// pathtag_reduce does; the LAST one to finish then does the work of the two small stages (n2 <= 256 workgroups' worth)
-// and leaves `reduced`, `reduced2` and `reduced_scan` exactly as the three dispatches would have.  Cross-workgroup data
-// travel as device-scope (write-through / L2-bypassing) stores and loads, ordered by a completed-stores wait in front of
-// the relaxed counter increment -- no fence (a fence writes back / invalidates a whole L2 on this 8-XCD part).
-JD void store_tm_dev(JlTagMonoid* dst, const MonoidK<5>& m) {
-    uint32_t* w = (uint32_t*)dst;
-#pragma unroll
-    for (int i = 0; i < 5; i++) __hip_atomic_store(&w[i], m.v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-JD MonoidK<5> load_tm_dev(const Buf<JlTagMonoid>& b, uint32_t i) {
-    MonoidK<5> m;
-#pragma unroll
-    for (int k = 0; k < 5; k++) m.v[k] = 0u;
-    if (i < b.n) {
-        const uint32_t* w = (const uint32_t*)&b.p[i];
-#pragma unroll
-        for (int k = 0; k < 5; k++) m.v[k] = __hip_atomic_load(&w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return m;
-}
-__global__ __launch_bounds__(JL_WG) void k_pathtag_reduce_fused(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> reduced,
-                                                                Buf<JlTagMonoid> reduced2, Buf<JlTagMonoid> reduced_scan, uint32_t n2,
-                                                                uint32_t* __restrict__ counter) {
-    __shared__ uint32_t sh[20];
-    __shared__ uint32_t s_last;
-    uint32_t ix = blockIdx.x * JL_WG + threadIdx.x;
-    MonoidK<5> agg = reduce_tag(scene.rd(cfg->layout.pathtag_base + ix));
-    MonoidK<5> t = block_reduce_monoid<5>(agg, sh);
-    if (threadIdx.x == 0) {
-        if (reduced.ok(blockIdx.x)) store_tm_dev(&reduced.p[blockIdx.x], t);
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the stores above have completed
-        // "who is last" over two levels: a device-scope atomic is performed behind the eight L2s, ~20 ns apiece when they all
-        // hit ONE word (782 workgroups: 15 us) -- so the workgroups count in up to 32 groups, each on a cache line of its
-        // own, and only the last of each group counts on the common word.
-        const uint32_t n1 = umin_(32u, gridDim.x), g = blockIdx.x % n1;
-        const uint32_t gsize = gridDim.x / n1 + (g < gridDim.x % n1 ? 1u : 0u);
-        uint32_t* c1 = counter + 32u * (g + 1u);
-        uint32_t last = 0u;
-        if (__hip_atomic_fetch_add(c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gsize) {
-            __hip_atomic_store(c1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
-            last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == n1 ? 1u : 0u;
-        }
-        s_last = last;
-    }
-    __syncthreads();
-    if (s_last == 0u) return;  // uniform per workgroup
-    // pathtag_reduce2.wgsl:23-41 for its first n2 workgroups: the ones whose results pathtag_scan1 (n2 workgroups) reads.  The
-    // recording dispatches 256 of them whatever the scene; the others reduce entries of `reduced` that pathtag_reduce never wrote
-    // into entries of `reduced2` that no command reads, and are left out.
-    // Then pathtag_scan1.wgsl:26-67 for its n2 workgroups.  Both stages read the same entries of `reduced`: they are fetched
-    // ONCE, four workgroups' worth per round with all loads in flight together (a device-scope load is a ~2 us round trip; taken
-    // one after the other, eight of them made this launch slower than the three it replaces), and the partial sums of
-    // `reduced2` stay in LDS (they are also stored: the buffer holds what the recording says).
-    __shared__ uint32_t s_r2[256][5];  // reduced2[b] of this launch
-    for (uint32_t b0 = 0u; b0 < n2; b0 += 4u) {  // (n2 <= 256; 4 for the 100 k-path frame)
-        MonoidK<5> v[4];
-#pragma unroll
-        for (uint32_t q = 0u; q < 4u; q++) {
-#pragma unroll
-            for (int i = 0; i < 5; i++) v[q].v[i] = 0u;
-            if (b0 + q < n2) v[q] = load_tm_dev(reduced, (b0 + q) * JL_WG + threadIdx.x);
-        }
-#pragma unroll
-        for (uint32_t q = 0u; q < 4u; q++) {
-            const uint32_t b = b0 + q;
-            if (b >= n2) break;  // uniform
-            MonoidK<5> r = block_reduce_monoid<5>(v[q], sh);
-            if (threadIdx.x == 0) {
-#pragma unroll
-                for (int i = 0; i < 5; i++) s_r2[b][i] = r.v[i];
-                if (reduced2.ok(b)) store_tm(&reduced2.p[b], r);
-            }
-            __syncthreads();
-            // scan1 of workgroup b: prefix = sum of reduced2[l] for l < b (all of them are in LDS by now), then the exclusive scan
-            MonoidK<5> pre;
-#pragma unroll
-            for (int i = 0; i < 5; i++) pre.v[i] = (threadIdx.x < b) ? s_r2[threadIdx.x][i] : 0u;
-            MonoidK<5> prefix = block_reduce_monoid<5>(pre, sh);
-            __syncthreads();
-            MonoidK<5> tot;
-            const uint32_t jx = b * JL_WG + threadIdx.x;
-            MonoidK<5> ex = block_excl_scan_monoid<5>(v[q], sh, &tot);
-            if (reduced_scan.ok(jx)) store_tm(&reduced_scan.p[jx], monoid_add(prefix, ex));
-            __syncthreads();
-        }
-    }
-    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
-}
-
+// (Round 3 ran pathtag_reduce + pathtag_reduce2 + pathtag_scan1 as ONE launch behind a finished-workgroups counter: 11.9 us
+// against ~14 us for the three, with the hand-off ordered by relaxed atomics around an s_waitcnt.  Written as the memory model
+// wants it -- release on every workgroup's count, acquire on the last one's -- the launch takes 21.6 us on C3: a release at
+// agent scope writes back the L2 of its XCD, 782 times.  Three launches it is again: 3 x 4.7 us)
 // pathtag_scan.wgsl:28-76
 template <bool SMALL>
 __global__ __launch_bounds__(JL_WG) void k_pathtag_scan(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> reduced,
@@ -428,19 +254,6 @@ int jh_launch_pathtag(const JhLaunch& L, int stage) {
             break;
         case 2:
             if (L.nb < 3) return -1;
-            if (L.absorb & JH_ABSORB_PATHTAG) {  // pathtag_reduce and pathtag_reduce2 were held back: one launch does all three
-                // L.extra / L.extra2: [config, scene] of pathtag_reduce; L.gz_fused = its grid; this stage's grid = reduce2's
-                const uint64_t ctr_bytes = 33u * 128u;  // the common word + 32 group words, a cache line each
-                uint32_t* ctr = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_PT_CTR, ctr_bytes);
-                if (!ctr) return -5;
-                uint32_t* clean = jh_scratch_flags(L.scratch);
-                if ((*clean & JH_CLEAN_PT_CTR) == 0u) (void)hipMemsetAsync(ctr, 0, jh_scratch_cap(L.scratch, JH_SCR_PT_CTR), L.stream);
-                *clean |= JH_CLEAN_PT_CTR;
-                hipLaunchKernelGGL(k_pathtag_reduce_fused, dim3(L.fused_grid), blk, 0, L.stream, (const JlConfig*)L.extra.ptr,
-                                   mkbuf<uint32_t>(L.extra2.ptr, L.extra2.size), mkbuf<JlTagMonoid>(L.b[0].ptr, L.b[0].size),
-                                   mkbuf<JlTagMonoid>(L.b[1].ptr, L.b[1].size), mkbuf<JlTagMonoid>(L.b[2].ptr, L.b[2].size), L.gx, ctr);
-                break;
-            }
             hipLaunchKernelGGL(k_pathtag_scan1, g, blk, 0, L.stream, mkbuf<JlTagMonoid>(L.b[0].ptr, L.b[0].size),
                                mkbuf<JlTagMonoid>(L.b[1].ptr, L.b[1].size), mkbuf<JlTagMonoid>(L.b[2].ptr, L.b[2].size));
             break;

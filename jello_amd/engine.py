@@ -249,6 +249,10 @@ class Engine:
         if rc != 0:
             raise RuntimeError("jh_debug_poison_scratch failed: %d" % rc)
 
+    def graph_self_cleans(self):
+        """Replays that found one of the internal counters dirty (failed frame, poisoned scratch) and zeroed it first."""
+        return int(self.hip.jh_debug_graph_self_cleans(self.ctx))
+
     def device_info(self):
         name = ctypes.create_string_buffer(256)
         cus, mem = ctypes.c_int(), ctypes.c_uint64()

@@ -966,20 +966,21 @@ JD int node_test_fast(V2 p0, V2 p1, V2 p2, V2 p3, float scale, uint32_t level, u
     const float tol = 0.25f;
     const NodeEnds ne = node_ends(p0, p1, p2, p3, level, t0_u);
     const float actual_dt = ne.t1 - ne.last_t;
-    // cubic_from_points_derivs (flatten.wgsl:94-114) up to d0 / d1, the same operations on the same values
+    // cubic_from_points_derivs (flatten.wgsl:94-114) up to d0 / d1: chord and h0 / h1 with the same operations on the same
+    // values, the roots and the quotient with the 1-ulp instructions (flatten_fast.h charges them)
     const V2 chord = ne.point - ne.last_p;
     const float chord_squared = dot(chord, chord);
-    const float chord_len = sqrt_(chord_squared);
     const V2 q0 = ne.last_q, q1 = ne.deriv;
     *v_est = 0.0f; *delta = 0.0f;
-    if (chord_squared < DERIV_THRESH_SQUARED) {  // no transcendentals in this branch: decided exactly
+    if (chord_squared < DERIV_THRESH_SQUARED) {  // no transcendentals in this branch: decided exactly, by the pinned operations
         const float chord_err = sqrt_((float)(9.0 / 32.0) * (dot(q0, q0) + dot(q1, q1))) * actual_dt;
         return (chord_err * scale <= tol) ? ffast::FF_ACCEPT : ffast::FF_REJECT;
     }
-    const float sc = actual_dt / chord_squared;
+    const float chord_len = FF_SQRT(chord_squared);
+    const float sc = actual_dt * FF_RCP(chord_squared);
     const V2 h0 = v2(q0.x * chord.x + q0.y * chord.y, q0.y * chord.x - q0.x * chord.y);
     const V2 h1 = v2(q1.x * chord.x + q1.y * chord.y, q1.x * chord.y - q1.y * chord.x);
-    const float len0 = length(h0), len1 = length(h1);
+    const float len0 = FF_SQRT(h0.x * h0.x + h0.y * h0.y), len1 = FF_SQRT(h1.x * h1.x + h1.y * h1.y);
     return ffast::ff_decide(h0.x, h0.y, len0, h1.x, h1.y, len1, len0 * sc, len1 * sc, chord_len, scale, tol, v_est, delta);
 }
 // th0, th1 and chord_len of an ACCEPTED interval (the pinned atan2; err is not needed any more)

@@ -37,7 +37,7 @@ BUMP_NAMES = ["failed", "binning", "ptcl", "tile", "seg_counts", "segments", "bl
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", choices=["c3", "c4", "c4n", "c2", "c1"], default="c3",
                     help="c3 = the headline scene (BASELINE.json configs[2]); c4 = configs[3]: nested clips + radial gradients + blends "
@@ -55,7 +55,9 @@ def parse_args(argv=None):
                          "links bound the job) or on rank (step mod N) -- consecutive gathers then use disjoint inbound links and, "
                          "being double-buffered on two communicators, overlap each other as well as the next render; "
                          "all (default) = time both, after the gather-free loop, in one run")
-    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; the line reports the median block")
+    ap.add_argument("--blocks", type=int, default=5,
+                    help="timed blocks of --steps steps each; the line reports the median block.  More blocks are added (up to 101) until "
+                         "the timed region of a mode covers >= 1 s, so that a short --steps still keeps the GPU busy long enough to be seen")
     ap.add_argument("--bands", action="store_true",
                     help="N > 1: ONE scene, every rank runs the element stages on it and coarse+fine for its band of bin rows "
                          "(strong scaling of one frame; SURVEY 8e) instead of one independent scene per rank")
@@ -199,7 +201,10 @@ def run_rank(args, world):
         for i in range(args.warmup):
             pipe.step(i, render, mode)
         blocks = []
-        for _ in range(max(1, args.blocks)):
+        n_blocks = max(1, args.blocks)
+        b = 0
+        while b < n_blocks:
+            b += 1
             pipe.drain()
             torch.cuda.synchronize(dev)
             if world > 1:
@@ -219,6 +224,9 @@ def run_rank(args, world):
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
             blocks.append(el)
+            if b == 1 and el > 0.0:  # (el is the max over ranks: every rank computes the same count)
+                need = int(1.0 / el) + 1
+                n_blocks = max(n_blocks, min(101, need | 1))
         return sorted(blocks)
 
     blocks_plain = timed(None)

@@ -118,6 +118,14 @@ int jh_sync(jh_ctx* ctx);
  * band -- are those of the unsharded run; the target image is written in the band's rows only.  (0, UINT32_MAX) = whole
  * target (default).  The reference has no counterpart: one wgpu device renders the whole target (render.go:399-434). */
 int jh_set_band(jh_ctx* ctx, uint32_t bin_row0, uint32_t bin_row1);
+/* Optional: an upper bound of the nesting depth of clip / blend layers (open BEGIN_CLIPs at any point of the draw tag stream)
+ * in the recordings run next; 0 = unknown.  fine keeps the blend-stack levels between its own LDS level and the WGSL's
+ * blend_spill (fine.wgsl:938-949, BLEND_STACK_SPLIT = 4) in a per-tile scratch slice of 4 KiB per level: without the hint it
+ * reserves the worst case, three levels (768 MiB for a 4096 x 4096 target), with it 0 / 1 / 2 / 3 levels for depth <= 1 / 2 /
+ * 3 / >= 4.  A hint that is too SMALL loses the saved colours of the deeper levels (wrong pixels, no out-of-bounds access).  The
+ * engine shims count the depth off encoding.DrawTags in RenderToTexture; the reference has no counterpart (its blend stack is
+ * `var blend_stack: array<array<vec4<f32>, 4>, 4>` in registers). */
+int jh_set_clip_depth_hint(jh_ctx* ctx, uint32_t max_depth);
 
 /* ---- buffers (ids are the recording's ResourceIDs; sizes in bytes) ---- */
 int jh_buffer_create(jh_ctx* ctx, uint64_t id, uint64_t size);
@@ -192,6 +200,7 @@ int jh_selftest_math(jh_ctx* ctx, int op, const float* a, const float* b, float*
  * with `byte` and forgets that any counter was left clean -- the state of freshly allocated device memory that happens
  * not to be zero.  Tests use it to show that no stage relies on what an earlier frame (or hipMalloc) left behind, the
  * way the reference's pooled buffers hold stale data (engine/wgpu_engine/wgpu.go:772-808). */
+uint64_t jh_debug_scratch_bytes(jh_ctx* ctx, int slot);   /* capacity of an internal scratch array (tests) */
 uint64_t jh_debug_graph_self_cleans(jh_ctx* ctx);  /* replays that had to zero an internal counter first (tests) */
 int jh_debug_poison_scratch(jh_ctx* ctx, int byte);
 

@@ -223,6 +223,25 @@ func grow(have, need uint32) uint32 {
 	return uint32(g)
 }
 
+// maxClipDepth is the deepest nesting of BeginClip ... EndClip in the encoding's draw tag stream.
+func maxClipDepth(enc *encoding.Encoding) uint32 {
+	var depth, deepest uint32
+	for _, tag := range enc.DrawTags {
+		switch tag {
+		case encoding.DrawTagBeginClip:
+			depth++
+			if depth > deepest {
+				deepest = depth
+			}
+		case encoding.DrawTagEndClip:
+			if depth > 0 {
+				depth--
+			}
+		}
+	}
+	return deepest
+}
+
 // RenderToTexture mirrors lib.go:244-264 and adds what the fixed sizes of renderer/config.go:141-151
 // need for scenes beyond the Vello test scenes: the recording is made with robust = true (it then
 // downloads BumpAllocators, render.go:458-460); if bump.Failed is set, the bump-allocated buffers are
@@ -239,7 +258,11 @@ func (e *Engine) RenderToTexture(arena *mem.Arena, enc *encoding.Encoding, targe
 		out := render.OutImage()
 		bumpID := render.BumpBuf().ID // (accessor added by the patch; the proxy of the "bumpBuf" buffer)
 		recording = e.renderer.RecordFine(arena, &render, e.fullShaders, recording, pgroup)
+		// fine's blend-stack scratch is sized from the nesting depth of the clip layers (include/jello_hip.h,
+		// jh_set_clip_depth_hint); the hint is taken back after the run so that it never outlives its scene
+		e.check(C.jh_set_clip_depth_hint(e.ctx, C.uint32_t(maxClipDepth(enc))), "set_clip_depth_hint")
 		e.RunRecording(recording, []ExternalImage{{Proxy: out, DevicePtr: target}}, "RunRecording")
+		e.check(C.jh_set_clip_depth_hint(e.ctx, 0), "set_clip_depth_hint")
 		raw := e.downloads[bumpID]
 		if len(raw) < 32 || attempt >= 6 {
 			e.check(C.jh_sync(e.ctx), "sync")

@@ -200,5 +200,8 @@ def _declare(L):
     hip.jh_pool_bytes.argtypes = [vp]
     hip.jh_device_info.argtypes = [vp, ctypes.c_char_p, ci, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_uint64)]
     hip.jh_debug_poison_scratch.argtypes = [vp, ci]
+    hip.jh_debug_scratch_bytes.restype = ctypes.c_uint64
+    hip.jh_debug_scratch_bytes.argtypes = [vp, ci]
+    hip.jh_set_clip_depth_hint.argtypes = [vp, ctypes.c_uint32]
     hip.jh_debug_graph_self_cleans.restype = ctypes.c_uint64
     hip.jh_debug_graph_self_cleans.argtypes = [vp]

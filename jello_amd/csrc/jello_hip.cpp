@@ -100,6 +100,7 @@ struct jh_ctx {
     std::vector<int> prof_stack;  // open groups (indices into prof)
     std::string last_error;
     uint32_t band_row0 = 0u, band_row1 = 0xffffffffu;  // jh_set_band
+    uint32_t clip_depth_hint = 0u;                     // jh_set_clip_depth_hint
     // Bumped whenever a device pointer a captured graph may have baked in goes away or moves: buffer / image free,
     // regrow or import, scratch regrow.  jh_graph_launch refuses a graph captured against an older generation.
     uint64_t generation = 0;
@@ -757,6 +758,7 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
     L.cfg_host = nullptr;
     L.band_row0 = ctx->band_row0;
     L.band_row1 = ctx->band_row1;
+    L.clip_depth_hint = ctx->clip_depth_hint;
     L.image_table = nullptr;
     if ((int)images.size() > JH_FINE_INLINE_IMAGES && stage >= JH_FINE_AREA) {
         // More images than fit in the kernel arguments: fine indexes a device table of descriptors (the reference binds
@@ -1066,6 +1068,16 @@ int jh_debug_poison_scratch(jh_ctx* ctx, int byte) {
     return JH_OK;
 }
 
+int jh_set_clip_depth_hint(jh_ctx* ctx, uint32_t max_depth) {
+    if (!ctx) return JH_ERR_INVALID;
+    // (a captured graph has the layout of its capture baked in and never looks at the hint again; its scratch pointer stays
+    // valid until the array is regrown, which bumps the generation by itself)
+    ctx->clip_depth_hint = max_depth;
+    return JH_OK;
+}
+uint64_t jh_debug_scratch_bytes(jh_ctx* ctx, int slot) {
+    return (ctx && slot >= 0 && slot < JH_SCR_COUNT) ? ctx->scratch.cap[slot] : 0;
+}
 uint64_t jh_debug_graph_self_cleans(jh_ctx* ctx) { return ctx ? ctx->graph_self_cleans : 0; }
 
 int jh_device_info(jh_ctx* ctx, char* name, int name_len, int* compute_units, uint64_t* total_mem) {

@@ -28,6 +28,7 @@
 #include <cstring>
 
 #include "kcommon.h"
+#include <algorithm>
 #include "srgb_lut.h"
 
 using namespace jk;
@@ -556,7 +557,8 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                                                   uint32_t out_h, const uint16_t* __restrict__ gradients, uint32_t grad_h, FineImages images,
                                                   uint32_t tiles_x, const uint32_t* __restrict__ mask_lut, uint32_t mask_lut_n,
                                                   uint32_t tile_row0,  // first tile row of the launch (band mode)
-                                                  float4* __restrict__ clip_scratch) {  // CLIPS: stack levels 2, 3: [tile][2][4][64]
+                                                  float4* __restrict__ clip_scratch,  // CLIPS: stack levels behind the LDS one: [tile][scr_levels][4][64]
+                                                  uint32_t scr_levels) {               // levels per tile in clip_scratch (0 ... FINE_SCR_LEVELS, from the scene's clip depth)
     const uint32_t tile_y = blockIdx.y + tile_row0;
     // FINE_WAVES independent waves (= tiles, side by side in x) per workgroup: the CU runs at most 16 workgroups, so
     // single-wave workgroups would cap the occupancy at 4 waves per SIMD.  The waves never synchronise with each other.
@@ -811,9 +813,13 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
 #pragma unroll
                     for (int k = 0; k < 4; k++) S.lvl[pushed_depth][k][lane] = make_float4(rgba[k].x, rgba[k].y, rgba[k].z, rgba[k].w);
                 } else if (pushed_depth < JL_BLEND_STACK_SPLIT) {
-                    float4* g = clip_scratch + (((size_t)scratch_tile * FINE_SCR_LEVELS + (pushed_depth - FINE_LDS_LEVELS)) * 4u) * 64u + lane;
+                    // (a level the launch has no scratch for can only be asked for when the caller's clip-depth hint was too
+                    // small: the save is dropped rather than written over another tile's slice)
+                    if (pushed_depth - FINE_LDS_LEVELS < scr_levels) {  // uniform
+                        float4* g = clip_scratch + (((size_t)scratch_tile * scr_levels + (pushed_depth - FINE_LDS_LEVELS)) * 4u) * 64u + lane;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) g[k * 64] = make_float4(rgba[k].x, rgba[k].y, rgba[k].z, rgba[k].w);
+                        for (int k = 0; k < 4; k++) g[k * 64] = make_float4(rgba[k].x, rgba[k].y, rgba[k].z, rgba[k].w);
+                    }
                 } else {
                     const uint32_t spill_base = blend_offset + (pushed_depth - JL_BLEND_STACK_SPLIT) * JL_TILE_WIDTH * JL_TILE_HEIGHT;
 #pragma unroll
@@ -1110,7 +1116,9 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                         const float4 t = S.lvl[level & (FINE_LDS_LEVELS - 1u)][k][lane];  // (written by this lane: no synchronisation)
                         bg = v4(t.x, t.y, t.z, t.w);
                     } else if (level < JL_BLEND_STACK_SPLIT) {
-                        const float4 t = clip_scratch[(((size_t)scratch_tile * FINE_SCR_LEVELS + (level - FINE_LDS_LEVELS)) * 4u + (uint32_t)k) * 64u + lane];
+                        float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (level - FINE_LDS_LEVELS < scr_levels)  // uniform (see materialize)
+                            t = clip_scratch[(((size_t)scratch_tile * scr_levels + (level - FINE_LDS_LEVELS)) * 4u + (uint32_t)k) * 64u + lane];
                         bg = v4(t.x, t.y, t.z, t.w);
                     } else {
                         const uint32_t spill_base = blend_offset + (level - JL_BLEND_STACK_SPLIT) * JL_TILE_WIDTH * JL_TILE_HEIGHT;
@@ -1366,15 +1374,22 @@ static int launch_fine(const JhLaunch& L, int aa) {
         fc.width_in_tiles = L.cfg_host->width_in_tiles;
         for (int i = 0; i < 4; i++) fc.base_color[i] = L.cfg_host->base_color[i];
     }
+    // Blend-stack levels behind the one in LDS and in front of blend_spill live in a per-tile slice of a scratch array, 4 KiB per
+    // level and tile.  How many levels a frame can need follows from the nesting depth of its clip layers, which the caller
+    // knows (jh_set_clip_depth_hint: the engine shims count it off the draw tags): none for depth <= 1, one for depth 2, ...;
+    // without a hint the worst case, 3 levels = 12 KiB per tile (768 MiB at 4096^2 -- what round 3 always reserved).
     float4* clip_scratch = nullptr;
-    if (clips) {  // stack levels 2 and 3 of every tile of the launch: 2 x 4 KiB each
-        clip_scratch = (float4*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)L.gx * (trow1 - trow0) * FINE_SCR_LEVELS * 4096u);
+    uint32_t scr_levels = 0u;
+    if (clips) {
+        scr_levels = FINE_SCR_LEVELS;
+        if (L.clip_depth_hint != 0u) scr_levels = L.clip_depth_hint > FINE_LDS_LEVELS ? std::min<uint32_t>(L.clip_depth_hint - FINE_LDS_LEVELS, FINE_SCR_LEVELS) : 0u;
+        clip_scratch = (float4*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)L.gx * (trow1 - trow0) * scr_levels * 4096u);
         if (!clip_scratch) return -5;
     }
 #define JH_FINE_LAUNCH(A, C, P)                                                                                                          \
     hipLaunchKernelGGL((k_fine_area<A, C, P>), dim3((L.gx + FINE_WG_WAVES(C) - 1) / FINE_WG_WAVES(C), trow1 - trow0), dim3(64 * FINE_WG_WAVES(C)), 0, L.stream, cfg, fc, seg_ptr, \
                        segments_n, (const uint32_t*)L.b[2].ptr, ptcl_n, (const uint32_t*)L.b[3].ptr, info_n, spill, (uint16_t*)out.ptr,         \
-                       out.width, out.height, (const uint16_t*)grad.ptr, grad_h, imgs, L.gx, mask_lut, mask_lut_n, trow0, clip_scratch)
+                       out.width, out.height, (const uint16_t*)grad.ptr, grad_h, imgs, L.gx, mask_lut, mask_lut_n, trow0, clip_scratch, scr_levels)
 #define JH_FINE_PICK(A)                                  \
     do {                                                 \
         if (clips && paints) JH_FINE_LAUNCH(A, true, true);   \

@@ -1159,14 +1159,27 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
                 float v_est, delta;
                 kind = node_test_fast(jp0, jp1, jp2, jp3, scale, level, t0_u, &v_est, &delta);
 #ifdef FL_FAST_CHECK  // (make VARIANT=ffcheck: both paths on every node; contradictions and bound violations are counted)
-                {
+            }
+            if (!exact_round) {  // (uniform; every lane takes part in the ballots: one atomic per wave and counter, not one per node)
+                bool c_unsure = false, c_contra = false, c_viol = false;
+                if (has) {
+                    float v2_, d2_;
+                    const int k2 = node_test_fast(jp0, jp1, jp2, jp3, scale, level, t0_u, &v2_, &d2_);
                     const NodeResult rx = node_test(jp0, jp1, jp2, jp3, scale, level, t0_u);
                     const float vx = rx.cp.err * scale;
-                    atomicAdd(&g_ff_stats[0], 1u);
-                    if (kind == ffast::FF_UNSURE) atomicAdd(&g_ff_stats[1], 1u);
-                    if ((kind == ffast::FF_ACCEPT && !rx.accept) || (kind == ffast::FF_REJECT && rx.accept)) atomicAdd(&g_ff_stats[2], 1u);
-                    if (delta > 0.0f && !(abs_(v_est - vx) <= delta)) atomicAdd(&g_ff_stats[3], 1u);
-                    if (delta == 0.0f && kind != ffast::FF_UNSURE && v_est != 0.0f && v_est != vx) atomicAdd(&g_ff_stats[3], 1u);
+                    c_unsure = k2 == ffast::FF_UNSURE;
+                    c_contra = (k2 == ffast::FF_ACCEPT && !rx.accept) || (k2 == ffast::FF_REJECT && rx.accept);
+                    c_viol = (d2_ > 0.0f && !(abs_(v2_ - vx) <= d2_)) || (d2_ == 0.0f && k2 != ffast::FF_UNSURE && v2_ != 0.0f);
+                }
+                const uint32_t n0 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(has));
+                const uint32_t n1 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(c_unsure));
+                const uint32_t n2 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(c_contra));
+                const uint32_t n3 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(c_viol));
+                if (lane == 0u) {
+                    atomicAdd(&g_ff_stats[0], n0);
+                    if (n1) atomicAdd(&g_ff_stats[1], n1);
+                    if (n2) atomicAdd(&g_ff_stats[2], n2);
+                    if (n3) atomicAdd(&g_ff_stats[3], n3);
                 }
 #endif
             }

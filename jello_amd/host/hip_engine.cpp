@@ -22,6 +22,8 @@ void Engine::run_recording(const Recording& rec, const std::vector<ExternalImage
     // pgroup = pgroup.Nest("RunRecording"); defer pgroup.End()  (wgpu.go:330-331) -- a no-op unless profiling is on
     check(jh_profile_group_begin(ctx_, "RunRecording"), "profile_group_begin");
     struct GroupEnd { jh_ctx* c; ~GroupEnd() { (void)jh_profile_group_end(c); } } group_end{ctx_};
+    // every recording brings its own bound (0 = unknown: fine reserves the worst case): a stale hint must never outlive its scene
+    check(jh_set_clip_depth_hint(ctx_, rec.max_clip_depth), "set_clip_depth_hint");
     for (const ExternalImage& e : ext_images)
         check(jh_image_import(ctx_, e.proxy.id, e.device_ptr, e.proxy.width, e.proxy.height, (int)e.proxy.format), "image_import");
     for (const ExternalBuffer& e : ext_buffers) check(jh_buffer_import(ctx_, e.proxy.id, e.device_ptr, e.proxy.size), "buffer_import");

@@ -53,7 +53,7 @@ class Engine {
         RenderConfig config;
         ImageProxy target;
         std::map<std::string, BufferProxy> buffers;
-        JlBump bump;       // valid when robust
+        JlBump bump{};     // what the frame's Download(bumpBuf) returned: only a robust recording has one (all zero otherwise)
         int attempts = 1;
     };
     Frame render_to_texture(const Encoding& enc, RenderParams params, void* out_device = nullptr, bool robust = false, bool retain = false);

@@ -458,6 +458,14 @@ Renderer::Result Renderer::render_full(const Encoding& enc, Resolver& resolver, 
     Result res;
     Recording& recording = res.recording;
     last_buffers.clear();
+    {   // the deepest nesting of BEGIN_CLIP ... END_CLIP in the draw tag stream
+        uint32_t depth = 0, deepest = 0;
+        for (uint32_t tag : enc.draw_tags) {
+            if (tag == JL_DRAWTAG_BEGIN_CLIP) { depth++; if (depth > deepest) deepest = depth; }
+            else if (tag == JL_DRAWTAG_END_CLIP && depth > 0) depth--;
+        }
+        recording.max_clip_depth = deepest;
+    }
     Resolver::Resolved rs = resolver.resolve(enc);
     const JlLayout& layout = rs.layout;
     ImageProxy gradient_image;

@@ -52,6 +52,10 @@ struct Command {  // recording.go:158-239
 class Recording {  // recording.go:38-103
    public:
     std::vector<Command> commands;
+    // Not in the reference's Recording: the deepest nesting of clip / blend layers in the encoding this recording renders
+    // (0 = unknown or none).  engine/hip_engine passes it to jh_set_clip_depth_hint, which sizes fine's blend-stack scratch
+    // (include/jello_hip.h); the Go shim counts it off encoding.DrawTags in RenderToTexture instead (integration/).
+    uint32_t max_clip_depth = 0;
     BufferProxy upload(const std::string& name, const void* data, size_t n);
     BufferProxy upload_uniform(const std::string& name, const void* data, size_t n);
     ImageProxy upload_image(uint32_t w, uint32_t h, JlImageFormat format, const void* data, size_t n);

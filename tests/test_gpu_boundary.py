@@ -229,6 +229,43 @@ def test_graph_replay_on_dirty_counters_cleans_them_first(engine):
     engine.release(rec)
 
 
+def _layers_scene(depth, size):
+    """`depth` nested blend layers (alternating mix modes, alpha 0.75), something drawn at every level."""
+    s = jello_amd.Scene()
+    mixes = [jello_amd.Mix.Multiply, jello_amd.Mix.Normal, jello_amd.Mix.Screen, jello_amd.Mix.Difference, jello_amd.Mix.Overlay, jello_amd.Mix.Darken]
+    for k in range(depth):
+        m = 8.0 * (k + 1)
+        s.push_layer(mixes[k % len(mixes)], jello_amd.Compose.SrcOver, 0.75, None, jello_amd.Path.circle(size / 2, size / 2, size / 2 - m))
+        s.fill(jello_amd.Fill.NonZero, None, jello_amd.Brush.solid((0.2 + 0.1 * k, 0.9 - 0.1 * k, 0.5, 0.6)), None,
+               jello_amd.Path.rect(m, size / 3, size - m, 2 * size / 3))
+    for _ in range(depth):
+        s.pop_layer()
+    return s, jello_amd.RenderParams(size, size, base_color=(0.1, 0.2, 0.3, 1.0))
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 4, 6])
+def test_blend_stack_scratch_follows_the_clip_depth(depth):
+    """fine keeps blend-stack levels 1..3 in a per-tile scratch slice (level 0 in LDS, levels >= 4 in blend_spill as in the WGSL).
+    Round 3 reserved all three for every tile of any scene with a clip (12 KiB per tile); the engine now passes the nesting depth
+    it counts off the draw tags (jh_set_clip_depth_hint) and fine reserves depth - 1 levels.  Image and buffers still equal the
+    oracle's at every depth, on a context of its own so that the scratch array's size can be read."""
+    size = 2048
+    eng = jello_amd.Engine(0)
+    try:
+        s, p = _layers_scene(depth, size)
+        # (small line buffers keep flatten's share of the same scratch slot small; depth 6 spills two levels per tile)
+        p.bump = BumpSizes(lines=1 << 16, seg_counts=1 << 18, segments=1 << 18, blend_spill=1 << 24)
+        compare(eng, s, p)
+        tiles = (size // 16) ** 2
+        levels = min(max(depth - 1, 0), 3)
+        cap = eng.hip.jh_debug_scratch_bytes(eng.ctx, 4)  # JH_SCR_D (shared with flatten's temporary lines: a few MiB here)
+        assert cap >= tiles * levels * 4096
+        if levels < 3:
+            assert cap < tiles * 3 * 4096, (cap, tiles * 3 * 4096)
+    finally:
+        eng.close()
+
+
 def test_launches_per_frame_of_a_large_scene(engine):
     """The launch diet, counted on the captured graph: a scene on the three-level pathtag path (more than 256 tag workgroups)
     is 28 kernel launches and no fill -- the held-back commands (bbox_clear, Clear(bump), both setup dispatches) and the

@@ -220,8 +220,13 @@ def test_empty_scene_after_a_failed_frame_sees_a_cleared_bump(engine):
     allocation is poisoned by a frame that fails (failed != 0, counters != 0) and is handed to the empty frame next."""
     s, p = scenes.scene_c3(400, 256)
     p.bump = BumpSizes(bin_data=256, tiles=512, lines=64, seg_counts=64, segments=64, blend_spill=256, ptcl=1 << 14)
-    rec, bump, attempts = engine.render(s, p, robust=False)
-    assert bump["failed"] != 0 and bump["lines"] != 0 and attempts == 1
+    rec = jello_amd.Host().record(s, p)
+    from jello_amd.engine import RUN_DISPATCHES, RUN_UPLOADS
+    engine.run(rec, RUN_UPLOADS | RUN_DISPATCHES)
+    engine.sync()
+    dirty = engine.download(rec.buffer("bumpBuf")[0], dtype=np.uint32)[:8].copy()
+    assert dirty[0] != 0 and dirty[7] != 0, dirty   # failed, lines
+    engine.release(rec)                              # the 32-byte allocation goes back to the pool as it is
     for _ in range(2):
         e = jello_amd.Scene()
         rec, bump, attempts = engine.render(e, jello_amd.RenderParams(64, 64, base_color=(0.5, 0.25, 1.0, 1.0)), robust=True, retain=True)
@@ -252,8 +257,18 @@ def test_regrow_loop_recovers_from_undersized_buffers(engine):
 def test_undersized_buffers_fail_cleanly_without_regrow(engine):
     s, p = scenes.scene_c3(800, 256)
     p.bump = BumpSizes(bin_data=256, tiles=512, lines=1024, seg_counts=1024, segments=1024, blend_spill=256, ptcl=1 << 14)
-    rec, bump, attempts = engine.render(s, p, robust=False, retain=False)
-    assert bump["failed"] != 0 and attempts == 1
+    # (a non-robust recording has no Download(bumpBuf), render.go:458-460: the allocators are read back by hand.  Until round 4
+    # this test looked at the bump array engine.render returns for such a frame -- uninitialised memory that happened to be
+    # non-zero; hip_engine::Frame::bump is zero-initialised now)
+    from jello_amd.engine import RUN_DISPATCHES, RUN_UPLOADS
+    rec = jello_amd.Host().record(s, p)
+    engine.run(rec, RUN_UPLOADS | RUN_DISPATCHES)
+    engine.sync()
+    bump = engine.download(rec.buffer("bumpBuf")[0], dtype=np.uint32)[:8].copy()
+    engine.release(rec)
+    assert bump[0] != 0, bump
+    rec2, bump2, attempts = engine.render(s, p, robust=False, retain=False)
+    assert attempts == 1 and all(v == 0 for v in bump2.values())  # nothing was downloaded: nothing is reported
 
 
 @pytest.mark.parametrize("n,size", [(1500, 512), (6000, 1024)])

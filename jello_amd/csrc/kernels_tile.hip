@@ -590,6 +590,9 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
 // every path its own tile range), hence
 //   seg_within_slice(k) = #{ j < k : key[j] == key[k] },   Tile.segment_count = that number + #{ j > k : ... } + 1,
 // the canonical (line, crossing) order by construction, from one ballot per DISTINCT tile of the path.
+#ifndef PCR_K
+#define PCR_K 16u  // consecutive paths per task of k_pc_rank_small (<= 64)
+#endif
 struct PcScatterArgs {  // the list route's scatter pass rides in the same launch (its last `blocks` workgroups): it and the
     const uint2* tile_of;   // ranking of the small paths touch different tiles and crossings, and both follow the
     const uint32_t* list_base;  // list-base scan; a launch of its own cost 4.7 us even when no path takes the route)
@@ -618,73 +621,94 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restr
     const uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
     const uint32_t lane = lane_id();
     const uint32_t waves = (rank_blocks * JL_WG) >> 6;
-    uint32_t P = (blockIdx.x * JL_WG + threadIdx.x) >> 6;
-    // The loop is a chain of dependent loads (range -> keys -> rank -> counts word), ~1 us of latency per path when taken one
-    // after the other: it runs two paths ahead instead -- the range of path P + 2 * waves, the keys and counts words of path
-    // P + waves are requested before path P is ranked.
-    auto usable = [&](uint32_t ps, uint32_t pe_all) -> bool { return umin_(pe_all, n) > ps && !npe_big(pe_all - ps); };  // (the same test as in k_pc_emit)
-    auto fetch = [&](uint32_t ps, uint32_t pe_all, uint32_t& key, uint32_t& cw) {
+    const uint32_t wave_ix = (blockIdx.x * JL_WG + threadIdx.x) >> 6;
+    // Round 4: a wave ranks a CHUNK of consecutive small paths at a time -- as many as fit its 64 lanes (a C3 path has 23
+    // crossings: one path per iteration used 36 % of the lanes, and ~60 % of an iteration's 173 instructions were per-path
+    // overhead).  Tiles are unique per path, so "same key" still means "same tile of the same path" inside a chunk, and the
+    // ballots per distinct tile rank the crossings of all the chunk's paths at once.  A wave takes tasks of PCR_K consecutive
+    // paths (their ranges: one coalesced load per task, requested a task ahead), cuts each task into chunks -- consecutive
+    // paths whose crossing ranges adjoin (an empty or a big path, or a range cut off at the buffer's end, ends a chunk) and
+    // together hold at most 64 crossings -- and requests the keys / counts words of chunk c + 1 before it ranks chunk c.
+    const uint32_t n_tasks = (n_paths + PCR_K - 1u) / PCR_K;
+    auto load_ranges = [&](uint32_t task, uint32_t& ps, uint32_t& pe) {
+        ps = 0u; pe = 0u;
+        const uint32_t P = task * PCR_K + lane;
+        if (task < n_tasks && lane < PCR_K && P < n_paths) path_range(P, pfirst, plast, counts, seg_bases, ps, pe);
+    };
+    uint32_t t_ps = 0u, t_pe = 0u;   // lane i < PCR_K: crossings [t_ps, t_pe) of path task * PCR_K + i (t_pe cut to the buffer)
+    uint64_t todo = 0ull;            // paths of the task still to rank (small, non-empty)
+    uint32_t task = wave_ix;
+    uint32_t r_ps, r_pe;             // the ranges of the NEXT task, in flight
+    load_ranges(task, r_ps, r_pe);
+    bool task_loaded = false;
+    auto advance = [&](uint32_t& cs, uint32_t& ce) -> bool {  // the next chunk [cs, ce) of this wave, false when there is none (uniform)
+        for (;;) {
+            if (todo != 0ull) {
+                const uint32_t a = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                cs = (uint32_t)__builtin_amdgcn_readlane((int)t_ps, (int)a);
+                ce = (uint32_t)__builtin_amdgcn_readlane((int)t_pe, (int)a);
+                while (todo != 0ull) {
+                    const uint32_t b2 = (uint32_t)__builtin_ctzll(todo);
+                    const uint32_t nps = (uint32_t)__builtin_amdgcn_readlane((int)t_ps, (int)b2);
+                    const uint32_t npe = (uint32_t)__builtin_amdgcn_readlane((int)t_pe, (int)b2);
+                    if (nps != ce || npe - cs > 64u) break;
+                    ce = npe;
+                    todo &= todo - 1ull;
+                }
+                return true;
+            }
+            if (task_loaded) task += waves;
+            if (task >= n_tasks) return false;
+            task_loaded = true;
+            const uint32_t ps = r_ps, pe_all = r_pe;
+            load_ranges(task + waves, r_ps, r_pe);
+            t_ps = ps;
+            t_pe = umin_(pe_all, n);
+            todo = __builtin_amdgcn_ballot_w64(lane < PCR_K && t_pe > ps && !npe_big(pe_all - ps));  // (the same test as in k_pc_emit)
+        }
+    };
+    auto fetch = [&](uint32_t cs, uint32_t ce, uint32_t& key, uint32_t& cw) {
         key = 0xffffffffu; cw = 0u;
-        const uint32_t k = ps + lane;
-        if (usable(ps, pe_all) && k < umin_(pe_all, n)) {
+        const uint32_t k = cs + lane;
+        if (k < ce) {
             key = keys[k];
             if (seg_counts.ok(k)) cw = seg_counts.p[k].counts;
         }
     };
-    uint32_t ps1 = 0u, pe1 = 0u, ps2 = 0u, pe2 = 0u;  // ranges of paths P and P + waves
-    uint32_t key1 = 0xffffffffu, cw1 = 0u;          // keys / counts words of path P
-    if (P < n_paths) path_range(P, pfirst, plast, counts, seg_bases, ps1, pe1);
-    if (P + waves < n_paths) path_range(P + waves, pfirst, plast, counts, seg_bases, ps2, pe2);
-    ps1 = uni32(ps1); pe1 = uni32(pe1);
-    fetch(ps1, pe1, key1, cw1);
-    for (; P < n_paths; P += waves) {
-        const uint32_t ps = ps1, pe_all = pe1, pe = umin_(pe_all, n);  // uniform: scalar registers
+    uint32_t c_s = 0u, c_e = 0u, key1 = 0xffffffffu, cw1 = 0u;
+    bool have = advance(c_s, c_e);
+    if (have) fetch(c_s, c_e, key1, cw1);
+    while (have) {  // uniform
+        const uint32_t cs = c_s, ce = c_e;
         const uint32_t my_key = key1, my_cw = cw1;
-        ps1 = uni32(ps2); pe1 = uni32(pe2);
-        ps2 = 0u; pe2 = 0u;
-        if (P + 2u * waves < n_paths) path_range(P + 2u * waves, pfirst, plast, counts, seg_bases, ps2, pe2);
-        if (P + waves < n_paths) fetch(ps1, pe1, key1, cw1);
-        if (!usable(ps, pe_all)) continue;
-        {
-            const uint32_t k = ps + lane;
-            const bool valid = k < pe;
-            uint32_t my_t = valid ? my_key : 0xffffffffu;
-            const bool mine = valid && my_t != 0xffffffffu;  // 0xffffffff: crossing outside the tile buffer
-            uint32_t before = 0u, after = 0u;
-            uint64_t rem = __builtin_amdgcn_ballot_w64(mine);
-            // One trip per DISTINCT tile: the lanes of that tile keep the trip's ballot (lanes that are not `mine` hold the key
-            // 0xffffffff, which no trip asks for); the ranks come out of the kept masks once, after the loop -- the loop itself is
-            // a scalar find-first, a lane read, a compare and two selects (it was 6 + 7 instructions per trip with the counts
-            // inside: the kernel is bound by instruction issue, 92 scalar + 81 vector instructions per path).
-            uint32_t grp_lo = 0u, grp_hi = 0u;
-            for (uint32_t it = 0u; it < 16u && rem != 0ull; it++) {
-                const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, (int)__builtin_ctzll(rem));
-                const bool eq = my_t == t;
-                const uint64_t m = __builtin_amdgcn_ballot_w64(eq);
-                grp_lo = eq ? (uint32_t)m : grp_lo;
-                grp_hi = eq ? (uint32_t)(m >> 32) : grp_hi;
-                rem &= ~m;
-            }
-            if (mine) {
-                before = __builtin_amdgcn_mbcnt_hi(grp_hi, __builtin_amdgcn_mbcnt_lo(grp_lo, 0u));
-                after = (uint32_t)__builtin_popcount(grp_lo) + (uint32_t)__builtin_popcount(grp_hi) - 1u - before;
-            }
-            // more than 16 distinct tiles (long lines: every crossing in another tile): the remaining lanes compare
-            // against all 64 keys instead (4 instructions per key, not 16 per distinct tile)
-            if (rem != 0ull) {
-                const bool todo = ((rem >> lane) & 1ull) != 0ull;
-                uint32_t b = 0u, a = 0u;
-                for (uint32_t jj = 0u; jj < 64u; jj++) {
-                    const bool eq = (uint32_t)__builtin_amdgcn_readlane((int)my_t, (int)jj) == my_t;
-                    b += (eq && jj < lane) ? 1u : 0u;
-                    a += (eq && jj > lane) ? 1u : 0u;
-                }
-                if (todo) { before = b; after = a; }
-            }
-            if (mine && seg_counts.ok(k)) {
-                seg_counts.p[k].counts = my_cw | (before << 16);
-                if (after == 0u && tile.ok(my_t)) tile.p[my_t].segment_count_or_ix = before + 1u;
-            }
+        have = advance(c_s, c_e);
+        if (have) fetch(c_s, c_e, key1, cw1);
+        const uint32_t k = cs + lane;
+        const bool valid = k < ce;
+        const uint32_t my_t = valid ? my_key : 0xffffffffu;
+        const bool mine = valid && my_t != 0xffffffffu;  // 0xffffffff: crossing outside the tile buffer
+        uint32_t before = 0u, after = 0u;
+        uint64_t rem = __builtin_amdgcn_ballot_w64(mine);
+        // One trip per DISTINCT tile: the lanes of that tile keep the trip's ballot (lanes that are not `mine` hold the key
+        // 0xffffffff, which no trip asks for); the ranks come out of the kept masks once, after the loop -- the loop itself is
+        // a scalar find-first, a lane read, a compare and two selects.
+        uint32_t grp_lo = 0u, grp_hi = 0u;
+        while (rem != 0ull) {  // at most 64 trips
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_t, (int)__builtin_ctzll(rem));
+            const bool eq = my_t == t;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(eq);
+            grp_lo = eq ? (uint32_t)m : grp_lo;
+            grp_hi = eq ? (uint32_t)(m >> 32) : grp_hi;
+            rem &= ~m;
+        }
+        if (mine) {
+            before = __builtin_amdgcn_mbcnt_hi(grp_hi, __builtin_amdgcn_mbcnt_lo(grp_lo, 0u));
+            after = (uint32_t)__builtin_popcount(grp_lo) + (uint32_t)__builtin_popcount(grp_hi) - 1u - before;
+        }
+        if (mine && seg_counts.ok(k)) {
+            seg_counts.p[k].counts = my_cw | (before << 16);
+            if (after == 0u && tile.ok(my_t)) tile.p[my_t].segment_count_or_ix = before + 1u;
         }
     }
 }

@@ -431,7 +431,7 @@ int jh_clear(jh_ctx* ctx, uint64_t id, uint64_t offset, int64_t size) {
     if (offset > a.size) return fail(ctx, JH_ERR_INVALID, "jh_clear: offset out of range");
     uint64_t n = size < 0 ? a.size - offset : (uint64_t)size;
     if (offset + n > a.size) n = a.size - offset;
-    const bool bump_like = n && offset == 0 && n == a.size && a.size == sizeof(JlBump);
+    const bool bump_like = !ctx->profiling && n && offset == 0 && n == a.size && a.size == sizeof(JlBump);  // (profiling: as recorded)
     for (const Deferred& d : ctx->deferred)
         if (!(bump_like && !d.is_clear && d.stage == JH_BBOX_CLEAR)) { JH_FLUSH(ctx); break; }
     if (bump_like) {
@@ -708,7 +708,9 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
             return fail(ctx, JH_ERR_INVALID, std::string("bad bindings for stage ") + jh_stage_name(stage) + ": config / bump / indirect buffer too small");
     }
     // Hold back the small stages a following stage can absorb (see Deferred); absorb or launch what is being held.
-    const bool deferrable = stage == JH_BBOX_CLEAR || stage == JH_PATH_COUNT_SETUP || stage == JH_PATH_TILING_SETUP;
+    // (not while profiling: a held-back stage's query would bracket nothing and its work would be charged to the stage that absorbs
+    // it -- with the profiler on every command is launched as recorded and every query times its own stage)
+    const bool deferrable = !ctx->profiling && (stage == JH_BBOX_CLEAR || stage == JH_PATH_COUNT_SETUP || stage == JH_PATH_TILING_SETUP);
     uint32_t absorb = 0u;
     JhBound extra;
     std::memset(&extra, 0, sizeof extra);

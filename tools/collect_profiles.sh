@@ -4,9 +4,14 @@
 #   tools/collect_profiles.sh <commit-id>   ->  gpurun_out/collect/
 R="$(cd "$(dirname "$0")/.." && pwd)"
 COMMIT=${1:-unknown}
+# PART=1 (counters, kernel statistics, bench lines) / PART=2 (fine split, PTCL statistics, other scenes, round-4 extras) / unset = both:
+# a gpurun call is limited to 20 minutes
+PART=${PART:-all}
 O=$R/gpurun_out/collect
-rm -rf "$O"; mkdir -p "$O"
+[ "$PART" != 2 ] && rm -rf "$O"
+mkdir -p "$O"
 cd "$R"
+if [ "$PART" != 2 ]; then
 # counters first: the bench lines below report roofline.traffic from profiles/fine_counters*.json only if those were measured on
 # the kernel sources being run (here: on the box's copy of profiles/; copy gpurun_out/collect/fine_counters*.json home afterwards)
 bash tools/pmc_fine.sh "$COMMIT" > "$O/pmc_c3.log" 2>&1 && echo "pmc c3 done"
@@ -21,9 +26,15 @@ for S in c3 c4 c4n; do
 done
 timeout -k 10 300 python3 bench.py --aa msaa8 --no-cpu-baseline > "$O/c3_msaa8_bench.json" 2>/dev/null
 timeout -k 10 300 python3 bench.py --aa msaa16 --no-cpu-baseline > "$O/c3_msaa16_bench.json" 2>/dev/null
+fi
+[ "$PART" = 1 ] && exit 0
 bash tools/fine_split.sh "$COMMIT" > "$O/fine_split.log" 2>&1 && cp gpurun_out/fine_split.json "$O/" && echo "fine split done"
 cp gpurun_out/fine_counters*.json "$O/" 2>/dev/null
 for S in c3 c4 c4n; do timeout -k 10 300 python3 tools/ptcl_stats.py $S > "$O/ptcl_stats_$S.json" 2>/dev/null; done
 echo "ptcl stats done"
 ( timeout -k 10 300 python3 tools/time_configs.py; timeout -k 10 300 python3 tools/time_shapes.py ) > "$O/other_scenes.txt" 2>&1
 echo "other scenes done"
+# round 4: the small configurations as bench lines, the counters of the flatten and tile-stage kernels, the split of k_flatten_items
+for S in c1 c2; do timeout -k 10 300 python3 bench.py --scene $S --no-cpu-baseline > "$O/${S}_bench.json" 2>/dev/null; done
+bash tools/pmc_flatten.sh > "$O/pmc_flatten_tile_kernels.txt" 2>&1 && echo "pmc flatten / tile kernels done"
+bash tools/flatten_split.sh > "$O/flatten_split.txt" 2>&1 && echo "flatten split done"

@@ -58,6 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--blocks", type=int, default=5,
                     help="timed blocks of --steps steps each; the line reports the median block.  More blocks are added (up to 101) until "
                          "the timed region of a mode covers >= 1 s, so that a short --steps still keeps the GPU busy long enough to be seen")
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="blocks are added until a mode's timed region covers this long (0: exactly --blocks blocks; the counter passes "
+                         "of tools/pmc*.sh use that -- every extra frame is rows in their CSVs)")
     ap.add_argument("--bands", action="store_true",
                     help="N > 1: ONE scene, every rank runs the element stages on it and coarse+fine for its band of bin rows "
                          "(strong scaling of one frame; SURVEY 8e) instead of one independent scene per rank")
@@ -224,8 +227,8 @@ def run_rank(args, world):
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
             blocks.append(el)
-            if b == 1 and el > 0.0:  # (el is the max over ranks: every rank computes the same count)
-                need = int(1.0 / el) + 1
+            if b == 1 and el > 0.0 and args.min_seconds > 0.0:  # (el is the max over ranks: every rank computes the same count)
+                need = int(args.min_seconds / el) + 1
                 n_blocks = max(n_blocks, min(101, need | 1))
         return sorted(blocks)
 

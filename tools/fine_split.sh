@@ -15,7 +15,7 @@ for n in 0 1 2 3 4 5; do
   fi
   export JELLO_HIP_LIB=$LIB
   python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench$n.json 2> $OUT/bench$n.err || tail -3 $OUT/bench$n.err
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/p$n" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-graph "$@" > "$OUT/p$n.log" 2>&1 || tail -3 "$OUT/p$n.log"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/p$n" -- python3 "$R/bench.py" --steps 2 --warmup 1 --blocks 1 --min-seconds 0 --no-cpu-baseline --no-graph "$@" > "$OUT/p$n.log" 2>&1 || tail -3 "$OUT/p$n.log"
 done
 unset JELLO_HIP_LIB
 python3 - "$OUT" "$COMMIT" "$R" <<'PY'

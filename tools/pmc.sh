@@ -11,7 +11,7 @@ i=0
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
            "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_WAVES SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/g$i" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-graph "$@" > "$OUT/g$i.log" 2>&1 || { tail -3 "$OUT/g$i.log"; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/g$i" -- python3 "$R/bench.py" --steps 2 --warmup 1 --blocks 1 --min-seconds 0 --no-cpu-baseline --no-graph "$@" > "$OUT/g$i.log" 2>&1 || { tail -3 "$OUT/g$i.log"; }
   python3 "$R/profiles/pmc.py" "$OUT"/g$i/*/*counter_collection.csv --k=$KS | tee -a "$OUT/summary.txt"
   rm -rf "$OUT/g$i"
 done

@@ -34,13 +34,14 @@ int main() {
     int per_wave_simd[4][4] = {};
     std::map<uint32_t, int> wave0_per_simd;  // key: (xcc, se, sh, cu, simd)
     std::map<uint32_t, int> wg_per_cu;
+    std::map<uint32_t, std::vector<int>> wgs_of_cu;
     for (int b = 0; b < G; b++)
         for (int w = 0; w < 4; w++) {
             const uint32_t hw = h[b * 4 + w].x, xcc = h[b * 4 + w].y & 15u;
             const uint32_t simd = (hw >> 4) & 3u, cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
             per_wave_simd[w][simd]++;
             const uint32_t cukey = (xcc << 12) | (se << 8) | (sh << 4) | cu;
-            if (w == 0) { wave0_per_simd[(cukey << 2) | simd]++; wg_per_cu[cukey]++; }
+            if (w == 0) { wave0_per_simd[(cukey << 2) | simd]++; wg_per_cu[cukey]++; wgs_of_cu[cukey].push_back(b * 4 + (int)simd); }
         }
     printf("LDS %d KB per workgroup, %d workgroups of 256 threads\nwave of the workgroup -> SIMD 0..3:\n", LDS_KB, G);
     for (int w = 0; w < 4; w++) printf("  wave %d: %5d %5d %5d %5d\n", w, per_wave_simd[w][0], per_wave_simd[w][1], per_wave_simd[w][2], per_wave_simd[w][3]);
@@ -53,6 +54,14 @@ int main() {
         const uint32_t hw = h[b * 4].x;
         printf("  wg %2d: %u %u %u %2u |", b, h[b * 4].y & 15u, (hw >> 13) & 7u, (hw >> 12) & 1u, (hw >> 8) & 15u);
         for (int w = 0; w < 4; w++) printf(" %u", (h[b * 4 + w].x >> 4) & 3u);
+        printf("\n");
+    }
+    printf("(workgroups of the first 6 CUs: id/simd-of-wave-0)\n");
+    int shown = 0;
+    for (auto& kv : wgs_of_cu) {
+        if (shown++ >= 6) break;
+        printf("  cu %05x:", kv.first);
+        for (int v : kv.second) printf(" %d/%d", v >> 2, v & 3);
         printf("\n");
     }
     return 0;

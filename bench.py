@@ -308,7 +308,7 @@ def run_rank(args, world):
             "launches_per_frame": None if not use_graph else dict(zip(("kernels", "fills_and_copies"), eng.graph_node_counts(graphs[0]))),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_source": "eager replay of the same %d steps with a hipEvent pair per stage" % args.steps,
-            "bump": bump_now, "sizing_attempts": attempts,
+            "bump": bump_now, "sizing_attempts": attempts, "bump_estimate_clamped": scene.bump_sizes_clamped(W, H),
             "stage_roofline": stage_roofline(cfg, bump_now, stage_ms, rec),
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -136,6 +136,8 @@ def _declare(L):
     L.jl_scene_stream.argtypes = [vp, ci, ctypes.POINTER(vp)]
     L.jl_scene_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
     L.jl_scene_bump_sizes.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp]
+    L.jl_scene_bump_sizes_clamped.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32]
+    L.jl_scene_bump_sizes_clamped.restype = ctypes.c_uint32
     L.jl_scene_bump_estimate.argtypes = [vp, dp, ctypes.POINTER(ctypes.c_uint32)]
     L.jl_scene_fill_stroke_cubics.argtypes = [vp, ci, dp, dp, dp, dp, ci, ci, ci]
     L.jl_ptcl_stats.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]

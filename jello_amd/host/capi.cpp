@@ -155,6 +155,13 @@ void jl_scene_bump_sizes(void* s, uint32_t width, uint32_t height, jl_bump_sizes
     out->bin_data = b.bin_data; out->tiles = b.tiles; out->lines = b.lines; out->seg_counts = b.seg_counts; out->segments = b.segments;
     out->blend_spill = b.blend_spill; out->ptcl = b.ptcl;
 }
+// which of those sizes were held below the estimator's bounds (the first attempt is capped at 16 x the reference's constants):
+// bit i = field i of jl_bump_sizes.  0 = the sizes are the bounds; otherwise render once with the regrow loop before capturing a graph
+uint32_t jl_scene_bump_sizes_clamped(void* s, uint32_t width, uint32_t height) {
+    uint32_t held = 0u;
+    (void)((Scene*)s)->bump_sizes(width, height, &held);
+    return held;
+}
 // the raw tally of the BumpEstimator: out = {binning, ptcl, tile, blend, seg_counts, segments, lines}
 void jl_scene_bump_estimate(void* s, const double* transform, uint32_t* out) {
     Affine a = to_affine(transform);

@@ -51,7 +51,7 @@ BumpEstimate Scene::bump_estimate(const Affine* transform) const {
     return estimator_.tally(&t);
 }
 
-BumpSizes Scene::bump_sizes(uint32_t width, uint32_t height) const {
+BumpSizes Scene::bump_sizes(uint32_t width, uint32_t height, uint32_t* clamped) const {
     BumpEstimate e = estimator_.tally(nullptr);
     uint64_t tiles = 0, bins = 0, ptcl = 0, blend = 0;
     footprint_.tally(width, height, &tiles, &bins, &ptcl, &blend);
@@ -62,18 +62,25 @@ BumpSizes Scene::bump_sizes(uint32_t width, uint32_t height) const {
     // put them at many GiB although the frame would fit the reference's fixed sizes: the FIRST attempt is held to 16 x the
     // reference constants (renderer/config.go:144-151; C3 needs 2.2 x at most) -- plus what cannot be less: the info words
     // and the tiles' static PTCL heads -- and the regrow loop (hip_engine.cpp) covers a frame that really needs more.
-    auto cap = [](uint64_t v, uint64_t ref, uint64_t floor_) {
+    // `clamped` (optional) receives one bit per size that was held below what the bounds ask for (bit order: bin_data, tiles,
+    // lines, seg_counts, segments, blend_spill, ptcl): a caller that renders WITHOUT the regrow loop -- hipGraph capture, a
+    // timed loop -- can see that the sizes may not do and run one robust render first.
+    uint32_t held = 0u;
+    auto cap = [&held](uint64_t v, uint64_t ref, uint64_t floor_, uint32_t bit) {
         const uint64_t want = std::max<uint64_t>(v + v / 8 + 1024, 4096);
-        return (uint32_t)std::min<uint64_t>(std::min<uint64_t>(want, std::max<uint64_t>(16u * ref, floor_ + ref)), 0xfffffff0ull);
+        const uint64_t got = std::min<uint64_t>(std::min<uint64_t>(want, std::max<uint64_t>(16u * ref, floor_ + ref)), 0xfffffff0ull);
+        if (got < want) held |= 1u << bit;
+        return (uint32_t)got;
     };
     BumpSizes b;
-    b.lines = cap(e.lines, 1u << 21, 0);
-    b.seg_counts = cap(e.seg_counts, 1u << 21, 0);
-    b.segments = cap(e.segments, 1u << 21, 0);
-    b.tiles = cap(tiles, 1u << 21, 0);
-    b.bin_data = cap(info + bins, 1u << 18, info);
-    b.ptcl = cap(ptcl + wt * ht * JL_PTCL_INITIAL_ALLOC, 1u << 23, wt * ht * JL_PTCL_INITIAL_ALLOC);
-    b.blend_spill = cap(blend, 1u << 21, 0);
+    b.bin_data = cap(info + bins, 1u << 18, info, 0);
+    b.tiles = cap(tiles, 1u << 21, 0, 1);
+    b.lines = cap(e.lines, 1u << 21, 0, 2);
+    b.seg_counts = cap(e.seg_counts, 1u << 21, 0, 3);
+    b.segments = cap(e.segments, 1u << 21, 0, 4);
+    b.blend_spill = cap(blend, 1u << 21, 0, 5);
+    b.ptcl = cap(ptcl + wt * ht * JL_PTCL_INITIAL_ALLOC, 1u << 23, wt * ht * JL_PTCL_INITIAL_ALLOC, 6);
+    if (clamped) *clamped = held;
     return b;
 }
 

@@ -42,7 +42,7 @@ class Scene {
     BumpEstimate bump_estimate(const Affine* transform = nullptr) const;
     // Element counts for the bump-allocated buffers of a width x height render: lines / seg_counts / segments from the
     // BumpEstimator, tiles / bin_data / ptcl / blend_spill from the draw objects' bounding boxes; never below `floor`.
-    BumpSizes bump_sizes(uint32_t width, uint32_t height) const;
+    BumpSizes bump_sizes(uint32_t width, uint32_t height, uint32_t* clamped = nullptr) const;
 
     // Pixel copies of the image brushes that entered through the C API, one per (key, contents): thousands of fills
     // with one image share one copy.  Entries live as long as the Scene; the patches hold references of their own.

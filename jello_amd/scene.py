@@ -261,6 +261,13 @@ class Scene:
         self._L.jl_scene_bump_sizes(self._h, int(width), int(height), ctypes.byref(out))
         return BumpSizes(**{f: getattr(out, f) for f in BumpSizes.FIELDS})
 
+    def bump_sizes_clamped(self, width, height):
+        """The fields of bump_sizes() that were held below the estimator's bounds (the first attempt is capped at 16 x the
+        reference's constants).  Empty: the sizes are the bounds.  Otherwise a caller without the regrow loop (hipGraph capture, a
+        timed loop) should render once with robust=True and keep the sizes that render ended with."""
+        mask = int(self._L.jl_scene_bump_sizes_clamped(self._h, int(width), int(height)))
+        return [f for i, f in enumerate(BumpSizes.FIELDS) if mask >> i & 1]
+
     def bump_estimate(self, transform=None):
         """The raw BumpEstimator tally (renderer/estimate.go:173-197)."""
         out = (ctypes.c_uint32 * 7)()

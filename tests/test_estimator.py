@@ -72,3 +72,19 @@ def test_raw_tally_follows_the_reference_formulas(built):
     s2.append(s, (2, 0, 0, 2, 0, 0))
     e2 = s2.bump_estimate()
     assert e2["lines"] == 3 and e2["segments"] == 29 * 4
+
+
+def test_held_back_sizes_are_reported(built):
+    """The first attempt is capped at 16 x the reference's constants (scene.cpp): a scene whose bounds ask for more must say so,
+    so that a caller without the regrow loop (graph capture, a timed loop) knows to render robustly once."""
+    from jello_amd import Brush, Fill, Path, Scene
+    s, p = scenes.scene_c3(4000, 1024)
+    assert s.bump_sizes_clamped(p.width, p.height) == []
+    heavy = Scene()
+    for i in range(3000):  # 3000 rectangles over a whole 4096^2 target: 3000 x 65536 tiles by the bounding-box bound
+        heavy.fill(Fill.NonZero, None, Brush.solid((0.1, 0.2, 0.3, 0.5)), None, Path.rect(0, 0, 4096, 4096))
+    held = heavy.bump_sizes_clamped(4096, 4096)
+    assert "tiles" in held and "ptcl" in held, held
+    sizes = heavy.bump_sizes(4096, 4096)
+    assert sizes.tiles == 16 * (1 << 21)
+    assert "lines" not in held

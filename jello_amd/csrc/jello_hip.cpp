@@ -51,9 +51,10 @@ struct ProfEntry {
     hipEvent_t start = nullptr, stop = nullptr;  // query only
 };
 
-// A recorded command that has not been launched yet.  Four of the recording's dispatches are 1-thread or trivially small
+// A recorded command that has not been launched yet.  Five of the recording's commands are 1-thread or trivially small
 // kernels in front of a stage that can do their work in passing (bbox_clear and Clear(bump) in front of flatten,
-// path_count_setup / path_tiling_setup in front of their indirect dispatches; render.go:230-237,369-374,415-420): the
+// path_count_setup / path_tiling_setup in front of their indirect dispatches, pathtag_reduce2 in front of pathtag_scan1;
+// render.go:186-197,230-237,369-374,415-420): the
 // engine holds them back until the next command and lets that stage absorb them when it is the one they were waiting for
 // (same buffers) -- or launches them as recorded before anything else happens (any other command, a download, a sync, the
 // end of a graph capture).  What every buffer holds after each command is what the recording says.
@@ -710,7 +711,10 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
     // Hold back the small stages a following stage can absorb (see Deferred); absorb or launch what is being held.
     // (not while profiling: a held-back stage's query would bracket nothing and its work would be charged to the stage that absorbs
     // it -- with the profiler on every command is launched as recorded and every query times its own stage)
-    const bool deferrable = !ctx->profiling && (stage == JH_BBOX_CLEAR || stage == JH_PATH_COUNT_SETUP || stage == JH_PATH_TILING_SETUP);
+    // (pathtag_reduce2: its consumer pathtag_scan1 redoes its sums in passing if it runs at most 16 workgroups itself --
+    // PT_ABSORB_MAX in kernels_scan.hip; the reference always dispatches reduce2 with 256, one thread per entry of reduced2)
+    const bool deferrable = !ctx->profiling && (stage == JH_BBOX_CLEAR || stage == JH_PATH_COUNT_SETUP || stage == JH_PATH_TILING_SETUP ||
+                                                (stage == JH_PATHTAG_REDUCE2 && gx > 0u && gx <= 256u && b.size() >= 2));
     uint32_t absorb = 0u;
     JhBound extra;
     std::memset(&extra, 0, sizeof extra);
@@ -727,6 +731,9 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
             if (stage == JH_FLATTEN && b.size() >= 6 && gx > 0u) {
                 if (d.is_clear) ok = d.clear_ptr == b[4].ptr && d.clear_bytes == b[4].size && b[4].size == sizeof(JlBump);
                 else ok = d.stage == JH_BBOX_CLEAR && d.b[0].ptr == b[0].ptr && d.b[1].ptr == b[3].ptr && d.b[1].size == b[3].size;
+            } else if (stage == JH_PATHTAG_SCAN1 && b.size() >= 3) {
+                ok = !d.is_clear && d.stage == JH_PATHTAG_REDUCE2 && gx > 0u && gx <= 16u && gx <= d.gx && d.b[0].ptr == b[0].ptr &&
+                     d.b[0].size == b[0].size && d.b[1].ptr == b[1].ptr && d.b[1].size == b[1].size;
             } else if (stage == JH_PATH_COUNT && indirect && b.size() >= 6) {
                 ok = !d.is_clear && d.stage == JH_PATH_COUNT_SETUP && d.b[0].ptr == b[1].ptr && d.b[1].ptr == (void*)indirect;
             } else if (stage == JH_PATH_TILING && indirect && b.size() >= 6) {
@@ -738,7 +745,11 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
             for (const Deferred& d : ctx->deferred) {
                 if (d.is_clear) absorb |= JH_ABSORB_BUMP_CLEAR;
                 else if (d.stage == JH_BBOX_CLEAR) absorb |= JH_ABSORB_BBOX_CLEAR;
-                else { absorb |= JH_ABSORB_SETUP; if (d.stage == JH_PATH_TILING_SETUP) extra = d.b[2]; }
+                else {
+                    absorb |= JH_ABSORB_SETUP;
+                    if (d.stage == JH_PATH_TILING_SETUP) extra = d.b[2];
+                    if (d.stage == JH_PATHTAG_REDUCE2) extra.size = d.gx;  // (entries of reduced2 the held-back dispatch writes)
+                }
             }
             ctx->deferred.clear();
         } else {

@@ -213,13 +213,42 @@ JD MonoidK<5> parent_prefix(const Buf<JlTagMonoid>& parent, uint32_t wg, uint32_
     return block_reduce_monoid<5>(agg, sh);
 }
 // pathtag_scan1.wgsl:26-67
-__global__ __launch_bounds__(JL_WG) void k_pathtag_scan1(Buf<JlTagMonoid> reduced, Buf<JlTagMonoid> reduced2, Buf<JlTagMonoid> out) {
+// WITH_REDUCE2: the held-back pathtag_reduce2 dispatch rides along (a launch of its own is 4.5 us for four workgroups' worth of work).
+// reduced2[w] is the sum of the w-th 256 entries of `reduced` -- exactly the block total this kernel's own scan produces -- and the
+// prefix of workgroup w the sum of the entries in front of its 256, which it adds up itself (integer sums: any association gives
+// the WGSL's words).  The reference dispatches reduce2 with 256 workgroups whatever the scene (render.go:186-190); the entries
+// of reduced2 behind this grid -- sums over the unused (or absent: robust reads) tail of `reduced` -- are written by workgroup 0,
+// one per thread.  Only for grids of at most PT_ABSORB_MAX workgroups (w * 256 loads per workgroup); the dispatcher decides.
+#define PT_ABSORB_MAX 16u
+template <bool WITH_REDUCE2>
+__global__ __launch_bounds__(JL_WG) void k_pathtag_scan1(Buf<JlTagMonoid> reduced, Buf<JlTagMonoid> reduced2, Buf<JlTagMonoid> out, uint32_t n_red2) {
     __shared__ uint32_t sh[20];
-    MonoidK<5> prefix = parent_prefix(reduced2, blockIdx.x, sh);
+    MonoidK<5> prefix;
+    if (WITH_REDUCE2) {
+        MonoidK<5> agg;
+#pragma unroll
+        for (int i = 0; i < 5; i++) agg.v[i] = 0;
+        for (uint32_t i = threadIdx.x; i < blockIdx.x * JL_WG; i += JL_WG) agg = monoid_add(agg, load_tm(reduced, i));
+        prefix = block_reduce_monoid<5>(agg, sh);
+        __syncthreads();
+    } else {
+        prefix = parent_prefix(reduced2, blockIdx.x, sh);
+    }
     uint32_t ix = blockIdx.x * JL_WG + threadIdx.x;
     MonoidK<5> tot;
     MonoidK<5> ex = block_excl_scan_monoid<5>(load_tm(reduced, ix), sh, &tot);
     if (out.ok(ix)) store_tm(&out.p[ix], monoid_add(prefix, ex));
+    if (WITH_REDUCE2) {
+        if (threadIdx.x == 0 && blockIdx.x < n_red2 && reduced2.ok(blockIdx.x)) store_tm(&reduced2.p[blockIdx.x], tot);
+        const uint32_t w = threadIdx.x;  // (n_red2 <= 256: one thread per entry behind the grid)
+        if (blockIdx.x == 0u && w >= gridDim.x && w < n_red2 && reduced2.ok(w)) {
+            MonoidK<5> agg;
+#pragma unroll
+            for (int i = 0; i < 5; i++) agg.v[i] = 0;
+            for (uint32_t i = w * JL_WG; i < (w + 1u) * JL_WG && i < reduced.n; i++) agg = monoid_add(agg, load_tm(reduced, i));
+            store_tm(&reduced2.p[w], agg);
+        }
+    }
 }
 // (Round 3 ran pathtag_reduce + pathtag_reduce2 + pathtag_scan1 as ONE launch behind a finished-workgroups counter: 11.9 us
 // against ~14 us for the three, with the hand-off ordered by relaxed atomics around an s_waitcnt.  Written as the memory model
@@ -254,8 +283,14 @@ int jh_launch_pathtag(const JhLaunch& L, int stage) {
             break;
         case 2:
             if (L.nb < 3) return -1;
-            hipLaunchKernelGGL(k_pathtag_scan1, g, blk, 0, L.stream, mkbuf<JlTagMonoid>(L.b[0].ptr, L.b[0].size),
-                               mkbuf<JlTagMonoid>(L.b[1].ptr, L.b[1].size), mkbuf<JlTagMonoid>(L.b[2].ptr, L.b[2].size));
+            // (JH_ABSORB_SETUP here: the dispatcher held pathtag_reduce2 back and found this dispatch to be its consumer)
+            // (L.extra.size: the workgroup count of the held-back dispatch = entries of reduced2 it would have written)
+            if ((L.absorb & JH_ABSORB_SETUP) != 0u)
+                hipLaunchKernelGGL(k_pathtag_scan1<true>, g, blk, 0, L.stream, mkbuf<JlTagMonoid>(L.b[0].ptr, L.b[0].size),
+                                   mkbuf<JlTagMonoid>(L.b[1].ptr, L.b[1].size), mkbuf<JlTagMonoid>(L.b[2].ptr, L.b[2].size), (uint32_t)L.extra.size);
+            else
+                hipLaunchKernelGGL(k_pathtag_scan1<false>, g, blk, 0, L.stream, mkbuf<JlTagMonoid>(L.b[0].ptr, L.b[0].size),
+                                   mkbuf<JlTagMonoid>(L.b[1].ptr, L.b[1].size), mkbuf<JlTagMonoid>(L.b[2].ptr, L.b[2].size), 0u);
             break;
         case 3:
         case 4: {

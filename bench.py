@@ -67,6 +67,10 @@ def parse_args(argv=None):
     ap.add_argument("--emulate-band-of", type=int, default=0, metavar="N",
                     help="with --bands on ONE GPU: time what rank N/2 of an N-GPU band job would do (its band of the frame)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--in-flight", type=int, choices=[1, 2], default=2,
+                    help="frames in flight per GPU: 2 (default) = two engine contexts (own stream, buffers, scratch, graph) take the steps "
+                         "in turn, so the kernels of frame i + 1 fill the launch gaps and tails of frame i; 1 = one context, one "
+                         "frame after the other (every round before round 4; also timed beside the default for comparison)")
     args = ap.parse_args(argv)
     if args.paths <= 0:
         args.paths = {"c3": 100_000, "c2": 300, "c1": 2}.get(args.scene, 30_000)
@@ -137,8 +141,16 @@ def run_rank(args, world):
     fine_stage = {"area": "fine_area", "msaa8": "fine_msaa8", "msaa16": "fine_msaa16"}[args.aa]
     eng = jello_amd.Engine(dev.index)
     host = jello_amd.Host()
-    stream = torch.cuda.current_stream(dev)
-    eng.set_stream(stream.cuda_stream)
+    n_ctx = 1 if (args.no_graph or args.bands) else args.in_flight  # (eager launches and band mode keep the one-context loop)
+    if n_ctx == 1:
+        streams = [torch.cuda.current_stream(dev)]
+        engs = [eng]
+    else:  # one non-blocking stream per context (the legacy default stream would order the two against each other)
+        streams = [torch.cuda.Stream(dev) for _ in range(n_ctx)]
+        engs = [eng] + [jello_amd.Engine(dev.index) for _ in range(n_ctx - 1)]
+    for e, st in zip(engs, streams):
+        e.set_stream(st.cuda_stream)
+    stream = streams[0]
 
     # ---- size the bump buffers once, outside the timed region: estimator first, regrow loop as the safety net ----
     params.bump = scene.bump_sizes(W, H)
@@ -159,7 +171,8 @@ def run_rank(args, world):
         gather_modes = ["0", "rotate"] if args.gather_dst == "all" else [args.gather_dst]
     gather = bool(gather_modes)
     # output images: torch owns the device memory (double-buffered for the overlapped gather)
-    outs = [torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(2 if gather else 1)]
+    outs = [torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(2 if (gather or n_ctx == 2) else 1)]
+    eng_of = [engs[k % n_ctx] for k in range(len(outs))]  # buffer k is rendered by context k (one context: both by the same)
     gathered = None
     gather_groups = [None, None]
     if gather:
@@ -174,37 +187,41 @@ def run_rank(args, world):
             eng.set_band(*sharding.band_for_rank(hb, args.emulate_band_of, args.emulate_band_of // 2))
         else:
             eng.set_band(*sharding.band_for_rank(hb, world, rank))
-    eng.run(rec, RUN_UPLOADS | RUN_DISPATCHES, outs[0].data_ptr())  # uploads scene/config; allocates every buffer
+    for k in range(n_ctx):  # uploads scene/config; allocates every buffer (of every context)
+        engs[k].run(rec, RUN_UPLOADS | RUN_DISPATCHES, outs[k].data_ptr())
     torch.cuda.synchronize(dev)
 
-    def frame_digest(o):
+    def frame_digest(k):
         """SHA-256 of the bump allocators and of the finished image: what a frame IS, for the replay check below."""
         import hashlib
         h = hashlib.sha256()
-        h.update(eng.download(rec.buffer("bumpBuf")[0], dtype=np.uint32)[:8].tobytes())
-        h.update(o.cpu().numpy().tobytes())
+        h.update(eng_of[k].download(rec.buffer("bumpBuf")[0], dtype=np.uint32)[:8].tobytes())
+        h.update(outs[k].cpu().numpy().tobytes())
         return h.hexdigest()
-    eager_digest = frame_digest(outs[0])  # an eagerly launched frame; every timed frame must reproduce it
+    eager_digest = frame_digest(0)  # an eagerly launched frame; every timed frame must reproduce it
 
     # One frame is ~45 short launches, so the dispatch-only replay of the recording is captured once into a hipGraph
     # per output buffer and the timed steps replay it.
     use_graph = not args.no_graph
-    graphs = [eng.capture(rec, o.data_ptr()) for o in outs] if use_graph else []
-    pipe = sharding.GatherPipeline(dist, rank, world, outs, gathered, gather_groups)
+    graphs = [eng_of[k].capture(rec, o.data_ptr()) for k, o in enumerate(outs)] if use_graph else []
+    pipe = sharding.GatherPipeline(dist, rank, world, outs, gathered, gather_groups, streams=streams if n_ctx == 2 else None,
+                                   alternate=n_ctx == 2)
+    pipe_one = sharding.GatherPipeline(dist, rank, world, outs[:1], None, None)  # one context, one frame after the other
 
     def render(k):
         if use_graph:
-            eng.replay(graphs[k])
+            eng_of[k].replay(graphs[k])
         else:
-            eng.run(rec, RUN_DISPATCHES, outs[k].data_ptr())
+            eng_of[k].run(rec, RUN_DISPATCHES, outs[k].data_ptr())
 
-    def timed(mode):
+    def timed(mode, pipe=pipe, n_blocks=None):
         """W warmup steps, then --blocks blocks of exactly K steps, each between barrier + synchronize on both sides and
         each the max over ranks; returns the block times (seconds), sorted.  mode: None / "0" / "rotate" (GatherPipeline)."""
         for i in range(args.warmup):
             pipe.step(i, render, mode)
         blocks = []
-        n_blocks = max(1, args.blocks)
+        fixed = n_blocks is not None
+        n_blocks = max(1, args.blocks if n_blocks is None else n_blocks)
         b = 0
         while b < n_blocks:
             b += 1
@@ -227,12 +244,14 @@ def run_rank(args, world):
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
             blocks.append(el)
-            if b == 1 and el > 0.0 and args.min_seconds > 0.0:  # (el is the max over ranks: every rank computes the same count)
+            if b == 1 and el > 0.0 and args.min_seconds > 0.0 and not fixed:  # (el is the max over ranks: every rank computes the same count)
                 need = int(args.min_seconds / el) + 1
                 n_blocks = max(n_blocks, min(101, need | 1))
         return sorted(blocks)
 
     blocks_plain = timed(None)
+    # (two frames in flight: the one-context loop of the earlier rounds timed beside it, three blocks)
+    blocks_one = timed(None, pipe_one, 3) if n_ctx == 2 else None
     blocks_by_mode = {m: timed(m) for m in gather_modes}
     head_mode = ("0" if "0" in gather_modes else gather_modes[0]) if gather else None  # C5 as written gathers on rank 0
     blocks = blocks_by_mode[head_mode] if gather else blocks_plain
@@ -241,7 +260,7 @@ def run_rank(args, world):
     # The frames that were timed are the frame that was checked: replayed (or re-run) frames must be bit-identical to the
     # eager one -- image and bump allocators -- or the number describes something else.
     for k, o in enumerate(outs):
-        d = frame_digest(o)
+        d = frame_digest(k)
         if d != eager_digest:
             raise RuntimeError("rank %d: the timed frame in output buffer %d differs from the eagerly launched frame (SHA-256 %s vs %s)"
                                % (rank, k, d[:16], eager_digest[:16]))
@@ -289,6 +308,8 @@ def run_rank(args, world):
         mode = ("bin-row bands of one scene x%d" % world) if args.bands else \
             "scene-per-gpu x%d%s" % (world, (" + RCCL image gather to %s (overlapped, double-buffered)" %
                                              ("rank 0" if head_mode == "0" else "rank (step mod N)")) if gather else "")
+        if n_ctx == 2:
+            mode += ", 2 frames in flight per GPU (two engine contexts take the steps in turn)"
         headline = args.scene == "c3" and args.paths == 100_000 and args.size == 4096
         metric = "Mpixels/sec fine-raster + paths/sec, 100k-path 4096^2 scene" if headline else \
             "Mpixels/sec fine-raster + paths/sec, %s scene, %d paths, %d^2 (NOT the headline configuration)" % (args.scene, args.paths, args.size)
@@ -304,6 +325,11 @@ def run_rank(args, world):
                        "paths": args.paths, "draw_objects": cfg["n_drawobj"], "width": W, "height": H, "parallelism": mode},
             "paths_per_s": round(args.paths * units / per, 1),
             "fine_mpixels_per_s": round(W * H / (fine_ms * 1e-3) / 1e6, 2),
+            "frames_in_flight": n_ctx,
+            "one_frame_at_a_time": None if blocks_one is None else {
+                "ms_per_step": round(blocks_one[len(blocks_one) // 2] / args.steps * 1e3, 4),
+                "value": round(W * H * units / (blocks_one[len(blocks_one) // 2] / args.steps) / 1e6, 2),
+                "note": "the gather-free loop on ONE context (no overlap between consecutive frames), as every round before round 4 timed it"},
             "launch": "hipGraph replay" if use_graph else "eager",
             "launches_per_frame": None if not use_graph else dict(zip(("kernels", "fills_and_copies"), eng.graph_node_counts(graphs[0]))),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
@@ -341,9 +367,10 @@ def run_rank(args, world):
             if gather:
                 result["value_with_gather"] = result["value"]
                 result["gather"] = sharding.gather_model(world, pp * 1e3, frame_bytes, head_mode)
-    for g in graphs:
-        eng.graph_destroy(g)
-    eng.release(rec)
+    for k, g in enumerate(graphs):
+        eng_of[k].graph_destroy(g)
+    for e in engs:
+        e.release(rec)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

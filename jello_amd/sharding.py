@@ -8,6 +8,7 @@ Two modes, neither needs a collective on the data path:
 The only (optional: `bench.py --gather`) exchange is the final image gather to rank 0 (`gather_images`): RCCL on GPUs ("nccl"
 backend), gloo in the CPU tests.
 """
+import contextlib
 import os
 import socket
 import subprocess
@@ -46,44 +47,60 @@ def gather_images(dist, local, rank, world, dst=0, async_op=False, out=None, gro
 
 
 class GatherPipeline:
-    """The N > 1 step loop of bench.py (and of the gloo tests): render frame i into buffer i & 1, then hand it to an
+    """The step loop of bench.py (and of the gloo tests): render frame i into buffer i & 1, then hand it to an
     asynchronous gather whose destination depends on the mode -- None: no gather (the frame stays on the GPU that rendered
     it), "0": rank 0, "rotate": rank (i mod N).  Each buffer of the double buffer has its own communicator (two gathers on
     ONE communicator run one after the other), so the gather of frame i overlaps the render of frame i + 1.  One object
-    runs all three modes one after the other (`drain()` in between)."""
+    runs all three modes one after the other (`drain()` in between).
 
-    def __init__(self, dist, rank, world, outs, gathered=None, groups=None):
+    Two frames in flight (round 4): with `streams` = one HIP stream per buffer (torch.cuda.Stream objects; the caller renders
+    buffer k with an engine of its own that launches on streams[k]) everything that concerns buffer k -- waiting for its previous
+    gather, the render, the next gather -- is ordered on streams[k] alone, so frame i + 1 does not wait for frame i at all and
+    the two contexts' kernels fill each other's launch gaps and tails.  `alternate` makes the gather-free mode use both buffers
+    too (without it mode None renders into buffer 0 only, as before)."""
+
+    def __init__(self, dist, rank, world, outs, gathered=None, groups=None, streams=None, alternate=False):
         self.dist, self.rank, self.world, self.outs = dist, rank, world, outs
         self.gathered = gathered      # [buffer][source rank] on every rank that can be a destination, else None
         self.groups = groups or [None, None]
         self.pending = [None, None]   # (work, step, destination) of the gather that last read outs[k]
+        self.streams = streams
+        self.alternate = bool(alternate) and len(outs) >= 2
+
+    def _on(self, k):
+        if self.streams is None:
+            return contextlib.nullcontext()
+        import torch
+        return torch.cuda.stream(self.streams[k])
 
     def _finish(self, k, on_gathered):
         if self.pending[k] is None:
             return
         work, step, dst = self.pending[k]
-        work.wait()  # (stream-ordered on RCCL: the host does not block)
+        work.wait()  # (stream-ordered on RCCL: the host does not block; the CURRENT stream waits -- streams[k] under _on(k))
         if on_gathered is not None and dst == self.rank:
             on_gathered(step, self.gathered[k])
         self.pending[k] = None
 
     def step(self, i, render, mode, on_gathered=None):
         """render(k) must leave frame i in outs[k].  With a gather mode the buffer is not reused before its gather is done."""
-        k = (i & 1) if mode is not None else 0
-        self._finish(k, on_gathered)
-        render(k)
-        if mode is None or self.world == 1:
-            return
-        dst = gather_dst_for_step(i, self.world, mode)
-        if dst == self.rank and self.gathered is None:
-            raise RuntimeError("rank %d is the destination of step %d but has no receive buffers" % (self.rank, i))
-        _, work = gather_images(self.dist, self.outs[k], self.rank, self.world, dst=dst, async_op=True,
-                                out=self.gathered[k] if dst == self.rank else None, group=self.groups[k])
-        self.pending[k] = (work, i, dst)
+        k = (i & 1) if (mode is not None or self.alternate) else 0
+        with self._on(k):
+            self._finish(k, on_gathered)
+            render(k)
+            if mode is None or self.world == 1:
+                return
+            dst = gather_dst_for_step(i, self.world, mode)
+            if dst == self.rank and self.gathered is None:
+                raise RuntimeError("rank %d is the destination of step %d but has no receive buffers" % (self.rank, i))
+            _, work = gather_images(self.dist, self.outs[k], self.rank, self.world, dst=dst, async_op=True,
+                                    out=self.gathered[k] if dst == self.rank else None, group=self.groups[k])
+            self.pending[k] = (work, i, dst)
 
     def drain(self, on_gathered=None):
         for k in range(2):
-            self._finish(k, on_gathered)
+            with self._on(k):
+                self._finish(k, on_gathered)
 
 
 XGMI_ONE_WAY_GBS = 76.8  # one xGMI link of an MI355X: 153.6 GB/s bidirectional; every GPU pair of a node has its own link

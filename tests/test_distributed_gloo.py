@@ -130,6 +130,26 @@ def test_rotating_gather_destination_double_buffered(built):
     assert results[1]["rotate"][0] == {i: [3000 + 100 * i, 3000 + 100 * i + 1] for i in (1, 3, 5)}
 
 
+def test_two_frames_in_flight_alternate_the_buffers_in_every_mode():
+    """bench.py --in-flight 2: the gather-free loop takes the two buffers (= the two engine contexts) in turn as well; without
+    `alternate` (one context) it keeps to buffer 0.  (The per-buffer HIP streams are the GPU test's business:
+    test_gpu_boundary.py::test_two_contexts_in_flight_render_the_same_frame.)"""
+    sys.path.insert(0, ROOT)
+    from jello_amd import sharding
+    for alternate, want in ((True, [0, 1, 0, 1, 0]), (False, [0, 0, 0, 0, 0])):
+        pipe = sharding.GatherPipeline(None, 0, 1, [object(), object()], None, None, streams=None, alternate=alternate)
+        seen = []
+        for i in range(5):
+            pipe.step(i, seen.append, None)
+        pipe.drain()
+        assert seen == want
+    one = sharding.GatherPipeline(None, 0, 1, [object()], None, None, alternate=True)  # a single buffer cannot alternate
+    seen = []
+    for i in range(3):
+        one.step(i, seen.append, None)
+    assert seen == [0, 0, 0]
+
+
 def test_gather_model_states_the_ceiling():
     sys.path.insert(0, ROOT)
     from jello_amd import sharding

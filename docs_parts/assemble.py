@@ -14,11 +14,15 @@ if c3:
              FINE_MS=f(c3["roofline"]["avg_ms"]), FRAC=f(100 * c3["roofline"]["frac"], 2),
              FRAC_COPY=f(100 * c3["roofline"]["achieved"] / c3["roofline"]["peak_measured_copy"], 1) if c3["roofline"].get("peak_measured_copy") else "n/a",
              FLATTEN_MS=f(st["flatten"]), PC_MS=f(st["path_count"]), COARSE_MS=f(st["coarse"]), PT_MS=f(st["path_tiling"]))
+    one = c3.get("one_frame_at_a_time") or {"ms_per_step": c3["ms_per_step"], "value": c3["value"]}
+    v.update(FRAME1_MS=f(one["ms_per_step"]), MPIX1="%d" % round(one["value"]))
     cb = c3.get("cpu_baseline") or {}
     v.update(CPU_MPIX=f(cb.get("value", 0), 1), CPU1_MPIX=f(cb.get("value_1thread", 0), 1))
 for key, j in (("C4", c4), ("C4N", c4n), ("C1", c1), ("C2", c2)):
     if j:
-        v[key + "_MS"] = f(j["ms_per_step"], 3 if key in ("C1", "C2") else 2)
+        one = j.get("one_frame_at_a_time") or {"ms_per_step": j["ms_per_step"]}
+        v[key + "_MS"] = f(one["ms_per_step"], 3 if key in ("C1", "C2") else 2)  # one frame at a time
+        v[key + "_IF2"] = f(j["ms_per_step"], 3 if key in ("C1", "C2") else 2)  # the line's value: two frames in flight
         if key == "C4":
             v["C4_FINE"] = f(j["stage_ms"]["fine_area"], 2); v["C4_COARSE"] = f(j["stage_ms"]["coarse"], 2)
 for k in ("N_CPU", "N_GPU"):

@@ -21,8 +21,9 @@
  *
  * Conventions: plain pointers and sizes only; every call returns 0 on success or a negative
  * jh_status (never aborts -- the reference panics, wgpu.go:77,213,282,544,558,594,955);
- * one jh_ctx = one device + one stream, not thread-safe; several contexts (one per GPU) may be
- * used concurrently from different threads/processes.  Work is enqueued asynchronously; only
+ * one jh_ctx = one device + one stream, not thread-safe; several contexts (one per GPU -- or two on
+ * ONE GPU that take a stream of frames in turn, which fills the holes a single chain of dependent
+ * launches leaves: INTEGRATION.md) may be used concurrently.  Work is enqueued asynchronously; only
  * jh_download, jh_image_download, jh_sync and jh_profile_collect[_tree] wait for the device.
  * Uploads copy the caller's bytes into a pinned staging arena before returning (the slice may be
  * reused at once, as with queue.WriteBuffer) and leave the DMA in flight.

@@ -258,6 +258,9 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #if FINE_SKIP != 0 && !defined(JH_VARIANT_BUILD)
 #error "FINE_SKIP changes results: build it as a variant library (make VARIANT=name EXTRA='-DJH_VARIANT_BUILD -DFINE_SKIP=n')"
 #endif
+#define RK_NONEG 1u
+#define RK_RANGE 2u
+#define RK_LUM 4u
 #define FINE_TRIP_WORDS 13u  // PTCL words one trip of the command loop may consume
 // Everything a batch leaves behind for stage 4 lives in LDS, not in registers: the command loop then carries no per-lane
 // batch state around its back edge (as registers the nine values cost ~30 moves per command: the compiler keeps a second
@@ -833,24 +836,36 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
     };
     // END_CLIP of a layer that is still pending (see the END_CLIP command below for why these are exact): true if the layer
     // was closed here -- rgba is then what the full formula gives --, false if the full formula has to be taken.
-    auto end_clip_fast = [&](uint32_t blend, float alpha, uint32_t level) -> bool {
+    // What the caller already knows (uniform), so that a RUN of empty layers over one unchanged backdrop -- C4: 213 per tile -- tests the
+    // backdrop once instead of once per layer: area_is_one: the four areas are exactly 1 (a SOLID set them); `known`, bits: RK_NONEG no
+    // channel of the wave's pixels is -0 (a `+ 0.0` was applied or the range was verified), RK_RANGE every channel is in [+0, 16] (bit
+    // patterns), RK_LUM lum(cb) <= 1 for every pixel.  Bits are raised here when a test passes; the caller clears them whenever rgba may
+    // have changed.  Without a -0 among the channels the `+ 0.0` of the plain arm is the identity: skipped.
+    auto end_clip_fast = [&](uint32_t blend, float alpha, uint32_t level, bool area_is_one, uint32_t& known) -> bool {
         bool fast = false;
-        if (clip_depth != 0u && pushed_depth <= level && alpha >= 0.0f && alpha < __builtin_inff()) {  // uniform
+        // (0 <= alpha < inf as an unsigned comparison of the bit pattern -- a scalar compare; an alpha of -0 takes the full formula)
+        if (clip_depth != 0u && pushed_depth <= level && f2u(alpha) < 0x7f800000u) {  // uniform
             const bool plain = (blend & 0x7fffu) == 0u;
             const uint32_t mixm = blend >> 8;
             const bool separable = (blend & 0xffu) == 0u && mixm >= 1u && mixm <= 14u;
             const bool needs_lum = mixm >= 12u;
             if (plain || separable) {
-                // (the range tests are unsigned comparisons of bit patterns: one comparison of the MAXIMUM pattern per
-                // group of values -- v_max3_u32 -- instead of one comparison and one mask operation per value)
-                auto umax3 = [](uint32_t a, uint32_t b, uint32_t c) -> uint32_t { return umax_(umax_(a, b), c); };
-                bool ok = umax_(umax3(f2u(area[0]), f2u(area[1]), f2u(area[2])), f2u(area[3])) <= 0x3f800000u;
-                if (!plain) {
-                    uint32_t m[4];
+                const bool t_area = !area_is_one, t_rgba = !plain && (known & RK_RANGE) == 0u, t_lum = !plain && needs_lum && (known & RK_LUM) == 0u;
+                if (!(t_area || t_rgba || t_lum)) {  // uniform: everything this layer needs has been established by an earlier one
+                    fast = true;
+                } else {
+                    // (the range tests are unsigned comparisons of bit patterns: one comparison of the MAXIMUM pattern per
+                    // group of values -- v_max3_u32 -- instead of one comparison and one mask operation per value)
+                    auto umax3 = [](uint32_t a, uint32_t b, uint32_t c) -> uint32_t { return umax_(umax_(a, b), c); };
+                    bool ok = true;
+                    if (t_area) ok = umax_(umax3(f2u(area[0]), f2u(area[1]), f2u(area[2])), f2u(area[3])) <= 0x3f800000u;
+                    if (t_rgba) {
+                        uint32_t m[4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) m[k] = umax_(umax3(f2u(rgba[k].x), f2u(rgba[k].y), f2u(rgba[k].z)), f2u(rgba[k].w));
-                    ok = ok && umax_(umax3(m[0], m[1], m[2]), m[3]) <= 0x41800000u;
-                    if (needs_lum) {  // uniform
+                        for (int k = 0; k < 4; k++) m[k] = umax_(umax3(f2u(rgba[k].x), f2u(rgba[k].y), f2u(rgba[k].z)), f2u(rgba[k].w));
+                        ok = ok && umax_(umax3(m[0], m[1], m[2]), m[3]) <= 0x41800000u;
+                    }
+                    if (t_lum) {  // uniform
                         uint32_t lm = 0u;
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
@@ -860,11 +875,13 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                         }
                         ok = ok && lm <= 0x3f800000u;
                     }
+                    fast = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+                    if (fast && !plain) known |= RK_NONEG | RK_RANGE | (needs_lum ? RK_LUM : 0u);  // (what was not tested now was known before)
                 }
-                fast = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
-                if (fast && plain) {
+                if (fast && plain && (known & RK_NONEG) == 0u) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) rgba[k] = v4(rgba[k].x + 0.0f, rgba[k].y + 0.0f, rgba[k].z + 0.0f, rgba[k].w + 0.0f);
+                    known |= RK_NONEG;
                 }
             }
         }
@@ -1020,7 +1037,85 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             // loop of their own: the BEGIN_CLIPs only count, SOLID sets the area, and an END_CLIP that the shortcut can close leaves
             // the loop's state as the general decoder would.  Anything else falls through to the decoder with the words consumed so
             // far accounted for (exactly what its own folding of BEGIN_CLIP / SOLID does).
+            // Inside the loop nothing but the plain arm's `+ 0.0` touches rgba and nothing but SOLID touches the area, so what one
+            // layer's tests established holds for the layers behind it: once the area is 1 and the backdrop's tests have passed, the
+            // commands of an empty layer need NOTHING but counting -- the scalar loop at the head of every trip.  (Round 4.  The C4
+            // tile is bound by the CU's one scalar pipe: 118 scalar instructions per empty layer before, the compiler's boolean
+            // bookkeeping around the decoder; the counting loop is one compare-and-branch per condition.)
+            uint32_t rgba_known = 0u;  // (of this run of empty layers: see end_clip_fast)
+            bool area_one = false;
             for (uint32_t hot = 0; hot < (1u << 24); hot++) {  // uniform
+                if (area_one) {
+                    // The counting loop, by hand: one compare-and-branch per condition, ~47 scalar instructions per BEGIN_CLIP SOLID END_CLIP
+                    // (as C++ the structuriser turned the chain of exits into state codes and mask bookkeeping, no better than before).
+                    //   BEGIN_CLIP: depth + 1.   SOLID: nothing (the area is 1).   END_CLIP blend alpha: closes an EMPTY layer (one that
+                    //   was never materialised: pushed_depth < depth) if 0 <= alpha < inf (bit pattern), the compose operator is src-over
+                    //   and what end_clip_fast would test for the mix mode -- plain / clip: RK_NONEG, modes 1..11: + RK_RANGE, hue /
+                    //   saturation / color: + RK_LUM -- is already in rgba_known.  Anything else, or fewer than FINE_TRIP_WORDS words left
+                    //   in the register window: out (the window is re-based and the loop entered again, or the trip below takes over).
+                    for (uint32_t sk = 0; sk < (1u << 24); sk++) {  // uniform
+                        ensure_window();
+#if defined(__HIP_DEVICE_COMPILE__)
+                        uint32_t t_i, t_t, t_b;
+                        asm volatile(
+                            "1:\n"
+                            "  s_sub_u32 %[i], %[pc], %[wb]\n"
+                            "  s_cmp_gt_u32 %[i], %[lim]\n"
+                            "  s_cbranch_scc1 9f\n"
+                            "  v_readlane_b32 %[t], %[w], %[i]\n"
+                            "  s_cmp_eq_u32 %[t], 10\n"
+                            "  s_cbranch_scc0 2f\n"
+                            "  s_add_u32 %[d], %[d], 1\n"
+                            "  s_add_u32 %[pc], %[pc], 1\n"
+                            "  s_branch 1b\n"
+                            "2:\n"
+                            "  s_cmp_eq_u32 %[t], 3\n"
+                            "  s_cbranch_scc0 3f\n"
+                            "  s_add_u32 %[pc], %[pc], 1\n"
+                            "  s_branch 1b\n"
+                            "3:\n"
+                            "  s_cmp_eq_u32 %[t], 11\n"
+                            "  s_cbranch_scc0 9f\n"
+                            "  s_cmp_eq_u32 %[d], 0\n"
+                            "  s_cbranch_scc1 9f\n"
+                            "  s_cmp_ge_u32 %[pd], %[d]\n"
+                            "  s_cbranch_scc1 9f\n"
+                            "  s_add_u32 %[t], %[i], 1\n"
+                            "  s_add_u32 %[i], %[i], 2\n"
+                            "  v_readlane_b32 %[b], %[w], %[t]\n"
+                            "  v_readlane_b32 %[i], %[w], %[i]\n"
+                            "  s_cmp_gt_u32 %[i], 0x7f7fffff\n"
+                            "  s_cbranch_scc1 9f\n"
+                            "  s_and_b32 %[t], %[b], 0xff\n"
+                            "  s_cbranch_scc1 9f\n"
+                            "  s_mov_b32 %[t], 1\n"
+                            "  s_and_b32 %[i], %[b], 0x7fff\n"
+                            "  s_cbranch_scc0 4f\n"
+                            "  s_mov_b32 %[t], 3\n"
+                            "  s_cmp_lt_u32 %[b], 0xc00\n"
+                            "  s_cbranch_scc1 4f\n"
+                            "  s_mov_b32 %[t], 7\n"
+                            "  s_cmp_lt_u32 %[b], 0xf00\n"
+                            "  s_cbranch_scc0 9f\n"
+                            "4:\n"
+                            "  s_andn2_b32 %[t], %[t], %[kn]\n"
+                            "  s_cbranch_scc1 9f\n"
+                            "  s_sub_u32 %[d], %[d], 1\n"
+                            "  s_add_u32 %[pc], %[pc], 3\n"
+                            "  s_branch 1b\n"
+                            "9:\n"
+                            : [pc] "+s"(pc), [d] "+s"(clip_depth), [i] "=&s"(t_i), [t] "=&s"(t_t), [b] "=&s"(t_b)
+                            : [wb] "s"(wbase), [pd] "s"(pushed_depth), [kn] "s"(rgba_known), [w] "v"(wcur), [lim] "n"(64 - (int)FINE_TRIP_WORDS)
+                            : "scc");
+#endif
+                        if (pc - wbase <= 64u - FINE_TRIP_WORDS) break;  // (else: the window ran out, not the commands)
+                    }
+                    woff = pc - wbase;
+                    tag = W(0);  // (what the decoder below sees if this trip leaves the loop)
+                }
+#ifdef FINE_NO_COUNTING_LOOP  // (A/B builds only: every layer is tested and decoded by the trip below, as before round 4)
+                area_one = false; rgba_known = 0u;
+#endif
                 uint32_t k = 0u, nb = 0u;
                 while (nb < 3u && W(k) == JL_CMD_BEGIN_CLIP) { nb++; k++; }
                 const bool solid = W(k) == JL_CMD_SOLID;
@@ -1028,14 +1123,15 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                 if (W(k) != JL_CMD_END_CLIP) break;
                 // (the decoder's order: BEGIN_CLIPs, then SOLID, then the command)
                 clip_depth += nb;
-                if (solid) {
+                if (solid && !area_one) {
 #pragma unroll
                     for (int q = 0; q < 4; q++) area[q] = 1.0f;
+                    area_one = true;
                 }
                 pc += k; woff += k;
                 tag = JL_CMD_END_CLIP;
                 if (clip_depth == 0u) break;  // (a stray END_CLIP: the decoder's business)
-                if (!end_clip_fast(W(1), u2f(W(2)), clip_depth - 1u)) break;
+                if (!end_clip_fast(W(1), u2f(W(2)), clip_depth - 1u, area_one, rgba_known)) break;
                 clip_depth -= 1u;
                 pc += 3u;
                 ensure_window();
@@ -1106,7 +1202,8 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             //                      backdrops: no shortcut.)
             // Anything else (other compose operators, a backdrop outside [+0, 16], NaNs) performs the pending saves and takes
             // the full formula.  The unsigned comparison of the bit patterns tests "+0 <= v <= limit".
-            const bool fast = end_clip_fast(blend, alpha, level);
+            uint32_t no_memo = 0u;
+            const bool fast = end_clip_fast(blend, alpha, level, false, no_memo);
             if (!fast) {
                 materialize();
 #pragma unroll

@@ -70,8 +70,13 @@ JD void alloc_cmd(Cmd& c, uint32_t size) {  // coarse.wgsl:70-88
 #ifndef COARSE_TILE_CACHE
 #define COARSE_TILE_CACHE 1536u  // with the rest of the LDS 37.5 KiB: four workgroups per CU (>= 256: the pairs of one element)
 #endif
+// Workgroups per CU the bins are split for.  Every workgroup of a bin repeats the merge of the bin's element lists, so more of
+// them buy latency with redundant work.  With ONE frame on the device 4 is the optimum (C3 coarse 0.110 ms, C4 0.68; with 2: 0.114
+// / 0.76); with TWO frames in flight (bench.py's default) the other frame's kernels fill the idle CUs anyway and the
+// redundant work is what counts: 2 gives C3 0.947 -> 0.919 ms per frame and C4 1.90 -> 1.63 (1: 0.913 / 1.59, but +2 % / +9 % for a
+// frame on its own).  profiles/r04_variants_in_flight.txt
 #ifndef COARSE_WG_PER_CU
-#define COARSE_WG_PER_CU 4u
+#define COARSE_WG_PER_CU 2u
 #endif
 #ifndef COARSE_MAX_SPLIT
 #define COARSE_MAX_SPLIT 16u
@@ -611,7 +616,7 @@ int jh_launch_coarse(const JhLaunch& L) {
     auto tiles = mkbuf<JlTile>(L.b[6].ptr, L.b[6].size);
     JlBump* bump = (JlBump*)L.b[7].ptr;
     auto ptcl = mkbuf<uint32_t>(L.b[8].ptr, L.b[8].size);
-    // workgroups per bin: enough to give every CU four workgroups (the LDS of one allows four per CU)
+    // workgroups per bin: enough to give every CU COARSE_WG_PER_CU workgroups (the LDS of one allows four per CU)
     const uint32_t want = COARSE_WG_PER_CU * (uint32_t)(L.num_cus > 0 ? L.num_cus : 256);
     uint32_t split = 1u;
     while (split < COARSE_MAX_SPLIT && L.gx * L.gy * split < want) split *= 2u;

@@ -8,6 +8,6 @@ for v in "$@"; do
   python3 - $R/gpurun_out/var/$v.json $v <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(sys.argv[2], "frame", d["ms_per_step"], "fine", d["roofline"]["avg_ms"], "stages", {k:round(v,4) for k,v in d.get("stage_ms",{}).items()} if "stage_ms" in d else "")
+print(sys.argv[2], "frame", d["ms_per_step"], "one at a time", (d.get("one_frame_at_a_time") or {}).get("ms_per_step"), "fine", d["roofline"]["avg_ms"], "stages", {k:round(v,4) for k,v in d.get("stage_ms",{}).items()} if "stage_ms" in d else "")
 PY
 done

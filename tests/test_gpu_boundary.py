@@ -376,6 +376,72 @@ def test_two_contexts_in_flight_render_the_same_frame(engine):
             e.close()
 
 
+def test_gather_pipeline_orders_each_buffer_on_its_own_stream():
+    """The N > 1 step loop of bench.py with two frames in flight, on ONE GPU with a stand-in for RCCL: `gather` copies the frame on a
+    side stream that waits for the stream it was called on, `work.wait()` makes the calling stream wait for that copy -- the stream
+    semantics of an asynchronous NCCL collective.  Every gathered frame must be the frame of ITS step (a render that overwrote a buffer
+    before its gather had read it, or a gather that did not wait for its render, shows up as a wrong value), in all three modes,
+    although nothing here ever synchronises the two per-buffer streams with each other."""
+    import torch
+    from jello_amd import sharding
+    dev = torch.device("cuda", 0)
+    n = 1 << 22  # 16 MB frames: the copies take long enough to be overtaken if nothing orders them
+
+    class Work:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream(dev).wait_event(self.ev)
+
+    class FakeDist:  # rank 0 of a "world" of 2; rank 1's frame is a copy of ours
+        def __init__(self):
+            self.side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+            self.sink = torch.empty(n, dtype=torch.int32, device=dev)
+
+        def gather(self, local, out, dst=0, async_op=False, group=None):
+            side = self.side[group]
+            side.wait_stream(torch.cuda.current_stream(dev))  # the collective starts behind what the caller's stream holds
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(2_000_000)  # ~1 ms before the frame is read: a caller that does not wait is caught (checked once
+                if out is not None:           # with wait() as a no-op: the values below come out wrong)
+                    for o in out:
+                        o.copy_(local, non_blocking=True)
+                else:
+                    self.sink.copy_(local, non_blocking=True)  # a send: the frame is read all the same
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return Work(ev)
+
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    outs = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
+    gathered = [[torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)] for _ in range(2)]
+    pipe = sharding.GatherPipeline(FakeDist(), 0, 2, outs, gathered, [0, 1], streams=streams, alternate=True)
+    for mode, base in ((None, 1000), ("0", 2000), ("rotate", 3000)):
+        seen = {}
+        step_of = []
+
+        def render(k, _s=step_of):
+            i = len(_s)
+            _s.append(k)
+            assert torch.cuda.current_stream(dev) == streams[k]
+            outs[k].fill_(base + i)  # (on streams[k]: the pipeline made it the current stream)
+
+        def on_gathered(step, bufs, _seen=seen):
+            # (enqueued on the buffer's stream behind the wait for its gather: reads what the gather delivered)
+            _seen[step] = [b[::4099].clone() for b in bufs]
+        for i in range(12):
+            pipe.step(i, render, mode, on_gathered)
+        pipe.drain(on_gathered)
+        torch.cuda.synchronize(dev)
+        assert step_of == [0, 1] * 6
+        want_steps = {None: [], "0": list(range(12)), "rotate": [0, 2, 4, 6, 8, 10]}[mode]
+        assert sorted(seen) == want_steps
+        for step, bufs in seen.items():
+            for b in bufs:
+                assert int(b.min()) == base + step and int(b.max()) == base + step, (mode, step, int(b.min()), int(b.max()))
+
+
 def test_too_small_buffers_are_refused_not_read(engine):
     hip, ctx = engine.hip, engine.ctx
     hip.jh_dispatch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(Binding), ctypes.c_int]

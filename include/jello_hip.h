@@ -112,6 +112,10 @@ const char* jh_last_error(jh_ctx* ctx);
 const char* jh_stage_name(int stage);
 /* Run on a caller-owned HIP stream (e.g. torch's current stream); NULL = the context's own. */
 int jh_set_stream(jh_ctx* ctx, void* hip_stream);
+/* A stream of the lowest (level < 0), default (0) or highest (> 0) launch priority of the context's device -- for a caller that puts
+ * a stage on a stream of its own (no reference counterpart; tools/fine_priority.py).  jh_stream_destroy releases it. */
+int jh_stream_create(jh_ctx* ctx, int level, void** hip_stream);
+int jh_stream_destroy(jh_ctx* ctx, void* hip_stream);
 int jh_sync(jh_ctx* ctx);
 /* Band mode (sharding ONE target over several GPUs): this context writes the PTCL and rasterises only the
  * bin rows [bin_row0, bin_row1) (a bin row = 16 tile rows = 256 pixel rows).  Every other stage, and the counting pass

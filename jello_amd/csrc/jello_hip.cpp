@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -317,6 +318,25 @@ int jh_set_stream(jh_ctx* ctx, void* hip_stream) {
         ctx->staging.used = 0;
     }
     ctx->stream = next;
+    return JH_OK;
+}
+
+// A stream of the lowest (level < 0), the default (0) or the highest (> 0) launch priority of the context's device, for callers that
+// want a stage on a stream of its own (tools/fine_priority.py).  Destroy with jh_stream_destroy.
+int jh_stream_create(jh_ctx* ctx, int level, void** hip_stream) {
+    if (!ctx || !hip_stream) return JH_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int least = 0, greatest = 0;
+    HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t st = nullptr;
+    HIP_TRY(ctx, hipStreamCreateWithPriority(&st, hipStreamNonBlocking, level < 0 ? least : (level > 0 ? greatest : 0)));
+    *hip_stream = (void*)st;
+    return JH_OK;
+}
+int jh_stream_destroy(jh_ctx* ctx, void* hip_stream) {
+    if (!ctx || !hip_stream) return JH_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamDestroy((hipStream_t)hip_stream));
     return JH_OK;
 }
 
@@ -892,6 +912,8 @@ int jh_graph_end(jh_ctx* ctx, void** graph_exec) {
                 }
         }
     }
+    // (Launch priorities per kernel node -- hipGraphKernelNodeSetAttribute(hipKernelNodeAttributePriority) -- are refused by this ROCm for
+    // every node; priorities through streams do not help either: profiles/r04_fine_priority.txt.)
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);

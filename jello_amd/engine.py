@@ -20,6 +20,7 @@ class CMD:
 
 
 RUN_UPLOADS, RUN_DISPATCHES, RUN_FREES, RUN_ALL = 1, 2, 4, 7
+RUN_SKIP_FINE, RUN_ONLY_FINE = 8, 16  # with RUN_DISPATCHES: everything but the fine stage / the fine stage alone
 
 
 class Recording:

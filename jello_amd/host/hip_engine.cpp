@@ -94,27 +94,29 @@ void Engine::run_recording(const Recording& rec, const std::vector<ExternalImage
                 break;
             case Command::Dispatch:
                 if (flags & kRunDispatches) {
+                    const bool is_fine = cmd.shader == JH_FINE_AREA || cmd.shader == JH_FINE_MSAA8 || cmd.shader == JH_FINE_MSAA16;
+                    if ((is_fine && (flags & kRunSkipFine)) || (!is_fine && (flags & kRunOnlyFine))) break;
                     bind(cmd.bindings);
                     check(jh_dispatch(ctx_, cmd.shader, cmd.wg_count[0], cmd.wg_count[1], cmd.wg_count[2], bindings.data(), (int)bindings.size()),
                           jh_stage_name(cmd.shader));
                 }
                 break;
             case Command::DispatchIndirect:
-                if (flags & kRunDispatches) {
+                if ((flags & kRunDispatches) && !(flags & kRunOnlyFine)) {
                     bind(cmd.bindings);
                     check(jh_dispatch_indirect(ctx_, cmd.shader, cmd.buffer.id, cmd.offset, bindings.data(), (int)bindings.size()),
                           jh_stage_name(cmd.shader));
                 }
                 break;
             case Command::Download:
-                if (flags & kRunDispatches) {
+                if ((flags & kRunDispatches) && !(flags & kRunOnlyFine)) {
                     std::vector<uint8_t>& dst = downloads_[cmd.buffer.id];
                     dst.resize(cmd.buffer.size);
                     check(jh_download(ctx_, cmd.buffer.id, dst.data(), 0, cmd.buffer.size), "download");
                 }
                 break;
             case Command::Clear:
-                if (flags & kRunDispatches) {
+                if ((flags & kRunDispatches) && !(flags & kRunOnlyFine)) {
                     if (jh_buffer_device_ptr(ctx_, cmd.buffer.id) != nullptr) {
                         check(jh_clear(ctx_, cmd.buffer.id, cmd.offset, cmd.size), "clear");
                     } else {

@@ -27,6 +27,8 @@ enum RunFlags : unsigned {
     kRunUploads = 1,     // Upload / UploadUniform / UploadImage
     kRunDispatches = 2,  // Dispatch / DispatchIndirect / Clear / Download
     kRunFrees = 4,       // FreeBuffer / FreeImage (deferred to the end of the recording, wgpu.go:601-616)
+    kRunSkipFine = 8,    // with kRunDispatches: every dispatch but the fine stage's (the last one of a RenderFull recording)
+    kRunOnlyFine = 16,   // with kRunDispatches: the fine stage's dispatch alone -- the two let a caller put fine on a stream of its own
     kRunAll = 7
 };
 

@@ -249,9 +249,21 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #define FINE_WAVES 1  // tile-waves per workgroup (round 3, C3: 0.405 ms with 1, 0.421 with 2, 0.428 with 4: the CU takes 24 one-wave workgroups)
 #endif
 #define FB_PLANE 65
+#ifndef FINE_FINAL_ASM
+#define FINE_FINAL_ASM 1  // (C3 fine 351.3 -> 347.0 us on the same box)
+#endif
+#ifndef FINE_CROSS_INLANE
+#define FINE_CROSS_INLANE 1  // (0: every crossing pixel through the lane = crossing pixel passes, as up to round 4: C3 fine 362.6 -> 354.5 us with 1)
+#endif
 // FINE_SKIP (differential builds, `make VARIANT=... EXTRA=-DFINE_SKIP=n`; results are WRONG, only counters and times of
 // such a library are of interest -- tools/fine_split.sh): 1 no crossing-pixel formula (stage 3), 2 no row walk / y_edge
-// terms (stage 4), 3 no pair evaluation (stages 2 + 3), 4 no batches at all, 5 no compositing of solid colours
+// terms (stage 4), 3 no pair evaluation (stages 2 + 3), 4 no batches at all, 5 no compositing of solid colours,
+// 6 the FLOOR build (round 5): the real PTCL, the real segment windows, the real number of pairs and crossing pixels, but of
+// the coverage pipeline only the arithmetic the output is made of -- the WGSL's y-part once per (segment,row) pair, its
+// trapezoid formula (with the IEEE division) once per crossing pixel, two packed additions per segment of a fill (the WGSL's
+// own `area += a * dy`), finalisation, composite, store -- and none of what moves it between lanes (pair -> segment mapping,
+// row sort, entries, marks, owner scan, row walk).  What stage 1 and the classification cost is in it: without them the
+// number of pairs and crossing pixels is not known.
 #ifndef FINE_SKIP
 #define FINE_SKIP 0
 #endif
@@ -688,6 +700,43 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         F.pairflag[lane] = 0u;
         if (lane < 16u) F.rowmask[lane] = 0ull;
         batch_hi = so + e_rel;
+#if FINE_SKIP == 6
+        {   // floor build: every pair lane evaluates the y-part and the classification on the values its own lane holds
+            next_seg = so;
+            const bool is_pair = lane < n_pairs;
+            const float y = c_p0y - (float)(ra & 15);
+            const float y0 = clamp_(y, 0.0f, 1.0f);
+            const float y1 = clamp_(y + dly, 0.0f, 1.0f);
+            const float s2_dy = y0 - y1;
+            const float vec_y_recip = 1.0f / dly;
+            const float s2_tx0 = ((y0 - y) * vec_y_recip) * dlx, s2_tx1 = ((y1 - y) * vec_y_recip) * dlx;
+            const float gx0 = c_p0x + s2_tx0, gx1 = c_p0x + s2_tx1;
+            const float xmin0 = fmin_(gx0, gx1), xmax0 = fmax_(gx0, gx1);
+            const bool guard = sane && abs_(xmin0) <= 40.0f && abs_(xmax0) <= 40.0f;
+            const int32_t c1 = guard ? iclamp_((int32_t)ceil_(xmax0 + 1.0e-3f), 0, 16) : 16;
+            const int32_t n0 = guard ? iclamp_((int32_t)floor_(xmin0 - 1.0e-3f), 0, 16) : 0;
+            const uint32_t ncross = (is_pair && s2_dy != 0.0f) ? (uint32_t)imax_(c1 - n0, 0) : 0u;
+            const uint32_t nspec = wave_reduce_u32(ncross);
+            float sink = 0.0f;
+            for (uint32_t k0 = 0u; k0 < nspec; k0 += 64u) {  // uniform: one formula per 64 crossing pixels
+                const uint32_t X = ((uint32_t)n0 + k0) & 15u;
+                const float i_f = (float)(X & 3u);
+                const float startx = c_p0x - (float)(4u * (X >> 2));
+                const float x0 = startx + s2_tx0, x1 = startx + s2_tx1;
+                const float xmn0 = fmin_(x0, x1), xmx0 = fmax_(x0, x1);
+                float xmin = fmin_(xmn0 - i_f, 1.0f) - 1.0e-6f;
+                float xmax = xmx0 - i_f;
+                float b = fmin_(xmax, 1.0f);
+                float c = fmax_(b, 0.0f);
+                float d = fmax_(xmin, 0.0f);
+                float a = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
+                sink = a * s2_dy;
+                asm volatile("" : "+v"(sink));
+            }
+            asm volatile("" ::"v"(sink));
+            return;
+        }
+#endif
         wave_sync();
         if (lane < e_rel && my_cnt != 0u) F.pairflag[first & 63u] = lane + 1u;
         wave_sync();
@@ -753,21 +802,45 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
 #pragma unroll
             for (int q = 0; q < 4; q++) F.ent[q][pos] = make_float4(cv[4 * q], cv[4 * q + 1], cv[4 * q + 2], cv[4 * q + 3]);
         }
-        const uint32_t sincl = wave_incl_scan_u32(ncross);
-        const uint32_t spos = sincl - ncross;
+#if FINE_CROSS_INLANE
+        // The pair's own lane evaluates its FIRST crossing pixel (round 5): all operands are in its registers, so the pixel
+        // costs the formula and one store -- not a mark, a share of the owner scan and five lane shuffles.  Only the
+        // pixels behind it (0.8 per pair on C3 instead of 1.8) go through the lane = crossing pixel passes below.
+        if (ncross != 0u) {
+            const uint32_t X = (uint32_t)n0 & 15u;
+            const float i_f = (float)(X & 3u);
+            const float startx = p0x - (float)(4u * (X >> 2));
+            const float x0 = startx + s2_tx0, x1 = startx + s2_tx1;
+            const float xmn0 = fmin_(x0, x1), xmx0 = fmax_(x0, x1);
+            float xmin = fmin_(xmn0 - i_f, 1.0f) - 1.0e-6f;
+            float xmax = xmx0 - i_f;
+            float b = fmin_(xmax, 1.0f);
+            float c = fmax_(b, 0.0f);
+            float d = fmax_(xmin, 0.0f);
+            float a = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
+            ((float*)&F.ent[X >> 2][pos])[X & 3u] = a * s2_dy;
+        }
+        const uint32_t nrest = ncross != 0u ? ncross - 1u : 0u;
+        const int32_t n0r = n0 + 1;
+#else
+        const uint32_t nrest = ncross;
+        const int32_t n0r = n0;
+#endif
+        const uint32_t sincl = wave_incl_scan_u32(nrest);
+        const uint32_t spos = sincl - nrest;
         const uint32_t nspec = (FINE_SKIP == 1 || FINE_SKIP == 3) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
         // stage 3, lane = crossing pixel, in passes of FB_SPEC of them (one pass unless the batch is full of long flat
         // segments).  Crossing pixel k of the batch belongs to the last pair whose first crossing pixel (spos) is <= k:
         // the pairs mark their starts in a byte array, a running maximum over the lanes turns the marks into owners.
-        const uint32_t packed = (uint32_t)n0 | (pos << 4) | (spos << 10);
+        const uint32_t packed = ((uint32_t)n0r & 15u) | (pos << 4) | (spos << 10);
         for (uint32_t pass = 0u; pass < nspec; pass += FB_SPEC) {
             wave_sync();  // (the entries above / the previous pass's mark reads are done)
             ((uint16_t*)F.specmark)[lane] = 0u;
             wave_sync();
-            if (ncross != 0u && spos - pass < FB_SPEC) F.specmark[spos - pass] = (uint8_t)(lane + 1u);
+            if (nrest != 0u && spos - pass < FB_SPEC) F.specmark[spos - pass] = (uint8_t)(lane + 1u);
             wave_sync();
             // the pair the first position of the pass belongs to when it does not start there
-            const uint64_t before = __builtin_amdgcn_ballot_w64(ncross != 0u && spos < pass);
+            const uint64_t before = __builtin_amdgcn_ballot_w64(nrest != 0u && spos < pass);
             uint32_t carry = before != 0ull ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
             const uint32_t n_here = umin_(nspec - pass, FB_SPEC);
             for (uint32_t k0 = 0u; k0 < n_here; k0 += 64u) {
@@ -929,7 +1002,16 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             if (sa != next_seg) done = (uint32_t)__builtin_popcountll(my_rowmask & below(first_of(r0)));  // (a fill that does not continue the previous one)
             uint32_t cur = row_addr + done * 16u;
             uint64_t em = edge_mask & (below(r0 + take) & ~below(r0));
-            for (; FINE_SKIP != 2 && FINE_SKIP != 4;) {  // uniform
+#if FINE_SKIP == 6
+            {   // floor build: the WGSL's own two packed additions per segment (the value is the lane's y coordinate: anything)
+                jk_v2f a01 = {area[0], area[1]}, a23 = {area[2], area[3]};
+                for (uint32_t s_ = 0u; s_ < take; s_++) {  // uniform
+                    asm volatile("v_pk_add_f32 %0, %0, %2 op_sel_hi:[1,0]\n\tv_pk_add_f32 %1, %1, %2 op_sel_hi:[1,0]" : "+v"(a01), "+v"(a23) : "v"(make_float2(lyf, lyf)));
+                }
+                area[0] = a01.x; area[1] = a01.y; area[2] = a23.x; area[3] = a23.y;
+            }
+#endif
+            for (; FINE_SKIP != 2 && FINE_SKIP != 4 && FINE_SKIP != 6;) {  // uniform
                 const uint32_t e_sl = em != 0ull ? (uint32_t)__builtin_ctzll(em) : 0u;
                 const uint32_t seg_end = em != 0ull ? e_sl + 1u : r0 + take;  // the run covers window segments < seg_end
                 done = (uint32_t)__builtin_popcountll(my_rowmask & below(first_of(seg_end)));
@@ -990,7 +1072,15 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             for (int k = 0; k < 4; k++) { float a = area[k]; area[k] = abs_(a - 2.0f * round_(0.5f * a)); }
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) area[k] = fmin_(abs_(area[k]), 1.0f);
+            for (int k = 0; k < 4; k++) {
+#if FINE_FINAL_ASM && defined(__HIP_DEVICE_COMPILE__)
+                // min(|a|, 1) as ONE instruction: the compiler puts a canonicalising v_max |a|, |a| in front of its v_min because the sum
+                // comes out of inline assembly (it cannot know that an addition's result is never a signalling NaN).
+                asm("v_min_f32_e64 %0, |%1|, 1.0" : "=v"(area[k]) : "v"(area[k]));
+#else
+                area[k] = fmin_(abs_(area[k]), 1.0f);
+#endif
+            }
         }
       } else {
         (void)n_segs; (void)even_odd;

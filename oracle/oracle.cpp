@@ -2219,6 +2219,12 @@ static void fill_path_ms_tile(int SAMPLES, uint32_t size_and_rule, uint32_t seg_
 }
 
 extern "C" void oracle_set_threads(int n) { g_oracle_threads = n < 1 ? 1 : n; }
+// EXPERIMENT switch (tools/fine_order_ulp.py; never set by a test or by bench.py): the association of fill_path's sum.
+// 0: the WGSL's (the oracle proper).  1: the terms of a fill are summed on their own, the backdrop is added last -- what a
+// per-(fill,row) segmented sum would compute.  2: the segments of a fill in reverse order.  Used to MEASURE what
+// north_star's "within 1 ULP" would leave of the image if the f32 order of fine.wgsl:832-864 were given up.
+static int g_oracle_fine_order = 0;
+extern "C" void oracle_set_fine_order(int o) { g_oracle_fine_order = o; }
 extern "C" void oracle_set_parallel_alloc(int on) { g_oracle_parallel_alloc = on != 0; }
 
 // aa = 0: analytic area (fine_area); 8 / 16: fine_msaa8 / fine_msaa16 with the mask LUT as last binding
@@ -2292,8 +2298,10 @@ static void fine_area(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b, int nb, int aa 
                                     break;
                                 }
                                 float backdrop_f = (float)backdrop;
-                                for (int i = 0; i < 4; i++) area[i] = backdrop_f;
-                                for (uint32_t s = 0; s < n_segs; s++) {
+                                const int order = g_oracle_fine_order;
+                                for (int i = 0; i < 4; i++) area[i] = order == 1 ? 0.0f : backdrop_f;
+                                for (uint32_t s_ = 0; s_ < n_segs; s_++) {
+                                    const uint32_t s = order == 2 ? n_segs - 1u - s_ : s_;
                                     Segment seg = segments.rd((size_t)seg_data + s);
                                     float y = seg.p0[1] - lxyy;
                                     float dlx = seg.p1[0] - seg.p0[0], dly = seg.p1[1] - seg.p0[1];
@@ -2323,6 +2331,7 @@ static void fine_area(uint32_t n_wg_x, uint32_t n_wg_y, OBuf* b, int nb, int aa 
                                     float y_edge = sign_(dlx) * clamp_(lxyy - seg.y_edge + 1.0f, 0.0f, 1.0f);
                                     for (int i = 0; i < 4; i++) area[i] += y_edge;
                                 }
+                                if (order == 1) for (int i = 0; i < 4; i++) area[i] = backdrop_f + area[i];
                                 if (even_odd) {
                                     for (int i = 0; i < 4; i++) { float a = area[i]; area[i] = abs_(a - 2.0f * round_(0.5f * a)); }
                                 } else {

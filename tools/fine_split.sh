@@ -8,7 +8,7 @@ COMMIT=${1:-unknown}; shift
 OUT=$R/gpurun_out/fine_split
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for n in 0 1 2 3 4 5; do
+for n in 0 1 2 3 4 5 6; do
   if [ $n = 0 ]; then LIB=$R/jello_amd/libjello_hip.so; else
     make -s -j8 -C $R/jello_amd/csrc VARIANT=skip$n EXTRA="-DJH_VARIANT_BUILD -DFINE_SKIP=$n" > $OUT/build$n.log 2>&1 || { tail -5 $OUT/build$n.log; exit 1; }
     LIB=$R/jello_amd/libjello_hip_skip$n.so
@@ -22,9 +22,10 @@ python3 - "$OUT" "$COMMIT" "$R" <<'PY'
 import csv, glob, json, sys, collections
 out, commit, root = sys.argv[1:4]
 names = {0: "product library", 1: "without stage 3 (crossing-pixel formula)", 2: "without stage 4 (row walk, y_edge terms)",
-         3: "without stages 2 + 3 (pair evaluation)", 4: "without batches (stages 1-4)", 5: "without the solid-colour composite"}
+         3: "without stages 2 + 3 (pair evaluation)", 4: "without batches (stages 1-4)", 5: "without the solid-colour composite",
+         6: "FLOOR: real PTCL / windows / pair and crossing-pixel counts, only the arithmetic of the output (y-part per pair, formula per crossing pixel, two packed adds per segment, finalisation, composite, store)"}
 rows = []
-for n in range(6):
+for n in range(7):
     agg = collections.defaultdict(list)
     for f in glob.glob("%s/p%d/*/*counter_collection.csv" % (out, n)):
         for r in csv.DictReader(open(f)):

@@ -175,11 +175,17 @@ def run_rank(args, world):
     eng_of = [engs[k % n_ctx] for k in range(len(outs))]  # buffer k is rendered by context k (one context: both by the same)
     gathered = None
     gather_groups = [None, None]
+    mode_errors = {}  # gather mode -> why it could not be timed (the gather-free mode and the line survive it)
     if gather:
-        # one communicator per buffer of the double buffer: two gathers on ONE communicator run one after the other
-        gather_groups = [dist.new_group(ranks=list(range(world))) for _ in range(2)]
-        if rank == 0 or "rotate" in gather_modes:
-            gathered = [[torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(world)] for _ in range(2)]
+        try:
+            # one communicator per buffer of the double buffer: two gathers on ONE communicator run one after the other
+            gather_groups = [dist.new_group(ranks=list(range(world))) for _ in range(2)]
+            if rank == 0 or "rotate" in gather_modes:
+                gathered = [[torch.empty((H, W, 4), dtype=torch.float16, device=dev) for _ in range(world)] for _ in range(2)]
+        except Exception as e:  # noqa: BLE001 - RCCL / allocation trouble must not cost the gather-free measurement
+            for m in gather_modes:
+                mode_errors[m] = "gather set-up failed on rank %d: %s: %s" % (rank, type(e).__name__, e)
+            gather_groups, gathered = [None, None], None
 
     if args.bands:  # (buffers were sized by the unsharded render above; from here on this rank owns its band only)
         hb = (cfg["height_in_tiles"] + 15) // 16
@@ -252,8 +258,18 @@ def run_rank(args, world):
     blocks_plain = timed(None)
     # (two frames in flight: the one-context loop of the earlier rounds timed beside it, three blocks)
     blocks_one = timed(None, pipe_one, 3) if n_ctx == 2 else None
-    blocks_by_mode = {m: timed(m) for m in gather_modes}
-    head_mode = ("0" if "0" in gather_modes else gather_modes[0]) if gather else None  # C5 as written gathers on rank 0
+    # Each gather mode on its own: one that raises (the first contact of this path with RCCL on real hardware has not
+    # happened yet) is reported as {"error": ...} under `modes`; the gather-free measurement above and the line survive,
+    # and the process exits non-zero.  The ranks agree on a mode's fate through the default group (gloo-free: a MIN
+    # all-reduce of one flag); if even that fails the remaining modes are skipped.
+    def timed_mode(m):
+        fresh = sharding.GatherPipeline(dist, rank, world, outs, gathered, gather_groups, streams=streams if n_ctx == 2 else None,
+                                        alternate=n_ctx == 2)  # (a pipeline of its own: nothing pending from a mode that died)
+        return timed(m, fresh)
+    blocks_by_mode, mode_errors = sharding.time_modes_surviving_failures(dist, rank, gather_modes, timed_mode, dev, mode_errors) if gather_modes else ({}, mode_errors)
+    good_modes = [m for m in gather_modes if m in blocks_by_mode]
+    gather = bool(good_modes)
+    head_mode = ("0" if "0" in good_modes else good_modes[0]) if gather else None  # C5 as written gathers on rank 0
     blocks = blocks_by_mode[head_mode] if gather else blocks_plain
     elapsed_plain = blocks_plain[len(blocks_plain) // 2]
     elapsed = blocks[len(blocks) // 2]  # the median block
@@ -323,7 +339,12 @@ def run_rank(args, world):
             "config": {"workload": "%s, %dx%d RGBA16F target, %s AA, %s" % (what, W, H, args.aa,
                                    "one scene split into bin-row bands" if args.bands else "one independent scene per GPU"),
                        "paths": args.paths, "draw_objects": cfg["n_drawobj"], "width": W, "height": H, "parallelism": mode},
+            "value_definition": ("finished frames per second of the whole job x width x height: K steps between barrier + synchronize, "
+                                 "%d frame(s) in flight per GPU%s" % (n_ctx, "" if world == 1 else ", %d GPUs, one scene each" % world)),
             "paths_per_s": round(args.paths * units / per, 1),
+            "paths_per_s_definition": "a RATE (user paths of the frames finished per second), not SURVEY 8(d)'s scene-resident -> image-complete "
+                                      "time of one frame: that is paths_per_s_latency",
+            "paths_per_s_latency": None if blocks_one is None else round(args.paths / (blocks_one[len(blocks_one) // 2] / args.steps), 1),
             "fine_mpixels_per_s": round(W * H / (fine_ms * 1e-3) / 1e6, 2),
             "frames_in_flight": n_ctx,
             "one_frame_at_a_time": None if blocks_one is None else {
@@ -340,6 +361,8 @@ def run_rank(args, world):
             "cpu_baseline": cpu,
             "device": eng.device_info()["name"],
         }
+        if world == 1:
+            result["value_mode"] = "%d frame(s) in flight on one GPU%s" % (n_ctx, "" if n_ctx == 1 else " (the one-context figure of rounds 1-3 is one_frame_at_a_time.value)")
         if world > 1 and not args.bands:
             # Every mode of this run side by side.  `render` = the gather-free step of THIS run (every rank finishes one frame
             # per step), so N * render / step is the speed-up over one of this run's own ranks that a mode delivers.
@@ -359,8 +382,19 @@ def run_rank(args, world):
                 return e
             result["modes"] = {"no_gather": mode_entry("no_gather", blocks_plain, None)}
             for m in gather_modes:
-                result["modes"]["gather_to_rank0" if m == "0" else "gather_to_rank_step_mod_n"] = mode_entry(
-                    m, blocks_by_mode[m], sharding.gather_model(world, pp * 1e3, frame_bytes, m))
+                key = "gather_to_rank0" if m == "0" else "gather_to_rank_step_mod_n"
+                model = sharding.gather_model(world, pp * 1e3, frame_bytes, m)
+                if m in blocks_by_mode:
+                    result["modes"][key] = mode_entry(m, blocks_by_mode[m], model)
+                else:
+                    result["modes"][key] = {"error": mode_errors.get(m, "not timed"), "wire_model": model, "ceiling_speedup": model["ceiling_speedup"]}
+            # north_star asks for >= 6 x at 8 GPUs: which mode can deliver that, from the wire alone, at this run's render time
+            for key, m in (("no_gather", None), ("gather_to_rank0", "0"), ("gather_to_rank_step_mod_n", "rotate")):
+                if key in result["modes"]:
+                    c8 = 8.0 if m is None else sharding.gather_model(8, pp * 1e3, frame_bytes, m)["ceiling_speedup"]
+                    result["modes"][key]["ceiling_speedup_at_8_gpus"] = c8
+                    result["modes"][key]["can_meet_6x_at_8_gpus"] = bool(c8 >= 6.0)
+            result["mode_errors"] = mode_errors or None
             result["value_mode"] = "no_gather" if not gather else ("gather_to_rank0" if head_mode == "0" else "gather_to_rank_step_mod_n")
             result["value_no_gather"] = result["modes"]["no_gather"]["value"]
             result["ms_per_step_no_gather"] = round(pp * 1e3, 4)
@@ -376,6 +410,8 @@ def run_rank(args, world):
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+    if mode_errors:  # the line is out; a gather mode that failed still fails the run
+        sys.exit(3)
 
 
 def measured_copy_gbs(torch, dev):

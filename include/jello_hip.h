@@ -131,6 +131,10 @@ int jh_set_band(jh_ctx* ctx, uint32_t bin_row0, uint32_t bin_row1);
  * engine shims count the depth off encoding.DrawTags in RenderToTexture; the reference has no counterpart (its blend stack is
  * `var blend_stack: array<array<vec4<f32>, 4>, 4>` in registers). */
 int jh_set_clip_depth_hint(jh_ctx* ctx, uint32_t max_depth);
+/* Blend-stack saves fine dropped since the last reset because the hint above was smaller than the scene's real nesting depth
+ * (each one is a wrong pixel colour; memory safety is never at stake): 0 after every frame rendered with a correct hint or
+ * with no hint.  A caller that sets hints should check it in debug builds.  Synchronises the context's stream. */
+int jh_debug_clip_hint_overflows(jh_ctx* ctx, uint32_t* count, int reset);
 
 /* ---- buffers (ids are the recording's ResourceIDs; sizes in bytes) ---- */
 int jh_buffer_create(jh_ctx* ctx, uint64_t id, uint64_t size);

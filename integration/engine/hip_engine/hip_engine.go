@@ -260,9 +260,13 @@ func (e *Engine) RenderToTexture(arena *mem.Arena, enc *encoding.Encoding, targe
 		recording = e.renderer.RecordFine(arena, &render, e.fullShaders, recording, pgroup)
 		// fine's blend-stack scratch is sized from the nesting depth of the clip layers (include/jello_hip.h,
 		// jh_set_clip_depth_hint); the hint is taken back after the run so that it never outlives its scene
-		e.check(C.jh_set_clip_depth_hint(e.ctx, C.uint32_t(maxClipDepth(enc))), "set_clip_depth_hint")
-		e.RunRecording(recording, []ExternalImage{{Proxy: out, DevicePtr: target}}, "RunRecording")
-		e.check(C.jh_set_clip_depth_hint(e.ctx, 0), "set_clip_depth_hint")
+		// (taken back by a deferred call: a panic inside RunRecording must not leave a stale hint on the context -- a hint
+		// that is too small for a later scene loses colours without an error; jh_debug_clip_hint_overflows would tell)
+		func() {
+			e.check(C.jh_set_clip_depth_hint(e.ctx, C.uint32_t(maxClipDepth(enc))), "set_clip_depth_hint")
+			defer C.jh_set_clip_depth_hint(e.ctx, 0)
+			e.RunRecording(recording, []ExternalImage{{Proxy: out, DevicePtr: target}}, "RunRecording")
+		}()
 		raw := e.downloads[bumpID]
 		if len(raw) < 32 || attempt >= 6 {
 			e.check(C.jh_sync(e.ctx), "sync")

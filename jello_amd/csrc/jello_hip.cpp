@@ -113,6 +113,7 @@ struct jh_ctx {
     // fine: descriptor table of the bound image array when it has more entries than fit in the kernel arguments
     void* image_table = nullptr;
     uint64_t image_table_cap = 0;
+    uint32_t* hint_overflow = nullptr;  // device word: blend-stack saves fine had to drop because the clip-depth hint was too small
     std::vector<JhImageDesc> image_table_host;
     std::vector<Deferred> deferred;  // held-back commands, in recording order
 };
@@ -170,6 +171,11 @@ void* jh_scratch_get(JhScratch* s, int slot, uint64_t bytes) {
     if (slot < 0 || slot >= JH_SCR_COUNT) return nullptr;
     if (bytes < 256) bytes = 256;
     if (s->cap[slot] >= bytes) return s->ptr[slot];
+    // A capture records pointers: growing an array now would leave the graph with a mix of old and new ones, and
+    // jh_graph_end would put the "left clean" flag of the NEW, uninitialised memory back up.  The contract --
+    // run the recording once eagerly before capturing it -- makes every array big enough; a capture that still has to grow
+    // one is refused (the dispatch answers JH_ERR_OOM with a message that says so).
+    if (s->ctx->capturing) return nullptr;
     uint64_t cap = pool_size_class(bytes);
     void* p = nullptr;
     // Every slot starts at its own offset (a multiple of 256 B) into its allocation: the flatten kernels walk up to
@@ -282,6 +288,7 @@ int jh_create(jh_ctx** out, int device) {
     std::memset(&ctx->scratch.base, 0, sizeof ctx->scratch.base);
     ctx->scratch.clean_flags = 0u;
     ctx->scratch.ctx = ctx;
+    if (hipMalloc((void**)&ctx->hint_overflow, 256) != hipSuccess || hipMemset(ctx->hint_overflow, 0, 256) != hipSuccess) ctx->hint_overflow = nullptr;
     *out = ctx;
     return JH_OK;
 }
@@ -300,6 +307,7 @@ void jh_destroy(jh_ctx* ctx) {
     scratch_release_retired(&ctx->scratch);
     if (ctx->staging.base) (void)hipHostFree(ctx->staging.base);
     if (ctx->image_table) (void)hipFree(ctx->image_table);
+    if (ctx->hint_overflow) (void)hipFree(ctx->hint_overflow);
     for (auto& p : ctx->prof)
         if (p.kind == JH_PROF_QUERY) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (auto& e : ctx->free_events) (void)hipEventDestroy(e);
@@ -792,6 +800,7 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
     L.band_row0 = ctx->band_row0;
     L.band_row1 = ctx->band_row1;
     L.clip_depth_hint = ctx->clip_depth_hint;
+    L.hint_overflow = ctx->hint_overflow;
     L.image_table = nullptr;
     if ((int)images.size() > JH_FINE_INLINE_IMAGES && stage >= JH_FINE_AREA) {
         // More images than fit in the kernel arguments: fine indexes a device table of descriptors (the reference binds
@@ -825,6 +834,15 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
         auto sh = ctx->config_shadow.find(bindings[0].id);
         if (sh != ctx->config_shadow.end()) L.cfg_host = &sh->second;
     }
+    // binning and coarse address a bin by its index in a 256-entry table (one per lane of the 256-thread workgroup:
+    // binning.wgsl:52,131; coarse.wgsl:153-176): a target of more than 256 bins of 256 x 256 px -- beyond 4096 px in a
+    // direction -- silently loses the bins past the 256th in the reference.  Here the dispatch is refused instead.
+    if ((stage == JH_BINNING || stage == JH_COARSE) && L.cfg_host) {
+        const uint64_t wb = (L.cfg_host->width_in_tiles + 15u) / 16u, hb = (L.cfg_host->height_in_tiles + 15u) / 16u;
+        if (wb * hb > 256u)
+            return fail(ctx, JH_ERR_INVALID, std::string(jh_stage_name(stage)) + ": the target has " + std::to_string(wb * hb) +
+                                                 " bins of 256 x 256 px, the pipeline addresses 256 (at most 4096 x 4096 px or any shape of <= 256 bins)");
+    }
     ProfEntry pe;
     if (ctx->profiling) {
         auto get_event = [&](hipEvent_t* e) {
@@ -857,7 +875,9 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
         pe.cpu_end_ms = now_ms();
         ctx->prof.push_back(pe);
     }
-    if (rc == -5) return fail(ctx, JH_ERR_OOM, "scratch allocation failed");
+    if (rc == -5)
+        return fail(ctx, JH_ERR_OOM, ctx->capturing ? "a scratch array would have to grow during graph capture: run the recording once eagerly first"
+                                                    : "scratch allocation failed");
     if (rc) return fail(ctx, JH_ERR_INVALID, std::string("bad bindings for stage ") + jh_stage_name(stage));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(ctx, e, jh_stage_name(stage));
@@ -1108,6 +1128,16 @@ int jh_set_clip_depth_hint(jh_ctx* ctx, uint32_t max_depth) {
     // (a captured graph has the layout of its capture baked in and never looks at the hint again; its scratch pointer stays
     // valid until the array is regrown, which bumps the generation by itself)
     ctx->clip_depth_hint = max_depth;
+    return JH_OK;
+}
+// Blend-stack saves the fine stage dropped since the last reset because jh_set_clip_depth_hint promised a shallower scene than
+// it got (every one of them is a wrong pixel colour): 0 for every correct hint.  Synchronises the stream.
+int jh_debug_clip_hint_overflows(jh_ctx* ctx, uint32_t* count, int reset) {
+    if (!ctx || !ctx->hint_overflow) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (count) HIP_TRY(ctx, hipMemcpy(count, ctx->hint_overflow, 4, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(ctx, hipMemset(ctx->hint_overflow, 0, 4));
     return JH_OK;
 }
 uint64_t jh_debug_scratch_bytes(jh_ctx* ctx, int slot) {

@@ -212,6 +212,7 @@ struct JhLaunch {
     uint32_t band_row0, band_row1;  // jh_set_band: bin rows [row0, row1) this context writes PTCL for and rasterises (0, ~0u = all)
     const JhImageDesc* image_table;  // device table of all n_images descriptors when n_images > JH_FINE_INLINE_IMAGES, else nullptr
     uint32_t clip_depth_hint;  // jh_set_clip_depth_hint: upper bound of the clip layers' nesting depth, 0 = unknown
+    uint32_t* hint_overflow;   // device counter of the blend-stack saves dropped because that hint was too small (or nullptr)
     uint32_t absorb;  // JH_ABSORB_*: held-back commands this stage performs in passing (jello_hip.cpp, Deferred)
     JhBound extra;    // JH_ABSORB_SETUP of path_tiling: the ptcl buffer of path_tiling_setup (ptcl[0] = ~0 on failure)
 };

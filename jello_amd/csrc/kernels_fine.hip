@@ -573,7 +573,8 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                                                   uint32_t tiles_x, const uint32_t* __restrict__ mask_lut, uint32_t mask_lut_n,
                                                   uint32_t tile_row0,  // first tile row of the launch (band mode)
                                                   float4* __restrict__ clip_scratch,  // CLIPS: stack levels behind the LDS one: [tile][scr_levels][4][64]
-                                                  uint32_t scr_levels) {               // levels per tile in clip_scratch (0 ... FINE_SCR_LEVELS, from the scene's clip depth)
+                                                  uint32_t scr_levels,                 // levels per tile in clip_scratch (0 ... FINE_SCR_LEVELS, from the scene's clip depth)
+                                                  uint32_t* __restrict__ hint_overflow) {  // counts the saves dropped for want of a level (a clip-depth hint that was too small)
     const uint32_t tile_y = blockIdx.y + tile_row0;
     // FINE_WAVES independent waves (= tiles, side by side in x) per workgroup: the CU runs at most 16 workgroups, so
     // single-wave workgroups would cap the occupancy at 4 waves per SIMD.  The waves never synchronise with each other.
@@ -895,6 +896,8 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                         float4* g = clip_scratch + (((size_t)scratch_tile * scr_levels + (pushed_depth - FINE_LDS_LEVELS)) * 4u) * 64u + lane;
 #pragma unroll
                         for (int k = 0; k < 4; k++) g[k * 64] = make_float4(rgba[k].x, rgba[k].y, rgba[k].z, rgba[k].w);
+                    } else if (hint_overflow != nullptr && lane == 0u) {
+                        atomicAdd(hint_overflow, 1u);  // detectable: jh_debug_clip_hint_overflows
                     }
                 } else {
                     const uint32_t spill_base = blend_offset + (pushed_depth - JL_BLEND_STACK_SPLIT) * JL_TILE_WIDTH * JL_TILE_HEIGHT;
@@ -1576,7 +1579,7 @@ static int launch_fine(const JhLaunch& L, int aa) {
 #define JH_FINE_LAUNCH(A, C, P)                                                                                                          \
     hipLaunchKernelGGL((k_fine_area<A, C, P>), dim3((L.gx + FINE_WG_WAVES(C) - 1) / FINE_WG_WAVES(C), trow1 - trow0), dim3(64 * FINE_WG_WAVES(C)), 0, L.stream, cfg, fc, seg_ptr, \
                        segments_n, (const uint32_t*)L.b[2].ptr, ptcl_n, (const uint32_t*)L.b[3].ptr, info_n, spill, (uint16_t*)out.ptr,         \
-                       out.width, out.height, (const uint16_t*)grad.ptr, grad_h, imgs, L.gx, mask_lut, mask_lut_n, trow0, clip_scratch, scr_levels)
+                       out.width, out.height, (const uint16_t*)grad.ptr, grad_h, imgs, L.gx, mask_lut, mask_lut_n, trow0, clip_scratch, scr_levels, L.hint_overflow)
 #define JH_FINE_PICK(A)                                  \
     do {                                                 \
         if (clips && paints) JH_FINE_LAUNCH(A, true, true);   \

@@ -492,6 +492,13 @@ Renderer::Result Renderer::render_full(const Encoding& enc, Resolver& resolver, 
             images_[img.key] = proxy;
         }
     }
+    {   // binning.wgsl:52,131 / coarse.wgsl: a bin is an index into a 256-entry table, so bins past the 256th are lost without
+        // a trace in the reference (a wrong frame); the recording is refused here instead
+        const uint64_t wb = ((uint64_t)params.width + 255u) / 256u, hb = ((uint64_t)params.height + 255u) / 256u;
+        if (wb * hb > 256u)
+            throw std::invalid_argument("render: a " + std::to_string(params.width) + " x " + std::to_string(params.height) + " target has " +
+                                        std::to_string(wb * hb) + " bins of 256 x 256 px; binning and coarse address 256 (at most 4096 x 4096)");
+    }
     res.config = new_render_config(layout, params.width, params.height, params.base_color, params.bump_sizes);
     const BufferSizes& sizes = res.config.buffer_sizes;
     const WorkgroupCounts& wg = res.config.workgroup_counts;

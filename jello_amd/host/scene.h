@@ -47,8 +47,11 @@ class Scene {
     // Pixel copies of the image brushes that entered through the C API, one per (key, contents): thousands of fills
     // with one image share one copy.  Entries live as long as the Scene; the patches hold references of their own.
     std::shared_ptr<const std::vector<uint8_t>> own_pixels(uint64_t key, const uint8_t* px, size_t n) {
+        // A key with the top bit set is derived from the contents by the caller (Brush.image's default): equal key and length
+        // mean equal pixels, so a fill with an image that is already stored costs a lookup.  Any other key is an identity the
+        // caller chose -- its pixels may have changed since, so they are compared (O(pixels) per draw).
         auto it = image_store_.find(key);
-        if (it != image_store_.end() && it->second->size() == n && std::memcmp(it->second->data(), px, n) == 0) return it->second;
+        if (it != image_store_.end() && it->second->size() == n && ((key >> 63) != 0u || std::memcmp(it->second->data(), px, n) == 0)) return it->second;
         auto copy = std::make_shared<const std::vector<uint8_t>>(px, px + n);
         image_store_[key] = copy;
         return copy;

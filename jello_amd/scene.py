@@ -115,17 +115,25 @@ class Brush:
     def radial(c0, r0, c1, r1, stops, extend=Extend.Pad): return Brush(Brush.RADIAL, p0=c0, p1=c1, r0=r0, r1=r1, stops=stops, extend=extend)
     @staticmethod
     def sweep(center, t0, t1, stops, extend=Extend.Pad): return Brush(Brush.SWEEP, p0=center, t0=t0, t1=t1, stops=stops, extend=extend)
-    _image_keys = itertools.count(1 << 48)
-
     @staticmethod
     def image(pixels_rgba8, key=None):
         """`key` is the image's identity for de-duplication (the Go code keys on the image.Image pointer).  The default
-        is a fresh number per Brush -- NOT the array's address, which another array can reuse after this one is freed.
-        The C++ Scene copies the pixels inside fill / stroke, so the array only has to live until that call returns."""
+        is derived from the CONTENTS (a 63-bit BLAKE2b of shape + bytes, top bit set to mark it): the same pixels wrapped in
+        a Brush N times are one atlas entry, as one image.Image drawn N times is in the reference -- and never the array's
+        address, which another array can reuse after this one is freed.  The C++ Scene copies the pixels inside fill /
+        stroke, so the array only has to live until that call returns."""
         px = np.ascontiguousarray(pixels_rgba8, dtype=np.uint8)
         if px.ndim != 3 or px.shape[2] != 4:
             raise ValueError("image pixels must be (height, width, 4) uint8")
-        return Brush(Brush.IMAGE, pixels=px, key=key if key is not None else next(Brush._image_keys))
+        if key is None:
+            import hashlib
+            h = hashlib.blake2b(digest_size=8)
+            h.update(np.asarray(px.shape, dtype=np.uint64).tobytes())
+            h.update(px.tobytes())
+            key = int.from_bytes(h.digest(), "little") | (1 << 63)
+        elif int(key) >> 63:
+            raise ValueError("image keys with the top bit set are reserved for content-derived keys")
+        return Brush(Brush.IMAGE, pixels=px, key=int(key))
 
     def _c(self):
         b = CBrush()

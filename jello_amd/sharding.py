@@ -103,6 +103,39 @@ class GatherPipeline:
                 self._finish(k, on_gathered)
 
 
+def time_modes_surviving_failures(dist, rank, modes, timed, device, already_failed=None):
+    """Time each gather mode on its own (`timed(mode)` -> block times).  A mode that raises on ANY rank is dropped on EVERY
+    rank -- the ranks agree through a MIN all-reduce of one flag on the default group -- and reported in the returned error
+    dict; the modes before and behind it are still timed.  If the agreement itself fails the process group is taken to be
+    unusable and the remaining modes are skipped.  Returns (blocks_by_mode, errors)."""
+    import torch
+    blocks, errors = {}, dict(already_failed or {})
+    comm_ok = True
+    for m in modes:
+        if m in errors:
+            continue
+        if not comm_ok:
+            errors[m] = "skipped: an earlier mode left the process group unusable"
+            continue
+        ok = 1
+        try:
+            blocks[m] = timed(m)
+        except Exception as e:  # noqa: BLE001 - whatever RCCL or the pipeline raises must not cost the other modes
+            ok = 0
+            errors[m] = "rank %d: %s: %s" % (rank, type(e).__name__, str(e)[:300])
+        try:
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                blocks.pop(m, None)
+                errors.setdefault(m, "failed on another rank")
+        except Exception as e:  # noqa: BLE001
+            comm_ok = False
+            blocks.pop(m, None)
+            errors.setdefault(m, "rank %d: agreement all-reduce failed: %s" % (rank, type(e).__name__))
+    return blocks, errors
+
+
 XGMI_ONE_WAY_GBS = 76.8  # one xGMI link of an MI355X: 153.6 GB/s bidirectional; every GPU pair of a node has its own link
 
 

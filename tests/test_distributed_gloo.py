@@ -217,3 +217,55 @@ def test_bench_gpus_2_without_gpus_fails_loudly():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert '"n_gpus"' not in r.stdout
+
+
+def _failing_mode_worker(rank, world, port, q):
+    """bench.py's mode loop (sharding.time_modes_surviving_failures) on gloo: mode "0" raises on rank 1 only (before any
+    collective of the mode), mode "rotate" works.  Both ranks must drop "0", keep "rotate", and stay in step."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from jello_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        groups = [dist.new_group(ranks=list(range(world))) for _ in range(2)]
+        outs = [torch.zeros(8, dtype=torch.int32) for _ in range(2)]
+        gathered = [[torch.zeros(8, dtype=torch.int32) for _ in range(world)] for _ in range(2)]
+
+        def timed(mode):
+            if mode == "0" and rank == 1:
+                raise RuntimeError("simulated RCCL failure")
+            if mode == "0":
+                return [1.0]  # (rank 0 believes the mode went fine: the agreement must overrule it)
+            pipe = sharding.GatherPipeline(dist, rank, world, outs, gathered, groups)
+            for i in range(4):
+                pipe.step(i, lambda k: outs[k].fill_(10 * i + rank), mode)
+            pipe.drain()
+            return [2.0, 3.0]
+        blocks, errors = sharding.time_modes_surviving_failures(dist, rank, ["0", "rotate"], timed, torch.device("cpu"))
+        q.put((rank, blocks, errors))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_gather_mode_is_reported_and_the_others_survive(built):
+    """a gather mode that fails on first contact with hardware must not cost the line."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_mode_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (b, e) for r, b, e in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        blocks, errors = res[r]
+        assert list(blocks) == ["rotate"] and blocks["rotate"] == [2.0, 3.0]
+        assert list(errors) == ["0"]
+    assert "simulated RCCL failure" in res[1][1]["0"] and res[0][1]["0"] == "failed on another rank"

@@ -42,3 +42,32 @@ def test_misuse_returns_error_codes(engine):
     s, p = scenes.scene_c1()
     rec, bump, attempts = engine.render(s, p, retain=False)
     assert bump["failed"] == 0
+
+
+def test_binning_and_coarse_refuse_more_than_256_bins(engine):
+    """A ConfigUniform whose target has more than 256 bins (binning.wgsl:52,131 index them in a 256-entry table): the dispatch
+    returns an error instead of producing a frame that misses the bins past the 256th."""
+    hip, ctx = engine.hip, engine.ctx
+    hip.jh_dispatch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(Binding), ctypes.c_int]
+    hip.jh_upload.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+    hip.jh_free.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+    cfg = np.zeros(25, np.uint32)  # a ConfigUniform is recognised by its size (100 bytes): the launchers read its host shadow
+    cfg[0], cfg[1] = 257, 256   # width / height in tiles: 17 x 16 = 272 bins
+    ids = [0x5b100 + i for i in range(9)]
+    buf = np.zeros(4096, np.uint8)
+    try:
+        assert hip.jh_upload(ctx, ids[0], cfg.ctypes.data, cfg.nbytes) == 0
+        for i in ids[1:]:
+            assert hip.jh_upload(ctx, i, buf.ctypes.data, buf.nbytes) == 0
+        b8 = (Binding * 8)(*[Binding(1, 0, i, None) for i in ids[:8]])
+        b9 = (Binding * 9)(*[Binding(1, 0, i, None) for i in ids[:9]])
+        assert hip.jh_dispatch(ctx, 11, 1, 1, 1, b8, 8) < 0    # JH_BINNING
+        assert b"bins" in hip.jh_last_error(ctx)
+        assert hip.jh_dispatch(ctx, 16, 17, 16, 1, b9, 9) < 0  # JH_COARSE
+        cfg[0] = 256
+        assert hip.jh_upload(ctx, ids[0], cfg.ctypes.data, cfg.nbytes) == 0
+        assert hip.jh_dispatch(ctx, 11, 1, 1, 1, b8, 8) == 0   # 256 bins: accepted (n_drawobj = 0: nothing to bin)
+        engine.sync()
+    finally:
+        for i in ids:
+            hip.jh_free(ctx, i)

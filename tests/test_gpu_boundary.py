@@ -262,6 +262,46 @@ def test_blend_stack_scratch_follows_the_clip_depth(depth):
         assert cap >= tiles * levels * 4096
         if levels < 3:
             assert cap < tiles * 3 * 4096, (cap, tiles * 3 * 4096)
+        n = ctypes.c_uint32(99)
+        assert eng.hip.jh_debug_clip_hint_overflows(eng.ctx, ctypes.byref(n), 0) == 0 and n.value == 0  # a correct hint drops no save
+    finally:
+        eng.close()
+
+
+def test_a_clip_depth_hint_that_is_too_small_is_detectable():
+    """jh_set_clip_depth_hint is sticky context state and a hint below the scene's real nesting depth drops blend-stack
+    saves (wrong colours, never a fault).  A direct user of the ABI can tell: jh_debug_clip_hint_overflows counts the dropped
+    saves.  Here the fine stage of a 3-deep scene is dispatched by hand with the hint forced to 1."""
+    from jello_amd.engine import CMD, RUN_SKIP_FINE
+
+    class Binding(ctypes.Structure):
+        _fields_ = [("kind", ctypes.c_uint32), ("count", ctypes.c_uint32), ("id", ctypes.c_uint64), ("ids", ctypes.POINTER(ctypes.c_uint64))]
+    eng = jello_amd.Engine(0)
+    try:
+        hip, ctx = eng.hip, eng.ctx
+        hip.jh_dispatch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(Binding), ctypes.c_int]
+        s, p = _layers_scene(3, 512)
+        p.bump = BumpSizes(lines=1 << 16, seg_counts=1 << 18, segments=1 << 18, blend_spill=1 << 20)
+        rec = jello_amd.Host().record(s, p)
+        eng.run(rec, RUN_UPLOADS | RUN_DISPATCHES | RUN_SKIP_FINE)
+        fine = [c for c in rec.commands() if c["kind"] == CMD.DISPATCH and c["shader"] == 19][0]  # JH_FINE_AREA
+        keep = []
+
+        def to_binding(b):
+            if b["kind"] == 3:
+                arr = (ctypes.c_uint64 * max(1, len(b["ids"])))(*b["ids"])
+                keep.append(arr)
+                return Binding(3, len(b["ids"]), 0, ctypes.cast(arr, ctypes.POINTER(ctypes.c_uint64)))
+            return Binding(b["kind"], 0, b["id"], None)
+        bs = (Binding * len(fine["bindings"]))(*[to_binding(b) for b in fine["bindings"]])
+        n = ctypes.c_uint32(0)
+        for hint, want_drops in ((3, False), (0, False), (1, True)):
+            assert hip.jh_set_clip_depth_hint(ctx, hint) == 0
+            assert hip.jh_dispatch(ctx, 19, fine["wg"][0], fine["wg"][1], fine["wg"][2], bs, len(bs)) == 0, hip.jh_last_error(ctx)
+            assert hip.jh_debug_clip_hint_overflows(ctx, ctypes.byref(n), 1) == 0
+            assert (n.value > 0) == want_drops, (hint, n.value)
+        hip.jh_set_clip_depth_hint(ctx, 0)
+        eng.release(rec)
     finally:
         eng.close()
 

@@ -148,3 +148,16 @@ def test_binding_contract_matches_render_go(built):
     assert "clip_leaf" in seen and "fine_area" in seen
     clears = [c for c in rec.commands() if c["kind"] == CMD.CLEAR]
     assert len(clears) == 1 and clears[0]["buf_name"] == "bumpBuf" and clears[0]["size"] == -1   # render.go:237
+
+
+def test_more_than_256_bins_is_refused(built):
+    """binning / coarse index bins in a 256-entry table (binning.wgsl:52,131): a larger target renders a wrong frame in the
+    reference; the recording is refused here.  Any shape of at most 256 bins is fine."""
+    from jello_amd import scenes
+    s, _ = scenes.scene_c1()
+    host = jello_amd.Host()
+    for w, h in ((4096, 4096), (8192, 2048), (2048, 8192), (16, 65536)):
+        host.record(s, jello_amd.RenderParams(w, h))
+    for w, h in ((4097, 4096), (4096, 4097), (8192, 8192)):
+        with pytest.raises(RuntimeError, match="bins"):
+            host.record(s, jello_amd.RenderParams(w, h))

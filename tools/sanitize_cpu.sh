@@ -18,7 +18,7 @@ CXX="${CXX:-g++}"
 SAN="-fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -g -O1"
 
 # the product libraries must exist (the host library links against libjello_hip.so; nothing in it runs without a GPU)
-make -s -C "$ROOT/jello_amd/csrc" -j8
+[ -s "$ROOT/jello_amd/libjello_hip.so" ] || make -s -C "$ROOT/jello_amd/csrc" -j8  # (needs hipcc: skipped when the library is there -- CPU-only boxes)
 FMAFLAG=$(grep -q -w fma /proc/cpuinfo 2>/dev/null && echo -mfma || true)
 echo "[sanitize] building oracle -> $OUT/liboracle.so"
 $CXX $SAN $FMAFLAG -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-strict-aliasing -fopenmp -shared \

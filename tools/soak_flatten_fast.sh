@@ -7,8 +7,8 @@ FIRST=${1:?first seed}; PER=${2:?seeds per process}; NPROC=${3:-4}
 [ "$NPROC" -le 5 ] || { echo "at most 5 processes"; exit 2; }
 cd "$R"
 LIB=$R/jello_amd/libjello_hip_ffcheck.so
-[ -s "$LIB" ] || make -C jello_amd/csrc VARIANT=ffcheck EXTRA=-DFL_FAST_CHECK > gpurun_out/ffcheck_build.log 2>&1 || exit 1
 mkdir -p gpurun_out
+[ -s "$LIB" ] || make -C jello_amd/csrc VARIANT=ffcheck EXTRA=-DFL_FAST_CHECK > gpurun_out/ffcheck_build.log 2>&1 || exit 1
 PIDS=()
 for ((i = 0; i < NPROC; i++)); do
   JELLO_HIP_LIB=$LIB timeout -k 10 ${SOAK_TIMEOUT:-1000} python3 tools/soak_flatten_fast.py $((FIRST + i * PER)) "$PER" \

@@ -252,6 +252,9 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #ifndef FINE_FINAL_ASM
 #define FINE_FINAL_ASM 1  // (C3 fine 351.3 -> 347.0 us on the same box)
 #endif
+#ifndef FINE_VECTOR_LAYERS
+#define FINE_VECTOR_LAYERS 1  // (0: the scalar counting loop of round 4)
+#endif
 #ifndef FINE_CROSS_INLANE
 #define FINE_CROSS_INLANE 1  // (0: every crossing pixel through the lane = crossing pixel passes, as up to round 4: C3 fine 362.6 -> 354.5 us with 1)
 #endif
@@ -1148,6 +1151,52 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                     //   in the register window: out (the window is re-based and the loop entered again, or the trip below takes over).
                     for (uint32_t sk = 0; sk < (1u << 24); sk++) {  // uniform
                         ensure_window();
+#if FINE_VECTOR_LAYERS
+                        // Round 5: the same counting, but by ALL 64 LANES AT ONCE on the register window instead of one scalar
+                        // branch chain per command (47 scalar instructions per BEGIN_CLIP SOLID END_CLIP, 10 k of the C4 tile's 19 k).
+                        // Lane k looks at word k of the window and at its two predecessors (DPP wave shifts) and decides whether
+                        // the stream is still countable THERE, given that it was up to there: a word behind an END_CLIP tag is its
+                        // blend (low byte 0 = src-over, mix class covered by rgba_known), the word behind that its alpha
+                        // (0 <= alpha < inf by bit pattern, and not one of the bit patterns 3 / 10 / 11, so that inside the accepted
+                        // stretch a word of value 3 / 10 / 11 is always a tag); every other word must be a BEGIN_CLIP, SOLID or
+                        // END_CLIP tag, an END_CLIP with its nesting depth > 0 and > pushed_depth (prefix counts of the BEGIN /
+                        // END tags below the lane: two mbcnt) and its two payload words inside the window.  The first lane that
+                        // says no ends the stretch; it is cut back to a command boundary and consumed in one step.
+                        {
+                            const uint32_t wo = pc - wbase;  // <= 64 - FINE_TRIP_WORDS
+                            const uint32_t w0 = wcur;
+                            const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x138, 0xf, 0xf, false);  // wave_shr:1: word k - 1
+                            const uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x138, 0xf, 0xf, false);  // word k - 2
+                            const bool in = lane >= wo;
+                            const bool tag0 = (w0 == JL_CMD_BEGIN_CLIP) | (w0 == JL_CMD_SOLID) | (w0 == JL_CMD_END_CLIP);
+                            const bool is_blend = (lane >= wo + 1u) & (w1 == JL_CMD_END_CLIP);
+                            const bool is_alpha = (lane >= wo + 2u) & (w2 == JL_CMD_END_CLIP) & (w1 != JL_CMD_END_CLIP);
+                            const uint64_t begins = __builtin_amdgcn_ballot_w64(in & (w0 == JL_CMD_BEGIN_CLIP));
+                            const uint64_t ends_ = __builtin_amdgcn_ballot_w64(in & (w0 == JL_CMD_END_CLIP));
+                            const uint32_t nb_below = __builtin_amdgcn_mbcnt_hi((uint32_t)(begins >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)begins, 0u));
+                            const uint32_t ne_below = __builtin_amdgcn_mbcnt_hi((uint32_t)(ends_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ends_, 0u));
+                            const uint32_t depth_here = clip_depth + nb_below - ne_below;
+                            const uint32_t need = (w0 & 0x7fffu) == 0u ? RK_NONEG : (w0 < 0xc00u ? (RK_NONEG | RK_RANGE) : (w0 < 0xf00u ? (RK_NONEG | RK_RANGE | RK_LUM) : 0xffffffffu));
+                            // (no branches: every lane evaluates the three tests, the kind of word selects -- as an if / else chain the
+                            // compiler built three divergent regions with their exec-mask bookkeeping, ~100 scalar instructions per step)
+                            const bool ok_blend = ((w0 & 0xffu) == 0u) & ((need & ~rgba_known) == 0u);
+                            const bool ok_alpha = (w0 <= 0x7f7fffffu) & !tag0;
+                            const bool ok_tag = tag0 & ((w0 != JL_CMD_END_CLIP) | ((depth_here != 0u) & (pushed_depth < depth_here) & (lane <= 61u)));
+                            const bool ok = (is_blend & ok_blend) | (!is_blend & is_alpha & ok_alpha) | (!is_blend & !is_alpha & ok_tag);
+                            const uint64_t bad_mask = __builtin_amdgcn_ballot_w64(in & !ok);
+                            const uint32_t bad = bad_mask != 0ull ? (uint32_t)__builtin_ctzll(bad_mask) : 64u;
+                            auto below = [](uint32_t P) -> uint64_t { return ~(~0ull << (P & 63u)) | (0ull - (uint64_t)(P >> 6)); };  // P <= 64
+                            const uint64_t tags = __builtin_amdgcn_ballot_w64(in & tag0 & !is_blend & !is_alpha) & below(bad);
+                            if (tags != 0ull) {  // uniform
+                                const uint32_t last = 63u - (uint32_t)__builtin_clzll(tags);
+                                const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)last) == JL_CMD_END_CLIP ? 3u : 1u;
+                                const uint32_t end = last + len <= bad ? last + len : last;
+                                const uint64_t range = below(end) & ~below(wo);
+                                clip_depth = clip_depth + (uint32_t)__builtin_popcountll(begins & range) - (uint32_t)__builtin_popcountll(ends_ & range);
+                                pc += end - wo;
+                            }
+                        }
+#else
 #if defined(__HIP_DEVICE_COMPILE__)
                         uint32_t t_i, t_t, t_b;
                         asm volatile(
@@ -1200,6 +1249,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                             : [pc] "+s"(pc), [d] "+s"(clip_depth), [i] "=&s"(t_i), [t] "=&s"(t_t), [b] "=&s"(t_b)
                             : [wb] "s"(wbase), [pd] "s"(pushed_depth), [kn] "s"(rgba_known), [w] "v"(wcur), [lim] "n"(64 - (int)FINE_TRIP_WORDS)
                             : "scc");
+#endif
 #endif
                         if (pc - wbase <= 64u - FINE_TRIP_WORDS) break;  // (else: the window ran out, not the commands)
                     }

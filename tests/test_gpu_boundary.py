@@ -272,7 +272,7 @@ def test_a_clip_depth_hint_that_is_too_small_is_detectable():
     """jh_set_clip_depth_hint is sticky context state and a hint below the scene's real nesting depth drops blend-stack
     saves (wrong colours, never a fault).  A direct user of the ABI can tell: jh_debug_clip_hint_overflows counts the dropped
     saves.  Here the fine stage of a 3-deep scene is dispatched by hand with the hint forced to 1."""
-    from jello_amd.engine import CMD, RUN_SKIP_FINE
+    from jello_amd.engine import CMD
 
     class Binding(ctypes.Structure):
         _fields_ = [("kind", ctypes.c_uint32), ("count", ctypes.c_uint32), ("id", ctypes.c_uint64), ("ids", ctypes.POINTER(ctypes.c_uint64))]
@@ -283,7 +283,7 @@ def test_a_clip_depth_hint_that_is_too_small_is_detectable():
         s, p = _layers_scene(3, 512)
         p.bump = BumpSizes(lines=1 << 16, seg_counts=1 << 18, segments=1 << 18, blend_spill=1 << 20)
         rec = jello_amd.Host().record(s, p)
-        eng.run(rec, RUN_UPLOADS | RUN_DISPATCHES | RUN_SKIP_FINE)
+        eng.run(rec, RUN_UPLOADS | RUN_DISPATCHES)  # (every buffer of the frame exists afterwards; fine is then dispatched again by hand)
         fine = [c for c in rec.commands() if c["kind"] == CMD.DISPATCH and c["shader"] == 19][0]  # JH_FINE_AREA
         keep = []
 

@@ -288,7 +288,14 @@ int jh_create(jh_ctx** out, int device) {
     std::memset(&ctx->scratch.base, 0, sizeof ctx->scratch.base);
     ctx->scratch.clean_flags = 0u;
     ctx->scratch.ctx = ctx;
-    if (hipMalloc((void**)&ctx->hint_overflow, 256) != hipSuccess || hipMemset(ctx->hint_overflow, 0, 256) != hipSuccess) ctx->hint_overflow = nullptr;
+    // (zeroed on the context's OWN stream: a hipMemset here would be the process's first use of the legacy default stream, and
+    // from then on the frames of two contexts no longer overlapped at all -- bench.py's two frames in flight fell from 0.91 to
+    // 1.05 ms per frame, found by bisection in round 5)
+#ifndef JH_NO_HINT_COUNTER
+    if (hipMalloc((void**)&ctx->hint_overflow, 256) != hipSuccess || hipMemsetAsync(ctx->hint_overflow, 0, 256, ctx->own_stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->own_stream) != hipSuccess)
+        ctx->hint_overflow = nullptr;
+#endif
     *out = ctx;
     return JH_OK;
 }
@@ -1136,8 +1143,14 @@ int jh_debug_clip_hint_overflows(jh_ctx* ctx, uint32_t* count, int reset) {
     if (!ctx || !ctx->hint_overflow) return JH_ERR_INVALID;
     JH_FLUSH(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (count) HIP_TRY(ctx, hipMemcpy(count, ctx->hint_overflow, 4, hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(ctx, hipMemset(ctx->hint_overflow, 0, 4));
+    if (count) {
+        HIP_TRY(ctx, hipMemcpyAsync(count, ctx->hint_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (reset) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->hint_overflow, 0, 4, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return JH_OK;
 }
 uint64_t jh_debug_scratch_bytes(jh_ctx* ctx, int slot) {

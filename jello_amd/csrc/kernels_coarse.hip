@@ -17,6 +17,8 @@
 // tile rows), one thread per tile in the command walk; bin bitmaps (8 x 256 u32), the batch's element
 // records and the Tiles of the current window of elements live in 37 KiB of LDS.
 // Algorithmic bytes: 4 B per (draw,bin) bin_data + 32 B Path + 8 B Tile per (draw,tile) + PTCL out.
+#include <cstring>
+
 #include "kcommon.h"
 
 using namespace jk;
@@ -33,6 +35,12 @@ struct Cmd {
     uint32_t chunk_base;   // word offset (relative to dyn_start) of this tile's first chunk
     uint32_t chunk_words;  // PTCL words of dynamic chunks taken so far
     uint32_t seg_base, seg_used;
+    // MODE 2 (one walk + relocation): `ptcl` is the scratch copy of the PTCL, chunks come from an arena in walk order
+    uint32_t* arena_ctr;            // words of the arena handed out so far
+    uint2* owner;                   // per arena chunk: (tile slot, ordinal of the chunk in its tile's stream)
+    unsigned long long* masks;      // per 64 words of the scratch PTCL: [0] seg_ix words of FILL commands, [1] JUMP target words
+    uint32_t* aux;                  // per 4 words (FILL commands are at least four words apart): the Tile of the FILL whose seg_ix lies there
+    uint32_t slot;
 };
 
 // PTCL words leave as 16-byte stores (dword-aligned addresses: gfx950 runs in unaligned-access mode; a 4-byte store
@@ -47,11 +55,13 @@ JD void ptcl_wr4(const Buf<uint32_t>& ptcl, uint32_t i, uint32_t a, uint32_t b, 
     }
 }
 
-template <bool WRITE>
+// MODE 0: count only.  1: write at the canonical addresses (bases known).  2: write into the scratch PTCL, chunks from the
+// arena; what depends on the canonical allocation (chunk addresses, JUMP targets, seg_ix) is left tile-relative and marked.
+template <int MODE>
 JD void alloc_cmd(Cmd& c, uint32_t size) {  // coarse.wgsl:70-88
     const bool need = c.cmd_offset + size >= c.cmd_limit;
     uint32_t new_cmd = c.dyn_start + c.chunk_base + c.chunk_words;
-    if (WRITE) {
+    if (MODE == 1) {
         if (need) {  // (rare: once per 254 words)
             if (new_cmd + JL_PTCL_INCREMENT > c.cfg->ptcl_size) {
                 new_cmd = 0u;
@@ -59,6 +69,24 @@ JD void alloc_cmd(Cmd& c, uint32_t size) {  // coarse.wgsl:70-88
             }
             c.ptcl.wr(c.cmd_offset, JL_CMD_JUMP);
             c.ptcl.wr(c.cmd_offset + 1u, new_cmd);
+        }
+    }
+    if (MODE == 2) {
+        if (need) {
+            const uint32_t off = atomicAdd(c.arena_ctr, (uint32_t)JL_PTCL_INCREMENT);
+            new_cmd = c.dyn_start + off;
+            // (an arena that overflows = a PTCL that overflows: the totals are the same; k_coarse_bases raises the flag)
+            if (new_cmd + JL_PTCL_INCREMENT > c.ptcl.n || new_cmd + JL_PTCL_INCREMENT < new_cmd) {
+                new_cmd = 0u;
+            } else {
+                c.owner[off / JL_PTCL_INCREMENT] = make_uint2(c.slot, c.chunk_words / JL_PTCL_INCREMENT);
+                unsigned long long* m = c.masks + (size_t)(new_cmd >> 6) * 2u;
+#pragma unroll
+                for (int i = 0; i < 8; i++) m[i] = 0ull;  // the chunk's four 64-word blocks: nothing marked yet
+            }
+            c.ptcl.wr(c.cmd_offset, JL_CMD_JUMP);
+            c.ptcl.wr(c.cmd_offset + 1u, new_cmd);  // (provisional: the relocation writes the canonical address over it)
+            if (c.cmd_offset + 1u < c.ptcl.n) atomicOr(c.masks + (size_t)((c.cmd_offset + 1u) >> 6) * 2u + 1u, 1ull << ((c.cmd_offset + 1u) & 63u));
         }
     }
     c.chunk_words += need ? JL_PTCL_INCREMENT : 0u;
@@ -77,6 +105,9 @@ JD void alloc_cmd(Cmd& c, uint32_t size) {  // coarse.wgsl:70-88
 // frame on its own).  profiles/r04_variants_in_flight.txt
 #ifndef COARSE_WG_PER_CU
 #define COARSE_WG_PER_CU 2u
+#endif
+#ifndef COARSE_RELOCATE
+#define COARSE_RELOCATE 1  // scenes with clip layers walk once and relocate (0: the two-pass route for every scene)
 #endif
 #ifndef COARSE_MAX_SPLIT
 #define COARSE_MAX_SPLIT 16u
@@ -114,12 +145,21 @@ struct Walk {
 
 // CLIPS = false: instantiation for scenes without clip layers (ConfigUniform.n_clip == 0): no BEGIN/END_CLIP draw
 // objects can occur, which removes the clip-depth state and half of the divergent control flow of the command walk.
-template <bool WRITE, bool CLIPS>
+struct CoarseReloc {  // MODE 2 only (see Cmd)
+    uint32_t* arena_ctr;
+    uint2* owner;
+    unsigned long long* masks;
+    uint32_t* aux;
+    uint32_t* end_pos;  // per tile slot: index of the stream's END word in the scratch PTCL
+};
+
+template <int MODE, bool CLIPS>
 __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlDrawMonoid> draw_monoids,
                                                   Buf<JlBinHeader> bin_headers, Buf<uint32_t> info_bin_data, Buf<JlPath> paths, Buf<JlTile> tiles,
                                                   JlBump* __restrict__ bump, Buf<uint32_t> ptcl, uint32_t* __restrict__ cnt_seg,
                                                   uint32_t* __restrict__ cnt_chunk, uint32_t* __restrict__ cnt_blend,
-                                                  uint32_t* __restrict__ wg_tot, uint32_t n_wg, uint32_t bin_row0, uint32_t split) {
+                                                  uint32_t* __restrict__ wg_tot, uint32_t n_wg, uint32_t bin_row0, uint32_t split, CoarseReloc R) {
+    constexpr bool WRITE = MODE != 0;
     // cnt_*[slot]: what the counting pass found per tile; wg_tot[c * n_wg + wg]: their sums per workgroup, wg = bin * split
     // + strip -- the canonical (bin, tile) order is workgroup-major, so the write pass gets a tile's bases as (sum over
     // the workgroups before its own) + (exclusive prefix inside its own): it scans for itself, no scan launches between.
@@ -172,11 +212,17 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         if (failed != 0u) {
             if (WRITE) {
                 if (blockIdx.x == 0u && blockIdx.y == 0u && lid == 0u) atomicOr(&bump->failed, failed);
-            } else {
+            }
+            if (MODE != 1) {
 #pragma unroll
                 for (uint32_t k = 0; k < COARSE_TPL; k++)
                     if (W[k].has_tile) { cnt_seg[W[k].slot] = 0u; cnt_chunk[W[k].slot] = 0u; cnt_blend[W[k].slot] = 0u; }
                 if (lid < 3u) wg_tot[lid * n_wg + bin_ix * split + blockIdx.z] = 0u;
+            }
+            if (MODE == 2) {
+#pragma unroll
+                for (uint32_t k = 0; k < COARSE_TPL; k++)
+                    if (W[k].has_tile) R.end_pos[W[k].slot] = 0xffffffffu;  // nothing to relocate
             }
             return;
         }
@@ -186,7 +232,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     const uint32_t bin_tile_y = JL_N_TILE_Y * bin_y;
     const uint32_t BLEND_CLIP = (128u << 8) | 0u;  // MIX_CLIP << 8 | COMPOSE_SRC_OVER (Jello numbering, blend.wgsl:199-202)
     uint32_t my_base_seg = 0u, my_base_chunk = 0u, my_base_blend = 0u;
-    if (WRITE) {
+    if (MODE == 1) {
         const uint32_t my_wg = bin_ix * split + blockIdx.z;
         MonoidK<3> before, all;
 #pragma unroll
@@ -228,6 +274,13 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         w.c.chunk_words = 0u;
         w.c.seg_base = my_base_seg;
         w.c.seg_used = 0u;
+        w.c.arena_ctr = R.arena_ctr; w.c.owner = R.owner; w.c.masks = R.masks; w.c.aux = R.aux; w.c.slot = w.slot;
+        // (only a tile of the target owns its head: the index of one beyond the right edge is another tile's)
+        if (MODE == 2 && w.has_tile && bin_tile_x + w.tile_x < cfg->width_in_tiles && bin_tile_y + w.tile_y < cfg->height_in_tiles &&
+            (size_t)this_tile_ix * JL_PTCL_INITIAL_ALLOC + JL_PTCL_INITIAL_ALLOC <= ptcl.n) {  // the head's 64-word block: nothing marked yet
+            R.masks[(size_t)this_tile_ix * 2u] = 0ull;
+            R.masks[(size_t)this_tile_ix * 2u + 1u] = 0ull;
+        }
         w.clip_zero_depth = 0u; w.clip_depth = 0u; w.render_blend_depth = 0u; w.max_blend_depth = 0u;
         w.blend_offset = w.c.cmd_offset;
         w.c.cmd_offset += 1u;
@@ -508,7 +561,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                 const uint32_t s1 = emit_path * (1u + 3u * has_segs);
                 const uint32_t seg_ix = c.seg_base + c.seg_used;
                 c.seg_used += emit_path * n_segs;
-                alloc_cmd<WRITE>(c, s1);  // (no-op for s1 == 0: cmd_offset < cmd_limit between commands)
+                alloc_cmd<MODE>(c, s1);  // (no-op for s1 == 0: cmd_offset < cmd_limit between commands)
                 // Stores: a command of fewer than four words is written as four -- the words behind it belong to this
                 // tile's chunk (cmd_offset + 1 < cmd_limit and the two words of headroom) and are either overwritten
                 // by the next command or never reached -- so that a trip has three predicated stores instead of eight.
@@ -517,7 +570,13 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                     const uint32_t rule = (n_segs << 1) | ((meta / CM_EVENODD_FILL) & 1u);
                     if (s1 == 4u) {
                         const uint32_t tile_ix = q0.z + q0.w * w.tile_y + w.tile_x;
-                        if (tiles.ok(tile_ix)) tiles.p[tile_ix].segment_count_or_ix = ~seg_ix;
+                        if (MODE == 1) {
+                            if (tiles.ok(tile_ix)) tiles.p[tile_ix].segment_count_or_ix = ~seg_ix;
+                        } else if (c.cmd_offset + 2u < c.ptcl.n) {  // seg_ix is tile-relative here: marked, the relocation adds the tile's base and writes the Tile
+                            const uint32_t at = c.cmd_offset + 2u;
+                            atomicOr(c.masks + (size_t)(at >> 6) * 2u, 1ull << (at & 63u));
+                            c.aux[at >> 2] = tile_ix;
+                        }
                     }
                     if (s1 != 0u) {
                         PtclQuad q; q.a = has_segs ? JL_CMD_FILL : JL_CMD_SOLID; q.b = rule; q.c = seg_ix; q.d = (uint32_t)tile.backdrop;
@@ -529,7 +588,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                 c.cmd_offset += s1;
                 // brush command: the words stage2 prepared
                 const uint32_t s2 = emit_brush * ((meta >> CM_NBRUSH_SHIFT) & 7u);
-                alloc_cmd<WRITE>(c, s2);
+                alloc_cmd<MODE>(c, s2);
                 if (WRITE) {
                     const bool room = c.cmd_offset + 8u <= c.ptcl.n && c.cmd_offset + 8u > c.cmd_offset;
                     if (s2 != 0u) {
@@ -564,7 +623,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         uint32_t scratch_size = 0u;
         const bool in_target = bin_tile_x + w.tile_x < cfg->width_in_tiles && bin_tile_y + w.tile_y < cfg->height_in_tiles;
         if (in_target && w.max_blend_depth > JL_BLEND_STACK_SPLIT) scratch_size = (w.max_blend_depth - JL_BLEND_STACK_SPLIT) * JL_TILE_WIDTH * JL_TILE_HEIGHT;
-        if (WRITE) {
+        if (MODE == 1) {
             if (in_target) {
                 w.c.ptcl.wr(w.c.cmd_offset, JL_CMD_END);
                 uint32_t blend_ix = 0u;
@@ -575,15 +634,135 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                 w.c.ptcl.wr(w.blend_offset, blend_ix);
             }
         } else {
+            if (MODE == 2) {  // (blend_ix is the relocation's business: it needs the prefix over the tiles)
+                if (in_target) w.c.ptcl.wr(w.c.cmd_offset, JL_CMD_END);
+                R.end_pos[w.slot] = in_target ? w.c.cmd_offset : 0xffffffffu;
+            }
             cnt_seg[w.slot] = w.c.seg_used;
             cnt_chunk[w.slot] = w.c.chunk_words;
             cnt_blend[w.slot] = scratch_size;
             my_tot.v[0] = w.c.seg_used; my_tot.v[1] = w.c.chunk_words; my_tot.v[2] = scratch_size;
         }
     }
-    if (!WRITE) {
+    if (MODE != 1) {
         const MonoidK<3> t = block_reduce_monoid<3>(my_tot, sh_red);
         if (lid < 3u) wg_tot[lid * n_wg + bin_ix * split + blockIdx.z] = lid == 0u ? t.v[0] : (lid == 1u ? t.v[1] : t.v[2]);
+    }
+}
+
+// ---- one walk + relocation (round 5; scenes with clip layers) ------------------------------------------------------------
+// k_coarse<2> has written every tile's stream into a scratch copy of the PTCL -- heads in place, chunks wherever the arena had
+// room -- and left per tile what it needs (segments, chunk words, blend space).  k_coarse_bases turns the needs into the
+// canonical bases (exclusive prefixes in (bin, tile) order: sum of the workgroups in front + prefix inside the workgroup, as
+// the write pass of the two-pass route does for itself), reports the totals and the PTCL overflow; k_coarse_relocate then
+// moves every live 64-word block to its canonical address and completes the marked words on the way: seg_ix + the tile's
+// segment base (and ~seg_ix into the FILL's Tile), JUMP targets, blend_ix.
+__global__ __launch_bounds__(JL_WG) void k_coarse_bases(const JlConfig* __restrict__ cfg, JlBump* __restrict__ bump, const uint32_t* __restrict__ cnt_seg,
+                                                        const uint32_t* __restrict__ cnt_chunk, const uint32_t* __restrict__ cnt_blend,
+                                                        const uint32_t* __restrict__ wg_tot, uint32_t n_wg, uint32_t split, uint32_t* __restrict__ base_seg,
+                                                        uint32_t* __restrict__ base_chunk, uint32_t* __restrict__ base_blend,
+                                                        uint32_t* __restrict__ arena_ctr, uint32_t* __restrict__ arena_used) {
+    __shared__ uint32_t sh_scan[8];
+    __shared__ uint32_t sh_red[12];
+    const uint32_t lid = threadIdx.x, my_wg = blockIdx.x;
+    const uint32_t bin_ix = my_wg / split, strip = my_wg % split;
+    const uint32_t part_rows = JL_N_TILE_Y / split, part_tiles = part_rows * JL_N_TILE_X;
+    MonoidK<3> before, all;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { before.v[c] = 0u; all.v[c] = 0u; }
+    const bool totals = my_wg == 0u;
+    for (uint32_t j = lid; j < (totals ? n_wg : my_wg); j += JL_WG) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const uint32_t v = wg_tot[(uint32_t)c * n_wg + j];
+            all.v[c] += v;
+            if (j < my_wg) before.v[c] += v;
+        }
+    }
+    const MonoidK<3> carry = block_reduce_monoid<3>(before, sh_red);
+    __syncthreads();
+    if (totals) {
+        const MonoidK<3> t = block_reduce_monoid<3>(all, sh_red);
+        if (lid == 0u) {
+            bump->segments = t.v[0]; bump->ptcl = t.v[1]; bump->blend = t.v[2];
+            // coarse.wgsl:76-79: the chunk that does not fit raises the flag -- the last one handed out ends at dyn_start + total
+            const uint64_t dyn_start = (uint64_t)cfg->width_in_tiles * cfg->height_in_tiles * JL_PTCL_INITIAL_ALLOC;
+            if (t.v[1] != 0u && dyn_start + t.v[1] > cfg->ptcl_size) atomicOr(&bump->failed, (uint32_t)JL_STAGE_COARSE);
+            *arena_used = *arena_ctr;  // (the walk is over: what the relocation has to look at)
+        }
+        __syncthreads();
+    }
+    const bool mine = lid < part_tiles;
+    const uint32_t slot = bin_ix * JL_N_TILE + strip * part_tiles + lid;
+    uint32_t tot;
+    const uint32_t a = carry.v[0] + block_excl_scan_u32(mine ? cnt_seg[slot] : 0u, sh_scan, &tot);
+    __syncthreads();
+    const uint32_t b = carry.v[1] + block_excl_scan_u32(mine ? cnt_chunk[slot] : 0u, sh_scan, &tot);
+    __syncthreads();
+    const uint32_t d = carry.v[2] + block_excl_scan_u32(mine ? cnt_blend[slot] : 0u, sh_scan, &tot);
+    if (mine) { base_seg[slot] = a; base_chunk[slot] = b; base_blend[slot] = d; }
+}
+
+// One wave per 64-word block of the scratch PTCL: the heads of the band's tiles (units [0, n_heads)), then the arena's chunks
+// (four blocks each).  Lane = word.
+__global__ __launch_bounds__(JL_WG) void k_coarse_relocate(const JlConfig* __restrict__ cfg, JlBump* __restrict__ bump, Buf<uint32_t> tmp, Buf<uint32_t> ptcl,
+                                                           Buf<JlTile> tiles, const uint32_t* __restrict__ cnt_chunk, const uint32_t* __restrict__ cnt_blend,
+                                                           const uint32_t* __restrict__ base_seg, const uint32_t* __restrict__ base_chunk,
+                                                           const uint32_t* __restrict__ base_blend, const uint32_t* __restrict__ end_pos,
+                                                           const uint2* __restrict__ owner, const unsigned long long* __restrict__ masks,
+                                                           const uint32_t* __restrict__ aux, const uint32_t* __restrict__ arena_used,
+                                                           uint32_t bin_row0, uint32_t bin_row1, uint32_t n_slots) {
+    const uint32_t lane = lane_id();
+    const uint32_t width_in_bins = (cfg->width_in_tiles + JL_N_TILE_X - 1u) / JL_N_TILE_X;
+    const uint32_t dyn_start = cfg->width_in_tiles * cfg->height_in_tiles * JL_PTCL_INITIAL_ALLOC;
+    const uint32_t slot0 = bin_row0 * width_in_bins * JL_N_TILE, slot1 = umin_(bin_row1 * width_in_bins * JL_N_TILE, n_slots);
+    const uint32_t n_heads = slot1 > slot0 ? slot1 - slot0 : 0u;
+    const uint32_t n_chunks = umin_(*arena_used, tmp.n > dyn_start ? tmp.n - dyn_start : 0u) / JL_PTCL_INCREMENT;
+    const uint32_t units = n_heads + n_chunks * 4u;
+    const uint32_t n_waves = (gridDim.x * JL_WG) >> 6;
+    for (uint32_t u = (blockIdx.x * JL_WG + threadIdx.x) >> 6; u < units; u += n_waves) {  // uniform per wave
+        uint32_t slot, src, dst, next_chunk;  // next_chunk: ordinal of the chunk a JUMP in this block leads to
+        bool head;
+        if (u < n_heads) {
+            slot = slot0 + u;
+            const uint32_t bin_ix = slot / JL_N_TILE, xy = slot % JL_N_TILE;
+            const uint32_t tx = (bin_ix % width_in_bins) * JL_N_TILE_X + xy % JL_N_TILE_X, ty = (bin_ix / width_in_bins) * JL_N_TILE_Y + xy / JL_N_TILE_X;
+            if (tx >= cfg->width_in_tiles || ty >= cfg->height_in_tiles) continue;
+            if (end_pos[slot] == 0xffffffffu) continue;
+            src = dst = (ty * cfg->width_in_tiles + tx) * JL_PTCL_INITIAL_ALLOC;
+            next_chunk = 0u;
+            head = true;
+        } else {
+            const uint32_t c = (u - n_heads) >> 2, q = (u - n_heads) & 3u;
+            const uint2 ow = owner[c];
+            slot = ow.x;
+            if (slot < slot0 || slot >= slot1) continue;  // (another band's tile, or a record nobody wrote)
+            const uint32_t k = ow.y, n_k = cnt_chunk[slot] / JL_PTCL_INCREMENT;
+            if (k >= n_k) continue;
+            src = dyn_start + c * JL_PTCL_INCREMENT + q * 64u;
+            // the stream's last chunk is live up to its END word; a chunk in front of it up to its JUMP (copied whole)
+            if (k + 1u == n_k && src > end_pos[slot]) continue;
+            dst = dyn_start + base_chunk[slot] + k * JL_PTCL_INCREMENT + q * 64u;
+            next_chunk = k + 1u;
+            head = false;
+        }
+        const unsigned long long fm = masks[(size_t)(src >> 6) * 2u], jm = masks[(size_t)(src >> 6) * 2u + 1u];
+        uint32_t w = tmp.rd(src + lane);
+        if ((fm >> lane) & 1ull) {
+            w += base_seg[slot];
+            const uint32_t tile_ix = aux[(src + lane) >> 2];
+            if (tiles.ok(tile_ix)) tiles.p[tile_ix].segment_count_or_ix = ~w;
+        }
+        if ((jm >> lane) & 1ull) w = dyn_start + base_chunk[slot] + next_chunk * JL_PTCL_INCREMENT;
+        if (head && lane == 0u) {  // blend_ix, coarse.wgsl:452-460
+            w = 0u;
+            const uint32_t need = cnt_blend[slot];
+            if (need != 0u) {
+                w = base_blend[slot];
+                if (w + need > cfg->blend_size) atomicOr(&bump->failed, (uint32_t)JL_STAGE_COARSE);
+            }
+        }
+        ptcl.wr(dst + lane, w);
     }
 }
 
@@ -628,13 +807,50 @@ int jh_launch_coarse(const JhLaunch& L) {
     const uint32_t row0 = L.band_row0 < L.gy ? L.band_row0 : L.gy, row1 = L.band_row1 < L.gy ? L.band_row1 : L.gy;
     dim3 grid_w(L.gx, row1 > row0 ? row1 - row0 : 0u, split);
     const bool clips = !(L.cfg_host && L.cfg_host->layout.n_clip == 0u);  // host shadow of the uploaded ConfigUniform
-#define JH_COARSE(W, C, G, ROW0) hipLaunchKernelGGL((k_coarse<W, C>), G, blk, 0, L.stream, cfg, scene, dm, bh, ibd, paths, tiles, bump, ptcl, cnt_seg, cnt_chunk, cnt_blend, wg_tot, n_wg, ROW0, split)
-    if (clips) JH_COARSE(false, true, grid, 0u); else JH_COARSE(false, false, grid, 0u);
+    CoarseReloc R;
+    std::memset(&R, 0, sizeof R);
+#define JH_COARSE(W, C, G, ROW0, P) hipLaunchKernelGGL((k_coarse<W, C>), G, blk, 0, L.stream, cfg, scene, dm, bh, ibd, paths, tiles, bump, P, cnt_seg, cnt_chunk, cnt_blend, wg_tot, n_wg, ROW0, split, R)
+#if COARSE_RELOCATE
+    // Scenes with clip layers: ONE walk into a scratch copy of the PTCL, then the relocation (the walk of such a scene is long --
+    // C4: ~640 trips per tile -- and the counting pass repeated all of it; for a scene without clips the relocation's traffic
+    // eats what it saves).
+    if (clips && ptcl.n != 0u) {
+        const uint64_t words = ptcl.n;
+        uint32_t* tmp = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_B, words * 4);
+        // [masks: 2 x u64 per 64 words | aux: u32 per 4 words | owner: uint2 per 256 words | end_pos, base_seg, base_chunk, base_blend: n each | arena counter, arena used]
+        const uint64_t n_blocks = (words + 63u) / 64u, n_aux = (words + 3u) / 4u, n_own = words / JL_PTCL_INCREMENT + 1u;
+        const uint64_t bytes = n_blocks * 16u + n_aux * 4u + n_own * 8u + (uint64_t)n * 16u + 256u;
+        uint8_t* side = (uint8_t*)jh_scratch_get(L.scratch, JH_SCR_C, bytes);
+        if (!tmp || !side) return -5;
+        R.masks = (unsigned long long*)side;
+        R.owner = (uint2*)(side + n_blocks * 16u);
+        R.aux = (uint32_t*)(side + n_blocks * 16u + n_own * 8u);
+        uint32_t* per_slot = R.aux + n_aux;
+        R.end_pos = per_slot;
+        uint32_t *base_seg = per_slot + n, *base_chunk = per_slot + 2 * (size_t)n, *base_blend = per_slot + 3 * (size_t)n;
+        R.arena_ctr = per_slot + 4 * (size_t)n;
+        uint32_t* arena_used = R.arena_ctr + 1;
+        (void)hipMemsetAsync(R.arena_ctr, 0, 8, L.stream);
+        // (owner records of chunks no tile took this frame must not look like one of the band's: slot ~0)
+        auto tmpbuf = mkbuf<uint32_t>(tmp, words * 4);
+        JH_COARSE(2, true, grid, 0u, tmpbuf);
+        hipLaunchKernelGGL(k_coarse_bases, dim3(n_wg), blk, 0, L.stream, cfg, bump, (const uint32_t*)cnt_seg, (const uint32_t*)cnt_chunk, (const uint32_t*)cnt_blend,
+                           (const uint32_t*)wg_tot, n_wg, split, base_seg, base_chunk, base_blend, R.arena_ctr, arena_used);
+        if (grid_w.y != 0u) {
+            const uint32_t rg = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * 8u;
+            hipLaunchKernelGGL(k_coarse_relocate, dim3(rg), blk, 0, L.stream, cfg, bump, tmpbuf, ptcl, tiles, (const uint32_t*)cnt_chunk, (const uint32_t*)cnt_blend,
+                               (const uint32_t*)base_seg, (const uint32_t*)base_chunk, (const uint32_t*)base_blend, (const uint32_t*)R.end_pos,
+                               (const uint2*)R.owner, (const unsigned long long*)R.masks, (const uint32_t*)R.aux, (const uint32_t*)arena_used, row0, row1, n);
+        }
+        return 0;
+    }
+#endif
+    if (clips) JH_COARSE(0, true, grid, 0u, ptcl); else JH_COARSE(0, false, grid, 0u, ptcl);
     if (grid_w.y == 0u) {  // an empty band: nobody to report the totals (otherwise the write pass's first workgroup does)
         hipLaunchKernelGGL(k_coarse_totals, dim3(1), blk, 0, L.stream, (const uint32_t*)wg_tot, n_wg, bump);
         return 0;
     }
-    if (clips) JH_COARSE(true, true, grid_w, row0); else JH_COARSE(true, false, grid_w, row0);
+    if (clips) JH_COARSE(1, true, grid_w, row0, ptcl); else JH_COARSE(1, false, grid_w, row0, ptcl);
 #undef JH_COARSE
     return 0;
 }

@@ -41,6 +41,9 @@ struct Cmd {
     unsigned long long* masks;      // per 64 words of the scratch PTCL: [0] seg_ix words of FILL commands, [1] JUMP target words
     uint32_t* aux;                  // per 4 words (FILL commands are at least four words apart): the Tile of the FILL whose seg_ix lies there
     uint32_t slot;
+    uint32_t* pool;                 // LDS, two words per wave: [next, end) of the wave's share of the arena.  (Not registers: the walk
+                                    // loop runs once per window of elements, a lane that left one early would come back with a stale copy --
+                                    // and, as the first active lane, hand out chunks a second time.)
 };
 
 // PTCL words leave as 16-byte stores (dword-aligned addresses: gfx950 runs in unaligned-access mode; a 4-byte store
@@ -55,6 +58,9 @@ JD void ptcl_wr4(const Buf<uint32_t>& ptcl, uint32_t i, uint32_t a, uint32_t b, 
     }
 }
 
+#ifndef COARSE_POOL_CHUNKS
+#define COARSE_POOL_CHUNKS 16u  // chunks a wave takes from the arena at a time (one-walk route)
+#endif
 // MODE 0: count only.  1: write at the canonical addresses (bases known).  2: write into the scratch PTCL, chunks from the
 // arena; what depends on the canonical allocation (chunk addresses, JUMP targets, seg_ix) is left tile-relative and marked.
 template <int MODE>
@@ -72,21 +78,47 @@ JD void alloc_cmd(Cmd& c, uint32_t size) {  // coarse.wgsl:70-88
         }
     }
     if (MODE == 2) {
-        if (need) {
-            const uint32_t off = atomicAdd(c.arena_ctr, (uint32_t)JL_PTCL_INCREMENT);
-            new_cmd = c.dyn_start + off;
-            // (an arena that overflows = a PTCL that overflows: the totals are the same; k_coarse_bases raises the flag)
-            if (new_cmd + JL_PTCL_INCREMENT > c.ptcl.n || new_cmd + JL_PTCL_INCREMENT < new_cmd) {
-                new_cmd = 0u;
-            } else {
-                c.owner[off / JL_PTCL_INCREMENT] = make_uint2(c.slot, c.chunk_words / JL_PTCL_INCREMENT);
-                unsigned long long* m = c.masks + (size_t)(new_cmd >> 6) * 2u;
-#pragma unroll
-                for (int i = 0; i < 8; i++) m[i] = 0ull;  // the chunk's four 64-word blocks: nothing marked yet
+        // Chunks come out of the WAVE's share of the arena, COARSE_POOL_CHUNKS at a time: a returning atomic in this loop waits for
+        // every PTCL store the wave has in flight (loads, stores and atomics share one in-order counter) -- with one atomic per
+        // chunk the walk took 803 us instead of 478 on C4.  The lanes that need a chunk in this trip take consecutive ones.
+        const uint64_t nm = __builtin_amdgcn_ballot_w64(need);
+        if (nm != 0ull) {  // uniform
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(nm) * JL_PTCL_INCREMENT;
+            uint32_t pn = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.pool[0]), pe = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.pool[1]);
+            if (pe - pn < cnt) {  // (what is left of the old share is given up: the arena has room for that, see jh_launch_coarse)
+                const uint32_t grab = umax_(cnt, COARSE_POOL_CHUNKS * JL_PTCL_INCREMENT);
+                uint32_t base = 0u;
+                if (lane_id() == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {  // the first lane still walking
+                    base = atomicAdd(c.arena_ctr, grab);
+                    // the chunks of the share that are not handed out right now have no owner yet -- and may never get one (the
+                    // tail of the wave's last share, a share given up early): the relocation must not take what an earlier frame
+                    // left in their records for one of its chunks
+                    for (uint32_t i = cnt; i < grab; i += JL_PTCL_INCREMENT)
+                        if (c.dyn_start + base + i + JL_PTCL_INCREMENT <= c.ptcl.n) c.owner[(base + i) / JL_PTCL_INCREMENT] = make_uint2(0xffffffffu, 0u);
+                }
+                pn = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                pe = pn + grab;
             }
-            c.ptcl.wr(c.cmd_offset, JL_CMD_JUMP);
-            c.ptcl.wr(c.cmd_offset + 1u, new_cmd);  // (provisional: the relocation writes the canonical address over it)
-            if (c.cmd_offset + 1u < c.ptcl.n) atomicOr(c.masks + (size_t)((c.cmd_offset + 1u) >> 6) * 2u + 1u, 1ull << ((c.cmd_offset + 1u) & 63u));
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
+            const uint32_t off = pn + rank * JL_PTCL_INCREMENT;
+            wave_sync();  // (every lane has read the pool)
+            if (lane_id() == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) { c.pool[0] = pn + cnt; c.pool[1] = pe; }
+            wave_sync();
+            if (need) {
+                new_cmd = c.dyn_start + off;
+                // (an arena that overflows: k_coarse_bases raises the flag -- the canonical PTCL may or may not have overflowed too)
+                if (new_cmd + JL_PTCL_INCREMENT > c.ptcl.n || new_cmd + JL_PTCL_INCREMENT < new_cmd) {
+                    new_cmd = 0u;
+                } else {
+                    c.owner[off / JL_PTCL_INCREMENT] = make_uint2(c.slot, c.chunk_words / JL_PTCL_INCREMENT);
+                    ulonglong2* m = (ulonglong2*)(c.masks + (size_t)(new_cmd >> 6) * 2u);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) m[i] = make_ulonglong2(0ull, 0ull);  // the chunk's four 64-word blocks: nothing marked yet
+                }
+                c.ptcl.wr(c.cmd_offset, JL_CMD_JUMP);
+                c.ptcl.wr(c.cmd_offset + 1u, new_cmd);  // (provisional: the relocation writes the canonical address over it)
+                if (c.cmd_offset + 1u < c.ptcl.n) atomicOr(c.masks + (size_t)((c.cmd_offset + 1u) >> 6) * 2u + 1u, 1ull << ((c.cmd_offset + 1u) & 63u));
+            }
         }
     }
     c.chunk_words += need ? JL_PTCL_INCREMENT : 0u;
@@ -188,6 +220,8 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     // from here ONLY: a global load inside its loop makes every trip wait for the PTCL stores of the trip before
     // (vmcnt counts loads and stores in one order) -- 1 us per trip in the write pass.
     __shared__ uint2 sh_tile_cache[COARSE_TILE_CACHE];
+    __shared__ uint32_t sh_pool[JL_WG / 64][2];  // MODE 2: the waves' shares of the chunk arena (alloc_cmd)
+    if (MODE == 2 && threadIdx.x < JL_WG / 64) { sh_pool[threadIdx.x][0] = 0u; sh_pool[threadIdx.x][1] = 0u; }  // (barriers follow before any walk)
 
     const uint32_t lid = threadIdx.x;
     const uint32_t width_in_bins = (cfg->width_in_tiles + JL_N_TILE_X - 1u) / JL_N_TILE_X;
@@ -275,6 +309,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         w.c.seg_base = my_base_seg;
         w.c.seg_used = 0u;
         w.c.arena_ctr = R.arena_ctr; w.c.owner = R.owner; w.c.masks = R.masks; w.c.aux = R.aux; w.c.slot = w.slot;
+        w.c.pool = &sh_pool[lid >> 6][0];
         // (only a tile of the target owns its head: the index of one beyond the right edge is another tile's)
         if (MODE == 2 && w.has_tile && bin_tile_x + w.tile_x < cfg->width_in_tiles && bin_tile_y + w.tile_y < cfg->height_in_tiles &&
             (size_t)this_tile_ix * JL_PTCL_INITIAL_ALLOC + JL_PTCL_INITIAL_ALLOC <= ptcl.n) {  // the head's 64-word block: nothing marked yet
@@ -661,7 +696,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse_bases(const JlConfig* __restri
                                                         const uint32_t* __restrict__ cnt_chunk, const uint32_t* __restrict__ cnt_blend,
                                                         const uint32_t* __restrict__ wg_tot, uint32_t n_wg, uint32_t split, uint32_t* __restrict__ base_seg,
                                                         uint32_t* __restrict__ base_chunk, uint32_t* __restrict__ base_blend,
-                                                        uint32_t* __restrict__ arena_ctr, uint32_t* __restrict__ arena_used) {
+                                                        uint32_t* __restrict__ arena_ctr, uint32_t* __restrict__ arena_used, uint32_t arena_cap) {
     __shared__ uint32_t sh_scan[8];
     __shared__ uint32_t sh_red[12];
     const uint32_t lid = threadIdx.x, my_wg = blockIdx.x;
@@ -689,6 +724,9 @@ __global__ __launch_bounds__(JL_WG) void k_coarse_bases(const JlConfig* __restri
             const uint64_t dyn_start = (uint64_t)cfg->width_in_tiles * cfg->height_in_tiles * JL_PTCL_INITIAL_ALLOC;
             if (t.v[1] != 0u && dyn_start + t.v[1] > cfg->ptcl_size) atomicOr(&bump->failed, (uint32_t)JL_STAGE_COARSE);
             *arena_used = *arena_ctr;  // (the walk is over: what the relocation has to look at)
+            // the arena gives up what is left of a wave's share when the wave takes a new one: it can run out although the
+            // canonical PTCL would have fitted -- reported like any other overflow (the regrow loop then grows both)
+            if (*arena_ctr > arena_cap) atomicOr(&bump->failed, (uint32_t)JL_STAGE_COARSE);
         }
         __syncthreads();
     }
@@ -703,8 +741,9 @@ __global__ __launch_bounds__(JL_WG) void k_coarse_bases(const JlConfig* __restri
     if (mine) { base_seg[slot] = a; base_chunk[slot] = b; base_blend[slot] = d; }
 }
 
-// One wave per 64-word block of the scratch PTCL: the heads of the band's tiles (units [0, n_heads)), then the arena's chunks
-// (four blocks each).  Lane = word.
+// A wave per 256 words of the scratch PTCL, a lane per four words (16-byte loads and stores): the heads of the band's tiles, four to
+// a wave (units [0, n_head_units)), then the arena's chunks.  (One 64-word block per wave took 102 us on C4: four dependent
+// look-ups in front of 256 bytes of traffic.)
 __global__ __launch_bounds__(JL_WG) void k_coarse_relocate(const JlConfig* __restrict__ cfg, JlBump* __restrict__ bump, Buf<uint32_t> tmp, Buf<uint32_t> ptcl,
                                                            Buf<JlTile> tiles, const uint32_t* __restrict__ cnt_chunk, const uint32_t* __restrict__ cnt_blend,
                                                            const uint32_t* __restrict__ base_seg, const uint32_t* __restrict__ base_chunk,
@@ -716,53 +755,64 @@ __global__ __launch_bounds__(JL_WG) void k_coarse_relocate(const JlConfig* __res
     const uint32_t width_in_bins = (cfg->width_in_tiles + JL_N_TILE_X - 1u) / JL_N_TILE_X;
     const uint32_t dyn_start = cfg->width_in_tiles * cfg->height_in_tiles * JL_PTCL_INITIAL_ALLOC;
     const uint32_t slot0 = bin_row0 * width_in_bins * JL_N_TILE, slot1 = umin_(bin_row1 * width_in_bins * JL_N_TILE, n_slots);
-    const uint32_t n_heads = slot1 > slot0 ? slot1 - slot0 : 0u;
+    const uint32_t n_head_units = slot1 > slot0 ? (slot1 - slot0 + 3u) / 4u : 0u;
     const uint32_t n_chunks = umin_(*arena_used, tmp.n > dyn_start ? tmp.n - dyn_start : 0u) / JL_PTCL_INCREMENT;
-    const uint32_t units = n_heads + n_chunks * 4u;
+    const uint32_t units = n_head_units + n_chunks;
     const uint32_t n_waves = (gridDim.x * JL_WG) >> 6;
+    const uint32_t part = lane >> 4, wl = (lane & 15u) * 4u;  // which 64-word block of the unit, which four words of it
     for (uint32_t u = (blockIdx.x * JL_WG + threadIdx.x) >> 6; u < units; u += n_waves) {  // uniform per wave
         uint32_t slot, src, dst, next_chunk;  // next_chunk: ordinal of the chunk a JUMP in this block leads to
-        bool head;
-        if (u < n_heads) {
-            slot = slot0 + u;
+        bool head = u < n_head_units, live = true;
+        if (head) {
+            slot = slot0 + u * 4u + part;
+            live = slot < slot1;
             const uint32_t bin_ix = slot / JL_N_TILE, xy = slot % JL_N_TILE;
             const uint32_t tx = (bin_ix % width_in_bins) * JL_N_TILE_X + xy % JL_N_TILE_X, ty = (bin_ix / width_in_bins) * JL_N_TILE_Y + xy / JL_N_TILE_X;
-            if (tx >= cfg->width_in_tiles || ty >= cfg->height_in_tiles) continue;
-            if (end_pos[slot] == 0xffffffffu) continue;
-            src = dst = (ty * cfg->width_in_tiles + tx) * JL_PTCL_INITIAL_ALLOC;
+            live = live && tx < cfg->width_in_tiles && ty < cfg->height_in_tiles;
+            if (live) live = end_pos[slot] != 0xffffffffu;
+            src = dst = (ty * cfg->width_in_tiles + tx) * JL_PTCL_INITIAL_ALLOC + wl;
             next_chunk = 0u;
-            head = true;
         } else {
-            const uint32_t c = (u - n_heads) >> 2, q = (u - n_heads) & 3u;
+            const uint32_t c = u - n_head_units;
             const uint2 ow = owner[c];
             slot = ow.x;
-            if (slot < slot0 || slot >= slot1) continue;  // (another band's tile, or a record nobody wrote)
-            const uint32_t k = ow.y, n_k = cnt_chunk[slot] / JL_PTCL_INCREMENT;
-            if (k >= n_k) continue;
-            src = dyn_start + c * JL_PTCL_INCREMENT + q * 64u;
-            // the stream's last chunk is live up to its END word; a chunk in front of it up to its JUMP (copied whole)
-            if (k + 1u == n_k && src > end_pos[slot]) continue;
-            dst = dyn_start + base_chunk[slot] + k * JL_PTCL_INCREMENT + q * 64u;
-            next_chunk = k + 1u;
-            head = false;
-        }
-        const unsigned long long fm = masks[(size_t)(src >> 6) * 2u], jm = masks[(size_t)(src >> 6) * 2u + 1u];
-        uint32_t w = tmp.rd(src + lane);
-        if ((fm >> lane) & 1ull) {
-            w += base_seg[slot];
-            const uint32_t tile_ix = aux[(src + lane) >> 2];
-            if (tiles.ok(tile_ix)) tiles.p[tile_ix].segment_count_or_ix = ~w;
-        }
-        if ((jm >> lane) & 1ull) w = dyn_start + base_chunk[slot] + next_chunk * JL_PTCL_INCREMENT;
-        if (head && lane == 0u) {  // blend_ix, coarse.wgsl:452-460
-            w = 0u;
-            const uint32_t need = cnt_blend[slot];
-            if (need != 0u) {
-                w = base_blend[slot];
-                if (w + need > cfg->blend_size) atomicOr(&bump->failed, (uint32_t)JL_STAGE_COARSE);
+            src = dyn_start + c * JL_PTCL_INCREMENT + part * 64u + wl;
+            dst = 0u; next_chunk = 0u;
+            live = slot >= slot0 && slot < slot1;  // (else: another band's tile)
+            if (live) {
+                const uint32_t k = ow.y, n_k = cnt_chunk[slot] / JL_PTCL_INCREMENT;
+                // the stream's last chunk is live up to its END word; a chunk in front of it up to its JUMP (copied whole)
+                live = k < n_k && !(k + 1u == n_k && (src & ~63u) > end_pos[slot]);
+                dst = dyn_start + base_chunk[slot] + k * JL_PTCL_INCREMENT + part * 64u + wl;
+                next_chunk = k + 1u;
             }
         }
-        ptcl.wr(dst + lane, w);
+        if (!live || src + 3u >= tmp.n) continue;
+        const unsigned long long fm = masks[(size_t)(src >> 6) * 2u] >> (src & 63u), jm = masks[(size_t)(src >> 6) * 2u + 1u] >> (src & 63u);
+        const uint4 in = *(const uint4*)(tmp.p + src);
+        uint32_t w[4] = {in.x, in.y, in.z, in.w};
+        if (((fm | jm) & 15ull) != 0ull || (head && wl == 0u)) {
+            const uint32_t jump_to = dyn_start + base_chunk[slot] + next_chunk * JL_PTCL_INCREMENT;
+#pragma unroll
+            for (uint32_t e = 0; e < 4u; e++) {
+                if ((fm >> e) & 1ull) {
+                    w[e] += base_seg[slot];
+                    const uint32_t tile_ix = aux[(src + e) >> 2];
+                    if (tiles.ok(tile_ix)) tiles.p[tile_ix].segment_count_or_ix = ~w[e];
+                }
+                if ((jm >> e) & 1ull) w[e] = jump_to;
+            }
+            if (head && wl == 0u) {  // blend_ix, coarse.wgsl:452-460
+                w[0] = 0u;
+                const uint32_t need = cnt_blend[slot];
+                if (need != 0u) {
+                    w[0] = base_blend[slot];
+                    if (w[0] + need > cfg->blend_size) atomicOr(&bump->failed, (uint32_t)JL_STAGE_COARSE);
+                }
+            }
+        }
+        if (dst + 3u < ptcl.n) *(uint4*)(ptcl.p + dst) = make_uint4(w[0], w[1], w[2], w[3]);
+        else { ptcl.wr(dst, w[0]); ptcl.wr(dst + 1u, w[1]); ptcl.wr(dst + 2u, w[2]); ptcl.wr(dst + 3u, w[3]); }
     }
 }
 
@@ -815,7 +865,10 @@ int jh_launch_coarse(const JhLaunch& L) {
     // C4: ~640 trips per tile -- and the counting pass repeated all of it; for a scene without clips the relocation's traffic
     // eats what it saves).
     if (clips && ptcl.n != 0u) {
-        const uint64_t words = ptcl.n;
+        // the scratch PTCL: the real one's size + what the waves' arena shares can leave unused (a share given up early, the tail of
+        // the last one): 2 x COARSE_POOL_CHUNKS chunks per walking wave
+        const uint64_t slack = (uint64_t)n_wg * 4u * 2u * COARSE_POOL_CHUNKS * JL_PTCL_INCREMENT;
+        const uint64_t words = (uint64_t)ptcl.n + slack > 0xfffffff0ull ? 0xfffffff0ull : (uint64_t)ptcl.n + slack;
         uint32_t* tmp = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_B, words * 4);
         // [masks: 2 x u64 per 64 words | aux: u32 per 4 words | owner: uint2 per 256 words | end_pos, base_seg, base_chunk, base_blend: n each | arena counter, arena used]
         const uint64_t n_blocks = (words + 63u) / 64u, n_aux = (words + 3u) / 4u, n_own = words / JL_PTCL_INCREMENT + 1u;
@@ -831,11 +884,13 @@ int jh_launch_coarse(const JhLaunch& L) {
         R.arena_ctr = per_slot + 4 * (size_t)n;
         uint32_t* arena_used = R.arena_ctr + 1;
         (void)hipMemsetAsync(R.arena_ctr, 0, 8, L.stream);
+        const uint64_t cfg_dyn = L.cfg_host ? (uint64_t)L.cfg_host->width_in_tiles * L.cfg_host->height_in_tiles * JL_PTCL_INITIAL_ALLOC : 0u;
         // (owner records of chunks no tile took this frame must not look like one of the band's: slot ~0)
         auto tmpbuf = mkbuf<uint32_t>(tmp, words * 4);
         JH_COARSE(2, true, grid, 0u, tmpbuf);
         hipLaunchKernelGGL(k_coarse_bases, dim3(n_wg), blk, 0, L.stream, cfg, bump, (const uint32_t*)cnt_seg, (const uint32_t*)cnt_chunk, (const uint32_t*)cnt_blend,
-                           (const uint32_t*)wg_tot, n_wg, split, base_seg, base_chunk, base_blend, R.arena_ctr, arena_used);
+                           (const uint32_t*)wg_tot, n_wg, split, base_seg, base_chunk, base_blend, R.arena_ctr, arena_used,
+                           (uint32_t)(words > (uint64_t)cfg_dyn ? words - cfg_dyn : 0u));
         if (grid_w.y != 0u) {
             const uint32_t rg = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * 8u;
             hipLaunchKernelGGL(k_coarse_relocate, dim3(rg), blk, 0, L.stream, cfg, bump, tmpbuf, ptcl, tiles, (const uint32_t*)cnt_chunk, (const uint32_t*)cnt_blend,

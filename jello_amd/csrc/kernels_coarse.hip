@@ -864,7 +864,7 @@ int jh_launch_coarse(const JhLaunch& L) {
     // Scenes with clip layers: ONE walk into a scratch copy of the PTCL, then the relocation (the walk of such a scene is long --
     // C4: ~640 trips per tile -- and the counting pass repeated all of it; for a scene without clips the relocation's traffic
     // eats what it saves).
-    if (clips && ptcl.n != 0u) {
+    if ((clips || COARSE_RELOCATE == 2) && ptcl.n != 0u) {
         // the scratch PTCL: the real one's size + what the waves' arena shares can leave unused (a share given up early, the tail of
         // the last one): 2 x COARSE_POOL_CHUNKS chunks per walking wave
         const uint64_t slack = (uint64_t)n_wg * 4u * 2u * COARSE_POOL_CHUNKS * JL_PTCL_INCREMENT;
@@ -887,7 +887,7 @@ int jh_launch_coarse(const JhLaunch& L) {
         const uint64_t cfg_dyn = L.cfg_host ? (uint64_t)L.cfg_host->width_in_tiles * L.cfg_host->height_in_tiles * JL_PTCL_INITIAL_ALLOC : 0u;
         // (owner records of chunks no tile took this frame must not look like one of the band's: slot ~0)
         auto tmpbuf = mkbuf<uint32_t>(tmp, words * 4);
-        JH_COARSE(2, true, grid, 0u, tmpbuf);
+        if (clips) JH_COARSE(2, true, grid, 0u, tmpbuf); else JH_COARSE(2, false, grid, 0u, tmpbuf);
         hipLaunchKernelGGL(k_coarse_bases, dim3(n_wg), blk, 0, L.stream, cfg, bump, (const uint32_t*)cnt_seg, (const uint32_t*)cnt_chunk, (const uint32_t*)cnt_blend,
                            (const uint32_t*)wg_tot, n_wg, split, base_seg, base_chunk, base_blend, R.arena_ctr, arena_used,
                            (uint32_t)(words > (uint64_t)cfg_dyn ? words - cfg_dyn : 0u));

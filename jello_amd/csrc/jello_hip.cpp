@@ -194,6 +194,7 @@ void* jh_scratch_get(JhScratch* s, int slot, uint64_t bytes) {
         case JH_SCR_SCAN_TMP: s->clean_flags &= ~(uint32_t)JH_CLEAN_SCAN; break;
         case JH_SCR_FL_CTR: s->clean_flags &= ~(uint32_t)JH_CLEAN_FL_CTR; break;
         case JH_SCR_BD_CTR: s->clean_flags &= ~(uint32_t)JH_CLEAN_BD_CTR; break;
+        case JH_SCR_PC_TOT: s->clean_flags &= ~(uint32_t)JH_CLEAN_PC_TOT; break;
         default: break;  // (the other arrays are written before they are read in every frame)
     }
     p = (char*)p + (uint64_t)slot * JH_SCR_SKEW;
@@ -969,7 +970,7 @@ int jh_graph_launch(jh_ctx* ctx, void* graph_exec) {
     const uint32_t dirty = g->assumes_clean & ~ctx->scratch.clean_flags;
     if (dirty) {
         static const struct { uint32_t flag; int slot; } kSlots[] = {
-            {JH_CLEAN_FL_CTR, JH_SCR_FL_CTR}, {JH_CLEAN_BD_CTR, JH_SCR_BD_CTR}, {JH_CLEAN_SCAN, JH_SCR_SCAN_TMP}};
+            {JH_CLEAN_FL_CTR, JH_SCR_FL_CTR}, {JH_CLEAN_BD_CTR, JH_SCR_BD_CTR}, {JH_CLEAN_SCAN, JH_SCR_SCAN_TMP}, {JH_CLEAN_PC_TOT, JH_SCR_PC_TOT}};
         for (const auto& k : kSlots)
             if ((dirty & k.flag) && ctx->scratch.ptr[k.slot] && ctx->scratch.cap[k.slot])
                 HIP_TRY(ctx, hipMemsetAsync(ctx->scratch.ptr[k.slot], 0, ctx->scratch.cap[k.slot], ctx->stream));

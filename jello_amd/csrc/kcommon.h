@@ -232,13 +232,14 @@ enum {  // scratch slots
     JH_SCR_J = 10,
     JH_SCR_FL_CTR = 11,  // flatten's list counters / chunk fills: NOT shared with other stages (they survive between frames)
     JH_SCR_BD_CTR = 12,  // backdrop's wide-row counter: likewise
-    JH_SCR_COUNT = 13
+    JH_SCR_PC_TOT = 13,  // path_count's crossings per path (atomic sums): likewise, zeroed by the stage's last kernel
+    JH_SCR_COUNT = 14
 };
 // Counters a stage needs zeroed when it starts are zeroed by the LAST kernel that runs before without using them (the
 // stage's own last kernel of the frame before, or a kernel of the stage in front) instead of by a fill launch of
 // ~4.4 us; a host-side flag per counter says whether that has happened since the counter was last used.  A stage that
 // finds its flag down (first frame, an aborted frame, a stage run on its own, a scratch reallocation) fills as before.
-enum { JH_CLEAN_FL_CTR = 1u, JH_CLEAN_BD_CTR = 2u, JH_CLEAN_SCAN = 8u };
+enum { JH_CLEAN_FL_CTR = 1u, JH_CLEAN_BD_CTR = 2u, JH_CLEAN_SCAN = 8u, JH_CLEAN_PC_TOT = 16u };
 uint32_t* jh_scratch_flags(JhScratch* s);
 uint64_t jh_scratch_cap(JhScratch* s, int slot);  // bytes the slot holds (>= what was last asked for)
 

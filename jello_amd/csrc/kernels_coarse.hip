@@ -726,7 +726,10 @@ __global__ __launch_bounds__(JL_WG) void k_coarse_bases(const JlConfig* __restri
             *arena_used = *arena_ctr;  // (the walk is over: what the relocation has to look at)
             // the arena gives up what is left of a wave's share when the wave takes a new one: it can run out although the
             // canonical PTCL would have fitted -- reported like any other overflow (the regrow loop then grows both)
-            if (*arena_ctr > arena_cap) atomicOr(&bump->failed, (uint32_t)JL_STAGE_COARSE);
+            if (*arena_ctr > arena_cap) {
+                atomicOr(&bump->failed, (uint32_t)JL_STAGE_COARSE);
+                bump->ptcl = umax_(bump->ptcl, *arena_ctr);  // (what the regrow loop sizes the next attempt from: the arena's real use)
+            }
         }
         __syncthreads();
     }

@@ -18,6 +18,8 @@
 //               happened to return is only used as a unique slot inside that temporary list.
 // The WGSL indirect dispatches become grid-stride loops bounded by the IndirectCount the setup
 // kernels write, so no host readback is needed.  All of this is HBM/atomic-bound integer work.
+#include <algorithm>
+
 #include "kcommon.h"
 
 using namespace jk;
@@ -364,7 +366,7 @@ JD LineSetup line_setup(const JlLineSoup& line, const Buf<JlPath>& paths) {
 // pass 1: crossings per line
 __global__ __launch_bounds__(JL_WG) void k_pc_count(const JlBump* __restrict__ bump, const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines,
                                                     Buf<JlPath> paths, uint32_t* __restrict__ counts, uint32_t counts_n,
-                                                    uint32_t* __restrict__ zero, uint32_t zero_n, uint32_t* __restrict__ line_path,
+                                                    uint32_t* __restrict__ zero, uint32_t zero_n, uint32_t* __restrict__ ptotal, uint32_t ptotal_n,
                                                     unsigned long long* __restrict__ bd_ctr,
                                                     JlIndirectCount* __restrict__ setup_out) {  // != nullptr: path_count_setup was held back (jello_hip.cpp,
                                                                                                 // Deferred): this kernel does its work (path_count_setup.wgsl:17-27)
@@ -382,35 +384,33 @@ __global__ __launch_bounds__(JL_WG) void k_pc_count(const JlBump* __restrict__ b
         ind_x = ind->x;
     }
     uint32_t n_threads = umin_(ind_x * JL_WG, counts_n);
-    for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
+    const uint32_t lane = lane_id();
+    for (uint32_t g0 = blockIdx.x * JL_WG + (threadIdx.x & ~63u); g0 < n_lines; g0 += gridDim.x * JL_WG) {  // uniform per wave
+        const uint32_t gid = g0 + lane;
         uint32_t c = 0u, pix = 0xffffffffu;
-        if (gid < n_threads && lines.ok(gid)) {
+        if (gid < n_lines && gid < n_threads && lines.ok(gid)) {
             pix = lines.p[gid].path_ix;
             LineSetup s = line_setup(lines.p[gid], paths);
             if (s.valid) c = s.imax - s.imin;
         }
-        counts[gid] = c;
-        line_path[gid] = pix;  // k_pc_paths needs nothing else of the line (4 instead of 24 bytes per line there)
+        if (gid < n_lines) counts[gid] = c;
+        // Crossings per PATH (k_pc_emit: a path of more than PC_BIG_PATH crossings takes the list route).  Lines are in path order,
+        // so a wave's lines are a few runs of equal path index: the run's sum comes out of one wave prefix sum, its last lane
+        // sends ONE atomic.  (Round 5: the sums used to be derived from first / last line of every path by a launch of its own,
+        // k_pc_paths, behind the scan; the ranges it also produced are written by k_pc_emit in passing now.)
+        const uint32_t incl = wave_incl_scan_u32(c);
+        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~pix, (int)pix, 0x138, 0xf, 0xf, false);  // wave_shr:1 (lane 0: a head)
+        const uint64_t heads = __builtin_amdgcn_ballot_w64(lane == 0u || pix != prev);
+        const uint32_t leader = 63u - (uint32_t)__builtin_clzll(heads & ((2ull << lane) - 1ull));  // nearest head at or before the lane
+        const uint32_t lead_incl = (uint32_t)__shfl((int)incl, (int)leader, 64), lead_c = (uint32_t)__shfl((int)c, (int)leader, 64);
+        const bool last_of_run = lane == 63u || ((heads >> (lane + 1u)) & 1ull) != 0ull;
+        const uint32_t run_sum = incl - (lead_incl - lead_c);
+        if (last_of_run && run_sum != 0u && pix < ptotal_n) atomicAdd(&ptotal[pix], run_sum);
     }
 }
 // Crossing ranges of the paths: lines are in path order (canonical LineSoup order), so the crossings of path P are
-// the contiguous range [pstart[P], pend[P]) of seg_counts.  Both arrays are zeroed before (paths without lines).
-// (Deriving the range from first/last line indices inside the consumers instead measured slower: five dependent
-// loads per line.)
-__global__ __launch_bounds__(JL_WG) void k_pc_paths(const JlBump* __restrict__ bump, const JlIndirectCount* __restrict__ ind,
-                                                    const uint32_t* __restrict__ line_path, const uint32_t* __restrict__ counts,
-                                                    const uint32_t* __restrict__ seg_bases, uint32_t bases_n, uint32_t* __restrict__ pstart,
-                                                    uint32_t* __restrict__ pend, uint32_t n_paths) {
-    uint32_t n_lines = umin_(umin_(bump->lines, bases_n), ind->x * JL_WG);
-    for (uint32_t gid = blockIdx.x * JL_WG + threadIdx.x; gid < n_lines; gid += gridDim.x * JL_WG) {
-        uint32_t P = line_path[gid];  // (0xffffffff for a line outside the buffer)
-        if (P >= n_paths) continue;
-        uint32_t prevP = gid > 0u ? line_path[gid - 1u] : 0xffffffffu;
-        uint32_t nextP = gid + 1u < n_lines ? line_path[gid + 1u] : 0xffffffffu;
-        if (P != prevP) pstart[P] = seg_bases[gid];
-        if (P != nextP) pend[P] = seg_bases[gid] + counts[gid];
-    }
-}
+// the contiguous range [pstart[P], pend[P]) of seg_counts.  Both arrays are zeroed before (paths without lines); k_pc_emit
+// writes them at the first and the last line of every path.
 // crossings [ps, pe) of path P (empty if it has no line)
 JD void path_range(uint32_t P, const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ pend, const uint32_t*, const uint32_t*,
                    uint32_t& ps, uint32_t& pe) {
@@ -444,6 +444,7 @@ struct EmitCtx {
     uint32_t* kbig;
     uint32_t tile_of_n;
 };
+JD bool pc_key_is_big(uint32_t key) { return key != 0xffffffffu && (key >> 31) != 0u; }  // keys[]: see emit_crossing
 JD void emit_backdrop_row(const EmitCtx& c, const LineSetup& s, int32_t y) {
     uint32_t base = (uint32_t)((int32_t)s.tiles + (y - s.bbox[1]) * s.stride);
     if (c.tile.ok(base)) atomicAdd(&c.tile.p[base].backdrop, s.delta);
@@ -475,8 +476,9 @@ JD void emit_crossing(const EmitCtx& c, const LineSetup& s, uint32_t i, uint32_t
         sc.counts = i;  // low 16 bits; the slice rank is OR-ed in by k_pc_rank_small / k_pc_rank
         c.seg_counts.p[seg_ix] = sc;
         if (seg_ix < c.tile_of_n) {
-            c.keys[seg_ix] = c.tile.ok(t) ? t : 0xffffffffu;
-            c.kbig[seg_ix] = big ? 1u : 0u;
+            // (the tile of the crossing; bit 31: a crossing of a big path, ranked by the list route -- a word of its own per crossing
+            // was 18 MB of C3's frame for a flag only that route reads.  A crossing without a valid tile is nobody's business.)
+            c.keys[seg_ix] = c.tile.ok(t) ? (t | (big ? 0x80000000u : 0u)) : 0xffffffffu;
             if (big) {
                 if (DEFER) {
                     want_t = t;
@@ -498,8 +500,8 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
                                                    const JlIndirectCount* __restrict__ ind, Buf<JlLineSoup> lines, Buf<JlPath> paths, Buf<JlTile> tile,
                                                    Buf<JlSegmentCount> seg_counts, const uint32_t* __restrict__ seg_bases, uint32_t bases_n,
                                                    uint2* __restrict__ tile_of, uint32_t* __restrict__ keys, uint32_t* __restrict__ kbig,
-                                                   uint32_t tile_of_n, const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ plast,
-                                                   const uint32_t* __restrict__ counts, uint32_t n_paths, uint32_t* __restrict__ gate) {
+                                                   uint32_t tile_of_n, uint32_t* __restrict__ pfirst, uint32_t* __restrict__ plast,
+                                                   const uint32_t* __restrict__ ptotal, uint32_t n_paths, uint32_t* __restrict__ gate) {
     EmitCtx c;
     c.cfg = cfg; c.bump = bump; c.tile = tile; c.seg_counts = seg_counts; c.tile_of = tile_of; c.keys = keys; c.kbig = kbig;
     c.tile_of_n = tile_of_n;
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
         const uint32_t gid = g0 + lane;
         LineSetup s;
         s.valid = false;
-        uint32_t P = 0u;
+        uint32_t P = 0xffffffffu;  // (a line outside the buffer)
         if (gid < n_lines && lines.ok(gid)) {
             P = lines.p[gid].path_ix;
             s = line_setup(lines.p[gid], paths);
@@ -517,15 +519,21 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
         // big path (or a path index outside the table): arrival slots by atomics, as the scatter pass / k_pc_rank expect
         bool big = true;
         uint32_t seg_base = 0u;
+        if (gid < n_lines) seg_base = seg_bases[gid];
         if (s.valid) {
-            if (P < n_paths) {
-                uint32_t ps, pe;
-                path_range(P, pfirst, plast, counts, seg_bases, ps, pe);
-                big = pe - ps > PC_BIG_PATH;
-            }
-            seg_base = seg_bases[gid];
+            if (P < n_paths) big = ptotal[P] > PC_BIG_PATH;  // (= pend - pstart: the crossings of all of the path's lines)
         } else {
             s.imin = 0u; s.imax = 0u; s.ymin = 0; s.ymax = 0;
+        }
+        {   // the path's crossing range, written at its first and its last line (the neighbours: a lane over, or the line next door)
+            uint32_t prevP = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x138, 0xf, 0xf, false);  // wave_shr:1
+            uint32_t nextP = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x130, 0xf, 0xf, false);  // wave_shl:1
+            if (lane == 0u) prevP = (gid > 0u && gid - 1u < n_lines && lines.ok(gid - 1u)) ? lines.p[gid - 1u].path_ix : 0xffffffffu;
+            if (lane == 63u) nextP = (gid + 1u < n_lines && lines.ok(gid + 1u)) ? lines.p[gid + 1u].path_ix : 0xffffffffu;
+            if (gid < n_lines && P < n_paths) {
+                if (P != prevP) pfirst[P] = seg_base;
+                if (P != nextP) plast[P] = seg_base + (s.valid ? s.imax - s.imin : 0u);
+            }
         }
         // open the gate of the list route: the number of tiles its list-base scan has to cover (one lane per wave, and
         // only while the word does not hold the value yet -- 200 k lines of one big path would queue on that word)
@@ -611,7 +619,10 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank_small(const JlConfig* __restr
                                                          const uint32_t* __restrict__ keys, uint32_t n_cap, const uint32_t* __restrict__ pfirst,
                                                          const uint32_t* __restrict__ plast, const uint32_t* __restrict__ counts,
                                                          const uint32_t* __restrict__ seg_bases, uint32_t n_paths,
-                                                         Buf<JlSegmentCount> seg_counts, PcScatterArgs sc) {
+                                                         Buf<JlSegmentCount> seg_counts, PcScatterArgs sc, uint32_t* __restrict__ ptotal_zero,
+                                                         uint32_t ptotal_words) {
+    // (the crossings-per-path sums have served k_pc_emit: back to zero for the next frame's atomics -- kcommon.h, JH_CLEAN_*)
+    for (uint32_t i = blockIdx.x * JL_WG + threadIdx.x; i < ptotal_words; i += gridDim.x * JL_WG) ptotal_zero[i] = 0u;
     const uint32_t rank_blocks = gridDim.x - sc.blocks;  // the scatter workgroups come last: they only look at the gate when it is closed
     if (blockIdx.x >= rank_blocks) {  // uniform
         pc_scatter_part(cfg, bump, tile, sc.tile_of, n_cap, sc.list_base, sc.tiles_cap, sc.list, sc.kbig, sc.gate, sc.dense, sc.dense_cap,
@@ -728,7 +739,7 @@ JD void pc_scatter_part(const JlConfig* __restrict__ cfg, const JlBump* __restri
         const uint32_t k = k0 + lane;
         bool first_of_dense = false;  // the crossing that arrived first in a tile with a long list announces the tile
         uint32_t t = 0u;
-        if (k < n && kbig[k] != 0u) {  // (others are ranked by k_pc_rank_small)
+        if (k < n && pc_key_is_big(kbig[k])) {  // (others are ranked by k_pc_rank_small)
             uint2 ta = tile_of[k];
             if (ta.x < tiles_cap && tile.ok(ta.x)) {
                 uint32_t pos = list_base[ta.x] + ta.y;
@@ -760,7 +771,7 @@ __global__ __launch_bounds__(JL_WG) void k_pc_rank(const JlConfig* __restrict__ 
     if (*gate == 0u) return;  // no big path in this frame
     uint32_t n = umin_(umin_(bump->seg_counts, cfg->seg_counts_size), n_cap);
     for (uint32_t k = blockIdx.x * JL_WG + threadIdx.x; k < n; k += gridDim.x * JL_WG) {
-        if (kbig[k] == 0u) continue;  // ranked by k_pc_rank_small
+        if (!pc_key_is_big(kbig[k])) continue;  // ranked by k_pc_rank_small
         uint32_t t = tile_of[k].x;
         if (t >= tiles_cap || !tile.ok(t) || !seg_counts.ok(k)) continue;
         uint32_t cnt = tile.p[t].segment_count_or_ix;
@@ -1130,29 +1141,35 @@ int jh_launch_path_count(const JhLaunch& L) {
     uint32_t* list = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)seg_cap * 4);
     uint32_t* list_base = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_E, (uint64_t)tiles_cap * 4);
     uint32_t* keys = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_F, (uint64_t)seg_cap * 4);
-    uint32_t* kbig = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_H, (uint64_t)seg_cap * 4);
+    uint32_t* kbig = keys;  // (the big-path flag is bit 31 of the crossing's key)
     uint32_t n_paths = paths.n;
     const uint32_t dense_cap = seg_cap / PC_DENSE_TILE + 1u;  // tiles with more than PC_DENSE_TILE crossings of a big path
     uint32_t* dense = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_G, (uint64_t)dense_cap * 4);
-    uint32_t* line_path = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_J, (uint64_t)lines_cap * 4);
-    if (!dense || !line_path) return -5;
-    // [pstart | pend | gate, number of dense tiles]: zeroed every frame (by k_pc_count) (the variables below keep the names of the path_range parameters)
-    uint32_t* prange = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_I, ((uint64_t)n_paths * 2 + 64) * 4);
+    if (!dense) return -5;
+    // [pstart | pend | gate, number of dense tiles ... | crossings per path]: zeroed every frame (by the launch in front of k_pc_count's atomics
+    // on the last part, see below) (the variables below keep the names of the path_range parameters)
+    uint32_t* prange = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_I, ((uint64_t)n_paths * 3 + 64) * 4);
     if (!counts || !bases || !tile_of || !list || !list_base || !keys || !kbig || !prange) return -5;
     uint32_t *pfirst = prange, *plast = prange + n_paths, *gate = prange + 2 * (size_t)n_paths;
     uint32_t gl = stride_grid(L, lines_cap), gs = stride_grid(L, seg_cap);
     unsigned long long* bd_ctr = (unsigned long long*)jh_scratch_get(L.scratch, JH_SCR_BD_CTR, 64);
     if (!bd_ctr) return -5;
+    // crossings per path: atomic sums of k_pc_count, so the array is zero BEFORE that kernel starts -- left so by k_pc_rank_small of
+    // the frame before, or filled here when the flag is down (first frame, regrown or poisoned scratch)
+    uint32_t* ptotal = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_PC_TOT, (uint64_t)n_paths * 4);
+    if (!ptotal) return -5;
+    const uint32_t ptotal_words = (uint32_t)std::min<uint64_t>(jh_scratch_cap(L.scratch, JH_SCR_PC_TOT) / 4, 0xffffffffull);
+    uint32_t* clean = jh_scratch_flags(L.scratch);
+    if ((*clean & JH_CLEAN_PC_TOT) == 0u) (void)hipMemsetAsync(ptotal, 0, (size_t)ptotal_words * 4, L.stream);
+    *clean &= ~(uint32_t)JH_CLEAN_PC_TOT;
     hipLaunchKernelGGL(k_pc_count, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, lines, paths, counts, lines_cap, prange,
-                       n_paths * 2u + 64u, line_path, bd_ctr, (L.absorb & JH_ABSORB_SETUP) ? (JlIndirectCount*)L.indirect : (JlIndirectCount*)nullptr);
+                       n_paths * 2u + 64u, ptotal, n_paths, bd_ctr, (L.absorb & JH_ABSORB_SETUP) ? (JlIndirectCount*)L.indirect : (JlIndirectCount*)nullptr);
     *jh_scratch_flags(L.scratch) |= JH_CLEAN_BD_CTR;
     int rc = jh_scan_u32(L, counts, 1, bases, lines_cap, &bump->lines, &bump->seg_counts);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_pc_paths, dim3(gl), dim3(JL_WG), 0, L.stream, (const JlBump*)bump, ind, (const uint32_t*)line_path, (const uint32_t*)counts,
-                       (const uint32_t*)bases, lines_cap, pfirst, plast, n_paths);
     const uint32_t *cpf = pfirst, *cpl = plast, *cc = counts, *cb = bases;
     hipLaunchKernelGGL(k_pc_emit, dim3(gl), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, ind, lines, paths, tile, segc, cb, lines_cap,
-                       tile_of, keys, kbig, seg_cap, cpf, cpl, cc, n_paths, gate);
+                       tile_of, keys, kbig, seg_cap, pfirst, plast, (const uint32_t*)ptotal, n_paths, gate);
     // Big paths only (`gate` = number of tiles if there is one, else 0: the scan then covers 0 elements and the kernels
     // return at once):
     // per-tile list bases = exclusive scan of Tile.segment_count_or_ix, scatter into the lists, rank inside the list.
@@ -1163,7 +1180,8 @@ int jh_launch_path_count(const JhLaunch& L) {
     sc.tile_of = tile_of; sc.list_base = list_base; sc.tiles_cap = tiles_cap; sc.list = list; sc.kbig = kbig; sc.gate = gate; sc.dense = dense;
     sc.dense_cap = dense_cap; sc.blocks = gs;
     hipLaunchKernelGGL(k_pc_rank_small, dim3(gs + stride_grid(L, (uint64_t)n_paths * 64u)), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile,
-                       (const uint32_t*)keys, seg_cap, cpf, cpl, cc, cb, n_paths, segc, sc);
+                       (const uint32_t*)keys, seg_cap, cpf, cpl, cc, cb, n_paths, segc, sc, ptotal, ptotal_words);
+    *clean |= JH_CLEAN_PC_TOT;
     hipLaunchKernelGGL(k_pc_rank, dim3(gs), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, tile, (const uint2*)tile_of, seg_cap,
                        (const uint32_t*)list_base, tiles_cap, (const uint32_t*)list, segc, (const uint32_t*)kbig, (const uint32_t*)gate,
                        (const uint32_t*)dense, dense_cap);

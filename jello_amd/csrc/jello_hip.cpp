@@ -1154,6 +1154,15 @@ int jh_debug_clip_hint_overflows(jh_ctx* ctx, uint32_t* count, int reset) {
     }
     return JH_OK;
 }
+#ifdef FINE_TIMING
+extern "C" int jh_debug_fine_timing(jh_ctx* ctx, unsigned long long* out6, int reset) {
+    if (!ctx || !ctx->hint_overflow) return JH_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (out6) { HIP_TRY(ctx, hipMemcpyAsync(out6, ctx->hint_overflow + 8, 48, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
+    if (reset) { HIP_TRY(ctx, hipMemsetAsync(ctx->hint_overflow + 8, 0, 48, ctx->stream)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
+    return JH_OK;
+}
+#endif
 uint64_t jh_debug_scratch_bytes(jh_ctx* ctx, int slot) {
     return (ctx && slot >= 0 && slot < JH_SCR_COUNT) ? ctx->scratch.cap[slot] : 0;
 }

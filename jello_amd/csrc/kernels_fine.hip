@@ -969,6 +969,11 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         }
         return fast;
     };
+#ifdef FINE_TIMING  // (variant builds only: where a tile's time goes; read back with jh_debug_clip_hint_overflows' buffer, words 8..)
+    uint64_t tm_batch = 0ull, tm_walk = 0ull;
+    uint32_t tm_nbatch = 0u, tm_nfill = 0u;
+    const uint64_t tm_start = __builtin_readcyclecounter();
+#endif
     // One FILL command (fill_path, fine.wgsl:824-878): leaves the finished coverage of the lane's four pixels in area[].
     auto do_fill = [&](uint32_t size_and_rule, uint32_t seg_data, int32_t backdrop) {
         uint32_t n_segs = size_and_rule >> 1;
@@ -981,13 +986,28 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         float backdrop_f = (float)backdrop;
 #pragma unroll
         for (int k = 0; k < 4; k++) area[k] = backdrop_f;
+#if FINE_SKIP != 0 && defined(__HIP_DEVICE_COMPILE__)
+        // (differential builds: the areas must stay opaque per-lane values.  Without the walk they would be the uniform backdrop, and
+        // the compiler would simplify the finalisation and the COMPOSITE behind them as well -- the round-3/4 splits charged that
+        // saving to stage 4: 0.10 ms "for the walk" of which a third was the composite's.  Found in round 5.)
+#pragma unroll
+        for (int k = 0; k < 4; k++) asm volatile("" : "+v"(area[k]));
+#endif
         uint32_t sa = seg_data, remaining = n_segs;
         while (remaining != 0u) {  // uniform
 #if FINE_SKIP == 4
             batch_hi = sa + remaining;
             cur_base = sa;
 #else
+#ifdef FINE_TIMING
+            const uint64_t tb0 = __builtin_readcyclecounter();
+            const bool builds = sa - cur_base >= batch_hi - cur_base;
+#endif
             if (sa - cur_base >= batch_hi - cur_base) build_batch(sa);
+#ifdef FINE_TIMING
+            const uint64_t tb1 = __builtin_readcyclecounter();
+            tm_batch += tb1 - tb0; tm_nbatch += builds ? 1u : 0u; tm_nfill += 1u;
+#endif
 #endif
             const uint32_t take = umin_(remaining, batch_hi - sa);
             const uint32_t r0 = sa - cur_base;  // window-relative segments [r0, r0 + take)
@@ -1072,6 +1092,9 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                 em &= em - 1ull;
             }
             if constexpr (CLIPS) lds_st_u16(lds_addr(&F.lanest[lane]) + 2u, (uint16_t)done); else s4_done = done;
+#ifdef FINE_TIMING
+            tm_walk += __builtin_readcyclecounter() - tb1;
+#endif
             next_seg = sa + take;
             sa += take;
             remaining -= take;
@@ -1551,6 +1574,17 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             for (int k = 0; k < 4; k++) rgba[k] = FINE_SKIP == 5 ? v4(rgba[k].x + area[k], rgba[k].y + fg.x, rgba[k].z + fg.y, rgba[k].w + fg.z * fg.w) : over(rgba[k], fg, area[k]);
         }
     }
+#ifdef FINE_TIMING
+    if (hint_overflow != nullptr && lane == 0u) {
+        unsigned long long* t = (unsigned long long*)(hint_overflow + 8);
+        atomicAdd(&t[0], (unsigned long long)(__builtin_readcyclecounter() - tm_start));
+        atomicAdd(&t[1], (unsigned long long)tm_batch);
+        atomicAdd(&t[2], (unsigned long long)tm_walk);
+        atomicAdd(&t[3], (unsigned long long)tm_nbatch);
+        atomicAdd(&t[4], (unsigned long long)tm_nfill);
+        atomicAdd(&t[5], 1ull);
+    }
+#endif
     if constexpr (AA == 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no window may still be in flight to this wave's LDS when it ends
     // fine.wgsl:1092-1102: un-premultiply, store RGBA16F (four adjacent pixels = 32 bytes per lane; 4 lanes = one 128-B row)
     const uint32_t cx0 = tile_x * 16u + lx * 4u;

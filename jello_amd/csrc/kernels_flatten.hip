@@ -1471,6 +1471,10 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
             V2 lp1;
             if (last_of_item) {
                 lp1 = v2(u2f(en.z), u2f(en.w));
+#if defined(FL_LSPLIT) && FL_LSPLIT == 1  // (measurement builds only, tools/flatten_split.sh: k_flatten_lines without the Euler evaluation -- results are wrong)
+            } else if (true) {
+                lp1 = v2(u2f(r0.x) + u2f(r2.y) * (float)(t - tp), u2f(r0.w) + u2f(r1.x) + u2f(r1.y) + u2f(r1.z) + u2f(r1.w) + u2f(r2.x) + u2f(r3.z) + u2f(r3.w));
+#endif
             } else {  // flatten.wgsl:404-461
                 EulerParams ep;
                 ep.th0 = u2f(r1.x); ep.th1 = 0.0f; ep.k0 = u2f(r1.y); ep.k1 = u2f(r1.z); ep.ch = u2f(r1.w);
@@ -1531,7 +1535,11 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
             for (int j = 0; j < 3; j++) {
                 const uint32_t ix = si[64u * (uint32_t)j + lane];
                 const uint2 d = sd[64u * (uint32_t)j + lane];
+#if defined(FL_LSPLIT) && FL_LSPLIT == 2  // (measurement builds only: the staged words are not stored -- results are wrong)
+                if (ix == 0xfffffffeu) w[ix] = d;
+#else
                 if (ix != 0xffffffffu) w[ix] = d;
+#endif
             }
         }
     }

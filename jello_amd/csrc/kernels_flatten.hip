@@ -5,19 +5,23 @@
 // LineSoup order run-dependent.  Here the stage is classify -> items -> scan -> lines -> bbox:
 //   k_flatten_classify   one thread per tag byte: splits it into up to 3 work items (see below) and appends them
 //                        to a heavy / light list; writes PathBbox.draw_flags/trans_ix;
-//   k_flatten_items      a wave per batch of 64 items: caps / joins / lines are written to a temporary buffer
-//                        (LDS-chunked, order-free allocation) with a key (item slot, k); the Euler jobs of the batch
-//                        are subdivided together -- the nodes of their subdivision trees sit on one LDS stack and 64
-//                        are tested per step, whichever jobs they belong to -- and leave one 64-byte record per
-//                        accepted piece in the temp slots the piece reserves; counts[slot] = lines of the item;
-//   jh_scan_u32          line base per slot; the total lands in bump.lines;
-//   k_flatten_lines      one thread per temp slot: evaluates the line's end point from the piece record and writes the
-//                        line to lines[bases[slot] + k] (its start is the end point of the line before it);
+//   k_flatten_items      a wave per batch of 64 items: caps / joins / lines leave one record per line; the Euler jobs of
+//                        the batch are subdivided together -- the nodes of their subdivision trees sit on one LDS stack and
+//                        64 are tested per step, whichever jobs they belong to -- and leave one 64-byte record per accepted
+//                        piece, densely, in the order the pieces were found.  Every LINE gets a temporary slot; the slots
+//                        of a batch are ONE range, laid out in the canonical order of its lines (job, piece, line), and
+//                        slot_info[slot] = (record, index of the line in its piece); counts[item] = lines of the item;
+//   jh_scan_u32          line base per item; the total lands in bump.lines;
+//   k_flatten_lines      one thread per temporary slot: evaluates the line's end point from the piece record and writes the
+//                        line to lines[bases[item] + k] (its start is the end point of the line before it);
 //   k_flatten_bbox       streams the finished lines and folds their boxes by path (segmented wave scan), honouring the
 //                        WGSL's per-tag extent rule -> path bounding boxes.
 // Result: lines are ordered by (tag byte, emission order) -- the reference's own sequential order
 // (shaders/cpu/flatten.go:664-823) -- with the subdivision arithmetic executed exactly once.
-// Algorithmic traffic: scene bytes + 20 B / tag word in, 24 B / line out (+ 64-80 B / piece through the temp).
+// Temporary memory: 8 bytes per slot + 64 bytes per record, both allocated EXACTLY (one returning atomic per batch and kind
+// on a packed 64-bit cursor: slots in the low half, records in the high half), capacity = the line buffer's: a frame whose
+// lines fit the line buffer fits the temporary.
+// Algorithmic traffic: scene bytes + 20 B / tag word in, 24 B / line out (+ 64 B / piece and 8 B / line through the temp).
 // k_flatten_items is VALU/latency-bound (f64 transcendentals, 1...30 subdivision attempts per job).
 #include <hip/hip_runtime.h>
 __shared__ double fl_atan_tab[9];  // dmath.h: atan(k/8) for the table-split arctangent, filled by atan_tab_fill()
@@ -46,56 +50,120 @@ struct PathTagData { uint32_t tag_byte; MonoidK<5> monoid; };
 #define TANGENT_THRESH 1e-6f
 
 #define FL_INVALID 0xffffffffu
-#define FL_INFO_PIECE 0x80000000u    // tinfo: an Euler piece starts here, low 16 bits = its line count; its record is pieces[slot]
-#define FL_INFO_DIRECT 0x20000000u   // tinfo: complete line
+// slot_info[t] = (record index, FL_INFO_* | lines of the piece << 8 | index of this line in the piece); every slot below the
+// slot cursor is written exactly once per frame (allocation is exact), so the array needs no clearing
+#define FL_INFO_PIECE 0x80000000u    // line i of an Euler piece (record: see "piece record" below)
+#define FL_INFO_DIRECT 0x40000000u   // complete line (record: {item, k, path_ix, -}, {p0, p1})
 #ifndef FL_REFILL_LANES
 #define FL_REFILL_LANES 32u  // idle lanes that trigger a refill of the wave
 #endif
 
-// Line sink.  EMIT: lines go to a TEMPORARY buffer in allocation order (fast, order-free allocation:
-// LDS atomic on the workgroup's chunk, global atomic only when the chunk is exhausted) together with a
-// key (slot, k) = (work item, index of the line inside the item); k_flatten_lines then moves every
-// line to lines[bases[slot] + k], the canonical position.  !EMIT: only counts.
+// The temporary: slot_info (8 B per slot) and records (64 B), each cut into K regions of R entries with a cursor of its own.
+// ONE cursor for everything is a hot word: it sustains ~60-90 returning atomics per microsecond, and the 20 000 allocations of
+// a C3 frame took 210 us longer than the arithmetic; K cursors in K memory channels scale.  An allocation takes n consecutive
+// entries of the caller's current region (one returning atomic); a region that cannot hold it is left for the next one, for
+// good (the caller's region index is sticky), and the slots it leaves unused at the region's end are marked empty.  Capacity:
+// no allocation is larger than FL_MAX_GRAB, a region wastes less than one allocation at its end, so K * R >= lines + K *
+// FL_MAX_GRAB holds every frame whose lines fit the line buffer.
+#define FL_MAX_REGIONS 8u
+#define FL_MAX_GRAB 51200u  // = the lines of one job of the cooperative subdivision (512 pieces of 100); an arc has < 31 416
+struct FlTemp {
+    uint2* sinfo;
+    uint4* recs;
+    uint32_t* ctr;  // the stage's counters (FL_CTR_*)
+    uint32_t K, R;
+};
+#define FL_CTR_CURSOR 512u    // word index of region 0's slot cursor; its record cursor 32 words on; next region FL_CUR_STRIDE on
+#define FL_CUR_STRIDE 64u
+// n consecutive slots (KIND 0) or records (KIND 1): the position, or FL_INVALID when every region is full (the frame has
+// overflowed its line buffer).  `home` is the wave's region: WAVE-UNIFORM, so that the lanes that allocate in one instruction
+// can share one atomic (wave_bump; one atomic per lane means 400 000 per C3 frame instead of 8 000: +370 us).  `failed` is raised when home could not serve: the wave moves
+// on at its next uniform point (fl_next_home).
+// [p, p + n) of a bump counter for every ACTIVE lane of the wave, with ONE atomic: the lanes are served value by value (the
+// lanes of a call site mostly ask for the same n: one round), a lane's offset = what the rounds before it and the lanes below
+// it in its own round take.  By hand, because LLVM's atomic optimizer in its DPP strategy -- which does the same with a wave
+// prefix sum -- returned wrong offsets for these call sites (divergent branches inside loops; test_c2_blobs_all_joins_caps_evenodd
+// failed with it and passes with the strategies None and Iterative), and None means 64 atomics per call.
+JD uint32_t wave_bump(uint32_t* ctr, uint32_t n) {
+    const uint64_t below = (1ull << lane_id()) - 1ull;
+    uint64_t todo = __builtin_amdgcn_ballot_w64(true);
+    const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+    uint32_t off = 0u, total = 0u;
+    while (todo != 0ull) {  // uniform among the active lanes
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)n, __builtin_ctzll(todo));
+        const uint64_t m = __builtin_amdgcn_ballot_w64(n == v);
+        if (n == v) off = total + v * (uint32_t)__builtin_popcountll(m & below);
+        total += v * (uint32_t)__builtin_popcountll(m);
+        todo &= ~m;
+    }
+    uint32_t p = 0u;
+    if (lane_id() == leader) p = atomicAdd(ctr, total);
+    return (uint32_t)__builtin_amdgcn_readlane((int)p, (int)leader) + off;
+}
+template <int KIND>
+JD uint32_t fl_grab(const FlTemp& T, uint32_t home, uint32_t n, bool& failed) {
+    // (the attempt on home stands apart from the loop over the other regions: inside the loop the region is a per-lane value)
+    uint32_t p = wave_bump(T.ctr + FL_CTR_CURSOR + FL_CUR_STRIDE * home + (KIND ? 32u : 0u), n);
+    if (__builtin_expect(p <= T.R && n <= T.R - p, 1)) return home * T.R + p;
+    failed = true;
+    uint32_t region = home;
+    for (uint32_t tries = 1u;; tries++) {
+        if (KIND == 0 && p < T.R)  // the region's last slots stay empty
+            for (uint32_t i = p; i < T.R; i++) T.sinfo[(size_t)region * T.R + i] = make_uint2(0u, 0u);
+        if (tries >= T.K) return FL_INVALID;
+        region = region + 1u == T.K ? 0u : region + 1u;
+        p = atomicAdd(T.ctr + FL_CTR_CURSOR + FL_CUR_STRIDE * region + (KIND ? 32u : 0u), n);
+        if (p <= T.R && n <= T.R - p) return region * T.R + p;
+    }
+}
+// (wave-uniform) the next region that still has room, seen from `home`; home itself if none has
+JD uint32_t fl_next_home(const FlTemp& T, uint32_t home, int kind) {
+    uint32_t region = home;
+    for (uint32_t tries = 0u; tries < T.K; tries++) {
+        const uint32_t cur = __hip_atomic_load(T.ctr + FL_CTR_CURSOR + FL_CUR_STRIDE * region + (kind ? 32u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur < T.R) return region;
+        region = region + 1u == T.K ? 0u : region + 1u;
+    }
+    return home;
+}
+
+// Line sink of the DIRECT items (caps, joins, straight segments) and of the sequential fall-back walk.  EMIT: an allocation
+// of n lines takes n temporary slots and n records (two returning atomics on different words; lanes that allocate in the same
+// instruction are combined by the compiler's atomic optimizer), a line leaves its record and its slot_info; k_flatten_lines
+// then moves it to lines[bases[item] + k], the canonical position.  !EMIT: only counts.
 template <bool EMIT>
 struct Out {
     const JlConfig* cfg;
-    JlLineSoup* tlines;
-    uint2* tkeys;
-    uint32_t* tinfo;  // per temp slot: FL_INFO_* marker (0 = nothing starts here)
-    uint32_t overflow_start;  // first temp slot behind the workgroup chunks
-    uint32_t tcap;
+    FlTemp T;
+    uint32_t home_s, home_r;   // the wave's current slot / record region (uniform)
+    bool failed_s, failed_r;   // an allocation of this lane found the region full
     uint32_t slot;
     uint32_t cursor;           // lines emitted so far by this item (local index of the next line)
-    uint32_t a_first, a_tpos;  // current allocation: first local index and its temp position
-    uint32_t* lds_next;        // workgroup chunk cursor (LDS)
-    uint32_t lds_limit;
-    uint32_t* g_next;          // global temp cursor
-    float bx0, by0, bx1, by1;
+    uint32_t a_first, a_spos, a_rpos;  // current allocation: first local index, its slot and its record
 
     JD uint32_t alloc(uint32_t n) {
         uint32_t first = cursor;
         cursor += n;
         if (EMIT) {
-            uint32_t p = atomicAdd(lds_next, n);
-            if (p + n > lds_limit) p = atomicAdd(g_next, n);
             a_first = first;
-            a_tpos = p;
+#if defined(FL_ISPLIT) && FL_ISPLIT == 2  // (measurement builds only: direct lines allocate nothing -- results are wrong)
+            a_spos = a_rpos = FL_INVALID;
+#else
+            a_spos = fl_grab<0>(T, home_s, n, failed_s);
+            a_rpos = fl_grab<1>(T, home_r, n, failed_r);
+#endif
         }
         return first;
     }
     JD void write_line(uint32_t line_ix, uint32_t path_ix, V2 p0, V2 p1) {  // flatten.wgsl:749-756
         if (EMIT) {
-            bx0 = fmin_(bx0, fmin_(p0.x, p1.x));
-            by0 = fmin_(by0, fmin_(p0.y, p1.y));
-            bx1 = fmax_(bx1, fmax_(p0.x, p1.x));
-            by1 = fmax_(by1, fmax_(p0.y, p1.y));
-            uint32_t t = a_tpos + (line_ix - a_first);
-            if (t < tcap) {
-                JlLineSoup l;
-                l.path_ix = path_ix; l.pad = 0; l.p0[0] = p0.x; l.p0[1] = p0.y; l.p1[0] = p1.x; l.p1[1] = p1.y;
-                tlines[t] = l;
-                tkeys[t] = make_uint2(slot, line_ix);
-                tinfo[t] = FL_INFO_DIRECT;
+            if (a_spos != FL_INVALID && a_rpos != FL_INVALID) {
+                const uint32_t t = a_spos + (line_ix - a_first), r = a_rpos + (line_ix - a_first);
+                T.recs[(size_t)r * 4u] = make_uint4(slot, line_ix, path_ix, 0u);
+                T.recs[(size_t)r * 4u + 1u] = make_uint4(f2u(p0.x), f2u(p0.y), f2u(p1.x), f2u(p1.y));
+                T.sinfo[t] = make_uint2(r, FL_INFO_DIRECT);
+            } else if (a_spos != FL_INVALID) {
+                T.sinfo[a_spos + (line_ix - a_first)] = make_uint2(0u, 0u);  // (a slot without a record: empty)
             }
         }
     }
@@ -313,28 +381,41 @@ struct Scene {
 // ------------------------------------------------------------------------------------------------
 // flatten_euler (flatten.wgsl:328-477) in two kernels.
 //
-// k_flatten_items: every lane owns one Euler job (a cubic + offset) and runs the adaptive subdivision exactly as in the
-// WGSL.  An ACCEPTED piece reserves its n line slots in the temporary buffer and leaves a 96-byte record there; its
-// lines are NOT evaluated in this kernel (that loop at 3 waves/SIMD and 35 % lane use cost 240 of the stage's 600 us).
-// k_flatten_lines (after the per-item line counts are scanned): one thread per temporary slot evaluates the END point
+// k_flatten_items decides the subdivision and, for every ACCEPTED piece, the number of its lines; the piece leaves a 64-byte
+// record, its lines are NOT evaluated in this kernel (that loop at 3 waves/SIMD and 35 % lane use cost 240 of the stage's
+// 600 us).  k_flatten_lines (after the per-item line counts are scanned): one thread per temporary slot evaluates the END point
 // of its line from the piece record (the WGSL's arithmetic per point), transforms it and writes it straight into the
 // canonical LineSoup position of the line AND as the START point of the following line of the item -- a line's start
 // is the end of the line before it (flatten.wgsl:462-468); only the item's first line takes its start from the
 // record.  Every point is computed once, with the same operations on the same values as in the sequential
-// formulation, hence the same bits.  Lines emitted directly (caps, joins) wait in the temp buffer and are copied.
+// formulation, hence the same bits.  Lines emitted directly (caps, joins) wait in records of their own and are copied.
 // ------------------------------------------------------------------------------------------------
 JD void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
-// piece record: one 64-byte sector, 4 x uint4 at pieces[4 * tpos] (the lines kernel fetches one sector per piece):
-//   0: es_p0.x es_p0.y es_p1.x es_p1.y   1: th0 k0 k1 ch   2: noff n slot first   3: path_ix trans_ix<<6|flags int0 integral
-// plus ends[tpos] = (t_start.x, t_start.y, t_end.x, t_end.y), read only for the first / last line of an item.
+// piece record: one 64-byte sector, 4 x uint4 at recs[4 * r]:
+//   0: es_p0.x es_p0.y es_p1.x es_p1.y   1: th0 th1 int0 integral   2: noff item path_ix trans_ix<<6|flags
+//   3: (first piece of its item ? t_start.x : index of the piece's first line in the item) t_start.y t_end.x t_end.y
+// t_start is read only by the item's first line, t_end only by its last.  The number of lines n comes with slot_info.
 // flags: bits 0-1 robust case, 4 = ends at t == 1 (last line ends in t_end), 8 = offset >= 0, 16 = offset == 0,
 //        32 = first piece of its item.  Of the subdivision constants of flatten.wgsl:404-433, int0 and integral (two
-//        espc_int_approx evaluations) travel in the record; a and b are recomputed from (k0, k1, ch, noff) by the same
-//        two products.
+//        espc_int_approx evaluations) travel in the record; the Euler parameters k0, k1, ch are recomputed from the two angles
+//        (es_params_from_angles: 45 binary32 operations, no transcendentals), a and b by the same two products.
+JD void piece_record_write(uint4* __restrict__ rec, V2 es_p0, V2 es_p1, float th0, float th1, float int0, float integral, float noff,
+                           uint32_t item, uint32_t path_ix, uint32_t trans_ix, uint32_t fl, uint32_t first, V2 t_start, V2 t_end) {
+    rec[0] = make_uint4(f2u(es_p0.x), f2u(es_p0.y), f2u(es_p1.x), f2u(es_p1.y));
+    rec[1] = make_uint4(f2u(th0), f2u(th1), f2u(int0), f2u(integral));
+    rec[2] = make_uint4(f2u(noff), item, path_ix, (trans_ix << 6) | fl);
+    rec[3] = make_uint4((fl & 32u) != 0u ? f2u(t_start.x) : first, f2u(t_start.y), f2u(t_end.x), f2u(t_end.y));
+}
+// slot_info of the n lines of a piece whose first line has slot tpos
+JD void piece_slots_write(uint2* __restrict__ sinfo, uint32_t tpos, uint32_t n_u, uint32_t r) {
+#if !(defined(FL_ISPLIT) && FL_ISPLIT == 1)  // (measurement builds only: no slot_info of pieces -- results are wrong)
+    for (uint32_t i = 0u; i < n_u; i++) sinfo[tpos + i] = make_uint2(r, FL_INFO_PIECE | (n_u << 8) | i);
+#endif
+}
 
 struct EulerJob {
     bool valid;
@@ -400,7 +481,7 @@ JD void euler_begin(EulerLane& e, const EulerJob& job) {  // flatten.wgsl:328-36
 // `refill()` is called (by the whole wave) when enough lanes are idle; it finalises finished items, gives idle
 // lanes new ones (euler_begin) and returns false once no lane is active and the queue is empty.
 template <class Refill>
-JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ pieces, uint4* __restrict__ ends, Refill&& refill) {
+JD void flatten_euler_wave(Out<true>& o, EulerLane& e, Refill&& refill) {
     V2 &p0 = e.p0, &p1 = e.p1, &p2 = e.p2, &p3 = e.p3;
     float& scale = e.scale;
     const float& offset = e.offset;
@@ -420,7 +501,7 @@ JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ piece
 
         bool accept = false;
         uint32_t n_u = 0u;
-        float pc_n = 0.0f, pc_noff = 0.0f, pc_int0 = 0.0f, pc_integral = 0.0f;
+        float pc_noff = 0.0f, pc_int0 = 0.0f, pc_integral = 0.0f;
         EulerParams ep;
         ep.th0 = ep.th1 = ep.k0 = ep.k1 = ep.ch = 0.0f;
         V2 es_p0 = v2(0, 0), es_p1 = v2(0, 0);
@@ -478,7 +559,7 @@ JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ piece
                     float n = clamp_(ceil_(n_frac * scale_multiplier), 1.0f, 100.0f);
                     n_u = to_u32(n);
                     accept = true;
-                    pc_n = n; pc_noff = normalized_offset; pc_int0 = int0; pc_integral = integral;  // (a, b: two products, recomputed)
+                    pc_noff = normalized_offset; pc_int0 = int0; pc_integral = integral;  // (a, b: two products, recomputed)
                     es_p0 = this_p0; es_p1 = this_pq1.point;
                     pc_flags = robust | ((t1 == 1.0f) ? 4u : 0u) | ((offset >= 0.0f) ? 8u : 0u) | ((offset == 0.0f) ? 16u : 0u);
                     last_p = this_pq1.point;
@@ -494,20 +575,17 @@ JD void flatten_euler_wave(Out<true>& o, EulerLane& e, uint4* __restrict__ piece
                 }
             }
         }
-        if (accept) {
+        if (accept) {  // (n slots and n records per piece, of which the piece uses the first: this walk is the rare fall-back)
             const uint32_t first = o.alloc(n_u);
-            const uint32_t tpos = o.a_tpos;
-            if (tpos < o.tcap && tpos + n_u <= o.tcap) {
-                uint4* rec = pieces + (size_t)tpos * 4u;
+            const uint32_t tpos = o.a_spos, r = o.a_rpos;
+            if (r != FL_INVALID) {
                 const uint32_t fl = pc_flags | (e.first_piece ? 32u : 0u);
-                rec[0] = make_uint4(f2u(es_p0.x), f2u(es_p0.y), f2u(es_p1.x), f2u(es_p1.y));
-                rec[1] = make_uint4(f2u(ep.th0), f2u(ep.k0), f2u(ep.k1), f2u(ep.ch));
-                rec[2] = make_uint4(f2u(pc_noff), f2u(pc_n), o.slot, first);
-                rec[3] = make_uint4(e.path_ix, (e.trans_ix << 6) | fl, f2u(pc_int0), f2u(pc_integral));
-                if ((fl & (32u | 4u)) != 0u) ends[tpos] = make_uint4(f2u(e.t_start.x), f2u(e.t_start.y), f2u(t_end.x), f2u(t_end.y));
-                o.tinfo[tpos] = FL_INFO_PIECE | n_u;
-                if (tpos >= o.overflow_start)  // only the chunk area is zeroed up front (rare path)
-                    for (uint32_t i = 1u; i < n_u; i++) o.tinfo[tpos + i] = 0u;
+                piece_record_write(o.T.recs + (size_t)r * 4u, es_p0, es_p1, ep.th0, ep.th1, pc_int0, pc_integral, pc_noff, o.slot, e.path_ix,
+                                   e.trans_ix, fl, first, e.t_start, t_end);
+            }
+            if (tpos != FL_INVALID) {
+                if (r != FL_INVALID) piece_slots_write(o.T.sinfo, tpos, n_u, r);
+                else for (uint32_t i = 0u; i < n_u; i++) o.T.sinfo[tpos + i] = make_uint2(0u, 0u);
             }
             e.first_piece = false;
         }
@@ -703,19 +781,18 @@ JD Seg load_seg(const Scene& s, uint32_t ix) {
 #ifndef FL_CLASSIFY_TAGS
 #define FL_CLASSIFY_TAGS 8u  // C3: 32 / 25 / 28 us with 4 / 8 / 16
 #endif
-// counters: [0] heavy items, [2] next overflow temp slot, [3] longest used chunk prefix, [FL_CTR_LIGHT] light items -- the
-// two list counters are hot (every workgroup of k_flatten_classify waits for its two returns) and live in different
-// memory channels
+// counters: [0] heavy items, [FL_CTR_LIGHT] light items -- the two list counters are hot (every workgroup of
+// k_flatten_classify waits for its two returns) and live in different memory channels --, from FL_CTR_CURSOR the cursors of
+// the temporary's regions (FlTemp)
 #define FL_CTR_LIGHT 256u
-#define FL_CTR_WORDS 512u
+#define FL_CTR_WORDS (FL_CTR_CURSOR + FL_CUR_STRIDE * FL_MAX_REGIONS)
 // tag bytes per thread: fewer workgroups => fewer atomics on the two hot list counters
 __global__ __launch_bounds__(JL_WG) void k_flatten_classify(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
                                                             Buf<JlPathBbox> path_bboxes, uint32_t* __restrict__ list,
                                                             uint32_t* __restrict__ counters, uint32_t cap, uint32_t n_tags,
-                                                            uint32_t temp_overflow_start, uint32_t* __restrict__ counts,
+                                                            uint32_t* __restrict__ counts,
                                                             uint32_t absorb, uint32_t* __restrict__ bump_words) {
     __shared__ uint32_t sh[12];
-    if (blockIdx.x == 0u && threadIdx.x == 0u) counters[2] = temp_overflow_start;  // first temp slot behind the workgroup chunks
     // Commands the engine held back for this stage (jello_hip.cpp, Deferred): bbox_clear (bbox_clear.wgsl:13-24; this kernel
     // writes only the draw_flags / trans_ix words of the boxes, the min / max words are first used by k_flatten_bbox) and
     // the recording's Clear(bump) (render.go:237; nothing of flatten touches bump before k_flatten_items).
@@ -882,12 +959,12 @@ JD void run_item(const JlConfig* cfg, const Scene& s, Out<EMIT>& o, uint32_t slo
 #endif
 struct FlBatch {
     uint32_t jhead[64];                // newest piece of the job + 1 (0 = none), lane = job
-    uint32_t jpend[64];                // nodes of the job that are still unresolved
     uint32_t stack[FLQ_STACK];         // job | level << 6 | t0_u << 11
-    uint32_t l_tpos[FLQ_LEAVES];       // phase A: the accepted node (same packing as the stack); phase B: its first temp slot
+    uint32_t l_tpos[FLQ_LEAVES];       // the accepted node (same packing as the stack); after phase B: the piece's first line in its job
     uint16_t l_key[FLQ_LEAVES];        // t0 in units of 2^-9 << 7 | n
     uint16_t l_link[FLQ_LEAVES];       // job << 10 | next piece of the job + 1
-    uint32_t unsure[128];              // nodes the transcendental-free test could not decide (flatten_fast.h): < 64 waiting + 64 new
+    uint32_t unsure[128];              // nodes the transcendental-free test could not decide (flatten_fast.h): < 64 waiting + 64 new;
+                                       // after phase B: [job] = lines of the batch's jobs before it
     uint32_t n_stack, n_leaves, bail, n_unsure;
 };
 // The job state (control points, scale, offset, ids) stays in the registers of the lane that set the job up; the lane
@@ -1065,11 +1142,7 @@ __device__ uint32_t g_ff_stats[8];  // nodes tested, undecided, contradictions, 
 __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_PER_EU, FL_WAVES_PER_EU))) void k_flatten_items(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
                                                          Buf<JlPathBbox> path_bboxes, const uint32_t* __restrict__ list,
                                                          uint32_t* __restrict__ counters, uint32_t cap, uint32_t* __restrict__ counts,
-                                                         JlLineSoup* __restrict__ tlines, uint2* __restrict__ tkeys, uint32_t tcap,
-                                                         uint32_t FL_CHUNK, uint32_t* __restrict__ tinfo, uint4* __restrict__ pieces,
-                                                         uint4* __restrict__ ends, uint32_t* __restrict__ chunk_used) {
-    __shared__ uint32_t sh_next;
-    __shared__ uint32_t sh_chunk;
+                                                         FlTemp T) {
     __shared__ uint32_t sh_item;  // next position of this workgroup's share of the item list
     __shared__ FlBatch sh_batch[JL_WG / 64];
     Scene s;
@@ -1078,24 +1151,13 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
     uint32_t n = n_heavy + n_light;
     if (blockIdx.x * 64u >= n) return;  // uniform: this workgroup's share of the list is empty
     atan_tab_fill();
-    if (threadIdx.x == 0) {
-        uint32_t cb = blockIdx.x * FL_CHUNK;  // static: the overflow area (counters[2]) starts behind the last chunk
-        sh_chunk = cb;
-        sh_next = cb;
-        sh_item = 0u;
-    }
+    if (threadIdx.x == 0) sh_item = 0u;
     __syncthreads();
-    uint32_t chunk = sh_chunk;
-    for (uint32_t i = threadIdx.x; i < FL_CHUNK; i += JL_WG)  // "nothing starts in this slot" for the workgroup's own chunk
-        if (chunk + i < tcap) tinfo[chunk + i] = 0u;
-    __syncthreads();  // before any wave of the workgroup marks a slot
     const uint32_t lane = lane_id();
     FlBatch& B = sh_batch[threadIdx.x >> 6];
     Out<true> o;
-    o.cfg = cfg; o.tlines = tlines; o.tkeys = tkeys; o.tinfo = tinfo; o.overflow_start = gridDim.x * FL_CHUNK; o.tcap = tcap; o.slot = 0u;
-    o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
-    o.lds_next = &sh_next; o.lds_limit = chunk + FL_CHUNK; o.g_next = &counters[2];
-    o.bx0 = 1e31f; o.by0 = 1e31f; o.bx1 = -1e31f; o.by1 = -1e31f;
+    o.cfg = cfg; o.T = T; o.home_s = o.home_r = blockIdx.x % T.K; o.failed_s = o.failed_r = false; o.slot = 0u;
+    o.cursor = 0u; o.a_first = 0u; o.a_spos = 0u; o.a_rpos = 0u;
     // Work distribution: the item list (heavy items first) is dealt to the workgroups in chunks of 64, round robin; a
     // wave takes one chunk (= one batch) at a time through the workgroup's LDS counter.
     for (;;) {
@@ -1105,6 +1167,9 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
         const uint32_t t_first = ((base >> 6) * gridDim.x + blockIdx.x) * 64u;
         if (t_first >= n) break;
         const uint32_t t = t_first + lane;
+        // (a region of the temporary that is full is left behind at this uniform point)
+        if (__builtin_amdgcn_ballot_w64(o.failed_s) != 0ull) { o.home_s = fl_next_home(T, o.home_s, 0); o.failed_s = false; }
+        if (__builtin_amdgcn_ballot_w64(o.failed_r) != 0ull) { o.home_r = fl_next_home(T, o.home_r, 1); o.failed_r = false; }
         // ---- set up the batch: direct items are emitted at once, Euler jobs go to LDS ----
         EulerJob job;
         job.valid = false; job.path_ix = 0u; job.trans_ix = 0u; job.offset = 0.0f;
@@ -1114,7 +1179,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
         uint32_t slot = FL_INVALID;
         if (t < n) {
             slot = t < n_heavy ? list[t] : list[cap - 1u - (t - n_heavy)];
-            o.slot = slot; o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
+            o.slot = slot; o.cursor = 0u; o.a_first = 0u; o.a_spos = 0u; o.a_rpos = 0u;
             uint32_t path_ix;
             run_item<true>(cfg, s, o, slot, job, path_ix);
             if (!job.valid) counts[slot] = o.cursor;  // a direct item is complete
@@ -1124,7 +1189,6 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
         const bool active = job.valid && !e.done;
         if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;  // uniform: nothing to subdivide in this batch
         B.jhead[lane] = 0u;
-        B.jpend[lane] = active ? 1u : 0u;
         {
             const uint64_t am = __builtin_amdgcn_ballot_w64(active);
             if (active) B.stack[(uint32_t)__builtin_popcountll(am & ((1ull << lane) - 1ull))] = lane;  // root: level 0, t0_u 0
@@ -1200,7 +1264,6 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
                 const uint32_t pos = ns_left + 2u * (uint32_t)__builtin_popcountll(rejm & below);
                 B.stack[pos] = j | ((level + 1u) << 6) | ((2u * t0_u + 1u) << 11);
                 B.stack[pos + 1u] = j | ((level + 1u) << 6) | ((2u * t0_u) << 11);  // the left half on top: popped first
-                atomicAdd(&B.jpend[j], 1u);
             }
             if (acc) {  // a piece: its record is written in phase B
                 const uint32_t li = nl + (uint32_t)__builtin_popcountll(accm & below);
@@ -1208,16 +1271,24 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
                 B.l_key[li] = (uint16_t)((t0_u << (FLQ_MAX_LEVEL - level)) << 7);
                 const uint32_t prev = atomicExch(&B.jhead[j], li + 1u);
                 B.l_link[li] = (uint16_t)((j << 10) | prev);
-                atomicSub(&B.jpend[j], 1u);
             }
             if (uns) B.unsure[nu_left + (uint32_t)__builtin_popcountll(unsm & below)] = node;  // (nu_left < 64 in a fast round)
             if (lane == 0u) { B.n_stack = ns_left + 2u * n_rej; B.n_leaves = nl + n_acc; B.n_unsure = nu_left + n_uns; }
             wave_fence();
         }
         // ---- phase B: the pieces, 64 at a time whichever jobs they belong to: the pinned angles (two atan2), the Euler
-        // parameters and the line count (flatten.wgsl:404-447), the temp slots, the record ----
+        // parameters and the line count (flatten.wgsl:404-447), the record.  The records of a batch are one dense range in the
+        // order of the piece list (one returning atomic per batch; its round trip passes under the first pass's arithmetic).
+        // A batch that gave up (bail) leaves no pieces: all its jobs take the sequential walk below. ----
         const bool bail = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.bail) != 0u;
-        const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.n_leaves);
+        const uint32_t nl = bail ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)B.n_leaves);
+        uint32_t rec_base = 0u;
+#if defined(FL_ISPLIT) && FL_ISPLIT == 3  // (measurement builds only: the batches allocate nothing -- results are wrong)
+        if (nl != 0u && lane == 0u) rec_base = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 640u % (T.K * T.R - 640u);
+#else
+        if (nl != 0u && lane == 0u) rec_base = fl_grab<1>(T, o.home_r, nl, o.failed_r);
+#endif
+        rec_base = (uint32_t)__builtin_amdgcn_readlane((int)rec_base, 0);
 #ifdef FL_SPLIT_NO_B  // (measurement builds only: no piece is written)
         for (uint32_t lbase = nl; lbase < nl; lbase += 64u) {
 #else
@@ -1233,56 +1304,70 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
             // a piece needs the ids of its job and, if it is the item's first or last, the item's end points
             const uint32_t j_slot = laneu(slot, j), j_path = laneu(e.path_ix, j), j_trans = laneu(e.trans_ix, j);
             const float j_tsx = lanef(e.t_start.x, j), j_tsy = lanef(e.t_start.y, j), j_tex = lanef(e.t_end.x, j), j_tey = lanef(e.t_end.y, j);
-            if (has && B.jpend[j] == 0u) {  // (an unfinished job -- bail -- is redone below)
+            if (has) {
                 const NodeEnds ne = node_ends(jp0, jp1, jp2, jp3, level, t0_u);
                 const CubicParams cp = piece_angles(ne);
                 const PieceParams pp = piece_params(cp, scale, offset);
-                const uint32_t n_u = pp.n_u;
-                uint32_t tpos = atomicAdd(o.lds_next, n_u);
-                if (tpos + n_u > o.lds_limit) tpos = atomicAdd(o.g_next, n_u);
                 const uint32_t fl = pp.robust | ((ne.t1 == 1.0f) ? 4u : 0u) | ((offset >= 0.0f) ? 8u : 0u) | ((offset == 0.0f) ? 16u : 0u) |
                                     ((t0_u == 0u) ? 32u : 0u);
-                if (tpos < tcap && tpos + n_u <= tcap) {
-                    uint4* rec = pieces + (size_t)tpos * 4u;
-                    rec[0] = make_uint4(f2u(ne.last_p.x), f2u(ne.last_p.y), f2u(ne.point.x), f2u(ne.point.y));
-                    rec[1] = make_uint4(f2u(pp.ep.th0), f2u(pp.ep.k0), f2u(pp.ep.k1), f2u(pp.ep.ch));
-                    ((uint2*)rec)[4] = make_uint2(f2u(pp.noff), f2u(pp.n));  // rec[2] = noff, n, slot, first line of the piece --
-                    ((uint32_t*)rec)[10] = j_slot;                            // the last word is written once, below
-                    rec[3] = make_uint4(j_path, (j_trans << 6) | fl, f2u(pp.int0), f2u(pp.integral));
-                    if ((fl & (32u | 4u)) != 0u) ends[tpos] = make_uint4(f2u(j_tsx), f2u(j_tsy), f2u(j_tex), f2u(j_tey));
-                    tinfo[tpos] = FL_INFO_PIECE | n_u;
-                    if (tpos >= o.overflow_start)  // only the chunk area is zeroed up front (rare path)
-                        for (uint32_t i = 1u; i < n_u; i++) tinfo[tpos + i] = 0u;
-                }
-                B.l_tpos[li] = tpos;
-                B.l_key[li] = (uint16_t)(B.l_key[li] | n_u);
+                const uint32_t r = rec_base + li;
+                if (rec_base != FL_INVALID)  // (word 12 of a piece that is not its item's first -- the index of its first line -- is written below)
+                    piece_record_write(T.recs + (size_t)r * 4u, ne.last_p, ne.point, pp.ep.th0, pp.ep.th1, pp.int0, pp.integral, pp.noff, j_slot, j_path,
+                                       j_trans, fl, 0u, v2(j_tsx, j_tsy), v2(j_tex, j_tey));
+                B.l_key[li] = (uint16_t)(B.l_key[li] | pp.n_u);
             }
         }
         wave_fence();
-        // ---- a piece's first line = the lines of its job's pieces before it; a job's line count ----
-        for (uint32_t li = lane; li < nl; li += 64u) {
-            const uint32_t j = B.l_link[li] >> 10, key = B.l_key[li];
-            if (B.jpend[j] != 0u) continue;  // unfinished (bail): the job is redone below, phase B left its pieces out
-            const uint32_t tpos = B.l_tpos[li];
-            const bool ok = tpos < tcap && tpos + (key & 127u) <= tcap;
-            uint32_t first = 0u;
-            for (uint32_t q = B.jhead[j]; q != 0u; q = B.l_link[q - 1u] & 1023u) {
-                const uint32_t k2 = B.l_key[q - 1u];
-                if ((k2 >> 7) < (key >> 7)) first += k2 & 127u;
-            }
-            if (ok) ((uint32_t*)pieces)[(size_t)tpos * 16u + 11u] = first;
-        }
-        const bool redo = active && B.jpend[lane] != 0u;
-        if (active && !redo) {
+        if (nl != 0u) {  // uniform
+            // ---- the lines of a job; the slots of the batch: ONE range (one returning atomic), the jobs in lane order ----
             uint32_t total = 0u;
-            for (uint32_t q = B.jhead[lane]; q != 0u; q = B.l_link[q - 1u] & 1023u) total += B.l_key[q - 1u] & 127u;
-            counts[slot] = total;
+            if (active)
+                for (uint32_t q = B.jhead[lane]; q != 0u; q = B.l_link[q - 1u] & 1023u) total += B.l_key[q - 1u] & 127u;
+            if (active) counts[slot] = total;
+            const uint32_t incl = wave_incl_scan_u32(total);
+            const uint32_t batch_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            // (a batch of more than FL_MAX_GRAB lines -- 64 jobs of 800 -- allocates job by job: no allocation may be larger)
+            const bool together = batch_total <= FL_MAX_GRAB;  // uniform
+            uint32_t grab = 0u;
+            if (together) {
+#if defined(FL_ISPLIT) && FL_ISPLIT == 3
+                if (lane == 0u) grab = FL_INVALID;
+#else
+                if (lane == 0u) grab = fl_grab<0>(T, o.home_s, batch_total, o.failed_s);
+#endif
+            } else if (active && total != 0u) {
+                grab = fl_grab<0>(T, o.home_s, total, o.failed_s);
+            }
+            // ---- a piece's first line = the lines of its job's pieces before it (in the meantime the atomic returns) ----
+            for (uint32_t li = lane; li < nl; li += 64u) {
+                const uint32_t j = B.l_link[li] >> 10, key = B.l_key[li];
+                uint32_t first = 0u;
+                for (uint32_t q = B.jhead[j]; q != 0u; q = B.l_link[q - 1u] & 1023u) {
+                    const uint32_t k2 = B.l_key[q - 1u];
+                    if ((k2 >> 7) < (key >> 7)) first += k2 & 127u;
+                }
+                B.l_tpos[li] = first;
+            }
+            {   // the first slot of every job
+                const uint32_t base0 = (uint32_t)__builtin_amdgcn_readlane((int)grab, 0);
+                B.unsure[lane] = together ? (base0 == FL_INVALID ? FL_INVALID : base0 + (incl - total)) : grab;
+            }
+            wave_fence();
+            // ---- the slots: in the canonical order of the batch's lines (job, piece, line), so that k_flatten_lines reads
+            // consecutive slots and writes consecutive lines ----
+            for (uint32_t li = lane; li < nl; li += 64u) {
+                const uint32_t j = B.l_link[li] >> 10, key = B.l_key[li], first = B.l_tpos[li];
+                const uint32_t r = rec_base + li, jb = B.unsure[j];
+                if (rec_base != FL_INVALID && (key >> 7) != 0u) ((uint32_t*)T.recs)[(size_t)r * 16u + 12u] = first;  // (t0 != 0: not the item's first piece)
+                if (jb == FL_INVALID) continue;
+                if (rec_base != FL_INVALID) piece_slots_write(T.sinfo, jb + first, key & 127u, r);
+                else for (uint32_t i = 0u; i < (key & 127u); i++) T.sinfo[jb + first + i] = make_uint2(0u, 0u);  // (slots without a record: empty)
+            }
+            wave_fence();
         }
-        wave_fence();
-        if (__builtin_expect(bail, 0)) {  // uniform, rare: the sequential walk for the jobs that did not finish
-            o.slot = slot; o.cursor = 0u; o.a_first = 0u; o.a_tpos = 0u;
-            if (!redo) e.done = true;
-            bool have = redo;
+        if (__builtin_expect(bail, 0)) {  // uniform, rare: the sequential walk for all jobs of the batch
+            o.slot = slot; o.cursor = 0u; o.a_first = 0u; o.a_spos = 0u; o.a_rpos = 0u;
+            bool have = active;
             auto finish = [&]() -> bool {
                 if (e.done && have) {
                     counts[o.slot] = o.cursor;
@@ -1290,148 +1375,75 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
                 }
                 return __builtin_amdgcn_ballot_w64(!e.done) != 0ull;
             };
-            flatten_euler_wave(o, e, pieces, ends, finish);
+            flatten_euler_wave(o, e, finish);
         }
-    }
-    // how much of the reserved chunk is in use (k_flatten_lines skips the unused tail); every wave reports, the last wins
-    if (lane == 0u) {
-        const uint32_t used = umin_(sh_next, chunk + FL_CHUNK) - chunk;
-        atomicMax(&chunk_used[chunk / FL_CHUNK], used);
-        // the longest used chunk prefix: k_flatten_lines visits no batch behind it (5120 waves on one word: only a wave
-        // that would raise what it reads -- possibly stale, i.e. smaller -- sends the atomic)
-        if (used > __hip_atomic_load(&counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&counters[3], used);
     }
 }
 
 // One thread per temporary slot: the Euler line (or the directly emitted line) that lives there, moved to
-// lines[bases[slot] + k], the canonical (tag byte, emission order) LineSoup position.
+// lines[bases[item] + k], the canonical (tag byte, emission order) LineSoup position.
 #ifndef FL_LINES_WAVES_PER_EU
 #define FL_LINES_WAVES_PER_EU 4  // C3: 152 / 121 / 106 / 120 / 159 us at 2 / 3 / 4 / 5 / 8 (tools/sweep_flatten.sh)
 #endif
 __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_WAVES_PER_EU, FL_LINES_WAVES_PER_EU))) void k_flatten_lines(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, const uint32_t* __restrict__ counters,
-                                                         const uint32_t* __restrict__ tinfo, const uint4* __restrict__ pieces,
-                                                         const uint4* __restrict__ ends, uint32_t tcap, const JlLineSoup* __restrict__ tlines, const uint2* __restrict__ tkeys,
-                                                         const uint32_t* __restrict__ chunk_used, uint32_t n_chunks, uint32_t FL_CHUNK,
-                                                         const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines) {
+                                                         FlTemp T, const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines) {
     __shared__ uint2 sh_wdat[JL_WG / 64][192];    // per wave: the words it stores this step, in lane order ...
     __shared__ uint32_t sh_widx[JL_WG / 64][192];  // ... and their 8-byte word indices in the line buffer (~0: none)
     atan_tab_fill();
-    const uint32_t n_t = umin_(counters[2], tcap);
     const uint32_t lines_lim = umin_(cfg->lines_size, lines.n);
     const uint32_t lane = lane_id();
-    // Work units = batches of JL_WG slots: batch bi of chunk c for bi below the longest used chunk prefix (interleaved
-    // over the chunks), then the overflow area.  (Walking the whole slot space cost a memory round trip for every batch
-    // in the unused tail of a chunk -- about half of them.)
-    const uint32_t chunk_batches = (umin_(counters[3], FL_CHUNK) + JL_WG - 1u) / JL_WG;
-    const uint32_t units_chunks = n_chunks * chunk_batches;
-    const uint32_t ov_start = n_chunks * FL_CHUNK;
-    const uint32_t units = units_chunks + (n_t > ov_start ? (n_t - ov_start + JL_WG - 1u) / JL_WG : 0u);
-    // first slot of work unit u (FL_INVALID for a batch in the unused tail of its chunk) and the number of its slots in use
-    auto unit_slot = [&](uint32_t u, uint32_t& lim) -> uint32_t {
-        lim = JL_WG;
-        if (u >= units) return FL_INVALID;
-        if (u >= units_chunks) return ov_start + (u - units_chunks) * JL_WG;
-        // (batch bi of chunk uc; the rotation by bi keeps a workgroup whose stride is a multiple of n_chunks from
-        // walking ONE chunk from end to end -- chunks are filled unevenly, and the fullest one set the kernel's time)
-        const uint32_t bi = u / n_chunks, uc = (u % n_chunks + bi * 61u) % n_chunks;
-        const uint32_t used = chunk_used[uc];
-        if (bi * JL_WG >= used) return FL_INVALID;
-        lim = used - bi * JL_WG;
-        return uc * FL_CHUNK + bi * JL_WG;
+    const uint2* __restrict__ sinfo = T.sinfo;
+    const uint4* __restrict__ recs = T.recs;
+    const uint32_t n_r = T.K * T.R;
+    // Work units = JL_WG consecutive slots of a region, below the region's cursor.  Every such slot was written by
+    // k_flatten_items (an allocation is exact; the slots a region could not give away are marked empty), and slot_info says
+    // which record a slot belongs to and which of the record's lines it is: no search, no neighbours.
+    uint32_t ru[FL_MAX_REGIONS], used[FL_MAX_REGIONS];  // units of the regions before region c, slots in use of region c (uniform; unrolled loops: registers)
+    uint32_t units = 0u;
+#pragma unroll
+    for (uint32_t c = 0u; c < FL_MAX_REGIONS; c++) {
+        ru[c] = units;
+        used[c] = c < T.K ? umin_(counters[FL_CTR_CURSOR + FL_CUR_STRIDE * c], T.R) : 0u;
+        units += (used[c] + JL_WG - 1u) / JL_WG;
+    }
+    auto fetch_info = [&](uint32_t u) -> uint2 {
+        if (u >= units) return make_uint2(0u, 0u);
+        uint32_t c = 0u, first_unit = 0u, in_use = used[0];
+#pragma unroll
+        for (uint32_t q = 1u; q < FL_MAX_REGIONS; q++)
+            if (u >= ru[q] && used[q] != 0u) { c = q; first_unit = ru[q]; in_use = used[q]; }
+        const uint32_t in_region = (u - first_unit) * JL_WG + threadIdx.x;
+        return in_region < in_use ? sinfo[(size_t)c * T.R + in_region] : make_uint2(0u, 0u);
     };
-    // The markers of the NEXT unit are fetched before this one is worked on: a unit is a chain of dependent round
-    // trips (chunk fill -> markers -> piece record -> line base), and the first two now overlap the previous unit.
-    // (the markers of the 64 slots in front of the wave's come with them: a piece that began in the previous wave's slots --
-    // four waves in ten -- is then found without a walk back through memory, one dependent round trip per step)
-    auto fetch_markers = [&](uint32_t t0, uint32_t& v, uint32_t& vp) {
-        v = 0u; vp = 0u;
-        if (t0 == FL_INVALID) return;
-        const uint32_t t = t0 + threadIdx.x;
-        if (t < n_t) v = tinfo[t];
-        if (t >= 64u && t - 64u < n_t) vp = tinfo[t - 64u];
+    // state of a slot: 0 nothing to do, 1 complete line (copied), 2 line i of a piece
+    auto state_of = [&](uint2 si) -> uint32_t {
+        if (si.x >= n_r) return 0u;
+        return (si.y & FL_INFO_PIECE) != 0u ? 2u : ((si.y & FL_INFO_DIRECT) != 0u ? 1u : 0u);
     };
-    // Software pipeline over the work units of a workgroup, two deep: while unit u is evaluated, the piece records of unit
-    // u + G (G = gridDim.x) are on their way and so are the markers of unit u + 2 G.  A unit used to be a chain of three
-    // dependent round trips (markers -> piece record -> transform / line base); one per unit is left.
-    // state of a slot: 0 nothing to do, 1 complete line (copied), 2 line k of a piece
-    auto resolve = [&](uint32_t t0, uint32_t lim, uint32_t v, uint32_t vp, uint32_t& tp, uint32_t& vout) -> uint32_t {
-        tp = 0u; vout = 0u;
-        if (t0 == FL_INVALID) return 0u;  // uniform
-        const uint32_t t = t0 + threadIdx.x;
-        // which piece covers slot t?  Its first slot carries the marker (pieces have at most 100 lines).  The wave looks
-        // at its 64 markers together: the nearest marker at or before a lane (DPP running maximum); lanes before the
-        // wave's first marker take the last marker of the 64 slots in front of the wave, and only if there is none
-        // either (a piece of more than 64 lines) walk back through memory.
-        const uint32_t mark = wave_incl_max_u32(v != 0u ? lane + 1u : 0u);  // 1 + lane of the nearest marker, 0 = none
-        tp = t;
-        uint32_t walk_from = lane + 1u;  // first distance the memory walk would have to look at
-        if (mark != 0u) {
-            v = (uint32_t)__shfl((int)v, (int)(mark - 1u), 64);
-            tp = t - (lane - (mark - 1u));
-        }
-        if (__builtin_amdgcn_ballot_w64(mark == 0u) != 0ull) {  // uniform
-            const uint32_t plast = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max_u32(vp != 0u ? lane + 1u : 0u), 63);
-            if (plast != 0u) {  // uniform
-                const uint32_t pv = (uint32_t)__builtin_amdgcn_readlane((int)vp, (int)(plast - 1u));
-                if (mark == 0u) {
-                    v = pv;
-                    tp = t - lane - 64u + (plast - 1u);
-                }
-            } else {
-                walk_from = lane + 65u;
-            }
-        }
-        // the workgroups' reserved chunks are the first n_chunks * FL_CHUNK slots; their unused tails hold nothing
-        if (t >= n_t || threadIdx.x >= lim) return 0u;
-        if (mark == 0u && v == 0u) {
-            for (uint32_t back = walk_from; back <= 100u && back <= t; back++) {
-                v = tinfo[t - back];
-                if (v != 0u) { tp = t - back; break; }
-            }
-        }
-        vout = v;
-        if ((v & FL_INFO_DIRECT) != 0u && tp == t) return 1u;
-        if ((v & FL_INFO_PIECE) == 0u) return 0u;
-        if (t - tp >= (v & 0xffffu)) return 0u;
-        return 2u;
-    };
-    auto fetch_rec = [&](uint32_t state, uint32_t tp, uint4& r0, uint4& r1, uint4& r2, uint4& r3) {
+    auto fetch_rec = [&](uint32_t state, uint32_t r, uint4& r0, uint4& r1, uint4& r2, uint4& r3) {
         r0 = r1 = r2 = r3 = make_uint4(0u, 0u, 0u, 0u);
-        if (state == 2u) {
-            const uint4* rec = pieces + (size_t)tp * 4u;
-            r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
-        } else if (state == 1u) {  // a complete line (tp == its own slot): its key and its 24 bytes come the same way, one step ahead
-            const uint2 key = tkeys[tp];
-            const uint2* src = (const uint2*)(tlines + tp);
-            const uint2 w0 = src[0], w1 = src[1], w2 = src[2];
-            r0 = make_uint4(key.x, key.y, 0u, 0u);
-            r1 = make_uint4(w0.x, w0.y, w1.x, w1.y);
-            r2 = make_uint4(w2.x, w2.y, 0u, 0u);
-        }
+        const uint4* rec = recs + (size_t)r * 4u;
+        if (state != 0u) { r0 = rec[0]; r1 = rec[1]; }
+        if (state == 2u) { r2 = rec[2]; r3 = rec[3]; }
     };
+    // Software pipeline over the work units of a workgroup, two deep: while unit u is evaluated, the records of unit u + G
+    // (G = gridDim.x) are on their way and so is the slot_info of unit u + 2 G.
     const uint32_t G = gridDim.x;
-    uint32_t lim_a, lim_b;
-    uint32_t t0_a = unit_slot(blockIdx.x, lim_a), t0_b = unit_slot(blockIdx.x + G, lim_b);
-    uint32_t mv_a, mp_a, mv_b, mp_b;
-    fetch_markers(t0_a, mv_a, mp_a);
-    fetch_markers(t0_b, mv_b, mp_b);
-    uint32_t tp_a, v_a;
-    uint32_t st_a = resolve(t0_a, lim_a, mv_a, mp_a, tp_a, v_a);
+    uint2 si_a = fetch_info(blockIdx.x), si_b = fetch_info(blockIdx.x + G);
+    uint32_t st_a = state_of(si_a);
     uint4 a0, a1, a2, a3;
-    fetch_rec(st_a, tp_a, a0, a1, a2, a3);
+    fetch_rec(st_a, si_a.x, a0, a1, a2, a3);
     for (uint32_t u = blockIdx.x; u < units; u += G) {  // uniform per workgroup
-        // the current unit: resolved, its records requested one trip ago
-        const uint32_t t0 = t0_a, st = st_a, tp = tp_a, v = v_a;
+        // the current unit: its records were requested one trip ago
+        const uint32_t st = st_a;
+        const uint2 si = si_a;
         const uint4 r0 = a0, r1 = a1, r2 = a2, r3 = a3;
-        // the next unit: its markers were requested one trip ago; resolve them and request its records
-        t0_a = t0_b; lim_a = lim_b;
-        st_a = resolve(t0_b, lim_b, mv_b, mp_b, tp_a, v_a);
-        fetch_rec(st_a, tp_a, a0, a1, a2, a3);
-        // the unit after that: markers
-        t0_b = unit_slot(u + 2u * G, lim_b);
-        fetch_markers(t0_b, mv_b, mp_b);
-        if (t0 == FL_INVALID) continue;  // uniform
-        const uint32_t t = t0 + threadIdx.x;
+        // the next unit: its slot_info was requested one trip ago; request its records
+        si_a = si_b;
+        st_a = state_of(si_a);
+        fetch_rec(st_a, si_a.x, a0, a1, a2, a3);
+        // the unit after that: slot_info
+        si_b = fetch_info(u + 2u * G);
         // What a slot writes: up to three 8-byte words of the line buffer (a LineSoup is {path, pad | p0 | p1} = 3 words).
         // A piece line stores its end point as p1 of its own record and, with the header, as p0 of the next one: the words
         // 3 dst + 2 ... 3 dst + 4, 24 contiguous bytes.  Stored straight from the lanes, each of the three store instructions
@@ -1440,52 +1452,49 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
         // LDS in lane order and leave as three stores of 64 CONSECUTIVE words each.
         uint32_t widx[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
         uint2 wdat[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
-        if (st == 1u) {  // complete line: copy (key and line fetched with the records)
-            const uint2 key = make_uint2(r0.x, r0.y);
-            if (key.x < n_slots) {
-                const uint32_t dst = bases[key.x] + key.y;
+        if (st == 1u) {  // complete line: copy
+            const uint32_t item = r0.x, k = r0.y;
+            if (item < n_slots) {
+                const uint32_t dst = bases[item] + k;
                 if (dst < lines_lim) {
-                    widx[0] = dst * 3u; wdat[0] = make_uint2(r1.x, r1.y);
-                    widx[1] = dst * 3u + 1u; wdat[1] = make_uint2(r1.z, r1.w);
-                    widx[2] = dst * 3u + 2u; wdat[2] = make_uint2(r2.x, r2.y);
+                    widx[0] = dst * 3u; wdat[0] = make_uint2(r0.z, 0u);
+                    widx[1] = dst * 3u + 1u; wdat[1] = make_uint2(r1.x, r1.y);
+                    widx[2] = dst * 3u + 2u; wdat[2] = make_uint2(r1.z, r1.w);
                 }
             }
         } else if (st == 2u) {
-            const uint32_t n_u = v & 0xffffu, i = t - tp;
-            const uint32_t flags = r3.y & 63u;
+            const uint32_t n_u = (si.y >> 8) & 127u, i = si.y & 127u;
+            const uint32_t flags = r2.w & 63u;
             const bool last_of_item = i + 1u == n_u && (flags & 4u) != 0u;
-            const uint32_t slot = r2.z, k = r2.w + i;
-            uint4 en = make_uint4(0u, 0u, 0u, 0u);
-            if (last_of_item || k == 0u) en = ends[tp];
+            const uint32_t slot = r2.y, k = ((flags & 32u) != 0u ? 0u : r3.x) + i;
             // (the transform and the line base only depend on the record: requested here, in front of the Euler evaluation, their
             // round trips pass under its ~500 instructions instead of following them)
             Xf tr;
             if ((flags & 16u) != 0u) {
                 tr = xf_identity();
             } else {
-                uint32_t tb = cfg->layout.transform_base + (r3.y >> 6) * 6u;
+                uint32_t tb = cfg->layout.transform_base + (r2.w >> 6) * 6u;
                 tr.m0 = u2f(scene.rd(tb)); tr.m1 = u2f(scene.rd(tb + 1u)); tr.m2 = u2f(scene.rd(tb + 2u));
                 tr.m3 = u2f(scene.rd(tb + 3u)); tr.t0 = u2f(scene.rd(tb + 4u)); tr.t1 = u2f(scene.rd(tb + 5u));
             }
             const uint32_t slot_base = slot < n_slots ? bases[slot] : 0u;
             V2 lp1;
             if (last_of_item) {
-                lp1 = v2(u2f(en.z), u2f(en.w));
-#if defined(FL_LSPLIT) && FL_LSPLIT == 1  // (measurement builds only, tools/flatten_split.sh: k_flatten_lines without the Euler evaluation -- results are wrong)
+                lp1 = v2(u2f(r3.z), u2f(r3.w));
+#if defined(FL_LSPLIT) && FL_LSPLIT == 1  // (measurement builds only, tools/lines_split.sh: k_flatten_lines without the Euler evaluation -- results are wrong)
             } else if (true) {
-                lp1 = v2(u2f(r0.x) + u2f(r2.y) * (float)(t - tp), u2f(r0.w) + u2f(r1.x) + u2f(r1.y) + u2f(r1.z) + u2f(r1.w) + u2f(r2.x) + u2f(r3.z) + u2f(r3.w));
+                lp1 = v2(u2f(r0.x) + (float)i, u2f(r0.w) + u2f(r1.x) + u2f(r1.y) + u2f(r1.z) + u2f(r1.w) + u2f(r2.x));
 #endif
             } else {  // flatten.wgsl:404-461
-                EulerParams ep;
-                ep.th0 = u2f(r1.x); ep.th1 = 0.0f; ep.k0 = u2f(r1.y); ep.k1 = u2f(r1.z); ep.ch = u2f(r1.w);
-                const float noff = u2f(r2.x), n = u2f(r2.y);
+                const EulerParams ep = es_params_from_angles(u2f(r1.x), u2f(r1.y));
+                const float noff = u2f(r2.x), n = (float)n_u;
                 const float tt = (float)(i + 1u) / n;
                 float sarg = tt;
                 const uint32_t robust = flags & 3u;
                 if (robust != 1u) {
                     const float k0 = ep.k0 - 0.5f * ep.k1, k1 = ep.k1;
                     const float dist_scaled = noff * ep.ch;
-                    const float int0 = u2f(r3.z), integral = u2f(r3.w);  // as k_flatten_items computed them
+                    const float int0 = u2f(r1.z), integral = u2f(r1.w);  // as k_flatten_items computed them
                     float a, b;
                     if (robust == 2u) {
                         a = k1;
@@ -1506,11 +1515,11 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
                 const uint32_t dst = slot_base + k;
                 const bool fwd = (flags & 8u) != 0u;  // offset >= 0: (start, end); else the line runs (end, start)
                 const bool has_next = !last_of_item && dst + 1u < lines_lim;
-                const uint2 hdr = make_uint2(r3.x, 0u), pt = make_uint2(f2u(q.x), f2u(q.y));
+                const uint2 hdr = make_uint2(r2.z, 0u), pt = make_uint2(f2u(q.x), f2u(q.y));
                 if (dst < lines_lim) {
                     if (k == 0u) {  // the item's first line: header and start point (the job's start point), once per item
                         uint2* w = (uint2*)lines.p;
-                        const V2 qs = xf_apply(tr, v2(u2f(en.x), u2f(en.y)));
+                        const V2 qs = xf_apply(tr, v2(u2f(r3.x), u2f(r3.y)));
                         w[(size_t)dst * 3u] = hdr;
                         w[(size_t)dst * 3u + (fwd ? 1u : 2u)] = make_uint2(f2u(qs.x), f2u(qs.y));
                     }
@@ -1525,15 +1534,15 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
         }
         {
             uint2* sd = sh_wdat[threadIdx.x >> 6];
-            uint32_t* si = sh_widx[threadIdx.x >> 6];
+            uint32_t* si_ = sh_widx[threadIdx.x >> 6];
             wave_fence();  // the previous unit's reads of the staging area are done
 #pragma unroll
-            for (int j = 0; j < 3; j++) { sd[3u * lane + (uint32_t)j] = wdat[j]; si[3u * lane + (uint32_t)j] = widx[j]; }
+            for (int j = 0; j < 3; j++) { sd[3u * lane + (uint32_t)j] = wdat[j]; si_[3u * lane + (uint32_t)j] = widx[j]; }
             wave_fence();
             uint2* w = (uint2*)lines.p;
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                const uint32_t ix = si[64u * (uint32_t)j + lane];
+                const uint32_t ix = si_[64u * (uint32_t)j + lane];
                 const uint2 d = sd[64u * (uint32_t)j + lane];
 #if defined(FL_LSPLIT) && FL_LSPLIT == 2  // (measurement builds only: the staged words are not stored -- results are wrong)
                 if (ix == 0xfffffffeu) w[ix] = d;
@@ -1733,48 +1742,41 @@ int jh_launch_flatten(const JhLaunch& L) {
     uint32_t cap_blocks = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * FL_BLOCKS_PER_CU;
     uint32_t g = (n_slots + JL_WG - 1) / JL_WG;
     if (g > cap_blocks) g = cap_blocks;
-    // temp slots a workgroup reserves up front: its fair share of (line capacity + one start-point slot per possible
-    // Euler job) + 25 %
-    uint64_t want = (uint64_t)lines.n + 2ull * n_tags;
-    uint32_t FL_CHUNK = (uint32_t)(((want / g) * 5 / 4 + 255) & ~255ull);
-    if (FL_CHUNK < 256u) FL_CHUNK = 256u;
-    // every workgroup zeroes its chunk's markers, so a small scene in a large line buffer must not get huge chunks
-    // (3 workgroups x 870 k slots cost 80 us); a workgroup that outgrows its chunk continues in the overflow area
-    if (FL_CHUNK > 16384u) FL_CHUNK = 16384u;
-    uint64_t tcap64 = want + (uint64_t)g * FL_CHUNK;
-    if (tcap64 > 0xfffffff0ull) return -1;
-    uint32_t tcap = (uint32_t)tcap64;
+    // The temporary (FlTemp): a slot per line and at most a record per line, K regions of R each; K * R = the line buffer's
+    // capacity + what the regions' ends can waste -- a frame that overflows the temporary has overflowed `lines` and fails as
+    // the reference's.  (At least 4096 lines: a frame that overflows a tiny line buffer by less still has every line of the
+    // buffer's range written, as the reference's `line_ix < lines_size` guard leaves them -- kat_words.json: lines_overflow_guard)
+    const uint64_t line_cap = std::min<uint64_t>(std::max<uint64_t>(lines.n, 4096), 0xf0000000ull);
+    FlTemp T;
+    T.K = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(line_cap >> 18, 1), FL_MAX_REGIONS);
+    T.R = (uint32_t)((line_cap + T.K - 1) / T.K) + FL_MAX_GRAB;
+    const uint64_t tcap = (uint64_t)T.K * T.R;
+    if (tcap > 0xfffffff0ull) return -1;
+    // (scratch slots are shared with the later stages: the two large arrays sit where path_count keeps its largest ones)
     uint32_t* counts = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_A, (uint64_t)n_slots * 4);
     uint32_t* bases = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_B, (uint64_t)n_slots * 4);
-    uint32_t* list = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_C, (uint64_t)n_slots * 4);
-    JlLineSoup* tlines = (JlLineSoup*)jh_scratch_get(L.scratch, JH_SCR_D, (uint64_t)tcap * sizeof(JlLineSoup));
-    uint2* tkeys = (uint2*)jh_scratch_get(L.scratch, JH_SCR_E, (uint64_t)tcap * sizeof(uint2));
-    uint32_t* tinfo = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_H, (uint64_t)tcap * 4);
-    uint4* pieces = (uint4*)jh_scratch_get(L.scratch, JH_SCR_I, (uint64_t)tcap * 64);
-    uint4* ends = (uint4*)jh_scratch_get(L.scratch, JH_SCR_F, (uint64_t)tcap * 16);
-    uint32_t* counters = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_FL_CTR, FL_CTR_WORDS * 4 + 2048u * 4);  // (g <= 2048)
-    if (!counts || !bases || !list || !counters || !tlines || !tkeys || !tinfo || !pieces || !ends) return -5;
-    uint32_t* chunk_used = counters + FL_CTR_WORDS;  // one word per workgroup chunk (g <= 2048 workgroups)
+    uint32_t* list = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_F, (uint64_t)n_slots * 4);
+    T.sinfo = (uint2*)jh_scratch_get(L.scratch, JH_SCR_C, tcap * sizeof(uint2));
+    T.recs = (uint4*)jh_scratch_get(L.scratch, JH_SCR_D, tcap * 64);
+    uint32_t* counters = (uint32_t*)jh_scratch_get(L.scratch, JH_SCR_FL_CTR, FL_CTR_WORDS * 4);
+    if (!counts || !bases || !list || !counters || !T.sinfo || !T.recs) return -5;
+    T.ctr = counters;
     uint32_t* clean = jh_scratch_flags(L.scratch);
-    // (always the whole fixed range, not this frame's g words: a later frame with more workgroups on the same, not regrown
-    // slot would otherwise read chunk_used words no frame has zeroed -- ADVICE r02)
-    if ((*clean & JH_CLEAN_FL_CTR) == 0u) (void)hipMemsetAsync(counters, 0, FL_CTR_WORDS * 4 + 2048u * 4, L.stream);
+    if ((*clean & JH_CLEAN_FL_CTR) == 0u) (void)hipMemsetAsync(counters, 0, FL_CTR_WORDS * 4, L.stream);
     *clean &= ~(uint32_t)JH_CLEAN_FL_CTR;
     hipLaunchKernelGGL(k_flatten_classify, dim3((L.gx + FL_CLASSIFY_TAGS - 1) / FL_CLASSIFY_TAGS), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list,
-                       counters, n_slots, n_tags, g * FL_CHUNK, counts, L.absorb, (uint32_t*)bump);
+                       counters, n_slots, n_tags, counts, L.absorb, (uint32_t*)bump);
     hipLaunchKernelGGL(k_flatten_items, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, (const uint32_t*)list, counters, n_slots, counts,
-                       tlines, tkeys, tcap, FL_CHUNK, tinfo, pieces, ends, chunk_used);
+                       T);
     int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);
     if (rc) return rc;
-    uint32_t gp = (tcap + JL_WG - 1) / JL_WG;
+    uint32_t gp = (uint32_t)((tcap + JL_WG - 1) / JL_WG);
     uint32_t gp_cap = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * 8u;
     // k_flatten_lines strides over its work units: exactly the workgroups that are resident together (more would run
     // as a second, partly filled round behind the first)
     uint32_t gl_cap = (uint32_t)(L.num_cus > 0 ? L.num_cus : 256) * FL_LINES_WAVES_PER_EU;
     if (gp > gl_cap) gp = gl_cap;
-    hipLaunchKernelGGL(k_flatten_lines, dim3(gp), dim3(JL_WG), 0, L.stream, cfg, scene, (const uint32_t*)counters, (const uint32_t*)tinfo,
-                       (const uint4*)pieces, (const uint4*)ends, tcap, (const JlLineSoup*)tlines, (const uint2*)tkeys, (const uint32_t*)chunk_used,
-                       g, FL_CHUNK, (const uint32_t*)bases, n_slots, lines);
+    hipLaunchKernelGGL(k_flatten_lines, dim3(gp), dim3(JL_WG), 0, L.stream, cfg, scene, (const uint32_t*)counters, T, (const uint32_t*)bases, n_slots, lines);
     // a wave per 64 lines of the buffer's capacity (the line count is only known on the device), at most 16 waves
     // per SIMD: the kernel lengthens the ranges to match
     uint64_t gb64 = ((uint64_t)lines.n + 255u) / 256u;  // four waves per workgroup
@@ -1785,7 +1787,7 @@ int jh_launch_flatten(const JhLaunch& L) {
 #endif
     uint32_t gb = gb64 > gb_max ? gb_max : (uint32_t)(gb64 < 1u ? 1u : gb64);
     hipLaunchKernelGGL(k_flatten_bbox, dim3(gb), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, (const uint32_t*)bases, n_slots, lines, pb,
-                       counters, FL_CTR_WORDS + 2048u);
+                       counters, FL_CTR_WORDS);
     *clean |= JH_CLEAN_FL_CTR;
     return 0;
 }

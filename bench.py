@@ -163,6 +163,9 @@ def run_rank(args, world):
                             tiles=margin(bump["tile"]), ptcl=margin(bump["ptcl"] + cfg0["width_in_tiles"] * cfg0["height_in_tiles"] * 64),
                             bin_data=margin(bump["binning"] + cfg0["bin_data_start"]), blend_spill=max(4096, margin(bump["blend"])))
     del rec0
+    # (the sizing render ran with the estimator's sizes -- three times the lines this frame has -- and the context's internal
+    # scratch arrays only grow: give them back, the timed frames allocate what their own sizes need)
+    eng.trim_scratch()
     rec = host.record(scene, params)
     cfg = rec.config
 
@@ -355,7 +358,7 @@ def run_rank(args, world):
             "launches_per_frame": None if not use_graph else dict(zip(("kernels", "fills_and_copies"), eng.graph_node_counts(graphs[0]))),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_source": "eager replay of the same %d steps with a hipEvent pair per stage" % args.steps,
-            "bump": bump_now, "sizing_attempts": attempts, "bump_estimate_clamped": scene.bump_sizes_clamped(W, H),
+            "bump": bump_now, "scratch_bytes_per_context": eng.scratch_bytes(), "sizing_attempts": attempts, "bump_estimate_clamped": scene.bump_sizes_clamped(W, H),
             "stage_roofline": stage_roofline(cfg, bump_now, stage_ms, rec),
             "roofline": roofline,
             "cpu_baseline": cpu,

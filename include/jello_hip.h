@@ -209,7 +209,12 @@ int jh_selftest_math(jh_ctx* ctx, int op, const float* a, const float* b, float*
  * with `byte` and forgets that any counter was left clean -- the state of freshly allocated device memory that happens
  * not to be zero.  Tests use it to show that no stage relies on what an earlier frame (or hipMalloc) left behind, the
  * way the reference's pooled buffers hold stale data (engine/wgpu_engine/wgpu.go:772-808). */
-uint64_t jh_debug_scratch_bytes(jh_ctx* ctx, int slot);   /* capacity of an internal scratch array (tests) */
+uint64_t jh_debug_scratch_bytes(jh_ctx* ctx, int slot);   /* capacity of an internal scratch array (tests); slot -1: all of them */
+/* Internal scratch arrays (count / offset arrays of the deterministic allocators, flatten's temporary) grow on demand and are
+   kept.  jh_scratch_trim waits for the stream and frees them all: after one frame that was much larger than the ones to come,
+   or after a first attempt with the estimator's generous bump sizes (the reference's pool keeps its buffers in the same way,
+   wgpu.go:601-616; this is the counterpart of dropping that pool).  Captured graphs become stale. */
+int jh_scratch_trim(jh_ctx* ctx);
 uint64_t jh_debug_graph_self_cleans(jh_ctx* ctx);  /* replays that had to zero an internal counter first (tests) */
 int jh_debug_poison_scratch(jh_ctx* ctx, int byte);
 

@@ -1164,7 +1164,34 @@ extern "C" int jh_debug_fine_timing(jh_ctx* ctx, unsigned long long* out6, int r
 }
 #endif
 uint64_t jh_debug_scratch_bytes(jh_ctx* ctx, int slot) {
-    return (ctx && slot >= 0 && slot < JH_SCR_COUNT) ? ctx->scratch.cap[slot] : 0;
+    if (!ctx) return 0;
+    if (slot == -1) {  // all of them
+        uint64_t sum = 0;
+        for (int i = 0; i < JH_SCR_COUNT; i++) sum += ctx->scratch.cap[i];
+        return sum;
+    }
+    return (slot >= 0 && slot < JH_SCR_COUNT) ? ctx->scratch.cap[slot] : 0;
+}
+// The scratch arrays only grow; a context that has rendered one much larger frame (or one frame with the estimator's generous
+// bump sizes before the regrow loop settled on the real ones) keeps that size.  This gives all of it back: waits for the
+// stream, frees every array; the next frame allocates what it needs.  Captured graphs hold the old pointers: they are stale
+// afterwards (generation check) and must be captured again.
+int jh_scratch_trim(jh_ctx* ctx) {
+    if (!ctx) return JH_ERR_INVALID;
+    if (ctx->capturing) return fail(ctx, JH_ERR_INVALID, "jh_scratch_trim during a graph capture");
+    JH_FLUSH(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    scratch_release_retired(&ctx->scratch);
+    for (int i = 0; i < JH_SCR_COUNT; i++) {
+        if (ctx->scratch.base[i]) (void)hipFree(ctx->scratch.base[i]);
+        ctx->scratch.base[i] = nullptr;
+        ctx->scratch.ptr[i] = nullptr;
+        ctx->scratch.cap[i] = 0;
+    }
+    ctx->scratch.clean_flags = 0;  // (new memory holds anything: every self-cleaned array is filled again on its next use)
+    ctx->generation++;
+    return JH_OK;
 }
 uint64_t jh_debug_graph_self_cleans(jh_ctx* ctx) { return ctx ? ctx->graph_self_cleans : 0; }
 

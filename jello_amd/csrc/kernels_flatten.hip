@@ -1157,6 +1157,9 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
     FlBatch& B = sh_batch[threadIdx.x >> 6];
     Out<true> o;
     o.cfg = cfg; o.T = T; o.home_s = o.home_r = blockIdx.x % T.K; o.failed_s = o.failed_r = false; o.slot = 0u;
+#ifdef FL_SOAK_HOME0  // (tools/soak_flatten_fallback.sh: every wave starts in region 0, so that regions fill up and are left behind)
+    o.home_s = o.home_r = 0u;
+#endif
     o.cursor = 0u; o.a_first = 0u; o.a_spos = 0u; o.a_rpos = 0u;
     // Work distribution: the item list (heavy items first) is dealt to the workgroups in chunks of 64, round robin; a
     // wave takes one chunk (= one batch) at a time through the workgroup's LDS counter.
@@ -1749,6 +1752,9 @@ int jh_launch_flatten(const JhLaunch& L) {
     const uint64_t line_cap = std::min<uint64_t>(std::max<uint64_t>(lines.n, 4096), 0xf0000000ull);
     FlTemp T;
     T.K = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(line_cap >> 18, 1), FL_MAX_REGIONS);
+#ifdef FL_SOAK_HOME0
+    T.K = FL_MAX_REGIONS;
+#endif
     T.R = (uint32_t)((line_cap + T.K - 1) / T.K) + FL_MAX_GRAB;
     const uint64_t tcap = (uint64_t)T.K * T.R;
     if (tcap > 0xfffffff0ull) return -1;

@@ -181,6 +181,14 @@ class Engine:
     def sync(self):
         self._check(self.hip.jh_sync(self.ctx), "sync")
 
+    def scratch_bytes(self, slot=-1):
+        """Capacity of the context's internal scratch arrays (all of them, or one slot)."""
+        return int(self.hip.jh_debug_scratch_bytes(self.ctx, slot))
+
+    def trim_scratch(self):
+        """Frees the internal scratch arrays (they only grow): after a frame much larger than the ones to come."""
+        self._check(self.hip.jh_scratch_trim(self.ctx), "scratch_trim")
+
     def set_stream(self, stream_ptr):
         self._check(self.hip.jh_set_stream(self.ctx, stream_ptr), "set_stream")
 

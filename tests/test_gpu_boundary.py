@@ -258,7 +258,7 @@ def test_blend_stack_scratch_follows_the_clip_depth(depth):
         compare(eng, s, p)
         tiles = (size // 16) ** 2
         levels = min(max(depth - 1, 0), 3)
-        cap = eng.hip.jh_debug_scratch_bytes(eng.ctx, 4)  # JH_SCR_D (shared with flatten's temporary lines: a few MiB here)
+        cap = eng.hip.jh_debug_scratch_bytes(eng.ctx, 4)  # JH_SCR_D (shared with flatten's piece records: a few MiB here)
         assert cap >= tiles * levels * 4096
         if levels < 3:
             assert cap < tiles * 3 * 4096, (cap, tiles * 3 * 4096)
@@ -509,3 +509,35 @@ def test_too_small_buffers_are_refused_not_read(engine):
     s, p = scenes.scene_c1()
     rec, bump, attempts = engine.render(s, p, retain=False)  # the context is still usable
     assert bump["failed"] == 0
+
+
+def test_scratch_of_the_headline_frame_and_trim():
+    """The internal scratch of a context rendering C3 (100 k paths, 4096^2) with buffers sized for the frame -- the count / offset
+    arrays of the deterministic allocators and flatten's temporary (8 B per line + 64 B per piece record, capacity = the line
+    buffer's) -- stays below 0.4 GB (round 4: 1.4 GB, the temporary alone 116 B x 11.7 M slots).  The arrays only grow: after the
+    first attempt with the estimator's sizes (three times the lines) jh_scratch_trim gives them back, and the frame after it is
+    the same frame."""
+    import hashlib
+    eng = jello_amd.Engine(0)
+    try:
+        s, p = scenes.scene_c3(100_000, 4096)
+        p.bump = s.bump_sizes(p.width, p.height)
+        rec0, bump, attempts = eng.render(s, p, robust=True)
+        assert bump["failed"] == 0 and attempts == 1
+        img0 = hashlib.sha256(eng.download_image(rec0.target["id"], 4096, 4096).tobytes()).hexdigest()
+        generous = eng.scratch_bytes()
+        eng.release(rec0)
+        eng.trim_scratch()
+        assert eng.scratch_bytes() == 0
+        margin = lambda x: int(x * 1.1) + 4096
+        p.bump = BumpSizes(lines=margin(bump["lines"]), seg_counts=margin(bump["seg_counts"]), segments=margin(bump["segments"]),
+                           tiles=margin(bump["tile"]), ptcl=margin(bump["ptcl"] + 256 * 256 * 64), bin_data=margin(bump["binning"] + 200_000))
+        rec1, bump1, attempts1 = eng.render(s, p, robust=True)
+        assert bump1 == bump and attempts1 == 1
+        assert hashlib.sha256(eng.download_image(rec1.target["id"], 4096, 4096).tobytes()).hexdigest() == img0
+        sized = eng.scratch_bytes()
+        assert sized <= 400_000_000, [eng.scratch_bytes(k) for k in range(14)]
+        assert generous > sized
+        eng.release(rec1)
+    finally:
+        eng.close()

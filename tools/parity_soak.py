@@ -1,5 +1,5 @@
 """Soak: many fuzz seeds (normal and extreme) through the HIP pipeline and the oracle, every buffer and the image.
-usage: python3 tools/parity_soak.py [first_seed [count]]"""
+usage: python3 tools/parity_soak.py [first_seed [count]]      TIGHT_LINES=1: the smallest line buffer the frame fits"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
@@ -17,6 +17,9 @@ for seed in range(first, first + count):
         s, p = scenes.scene_fuzz(seed, extreme=extreme, size=[256, 300, 512][seed % 3])
         p.bump = BumpSizes(lines=1 << 19, seg_counts=1 << 20, segments=1 << 20, tiles=1 << 21, ptcl=1 << 23, bin_data=1 << 19, blend_spill=1 << 21)
         p.aa = [Aa.Area, Aa.Msaa8, Aa.Msaa16][(seed // 3) % 3]
+        if os.environ.get("TIGHT_LINES"):
+            _, bump, _ = eng.render(s, p, robust=True)  # (only the robust path reads the bump allocators back)
+            p.bump.lines = int(bump["lines"]) + 1  # (the smallest line buffer the frame does not overflow)
         try:
             compare(eng, s, p)
         except AssertionError as e:

@@ -176,7 +176,11 @@ void* jh_scratch_get(JhScratch* s, int slot, uint64_t bytes) {
     // run the recording once eagerly before capturing it -- makes every array big enough; a capture that still has to grow
     // one is refused (the dispatch answers JH_ERR_OOM with a message that says so).
     if (s->ctx->capturing) return nullptr;
-    uint64_t cap = pool_size_class(bytes);
+    // (what is asked for + 1/16, in whole MiB: these arrays are internal, they do not go through the reference's pool and its
+    // size classes -- 2^k and 1.5 * 2^k, up to a third more than asked -- and the sixteenth keeps a slowly growing scene from
+    // reallocating every frame)
+    uint64_t cap = bytes + bytes / 16;
+    cap = cap < (1ull << 20) ? pool_size_class(cap) : (cap + ((1ull << 20) - 1)) & ~((1ull << 20) - 1);
     void* p = nullptr;
     // Every slot starts at its own offset (a multiple of 256 B) into its allocation: the flatten kernels walk up to
     // seven scratch arrays with the same index at once, and with all of them on 2 MiB boundaries k_flatten_lines

@@ -1751,7 +1751,7 @@ int jh_launch_flatten(const JhLaunch& L) {
     // buffer's range written, as the reference's `line_ix < lines_size` guard leaves them -- kat_words.json: lines_overflow_guard)
     const uint64_t line_cap = std::min<uint64_t>(std::max<uint64_t>(lines.n, 4096), 0xf0000000ull);
     FlTemp T;
-    T.K = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(line_cap >> 18, 1), FL_MAX_REGIONS);
+    T.K = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(line_cap >> 19, 1), FL_MAX_REGIONS);  // (C3: 6 regions, ~3 500 atomics per cursor and frame)
 #ifdef FL_SOAK_HOME0
     T.K = FL_MAX_REGIONS;
 #endif

@@ -790,9 +790,33 @@ __global__ __launch_bounds__(JL_WG) void k_coarse_relocate(const JlConfig* __res
                 next_chunk = k + 1u;
             }
         }
-        if (!live || src + 3u >= tmp.n) continue;
-        const unsigned long long fm = masks[(size_t)(src >> 6) * 2u] >> (src & 63u), jm = masks[(size_t)(src >> 6) * 2u + 1u] >> (src & 63u);
-        const uint4 in = *(const uint4*)(tmp.p + src);
+        // Words behind a unit's JUMP target or END are nobody's: they are not written (the two-pass route leaves them alone as well,
+        // and what the arena holds there depends on the order in which the waves took their chunks: tools/determinism.py hashes
+        // the whole buffer).  The JUMP mask of a chunk's earlier blocks comes from the first lane of their quarter of the wave.
+        // (all of a lane's loads are requested before any of them is looked at: one round trip, not two)
+        const bool in_range = src + 3u < tmp.n, fetch = live && in_range;
+        const unsigned long long raw_jm = fetch ? masks[(size_t)(src >> 6) * 2u + 1u] : 0ull;
+        const unsigned long long raw_fm = fetch ? masks[(size_t)(src >> 6) * 2u] : 0ull;
+        const uint4 in = fetch ? *(const uint4*)(tmp.p + src) : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t end_at = fetch ? end_pos[slot] : 0u;
+        bool dead_block = false;
+        if (!head) {  // uniform
+            const uint32_t lo = (uint32_t)raw_jm, hi = (uint32_t)(raw_jm >> 32);
+            const bool j0 = ((uint32_t)__builtin_amdgcn_readlane((int)lo, 0) | (uint32_t)__builtin_amdgcn_readlane((int)hi, 0)) != 0u;
+            const bool j1 = ((uint32_t)__builtin_amdgcn_readlane((int)lo, 16) | (uint32_t)__builtin_amdgcn_readlane((int)hi, 16)) != 0u;
+            const bool j2 = ((uint32_t)__builtin_amdgcn_readlane((int)lo, 32) | (uint32_t)__builtin_amdgcn_readlane((int)hi, 32)) != 0u;
+            dead_block = (part > 0u && j0) || (part > 1u && j1) || (part > 2u && j2);
+        }
+        if (!fetch || dead_block) continue;
+        const bool ends_here = head ? (end_at >> 6) == (src >> 6) : (end_at >= (src & ~63u) - part * 64u && end_at - ((src & ~63u) - part * 64u) < JL_PTCL_INCREMENT);
+        bool keep[4];
+#pragma unroll
+        for (uint32_t e = 0; e < 4u; e++) {
+            const uint32_t ix = (src & 63u) + e;
+            keep[e] = (raw_jm & ((1ull << ix) - 1ull)) == 0ull && !(ends_here && src + e > end_at);
+        }
+        if (!(keep[0] || keep[1] || keep[2] || keep[3])) continue;
+        const unsigned long long fm = raw_fm >> (src & 63u), jm = raw_jm >> (src & 63u);
         uint32_t w[4] = {in.x, in.y, in.z, in.w};
         if (((fm | jm) & 15ull) != 0ull || (head && wl == 0u)) {
             const uint32_t jump_to = dyn_start + base_chunk[slot] + next_chunk * JL_PTCL_INCREMENT;
@@ -814,8 +838,13 @@ __global__ __launch_bounds__(JL_WG) void k_coarse_relocate(const JlConfig* __res
                 }
             }
         }
-        if (dst + 3u < ptcl.n) *(uint4*)(ptcl.p + dst) = make_uint4(w[0], w[1], w[2], w[3]);
-        else { ptcl.wr(dst, w[0]); ptcl.wr(dst + 1u, w[1]); ptcl.wr(dst + 2u, w[2]); ptcl.wr(dst + 3u, w[3]); }
+        if (dst + 3u < ptcl.n && keep[0] && keep[1] && keep[2] && keep[3]) {
+            *(uint4*)(ptcl.p + dst) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+#pragma unroll
+            for (uint32_t e = 0; e < 4u; e++)
+                if (keep[e]) ptcl.wr(dst + e, w[e]);
+        }
     }
 }
 

@@ -215,6 +215,9 @@ uint64_t jh_debug_scratch_bytes(jh_ctx* ctx, int slot);   /* capacity of an inte
    or after a first attempt with the estimator's generous bump sizes (the reference's pool keeps its buffers in the same way,
    wgpu.go:601-616; this is the counterpart of dropping that pool).  Captured graphs become stale. */
 int jh_scratch_trim(jh_ctx* ctx);
+/* tests: bit 0 = every wave of flatten starts in region 0 of its temporary, bit 1 = always eight regions (kernels_flatten.hip,
+   FlTemp): ordinary scenes then fill regions up and move on, which the product only does close to the line buffer's capacity */
+int jh_debug_flatten_regions(jh_ctx* ctx, uint32_t flags);
 uint64_t jh_debug_graph_self_cleans(jh_ctx* ctx);  /* replays that had to zero an internal counter first (tests) */
 int jh_debug_poison_scratch(jh_ctx* ctx, int byte);
 

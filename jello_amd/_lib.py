@@ -204,6 +204,9 @@ def _declare(L):
     hip.jh_debug_poison_scratch.argtypes = [vp, ci]
     hip.jh_debug_scratch_bytes.restype = ctypes.c_uint64
     hip.jh_debug_scratch_bytes.argtypes = [vp, ci]
+    if hasattr(hip, "jh_debug_flatten_regions"):
+        hip.jh_debug_flatten_regions.restype = ci
+        hip.jh_debug_flatten_regions.argtypes = [vp, ctypes.c_uint32]
     if hasattr(hip, "jh_scratch_trim"):
         hip.jh_scratch_trim.restype = ci
         hip.jh_scratch_trim.argtypes = [vp]

@@ -103,6 +103,7 @@ struct jh_ctx {
     std::string last_error;
     uint32_t band_row0 = 0u, band_row1 = 0xffffffffu;  // jh_set_band
     uint32_t clip_depth_hint = 0u;                     // jh_set_clip_depth_hint
+    uint32_t debug_flatten = 0u;                       // jh_debug_flatten_regions
     // Bumped whenever a device pointer a captured graph may have baked in goes away or moves: buffer / image free,
     // regrow or import, scratch regrow.  jh_graph_launch refuses a graph captured against an older generation.
     uint64_t generation = 0;
@@ -813,6 +814,7 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
     L.band_row1 = ctx->band_row1;
     L.clip_depth_hint = ctx->clip_depth_hint;
     L.hint_overflow = ctx->hint_overflow;
+    L.debug_flatten = ctx->debug_flatten;
     L.image_table = nullptr;
     if ((int)images.size() > JH_FINE_INLINE_IMAGES && stage >= JH_FINE_AREA) {
         // More images than fit in the kernel arguments: fine indexes a device table of descriptors (the reference binds
@@ -1140,6 +1142,15 @@ int jh_set_clip_depth_hint(jh_ctx* ctx, uint32_t max_depth) {
     // (a captured graph has the layout of its capture baked in and never looks at the hint again; its scratch pointer stays
     // valid until the array is regrown, which bumps the generation by itself)
     ctx->clip_depth_hint = max_depth;
+    return JH_OK;
+}
+// Tests: flatten's temporary is cut into regions that a frame only fills up (and leaves behind, marking the slots at their ends
+// empty) when it comes close to the capacity of its line buffer.  Bit 0: every wave starts in region 0; bit 1: eight regions
+// whatever the capacity -- so that ordinary scenes take that path.  Results never depend on it.
+int jh_debug_flatten_regions(jh_ctx* ctx, uint32_t flags) {
+    if (!ctx) return JH_ERR_INVALID;
+    ctx->debug_flatten = flags;
+    ctx->generation++;  // (a captured graph holds the old kernel arguments)
     return JH_OK;
 }
 // Blend-stack saves the fine stage dropped since the last reset because jh_set_clip_depth_hint promised a shallower scene than

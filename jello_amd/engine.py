@@ -187,7 +187,8 @@ class Engine:
 
     def trim_scratch(self):
         """Frees the internal scratch arrays (they only grow): after a frame much larger than the ones to come."""
-        self._check(self.hip.jh_scratch_trim(self.ctx), "scratch_trim")
+        if hasattr(self.hip, "jh_scratch_trim"):  # (an older library under JELLO_HIP_LIB, tools/ab_kernels.sh: nothing to give back)
+            self._check(self.hip.jh_scratch_trim(self.ctx), "scratch_trim")
 
     def set_stream(self, stream_ptr):
         self._check(self.hip.jh_set_stream(self.ctx, stream_ptr), "set_stream")

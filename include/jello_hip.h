@@ -216,7 +216,8 @@ uint64_t jh_debug_scratch_bytes(jh_ctx* ctx, int slot);   /* capacity of an inte
    wgpu.go:601-616; this is the counterpart of dropping that pool).  Captured graphs become stale. */
 int jh_scratch_trim(jh_ctx* ctx);
 /* tests: bit 0 = every wave of flatten starts in region 0 of its temporary, bit 1 = always eight regions (kernels_flatten.hip,
-   FlTemp): ordinary scenes then fill regions up and move on, which the product only does close to the line buffer's capacity */
+   FlTemp): ordinary scenes then fill regions up and move on, which the product only does close to the line buffer's capacity;
+   bit 2 = a batch of more than 48 lines allocates its slots job by job (the product: more than 51 200) */
 int jh_debug_flatten_regions(jh_ctx* ctx, uint32_t flags);
 uint64_t jh_debug_graph_self_cleans(jh_ctx* ctx);  /* replays that had to zero an internal counter first (tests) */
 int jh_debug_poison_scratch(jh_ctx* ctx, int byte);

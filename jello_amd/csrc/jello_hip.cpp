@@ -1146,7 +1146,8 @@ int jh_set_clip_depth_hint(jh_ctx* ctx, uint32_t max_depth) {
 }
 // Tests: flatten's temporary is cut into regions that a frame only fills up (and leaves behind, marking the slots at their ends
 // empty) when it comes close to the capacity of its line buffer.  Bit 0: every wave starts in region 0; bit 1: eight regions
-// whatever the capacity -- so that ordinary scenes take that path.  Results never depend on it.
+// whatever the capacity -- so that ordinary scenes take that path; bit 2: batches allocate their slots job by job (the product does
+// above 51 200 lines per batch).  Results never depend on it.
 int jh_debug_flatten_regions(jh_ctx* ctx, uint32_t flags) {
     if (!ctx) return JH_ERR_INVALID;
     ctx->debug_flatten = flags;

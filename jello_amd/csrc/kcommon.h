@@ -213,7 +213,7 @@ struct JhLaunch {
     const JhImageDesc* image_table;  // device table of all n_images descriptors when n_images > JH_FINE_INLINE_IMAGES, else nullptr
     uint32_t clip_depth_hint;  // jh_set_clip_depth_hint: upper bound of the clip layers' nesting depth, 0 = unknown
     uint32_t* hint_overflow;   // device counter of the blend-stack saves dropped because that hint was too small (or nullptr)
-    uint32_t debug_flatten;    // jh_debug_flatten_regions (tests): bit 0 = every wave of k_flatten_items starts in region 0 of the temporary, bit 1 = always 8 regions
+    uint32_t debug_flatten;    // jh_debug_flatten_regions (tests): bit 0 = every wave of k_flatten_items starts in region 0 of the temporary, bit 1 = always 8 regions, bit 2 = batches allocate job by job
     uint32_t absorb;  // JH_ABSORB_*: held-back commands this stage performs in passing (jello_hip.cpp, Deferred)
     JhBound extra;    // JH_ABSORB_SETUP of path_tiling: the ptcl buffer of path_tiling_setup (ptcl[0] = ~0 on failure)
 };

@@ -1142,7 +1142,7 @@ __device__ uint32_t g_ff_stats[8];  // nodes tested, undecided, contradictions, 
 __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_PER_EU, FL_WAVES_PER_EU))) void k_flatten_items(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
                                                          Buf<JlPathBbox> path_bboxes, const uint32_t* __restrict__ list,
                                                          uint32_t* __restrict__ counters, uint32_t cap, uint32_t* __restrict__ counts,
-                                                         FlTemp T, uint32_t home0) {
+                                                         FlTemp T, uint32_t debug) {
     __shared__ uint32_t sh_item;  // next position of this workgroup's share of the item list
     __shared__ FlBatch sh_batch[JL_WG / 64];
     Scene s;
@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
     FlBatch& B = sh_batch[threadIdx.x >> 6];
     Out<true> o;
     o.cfg = cfg; o.T = T; o.home_s = o.home_r = blockIdx.x % T.K; o.failed_s = o.failed_r = false; o.slot = 0u;
-    if (home0 != 0u) o.home_s = o.home_r = 0u;  // (jh_debug_flatten_regions: regions fill up and are left behind on ordinary scenes)
+    if ((debug & 1u) != 0u) o.home_s = o.home_r = 0u;  // (jh_debug_flatten_regions: regions fill up and are left behind on ordinary scenes)
 #ifdef FL_SOAK_HOME0  // (tools/soak_flatten_fallback.sh: the same for every frame of the build)
     o.home_s = o.home_r = 0u;
 #endif
@@ -1331,7 +1331,7 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
             const uint32_t incl = wave_incl_scan_u32(total);
             const uint32_t batch_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             // (a batch of more than FL_MAX_GRAB lines -- 64 jobs of 800 -- allocates job by job: no allocation may be larger)
-            const bool together = batch_total <= FL_MAX_GRAB;  // uniform
+            const bool together = batch_total <= ((debug & 4u) != 0u ? 48u : FL_MAX_GRAB);  // uniform (jh_debug_flatten_regions bit 2: tests)
             uint32_t grab = 0u;
             if (together) {
 #if defined(FL_ISPLIT) && FL_ISPLIT == 3
@@ -1775,7 +1775,7 @@ int jh_launch_flatten(const JhLaunch& L) {
     hipLaunchKernelGGL(k_flatten_classify, dim3((L.gx + FL_CLASSIFY_TAGS - 1) / FL_CLASSIFY_TAGS), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list,
                        counters, n_slots, n_tags, counts, L.absorb, (uint32_t*)bump);
     hipLaunchKernelGGL(k_flatten_items, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, (const uint32_t*)list, counters, n_slots, counts,
-                       T, L.debug_flatten & 1u);
+                       T, L.debug_flatten);
     int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);
     if (rc) return rc;
     uint32_t gp = (uint32_t)((tcap + JL_WG - 1) / JL_WG);

@@ -543,14 +543,16 @@ def test_scratch_of_the_headline_frame_and_trim():
         eng.close()
 
 
+@pytest.mark.parametrize("flags", [3, 7])
 @pytest.mark.parametrize("which", ["c3", "c2", "polygon", "c4"])
-def test_flatten_regions_fill_up_and_are_left_behind(which):
+def test_flatten_regions_fill_up_and_are_left_behind(which, flags):
     """flatten's temporary (a slot per line, a record per piece or direct line) is cut into up to eight regions with a cursor each
     (kernels_flatten.hip, FlTemp).  A frame only fills a region up -- and leaves it for the next one, the slots at its end marked
     empty -- when it comes close to its line buffer's capacity.  Here every frame does: eight regions whatever the size, every
     wave starting in region 0 (jh_debug_flatten_regions), and a line buffer one line larger than the frame; curves (c3),
-    round joins and caps (c2: arcs of many lines), 170 k straight segments (polygon) and clip scenes (c4).  Everything against
-    the oracle, which knows nothing of any of this."""
+    round joins and caps (c2: arcs of many lines), 170 k straight segments (polygon) and clip scenes (c4); with flag 4 every
+    batch of more than 48 lines also allocates its slots job by job (the product: above 51 200 lines, which no test scene
+    reaches).  Everything against the oracle, which knows nothing of any of this."""
     s, p = {"c3": lambda: scenes.scene_c3(20000, 1024), "c2": lambda: scenes.scene_c2(4000, 1024),
             "polygon": lambda: scenes.scene_dense_polygon(170000, 512), "c4": lambda: scenes.scene_c4(6000, 1024)}[which]()
     eng = jello_amd.Engine(0)
@@ -559,7 +561,7 @@ def test_flatten_regions_fill_up_and_are_left_behind(which):
         _, bump, _ = eng.render(s, p, robust=True)
         assert bump["failed"] == 0 and bump["lines"] > 8 * 51200 // 7  # (more lines than region 0 holds)
         p.bump.lines = bump["lines"] + 1
-        assert eng.hip.jh_debug_flatten_regions(eng.ctx, 3) == 0
+        assert eng.hip.jh_debug_flatten_regions(eng.ctx, flags) == 0
         r = compare(eng, s, p)
         assert r["bump"]["failed"] == 0 and r["bump"]["lines"] == bump["lines"]
     finally:

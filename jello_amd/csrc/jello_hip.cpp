@@ -53,7 +53,7 @@ struct ProfEntry {
 };
 
 // A recorded command that has not been launched yet.  Five of the recording's commands are 1-thread or trivially small
-// kernels in front of a stage that can do their work in passing (bbox_clear and Clear(bump) in front of flatten,
+// kernels in front of a stage that can do their work in passing (the last pathtag scan, bbox_clear and Clear(bump) in front of flatten,
 // path_count_setup / path_tiling_setup in front of their indirect dispatches, pathtag_reduce2 in front of pathtag_scan1;
 // render.go:186-197,230-237,369-374,415-420): the
 // engine holds them back until the next command and lets that stage absorb them when it is the one they were waiting for
@@ -475,7 +475,7 @@ int jh_clear(jh_ctx* ctx, uint64_t id, uint64_t offset, int64_t size) {
     if (offset + n > a.size) n = a.size - offset;
     const bool bump_like = !ctx->profiling && n && offset == 0 && n == a.size && a.size == sizeof(JlBump);  // (profiling: as recorded)
     for (const Deferred& d : ctx->deferred)
-        if (!(bump_like && !d.is_clear && d.stage == JH_BBOX_CLEAR)) { JH_FLUSH(ctx); break; }
+        if (!(bump_like && !d.is_clear && (d.stage == JH_BBOX_CLEAR || d.stage == JH_PATHTAG_SCAN_SMALL || d.stage == JH_PATHTAG_SCAN_LARGE))) { JH_FLUSH(ctx); break; }
     if (bump_like) {
         // (the recording's Clear(bump) in front of flatten, render.go:237: flatten's first kernel does it in passing)
         Deferred d;
@@ -754,15 +754,22 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
     // it -- with the profiler on every command is launched as recorded and every query times its own stage)
     // (pathtag_reduce2: its consumer pathtag_scan1 redoes its sums in passing if it runs at most 16 workgroups itself --
     // PT_ABSORB_MAX in kernels_scan.hip; the reference always dispatches reduce2 with 256, one thread per entry of reduced2)
+    // (the last pathtag scan: flatten's classification kernel, which reads every tag word and its monoid back, produces the monoids
+    // in passing instead -- k_pathtag_scan_classify)
+    const bool is_last_scan = (stage == JH_PATHTAG_SCAN_SMALL || stage == JH_PATHTAG_SCAN_LARGE) && gx > 0u && b.size() >= 4;
     const bool deferrable = !ctx->profiling && (stage == JH_BBOX_CLEAR || stage == JH_PATH_COUNT_SETUP || stage == JH_PATH_TILING_SETUP ||
-                                                (stage == JH_PATHTAG_REDUCE2 && gx > 0u && gx <= 256u && b.size() >= 2));
+                                                (stage == JH_PATHTAG_REDUCE2 && gx > 0u && gx <= 256u && b.size() >= 2) || is_last_scan);
     uint32_t absorb = 0u;
     JhBound extra;
     std::memset(&extra, 0, sizeof extra);
     if (deferrable) {
-        // (only one kind of thing waits at a time, except bbox_clear + Clear(bump) in front of flatten)
-        for (const Deferred& d : ctx->deferred)
-            if (!(stage == JH_BBOX_CLEAR && d.is_clear)) { JH_FLUSH(ctx); break; }
+        // (only one kind of thing waits at a time, except what waits for flatten: the last pathtag scan, bbox_clear, Clear(bump) --
+        // one of each)
+        for (const Deferred& d : ctx->deferred) {
+            const bool d_scan = !d.is_clear && (d.stage == JH_PATHTAG_SCAN_SMALL || d.stage == JH_PATHTAG_SCAN_LARGE);
+            const bool joins = (stage == JH_BBOX_CLEAR && (d.is_clear || d_scan)) || (is_last_scan && (d.is_clear || d.stage == JH_BBOX_CLEAR));
+            if (!joins) { JH_FLUSH(ctx); break; }
+        }
     } else if (!ctx->deferred.empty()) {
         bool all = true;
         for (const Deferred& d : ctx->deferred) {
@@ -771,7 +778,12 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
             // flatten, renderer.cpp: flatten_wgs = 0 -- so bbox_clear and Clear(bump) run as recorded: ADVICE r03)
             if (stage == JH_FLATTEN && b.size() >= 6 && gx > 0u) {
                 if (d.is_clear) ok = d.clear_ptr == b[4].ptr && d.clear_bytes == b[4].size && b[4].size == sizeof(JlBump);
-                else ok = d.stage == JH_BBOX_CLEAR && d.b[0].ptr == b[0].ptr && d.b[1].ptr == b[3].ptr && d.b[1].size == b[3].size;
+                else if (d.stage == JH_BBOX_CLEAR) ok = d.b[0].ptr == b[0].ptr && d.b[1].ptr == b[3].ptr && d.b[1].size == b[3].size;
+                else  // the last pathtag scan: same config and scene, its output is the tag monoids flatten reads, and its threads
+                      // (one per tag word = four tag bytes) cover flatten's (one per tag byte)
+                    ok = (d.stage == JH_PATHTAG_SCAN_SMALL || d.stage == JH_PATHTAG_SCAN_LARGE) && d.b.size() >= 4 && d.b[0].ptr == b[0].ptr &&
+                         d.b[1].ptr == b[1].ptr && d.b[1].size == b[1].size && d.b[3].ptr == b[2].ptr && d.b[3].size == b[2].size &&
+                         (uint64_t)d.gx * 4u >= (uint64_t)gx && d.gy <= 1u && d.gz <= 1u;
             } else if (stage == JH_PATHTAG_SCAN1 && b.size() >= 3) {
                 ok = !d.is_clear && d.stage == JH_PATHTAG_REDUCE2 && gx > 0u && gx <= 16u && gx <= d.gx && d.b[0].ptr == b[0].ptr &&
                      d.b[0].size == b[0].size && d.b[1].ptr == b[1].ptr && d.b[1].size == b[1].size;
@@ -786,7 +798,12 @@ static int dispatch_common(jh_ctx* ctx, int stage, uint32_t gx, uint32_t gy, uin
             for (const Deferred& d : ctx->deferred) {
                 if (d.is_clear) absorb |= JH_ABSORB_BUMP_CLEAR;
                 else if (d.stage == JH_BBOX_CLEAR) absorb |= JH_ABSORB_BBOX_CLEAR;
-                else {
+                else if (d.stage == JH_PATHTAG_SCAN_SMALL || d.stage == JH_PATHTAG_SCAN_LARGE) {
+                    absorb |= JH_ABSORB_PATHTAG_SCAN;
+                    extra = d.b[2];
+                    extra.width = d.gx;
+                    extra.height = d.stage == JH_PATHTAG_SCAN_SMALL ? 1u : 0u;
+                } else {
                     absorb |= JH_ABSORB_SETUP;
                     if (d.stage == JH_PATH_TILING_SETUP) extra = d.b[2];
                     if (d.stage == JH_PATHTAG_REDUCE2) extra.size = d.gx;  // (entries of reduced2 the held-back dispatch writes)

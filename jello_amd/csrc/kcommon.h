@@ -164,6 +164,23 @@ JD MonoidK<5> reduce_tag(uint32_t tag_word) {
     c.v[3] = __popc(tag_word & (0x40u * 0x1010101u)) * 2u;       // style_ix
     return c;
 }
+JD void store_tm(JlTagMonoid* dst, const MonoidK<5>& m) {
+    dst->trans_ix = m.v[0]; dst->pathseg_ix = m.v[1]; dst->pathseg_offset = m.v[2]; dst->style_ix = m.v[3]; dst->path_ix = m.v[4];
+}
+JD MonoidK<5> load_tm(const Buf<JlTagMonoid>& b, uint32_t i) {
+    JlTagMonoid t = b.rd(i);
+    MonoidK<5> m;
+    m.v[0] = t.trans_ix; m.v[1] = t.pathseg_ix; m.v[2] = t.pathseg_offset; m.v[3] = t.style_ix; m.v[4] = t.path_ix;
+    return m;
+}
+// pathtag_scan.wgsl (small variant): the prefix of workgroup wg = the sum of the wg entries of `parent` in front of it (sh: 20 words)
+JD MonoidK<5> parent_prefix(const Buf<JlTagMonoid>& parent, uint32_t wg, uint32_t* sh) {
+    MonoidK<5> agg;
+#pragma unroll
+    for (int i = 0; i < 5; i++) agg.v[i] = 0;
+    if (threadIdx.x < wg) agg = load_tm(parent, threadIdx.x);
+    return block_reduce_monoid<5>(agg, sh);
+}
 // shared/drawtag.wgsl:46-53
 JD MonoidK<4> map_draw_tag(uint32_t t) {
     MonoidK<4> c;
@@ -215,9 +232,12 @@ struct JhLaunch {
     uint32_t* hint_overflow;   // device counter of the blend-stack saves dropped because that hint was too small (or nullptr)
     uint32_t debug_flatten;    // jh_debug_flatten_regions (tests): bit 0 = every wave of k_flatten_items starts in region 0 of the temporary, bit 1 = always 8 regions, bit 2 = batches allocate job by job
     uint32_t absorb;  // JH_ABSORB_*: held-back commands this stage performs in passing (jello_hip.cpp, Deferred)
-    JhBound extra;    // JH_ABSORB_SETUP of path_tiling: the ptcl buffer of path_tiling_setup (ptcl[0] = ~0 on failure)
+    JhBound extra;    // JH_ABSORB_SETUP of path_tiling: the ptcl buffer of path_tiling_setup (ptcl[0] = ~0 on failure); JH_ABSORB_PATHTAG_SCAN: see there
 };
-enum { JH_ABSORB_BBOX_CLEAR = 1u, JH_ABSORB_BUMP_CLEAR = 2u, JH_ABSORB_SETUP = 4u };
+enum { JH_ABSORB_BBOX_CLEAR = 1u, JH_ABSORB_BUMP_CLEAR = 2u, JH_ABSORB_SETUP = 4u,
+       // flatten: the last pathtag scan (pathtag_scan_small / _large) was held back; flatten's classification kernel produces the tag
+       // monoids in passing.  L.extra = the scan's `reduced` binding, extra.width = its workgroup count, extra.height = 1: the small variant
+       JH_ABSORB_PATHTAG_SCAN = 8u };
 
 enum {  // scratch slots
     JH_SCR_SCAN_TMP = 0,

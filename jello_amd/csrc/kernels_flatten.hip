@@ -778,21 +778,26 @@ JD Seg load_seg(const Scene& s, uint32_t ix) {
 // reserves the block's range, every lane writes its own slots.  (A per-lane atomicAdd on two hot
 // words costs ~3.7 ms for 1.2 M items on MI355X; this costs ~10 us.)  List order is irrelevant for the
 // result but this keeps it nearly sorted by tag, i.e. coalesced scene reads and line writes later on.
-#ifndef FL_CLASSIFY_TAGS
-#define FL_CLASSIFY_TAGS 8u  // C3: 32 / 25 / 28 us with 4 / 8 / 16
-#endif
 // counters: [0] heavy items, [FL_CTR_LIGHT] light items -- the two list counters are hot (every workgroup of
 // k_flatten_classify waits for its two returns) and live in different memory channels --, from FL_CTR_CURSOR the cursors of
 // the temporary's regions (FlTemp)
 #define FL_CTR_LIGHT 256u
 #define FL_CTR_WORDS (FL_CTR_CURSOR + FL_CUR_STRIDE * FL_MAX_REGIONS)
-// tag bytes per thread: fewer workgroups => fewer atomics on the two hot list counters
-__global__ __launch_bounds__(JL_WG) void k_flatten_classify(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
-                                                            Buf<JlPathBbox> path_bboxes, uint32_t* __restrict__ list,
-                                                            uint32_t* __restrict__ counters, uint32_t cap, uint32_t n_tags,
-                                                            uint32_t* __restrict__ counts,
-                                                            uint32_t absorb, uint32_t* __restrict__ bump_words) {
-    __shared__ uint32_t sh[12];
+// The classification: one thread per tag WORD (four tag bytes: the word and its monoid are read once, the bytes' monoids follow from
+// them; up to round 5 a thread took eight tag bytes and fetched word and monoid for each).  SCAN != 0: as an epilogue of the LAST
+// pathtag scan (pathtag_scan.wgsl:24-64 / pathtag_scan_large; the engine holds that dispatch back when flatten follows it,
+// jello_hip.cpp Deferred) -- the thread then HAS the word and its prefix monoid in registers instead of reading them back: one
+// launch, 20 us, where pathtag_scan took 4 and the classification 23.  What the scan writes (tag_monoids) and what the
+// classification writes (lists, counters, counts, draw_flags / trans_ix of the path boxes) are the same words either way.
+#define PSC_BLOCKS 2u  // blocks of 256 tag words per workgroup: the two hot list counters see one atomic pair per workgroup (782 -> 391 on C3)
+template <int SCAN>  // 0: tag_monoids are there; 1: + pathtag_scan_small; 2: + pathtag_scan_large
+__global__ __launch_bounds__(JL_WG) void k_flatten_classify(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> reduced,
+                                                                 Buf<JlTagMonoid> tag_monoids, uint32_t n_blocks, Buf<JlPathBbox> path_bboxes,
+                                                                 uint32_t* __restrict__ list, uint32_t* __restrict__ counters, uint32_t cap,
+                                                                 uint32_t n_tags, uint32_t* __restrict__ counts, uint32_t absorb,
+                                                                 uint32_t* __restrict__ bump_words) {
+    __shared__ uint32_t sh[20];
+    __shared__ uint32_t sh_base[2];
     // Commands the engine held back for this stage (jello_hip.cpp, Deferred): bbox_clear (bbox_clear.wgsl:13-24; this kernel
     // writes only the draw_flags / trans_ix words of the boxes, the min / max words are first used by k_flatten_bbox) and
     // the recording's Clear(bump) (render.go:237; nothing of flatten touches bump before k_flatten_items).
@@ -806,60 +811,98 @@ __global__ __launch_bounds__(JL_WG) void k_flatten_classify(const JlConfig* __re
         }
     }
     if ((absorb & JH_ABSORB_BUMP_CLEAR) && blockIdx.x == 0u && threadIdx.x < 8u) bump_words[threadIdx.x] = 0u;
-    __shared__ uint32_t sh_base[2];
-    Scene s;
-    s.cfg = cfg; s.scene = scene; s.tag_monoids = tag_monoids;
-    uint32_t ix0 = (blockIdx.x * JL_WG + threadIdx.x) * FL_CLASSIFY_TAGS;
-    // line counts of all slots start at zero (most slots are not work items); cheaper here than a separate memset
-    for (uint32_t q = 0u; q < 3u * FL_CLASSIFY_TAGS; q++) {
-        uint32_t sl = ix0 * 3u + q;
-        if (sl < cap) counts[sl] = 0u;
-    }
-    uint32_t nh[FL_CLASSIFY_TAGS], nl[FL_CLASSIFY_TAGS];
-    uint32_t th = 0u, tl = 0u;
+    uint32_t nh[PSC_BLOCKS][4], nl[PSC_BLOCKS][4];
+    uint32_t eh[PSC_BLOCKS], el[PSC_BLOCKS];  // this thread's exclusive prefix of heavy / light items inside the workgroup
+    uint32_t wg_h = 0u, wg_l = 0u;
 #pragma unroll
-    for (uint32_t k = 0; k < FL_CLASSIFY_TAGS; k++) {
-        uint32_t ix = ix0 + k;
-        nh[k] = 0u; nl[k] = 0u;
-        if (ix >= n_tags) continue;
-        Seg g = load_seg(s, ix);
-        uint32_t path_ix = g.tag.monoid.v[4];
-        if ((g.tag.tag_byte & JL_PATH_TAG_PATH) != 0u && path_bboxes.ok(path_ix)) {  // flatten.wgsl:825-828
-            path_bboxes.p[path_ix].draw_flags = ((g.style_flags & JL_STYLE_FLAGS_FILL) == 0u) ? 0u : 1u;
-            path_bboxes.p[path_ix].trans_ix = g.tag.monoid.v[0];
-        }
-        uint32_t seg_type = g.tag.tag_byte & JL_PATH_TAG_SEG_TYPE;
-        bool curved = seg_type != JL_PATH_TAG_LINETO;
-        // items of this tag byte: heavy subs first (0..nh-1), then light subs
-        if (seg_type != 0u) {
-            if (!g.is_stroke) {
-                if (curved) nh[k] = 1u; else nl[k] = 1u;
-            } else if ((g.tag.tag_byte & JL_PATH_TAG_SUBPATH_END) != 0u) {
-                if (curved) nl[k] = 1u;  // open path: start cap (closed: nothing)
-            } else {
-                if (curved) { nh[k] = 2u; nl[k] = 1u; } else { nl[k] = 3u; }
+    for (uint32_t blk = 0; blk < PSC_BLOCKS; blk++) {
+        const uint32_t block = blockIdx.x * PSC_BLOCKS + blk;  // = the workgroup index of the recorded scan dispatch
+        eh[blk] = 0u; el[blk] = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) { nh[blk][k] = 0u; nl[blk][k] = 0u; }
+        if (block >= n_blocks) continue;  // uniform
+        const uint32_t word_ix = block * JL_WG + threadIdx.x;
+        const uint32_t tag_word = scene.rd(cfg->layout.pathtag_base + word_ix);
+        MonoidK<5> pm;
+        if (SCAN != 0) {  // ---- the scan: this thread's tag word ----
+            MonoidK<5> prefix;
+            if (SCAN == 1) prefix = parent_prefix(reduced, block, sh); else prefix = load_tm(reduced, block);
+            MonoidK<5> tot5;
+            if (SCAN == 1) __syncthreads();  // (parent_prefix has used sh)
+            const MonoidK<5> ex = block_excl_scan_monoid<5>(reduce_tag(tag_word), sh, &tot5);
+            pm = monoid_add(prefix, ex);
+            if (tag_monoids.ok(word_ix)) {
+                store_tm(&tag_monoids.p[word_ix], pm);
+            } else {  // (robust access: a later read of a word behind the buffer sees zeros)
+#pragma unroll
+                for (int i = 0; i < 5; i++) pm.v[i] = 0u;
             }
+            __syncthreads();  // (sh is used again below)
+        } else {
+            pm = load_tm(tag_monoids, word_ix);
         }
-        th += nh[k];
-        tl += nl[k];
+        // ---- the classification of the word's four tag bytes ----
+        const uint32_t ix0 = word_ix * 4u;
+        for (uint32_t q = 0u; q < 12u; q++) {
+            const uint32_t sl = ix0 * 3u + q;
+            if (sl < cap) counts[sl] = 0u;
+        }
+        uint32_t th = 0u, tl = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) {
+            const uint32_t ix = ix0 + k;
+            if (ix >= n_tags) continue;
+            // compute_tag_monoid (flatten.wgsl:668-682) with the word and its prefix at hand
+            const MonoidK<5> tm = monoid_add(pm, reduce_tag(tag_word & ((1u << (k * 8u)) - 1u)));
+            const uint32_t tag_byte = (tag_word >> (k * 8u)) & 0xffu;
+            const uint32_t style_flags = scene.rd(cfg->layout.style_base + tm.v[3] - 2u);
+            const bool is_stroke = (style_flags & JL_STYLE_FLAGS_STYLE) != 0u;
+            const uint32_t path_ix = tm.v[4];
+            if ((tag_byte & JL_PATH_TAG_PATH) != 0u && path_bboxes.ok(path_ix)) {  // flatten.wgsl:825-828
+                path_bboxes.p[path_ix].draw_flags = ((style_flags & JL_STYLE_FLAGS_FILL) == 0u) ? 0u : 1u;
+                path_bboxes.p[path_ix].trans_ix = tm.v[0] - 1u;
+            }
+            const uint32_t seg_type = tag_byte & JL_PATH_TAG_SEG_TYPE;
+            const bool curved = seg_type != JL_PATH_TAG_LINETO;
+            if (seg_type != 0u) {
+                if (!is_stroke) {
+                    if (curved) nh[blk][k] = 1u; else nl[blk][k] = 1u;
+                } else if ((tag_byte & JL_PATH_TAG_SUBPATH_END) != 0u) {
+                    if (curved) nl[blk][k] = 1u;
+                } else {
+                    if (curved) { nh[blk][k] = 2u; nl[blk][k] = 1u; } else { nl[blk][k] = 3u; }
+                }
+            }
+            th += nh[blk][k];
+            tl += nl[blk][k];
+        }
+        MonoidK<2> m, tot;
+        m.v[0] = th; m.v[1] = tl;
+        const MonoidK<2> e2 = block_excl_scan_monoid<2>(m, sh, &tot);
+        eh[blk] = wg_h + e2.v[0];
+        el[blk] = wg_l + e2.v[1];
+        wg_h += tot.v[0];
+        wg_l += tot.v[1];
+        __syncthreads();
     }
-    MonoidK<2> m, tot;
-    m.v[0] = th; m.v[1] = tl;
-    MonoidK<2> ex = block_excl_scan_monoid<2>(m, sh, &tot);
     if (threadIdx.x == 0) {  // one atomic pair per workgroup (a hot word sustains only ~88 atomics/us)
-        sh_base[0] = tot.v[0] ? atomicAdd(&counters[0], tot.v[0]) : 0u;
-        sh_base[1] = tot.v[1] ? atomicAdd(&counters[FL_CTR_LIGHT], tot.v[1]) : 0u;
+        sh_base[0] = wg_h ? atomicAdd(&counters[0], wg_h) : 0u;
+        sh_base[1] = wg_l ? atomicAdd(&counters[FL_CTR_LIGHT], wg_l) : 0u;
     }
     __syncthreads();
-    uint32_t ph = sh_base[0] + ex.v[0], pl = sh_base[1] + ex.v[1];
 #pragma unroll
-    for (uint32_t k = 0; k < FL_CLASSIFY_TAGS; k++) {
-        uint32_t ix = ix0 + k;
-        uint32_t sub = 0u;
-        for (uint32_t q = 0; q < nh[k]; q++, sub++, ph++)
-            if (ph < cap) list[ph] = ix * 3u + sub;
-        for (uint32_t q = 0; q < nl[k]; q++, sub++, pl++)
-            if (pl < cap) list[cap - 1u - pl] = ix * 3u + sub;
+    for (uint32_t blk = 0; blk < PSC_BLOCKS; blk++) {
+        const uint32_t ix0 = ((blockIdx.x * PSC_BLOCKS + blk) * JL_WG + threadIdx.x) * 4u;
+        uint32_t ph = sh_base[0] + eh[blk], pl = sh_base[1] + el[blk];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) {
+            const uint32_t ix = ix0 + k;
+            uint32_t sub = 0u;
+            for (uint32_t q = 0; q < nh[blk][k]; q++, sub++, ph++)
+                if (ph < cap) list[ph] = ix * 3u + sub;
+            for (uint32_t q = 0; q < nl[blk][k]; q++, sub++, pl++)
+                if (pl < cap) list[cap - 1u - pl] = ix * 3u + sub;
+        }
     }
 }
 
@@ -1772,8 +1815,28 @@ int jh_launch_flatten(const JhLaunch& L) {
     uint32_t* clean = jh_scratch_flags(L.scratch);
     if ((*clean & JH_CLEAN_FL_CTR) == 0u) (void)hipMemsetAsync(counters, 0, FL_CTR_WORDS * 4, L.stream);
     *clean &= ~(uint32_t)JH_CLEAN_FL_CTR;
-    hipLaunchKernelGGL(k_flatten_classify, dim3((L.gx + FL_CLASSIFY_TAGS - 1) / FL_CLASSIFY_TAGS), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, list,
-                       counters, n_slots, n_tags, counts, L.absorb, (uint32_t*)bump);
+    {
+        const uint32_t n_words = (n_tags + 3u) / 4u;
+        uint32_t n_blocks = (n_words + JL_WG - 1u) / JL_WG;  // blocks of 256 tag words
+        auto red = mkbuf<JlTagMonoid>(nullptr, 0);
+        int scan = 0;
+        if ((L.absorb & JH_ABSORB_PATHTAG_SCAN) != 0u) {
+            // the held-back last pathtag scan rides in the classification (kcommon.h: extra = its `reduced`, width = its workgroups)
+            red = mkbuf<JlTagMonoid>(L.extra.ptr, L.extra.size);
+            n_blocks = L.extra.width;
+            scan = L.extra.height != 0u ? 1 : 2;
+        }
+        const dim3 gsc((n_blocks + PSC_BLOCKS - 1u) / PSC_BLOCKS);
+        if (scan == 1)
+            hipLaunchKernelGGL(k_flatten_classify<1>, gsc, dim3(JL_WG), 0, L.stream, cfg, scene, red, tm, n_blocks, pb, list, counters, n_slots, n_tags,
+                               counts, L.absorb, (uint32_t*)bump);
+        else if (scan == 2)
+            hipLaunchKernelGGL(k_flatten_classify<2>, gsc, dim3(JL_WG), 0, L.stream, cfg, scene, red, tm, n_blocks, pb, list, counters, n_slots, n_tags,
+                               counts, L.absorb, (uint32_t*)bump);
+        else
+            hipLaunchKernelGGL(k_flatten_classify<0>, gsc, dim3(JL_WG), 0, L.stream, cfg, scene, red, tm, n_blocks, pb, list, counters, n_slots, n_tags,
+                               counts, L.absorb, (uint32_t*)bump);
+    }
     hipLaunchKernelGGL(k_flatten_items, dim3(g), dim3(JL_WG), 0, L.stream, cfg, scene, tm, pb, (const uint32_t*)list, counters, n_slots, counts,
                        T, L.debug_flatten);
     int rc = jh_scan_u32(L, counts, 1, bases, n_slots, nullptr, &bump->lines);

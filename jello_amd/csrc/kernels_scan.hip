@@ -179,15 +179,7 @@ int jh_scan_u32(const JhLaunch& L, const uint32_t* in, uint32_t in_stride, uint3
 // ------------------------------------------------------------------------------------------------
 // pathtag (K1-K4)
 // ------------------------------------------------------------------------------------------------
-JD void store_tm(JlTagMonoid* dst, const MonoidK<5>& m) {
-    dst->trans_ix = m.v[0]; dst->pathseg_ix = m.v[1]; dst->pathseg_offset = m.v[2]; dst->style_ix = m.v[3]; dst->path_ix = m.v[4];
-}
-JD MonoidK<5> load_tm(const Buf<JlTagMonoid>& b, uint32_t i) {
-    JlTagMonoid t = b.rd(i);
-    MonoidK<5> m;
-    m.v[0] = t.trans_ix; m.v[1] = t.pathseg_ix; m.v[2] = t.pathseg_offset; m.v[3] = t.style_ix; m.v[4] = t.path_ix;
-    return m;
-}
+// (store_tm / load_tm / parent_prefix: kcommon.h -- flatten's classification kernel can stand in for the last scan)
 
 // pathtag_reduce.wgsl:21-42
 __global__ __launch_bounds__(JL_WG) void k_pathtag_reduce(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> reduced) {
@@ -205,13 +197,6 @@ __global__ __launch_bounds__(JL_WG) void k_pathtag_reduce2(Buf<JlTagMonoid> in, 
     if (threadIdx.x == 0 && out.ok(blockIdx.x)) store_tm(&out.p[blockIdx.x], t);
 }
 // Sum of parent[l] for l < wg (l < 256): the WGSL "reduce prefix of workgroups up to this one".
-JD MonoidK<5> parent_prefix(const Buf<JlTagMonoid>& parent, uint32_t wg, uint32_t* sh) {
-    MonoidK<5> agg;
-#pragma unroll
-    for (int i = 0; i < 5; i++) agg.v[i] = 0;
-    if (threadIdx.x < wg) agg = load_tm(parent, threadIdx.x);
-    return block_reduce_monoid<5>(agg, sh);
-}
 // pathtag_scan1.wgsl:26-67
 // WITH_REDUCE2: the held-back pathtag_reduce2 dispatch rides along (a launch of its own is 4.5 us for four workgroups' worth of work).
 // reduced2[w] is the sum of the w-th 256 entries of `reduced` -- exactly the block total this kernel's own scan produces -- and the

@@ -512,6 +512,11 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
         LineSetup s;
         s.valid = false;
         uint32_t P = 0xffffffffu;  // (a line outside the buffer)
+        // (the path indices of the lines next door -- lanes 0 and 63 need them for the path ranges below -- are requested with the
+        // wave's own lines, not behind line_setup's dependent loads: a round trip less)
+        uint32_t edgeP = 0xffffffffu;
+        if (lane == 0u && gid > 0u && gid - 1u < n_lines && lines.ok(gid - 1u)) edgeP = lines.p[gid - 1u].path_ix;
+        if (lane == 63u && gid + 1u < n_lines && lines.ok(gid + 1u)) edgeP = lines.p[gid + 1u].path_ix;
         if (gid < n_lines && lines.ok(gid)) {
             P = lines.p[gid].path_ix;
             s = line_setup(lines.p[gid], paths);
@@ -528,8 +533,8 @@ __global__ __launch_bounds__(JL_WG) void k_pc_emit(const JlConfig* __restrict__ 
         {   // the path's crossing range, written at its first and its last line (the neighbours: a lane over, or the line next door)
             uint32_t prevP = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x138, 0xf, 0xf, false);  // wave_shr:1
             uint32_t nextP = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x130, 0xf, 0xf, false);  // wave_shl:1
-            if (lane == 0u) prevP = (gid > 0u && gid - 1u < n_lines && lines.ok(gid - 1u)) ? lines.p[gid - 1u].path_ix : 0xffffffffu;
-            if (lane == 63u) nextP = (gid + 1u < n_lines && lines.ok(gid + 1u)) ? lines.p[gid + 1u].path_ix : 0xffffffffu;
+            if (lane == 0u) prevP = edgeP;
+            if (lane == 63u) nextP = edgeP;
             if (gid < n_lines && P < n_paths) {
                 if (P != prevP) pfirst[P] = seg_base;
                 if (P != nextP) plast[P] = seg_base + (s.valid ? s.imax - s.imin : 0u);

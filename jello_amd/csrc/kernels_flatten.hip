@@ -1180,7 +1180,8 @@ __device__ uint32_t g_ff_stats[8];  // nodes tested, undecided, contradictions, 
                            // and 149 VGPRs (same box); without the inlined fallback the loop needs 131 and runs in 182 us at 4 waves
 #endif
 #ifndef FL_BLOCKS_PER_CU
-#define FL_BLOCKS_PER_CU 5  // more workgroups than fit at once: the dynamic batch queue evens out the tail
+#define FL_BLOCKS_PER_CU 4  // = what is resident at 4 waves per SIMD (round 5, C3, same box: 162 / 139 / 129 / 136 / 138 / 147 us with 2 / 3 / 4 / 5 / 6 / 8;
+                            // a fifth workgroup per CU only starts when one has finished and then has a full share of batches in front of it)
 #endif
 __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_PER_EU, FL_WAVES_PER_EU))) void k_flatten_items(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> tag_monoids,
                                                          Buf<JlPathBbox> path_bboxes, const uint32_t* __restrict__ list,

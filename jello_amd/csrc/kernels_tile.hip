@@ -1068,9 +1068,18 @@ __global__ __launch_bounds__(JL_WG) void k_path_tiling(const JlBump* __restrict_
 
 }  // namespace
 
-static inline uint32_t stride_grid(const JhLaunch& L, uint64_t n_items) {
+#ifndef TILE_GRID_PER_CU
+#define TILE_GRID_PER_CU 8  // workgroups per CU of the grid-stride kernels of this file
+#endif
+#ifndef PC_EMIT_GRID_PER_CU
+#define PC_EMIT_GRID_PER_CU 32  // k_pc_emit: the crossings per line vary widely and a wave's share of a small grid is a long chain of dependent
+                                // loads: C3 64.9 / 52.2 / 44.0 / 42.2 / 41.0 / 42.6 us with 4 / 8 / 16 / 24 / 32 / 64 workgroups per CU (round 5, same box);
+                                // C4 55 -> 48.  The other kernels of the file do not care (k_pc_count 20.5 / 22.1 / 20.8 with 8 / 12 / 16, k_pc_rank_small
+                                // 30 / 31 / 31, k_path_tiling 65.5 / 66.8 / 65.2)
+#endif
+static inline uint32_t stride_grid(const JhLaunch& L, uint64_t n_items, uint32_t per_cu = TILE_GRID_PER_CU) {
     uint64_t blocks = (n_items + JL_WG - 1) / JL_WG;
-    uint64_t cap = (uint64_t)(L.num_cus > 0 ? L.num_cus : 256) * 8;
+    uint64_t cap = (uint64_t)(L.num_cus > 0 ? L.num_cus : 256) * per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
     return (uint32_t)blocks;
@@ -1173,7 +1182,7 @@ int jh_launch_path_count(const JhLaunch& L) {
     int rc = jh_scan_u32(L, counts, 1, bases, lines_cap, &bump->lines, &bump->seg_counts);
     if (rc) return rc;
     const uint32_t *cpf = pfirst, *cpl = plast, *cc = counts, *cb = bases;
-    hipLaunchKernelGGL(k_pc_emit, dim3(gl), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, ind, lines, paths, tile, segc, cb, lines_cap,
+    hipLaunchKernelGGL(k_pc_emit, dim3(stride_grid(L, lines_cap, PC_EMIT_GRID_PER_CU)), dim3(JL_WG), 0, L.stream, cfg, (const JlBump*)bump, ind, lines, paths, tile, segc, cb, lines_cap,
                        tile_of, keys, kbig, seg_cap, pfirst, plast, (const uint32_t*)ptotal, n_paths, gate);
     // Big paths only (`gate` = number of tiles if there is one, else 0: the scan then covers 0 elements and the kernels
     // return at once):

@@ -789,7 +789,10 @@ JD Seg load_seg(const Scene& s, uint32_t ix) {
 // jello_hip.cpp Deferred) -- the thread then HAS the word and its prefix monoid in registers instead of reading them back: one
 // launch, 20 us, where pathtag_scan took 4 and the classification 23.  What the scan writes (tag_monoids) and what the
 // classification writes (lists, counters, counts, draw_flags / trans_ix of the path boxes) are the same words either way.
-#define PSC_BLOCKS 2u  // blocks of 256 tag words per workgroup: the two hot list counters see one atomic pair per workgroup (782 -> 391 on C3)
+#ifndef PSC_BLOCKS
+#define PSC_BLOCKS 2u  // blocks of 256 tag words per workgroup: the two hot list counters see one atomic pair per workgroup (782 -> 391 on C3);
+                       // C3, with / without the scan in it: 24.5 / 24.0 us with 1, 20.3 / 19.0 with 2, 23.5 / 21.1 with 3, 25.1 / 22.2 with 4
+#endif
 template <int SCAN>  // 0: tag_monoids are there; 1: + pathtag_scan_small; 2: + pathtag_scan_large
 __global__ __launch_bounds__(JL_WG) void k_flatten_classify(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, Buf<JlTagMonoid> reduced,
                                                                  Buf<JlTagMonoid> tag_monoids, uint32_t n_blocks, Buf<JlPathBbox> path_bboxes,

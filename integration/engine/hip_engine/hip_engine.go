@@ -301,6 +301,13 @@ func (e *Engine) RenderToTexture(arena *mem.Arena, enc *encoding.Encoding, targe
 	}
 }
 
+// TrimScratch gives the context's internal scratch arrays back (the count / offset arrays of the deterministic allocators,
+// flatten's temporary: they grow on demand and are kept).  For the frame after one that was much larger -- or after a first
+// frame that ran with far more generous BumpSizes than the scenes need.  Waits for the stream.
+func (e *Engine) TrimScratch() {
+	e.check(C.jh_scratch_trim(e.ctx), "scratch_trim")
+}
+
 // SetBand: ONE target over several GPUs -- this engine then writes the PTCL and rasterises only the
 // 256-pixel bin rows [row0, row1) of the target, with every allocation offset identical to the
 // unsharded run (record the same Recording on every GPU; nothing else changes).

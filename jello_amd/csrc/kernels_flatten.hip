@@ -1438,11 +1438,8 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_WAVES_
 #endif
 __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_WAVES_PER_EU, FL_LINES_WAVES_PER_EU))) void k_flatten_lines(const JlConfig* __restrict__ cfg, Buf<uint32_t> scene, const uint32_t* __restrict__ counters,
                                                          FlTemp T, const uint32_t* __restrict__ bases, uint32_t n_slots, Buf<JlLineSoup> lines) {
-    __shared__ uint2 sh_wdat[JL_WG / 64][192];    // per wave: the words it stores this step, in lane order ...
-    __shared__ uint32_t sh_widx[JL_WG / 64][192];  // ... and their 8-byte word indices in the line buffer (~0: none)
     atan_tab_fill();
     const uint32_t lines_lim = umin_(cfg->lines_size, lines.n);
-    const uint32_t lane = lane_id();
     const uint2* __restrict__ sinfo = T.sinfo;
     const uint4* __restrict__ recs = T.recs;
     const uint32_t n_r = T.K * T.R;
@@ -1497,10 +1494,11 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
         si_b = fetch_info(u + 2u * G);
         // What a slot writes: up to three 8-byte words of the line buffer (a LineSoup is {path, pad | p0 | p1} = 3 words).
         // A piece line stores its end point as p1 of its own record and, with the header, as p0 of the next one: the words
-        // 3 dst + 2 ... 3 dst + 4, 24 contiguous bytes.  Stored straight from the lanes, each of the three store instructions
-        // of a wave touches every 64-byte segment of the wave's 1.5 KB -- 72 write requests where 24 carry the bytes, and the
-        // kernel is bound by exactly that (issuing every store twice took it from 117 to 207 us).  So the words go through
-        // LDS in lane order and leave as three stores of 64 CONSECUTIVE words each.
+        // 3 dst + 2 ... 3 dst + 4, 24 contiguous bytes.  They are stored straight from the lanes.  (Rounds 3 and 4 staged them
+        // through LDS so that a store instruction wrote 64 consecutive words: the slots were in allocation order then, a wave's
+        // lines lay scattered piece by piece and the kernel was bound by its write requests -- 117 -> 207 us with every store issued
+        // twice.  With the slots in canonical order consecutive lanes write consecutive lines; the staging cost more than it
+        // saved: 76.4 -> 74.8 us without it, and 9 KB of LDS per workgroup less.)
         uint32_t widx[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
         uint2 wdat[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
         if (st == 1u) {  // complete line: copy
@@ -1583,24 +1581,15 @@ __global__ __launch_bounds__(JL_WG) __attribute__((amdgpu_waves_per_eu(FL_LINES_
                 }
             }
         }
-        {
-            uint2* sd = sh_wdat[threadIdx.x >> 6];
-            uint32_t* si_ = sh_widx[threadIdx.x >> 6];
-            wave_fence();  // the previous unit's reads of the staging area are done
-#pragma unroll
-            for (int j = 0; j < 3; j++) { sd[3u * lane + (uint32_t)j] = wdat[j]; si_[3u * lane + (uint32_t)j] = widx[j]; }
-            wave_fence();
+        {   // (FL_LSPLIT == 2, measurement builds only: the words are not stored -- results are wrong)
             uint2* w = (uint2*)lines.p;
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const uint32_t ix = si_[64u * (uint32_t)j + lane];
-                const uint2 d = sd[64u * (uint32_t)j + lane];
-#if defined(FL_LSPLIT) && FL_LSPLIT == 2  // (measurement builds only: the staged words are not stored -- results are wrong)
-                if (ix == 0xfffffffeu) w[ix] = d;
+            for (int j = 0; j < 3; j++)
+#if defined(FL_LSPLIT) && FL_LSPLIT == 2
+                if (widx[j] == 0xfffffffeu) w[widx[j]] = wdat[j];
 #else
-                if (ix != 0xffffffffu) w[ix] = d;
+                if (widx[j] != 0xffffffffu) w[widx[j]] = wdat[j];
 #endif
-            }
         }
     }
 }

@@ -313,8 +313,9 @@ def test_poisoned_scratch_and_growing_scenes(engine):
     """The deterministic allocators keep counters in per-context scratch that a frame leaves zeroed for the next one
     ("self-cleaning", kcommon.h JH_CLEAN_*).  Nothing may depend on what else that memory held: poison it the way a fresh
     non-zero allocation would look, render a small scene (few workgroups touch few counters), then a larger one on the
-    same, not regrown allocations -- flatten's per-workgroup chunk counters beyond the small frame's workgroups must
-    have been zeroed all the same -- and a clip scene after a second poisoning."""
+    same, not regrown allocations -- every counter of flatten's block (the list counters, the region cursors of its temporary)
+    must have been zeroed all the same, whatever the small frame touched -- and a clip scene after a second
+    poisoning."""
     def sized(sp):
         s, p = sp
         p.bump = BumpSizes(lines=1 << 21, seg_counts=1 << 21, segments=1 << 21, tiles=1 << 21, ptcl=1 << 24, bin_data=1 << 20)

@@ -110,6 +110,9 @@ JD uint32_t fl_grab(const FlTemp& T, uint32_t home, uint32_t n, bool& failed) {
     for (uint32_t tries = 1u;; tries++) {
         if (KIND == 0 && p < T.R)  // the region's last slots stay empty
             for (uint32_t i = p; i < T.R; i++) T.sinfo[(size_t)region * T.R + i] = make_uint2(0u, 0u);
+        // (an add that found the region full already is taken back: the cursor of a full region stays within one allocation of R
+        // however many waves still try it before they move on -- it can never wrap and reopen the region)
+        if (p >= T.R) atomicSub(T.ctr + FL_CTR_CURSOR + FL_CUR_STRIDE * region + (KIND ? 32u : 0u), n);
         if (tries >= T.K) return FL_INVALID;
         region = region + 1u == T.K ? 0u : region + 1u;
         p = atomicAdd(T.ctr + FL_CTR_CURSOR + FL_CUR_STRIDE * region + (KIND ? 32u : 0u), n);

@@ -272,7 +272,17 @@ def run_rank(args, world):
     blocks_by_mode, mode_errors = sharding.time_modes_surviving_failures(dist, rank, gather_modes, timed_mode, dev, mode_errors) if gather_modes else ({}, mode_errors)
     good_modes = [m for m in gather_modes if m in blocks_by_mode]
     gather = bool(good_modes)
-    head_mode = ("0" if "0" in good_modes else good_modes[0]) if gather else None  # C5 as written gathers on rank 0
+    # Which mode is the line's `value` (round 6): a gather to ONE compositor GPU is capped by that GPU's inbound links (sharding.gather_model:
+    # 4.15 x at 8 GPUs at this render time, whatever the renderer does), so with `--gather-dst all` the headline is the gather whose
+    # destination rotates when it ran, else the gather-free loop; gather-to-rank-0 stays under `modes` with its ceiling.  An explicit
+    # `--gather-dst 0` / `rotate` is reported as asked.
+    if not gather:
+        head_mode = None
+    elif args.gather_dst == "all":
+        head_mode = "rotate" if "rotate" in good_modes else None
+    else:
+        head_mode = good_modes[0]
+    gather = head_mode is not None
     blocks = blocks_by_mode[head_mode] if gather else blocks_plain
     elapsed_plain = blocks_plain[len(blocks_plain) // 2]
     elapsed = blocks[len(blocks) // 2]  # the median block
@@ -358,6 +368,7 @@ def run_rank(args, world):
             "launches_per_frame": None if not use_graph else dict(zip(("kernels", "fills_and_copies"), eng.graph_node_counts(graphs[0]))),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_source": "eager replay of the same %d steps with a hipEvent pair per stage" % args.steps,
+            "stage_ms_regime": "one context, eager (a stage's duration is its own: the sum is a frame alone, not ms_per_step with %d frames in flight)" % n_ctx,
             "bump": bump_now, "scratch_bytes_per_context": eng.scratch_bytes(), "sizing_attempts": attempts, "bump_estimate_clamped": scene.bump_sizes_clamped(W, H),
             "stage_roofline": stage_roofline(cfg, bump_now, stage_ms, rec),
             "roofline": roofline,
@@ -399,6 +410,8 @@ def run_rank(args, world):
                     result["modes"][key]["can_meet_6x_at_8_gpus"] = bool(c8 >= 6.0)
             result["mode_errors"] = mode_errors or None
             result["value_mode"] = "no_gather" if not gather else ("gather_to_rank0" if head_mode == "0" else "gather_to_rank_step_mod_n")
+            result["value_mode_rule"] = ("--gather-dst all: the gather with a rotating destination when it ran, else no gather; gather-to-rank-0 (C5 as written) is "
+                                         "under modes.gather_to_rank0, wire-capped at modes.gather_to_rank0.ceiling_speedup_at_8_gpus x")
             result["value_no_gather"] = result["modes"]["no_gather"]["value"]
             result["ms_per_step_no_gather"] = round(pp * 1e3, 4)
             if gather:

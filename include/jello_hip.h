@@ -205,6 +205,13 @@ int jh_profile_collect_tree(jh_ctx* ctx, jh_profile_node* out, int max);
  * 3 acos, 4 asin, 5 |a|^(2/3), 6 a/b, 7 sqrt, 8 round-to-even, 9 u32(a), 10 i32(a), 11 f32->f16 bits,
  * 12 a*b+a (uncontracted), 13 floor(a*b+0.5), 14 min(a,b), 15 max(a,b), 16 clamp(a,0,1), 17 clamp(a*b,0,1). */
 int jh_selftest_math(jh_ctx* ctx, int op, const float* a, const float* b, float* out, uint32_t n);
+/* Runs the allocation patterns the kernels rely on -- a returning atomic add with a different value per lane on one address, inside
+ * a loop that lanes skip and leave at different trips -- on n_waves waves (1..4096) and compares with a serial execution on the
+ * host: form 0 the plain per-lane atomic (what the compiler's atomic optimizer makes of it), 1 the hand-aggregated wave_bump
+ * (kcommon.h) the hot call sites use, 2 the wave-private LDS forms (XOR into one word, 64-bit OR into a word per lane).
+ * Returns 0 when everything agrees, the number of violations (> 0) otherwise, a negative jh_status on misuse / device errors.
+ * (Round 5 met a compiler strategy that returned overlapping ranges for form 0; tests/test_gpu_math.py runs all three.) */
+int jh_selftest_atomics(jh_ctx* ctx, int form, uint32_t seed, uint32_t n_waves);
 /* Fills every per-context scratch allocation (the count / offset arrays and counters of the deterministic allocators)
  * with `byte` and forgets that any counter was left clean -- the state of freshly allocated device memory that happens
  * not to be zero.  Tests use it to show that no stage relies on what an earlier frame (or hipMalloc) left behind, the

@@ -1144,6 +1144,18 @@ int jh_selftest_math(jh_ctx* ctx, int op, const float* a, const float* b, float*
     return rc == 0 ? JH_OK : fail(ctx, JH_ERR_DEVICE, "selftest launch failed");
 }
 
+int jh_selftest_atomics_launch(hipStream_t stream, int form, uint32_t seed, uint32_t n_waves);
+
+int jh_selftest_atomics(jh_ctx* ctx, int form, uint32_t seed, uint32_t n_waves) {
+    if (!ctx) return JH_ERR_INVALID;
+    JH_FLUSH(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rc = jh_selftest_atomics_launch(ctx->stream, form, seed, n_waves);
+    if (rc == -1) return fail(ctx, JH_ERR_INVALID, "selftest_atomics: form 0..2, 1..4096 waves");
+    if (rc < 0) return fail(ctx, JH_ERR_DEVICE, "selftest_atomics: runtime error");
+    return rc;
+}
+
 int jh_debug_poison_scratch(jh_ctx* ctx, int byte) {
     if (!ctx) return JH_ERR_INVALID;
     JH_FLUSH(ctx);

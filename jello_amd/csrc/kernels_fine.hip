@@ -273,7 +273,20 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #ifndef FINE_SKIP
 #define FINE_SKIP 0
 #endif
-#if FINE_SKIP != 0 && !defined(JH_VARIANT_BUILD)
+// FINE_WHATIF (timing-only variant builds, results WRONG; round 6: what do the LDS bank conflicts cost?): bit 0 the row walk reads
+// its entries at conflict-free linear addresses (same trips, same instructions), bit 1 stage 2 writes its entries at [quad][lane]
+// instead of [quad][row-sorted position], bit 2 the crossing pixels' single floats go to [quad][lane] as well.
+#ifndef FINE_WHATIF
+#define FINE_WHATIF 0
+#endif
+#if FINE_WHATIF & 1
+#define FINE_WALK_RD "%[rd]"
+#define FINE_WALK_RD_OPERAND , [rd] "v"(lds_addr(&F.ent[0][0]) + lane * 16u)
+#else
+#define FINE_WALK_RD "%[cur]"
+#define FINE_WALK_RD_OPERAND
+#endif
+#if (FINE_SKIP != 0 || FINE_WHATIF != 0) && !defined(JH_VARIANT_BUILD)
 #error "FINE_SKIP changes results: build it as a variant library (make VARIANT=name EXTRA='-DJH_VARIANT_BUILD -DFINE_SKIP=n')"
 #endif
 #define RK_NONEG 1u
@@ -807,7 +820,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
 #pragma unroll
             for (int q = 0; q < 16; q++) cv[q] = clamp_((float)(q + 1) - c1f, 0.0f, 1.0f) * s2_dy;
 #pragma unroll
-            for (int q = 0; q < 4; q++) F.ent[q][pos] = make_float4(cv[4 * q], cv[4 * q + 1], cv[4 * q + 2], cv[4 * q + 3]);
+            for (int q = 0; q < 4; q++) F.ent[q][(FINE_WHATIF & 2) ? lane : pos] = make_float4(cv[4 * q], cv[4 * q + 1], cv[4 * q + 2], cv[4 * q + 3]);
         }
 #if FINE_CROSS_INLANE
         // The pair's own lane evaluates its FIRST crossing pixel (round 5): all operands are in its registers, so the pixel
@@ -825,7 +838,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             float c = fmax_(b, 0.0f);
             float d = fmax_(xmin, 0.0f);
             float a = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
-            ((float*)&F.ent[X >> 2][pos])[X & 3u] = a * s2_dy;
+            ((float*)&F.ent[X >> 2][(FINE_WHATIF & 4) ? lane : pos])[X & 3u] = a * s2_dy;
         }
         const uint32_t nrest = ncross != 0u ? ncross - 1u : 0u;
         const int32_t n0r = n0 + 1;
@@ -872,7 +885,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                     float c = fmax_(b, 0.0f);
                     float d = fmax_(xmin, 0.0f);
                     float a = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
-                    ((float*)&F.ent[X >> 2][epos])[X & 3u] = a * dy;
+                    ((float*)&F.ent[(FINE_WHATIF & 4) ? (lane >> 4) : (X >> 2)][(FINE_WHATIF & 4) ? lane : epos])[(FINE_WHATIF & 4) ? (lane & 3u) : (X & 3u)] = a * dy;
                 }
             }
         }
@@ -1058,12 +1071,12 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                         "1:\n"
                         "v_cmpx_lt_u32_e32 vcc, %[cur], %[hi]\n"
                         "s_cbranch_execz 3f\n"
-                        "ds_read_b128 v[72:75], %[cur]\n"
+                        "ds_read_b128 v[72:75], " FINE_WALK_RD "\n"
                         "v_add_u32_e32 %[t], 16, %[cur]\n"
                         "v_cmp_lt_u32_e32 vcc, %[t], %[hi]\n"
                         "s_mov_b64 %[s1], exec\n"
                         "s_and_b64 exec, exec, vcc\n"
-                        "ds_read_b128 v[76:79], %[cur] offset:16\n"
+                        "ds_read_b128 v[76:79], " FINE_WALK_RD " offset:16\n"
                         "s_mov_b64 exec, %[s1]\n"
                         "v_add_u32_e32 %[cur], 32, %[cur]\n"
                         "s_waitcnt lgkmcnt(1)\n"
@@ -1078,7 +1091,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                         "3:\n"
                         "s_mov_b64 exec, %[sv]\n"
                         : [cur] "+v"(cur), [a01] "+v"(a01), [a23] "+v"(a23), [sv] "=&s"(sv), [s1] "=&s"(s1), [t] "=&v"(t)
-                        : [hi] "v"(hi)
+                        : [hi] "v"(hi) FINE_WALK_RD_OPERAND
                         : "vcc", "memory", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79");
                     area[0] = a01.x; area[1] = a01.y; area[2] = a23.x; area[3] = a23.y;
                 }

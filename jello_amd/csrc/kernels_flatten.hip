@@ -79,27 +79,7 @@ struct FlTemp {
 // overflowed its line buffer).  `home` is the wave's region: WAVE-UNIFORM, so that the lanes that allocate in one instruction
 // can share one atomic (wave_bump; one atomic per lane means 400 000 per C3 frame instead of 8 000: +370 us).  `failed` is raised when home could not serve: the wave moves
 // on at its next uniform point (fl_next_home).
-// [p, p + n) of a bump counter for every ACTIVE lane of the wave, with ONE atomic: the lanes are served value by value (the
-// lanes of a call site mostly ask for the same n: one round), a lane's offset = what the rounds before it and the lanes below
-// it in its own round take.  By hand, because LLVM's atomic optimizer in its DPP strategy -- which does the same with a wave
-// prefix sum -- returned wrong offsets for these call sites (divergent branches inside loops; test_c2_blobs_all_joins_caps_evenodd
-// failed with it and passes with the strategies None and Iterative), and None means 64 atomics per call.
-JD uint32_t wave_bump(uint32_t* ctr, uint32_t n) {
-    const uint64_t below = (1ull << lane_id()) - 1ull;
-    uint64_t todo = __builtin_amdgcn_ballot_w64(true);
-    const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
-    uint32_t off = 0u, total = 0u;
-    while (todo != 0ull) {  // uniform among the active lanes
-        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)n, __builtin_ctzll(todo));
-        const uint64_t m = __builtin_amdgcn_ballot_w64(n == v);
-        if (n == v) off = total + v * (uint32_t)__builtin_popcountll(m & below);
-        total += v * (uint32_t)__builtin_popcountll(m);
-        todo &= ~m;
-    }
-    uint32_t p = 0u;
-    if (lane_id() == leader) p = atomicAdd(ctr, total);
-    return (uint32_t)__builtin_amdgcn_readlane((int)p, (int)leader) + off;
-}
+// (wave_bump: kcommon.h)
 template <int KIND>
 JD uint32_t fl_grab(const FlTemp& T, uint32_t home, uint32_t n, bool& failed) {
     // (the attempt on home stands apart from the loop over the other regions: inside the loop the region is a per-lane value)

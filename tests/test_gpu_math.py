@@ -112,3 +112,16 @@ def test_min_max_clamp_semantics(engine):
     cl2 = np.empty_like(a)
     L.oracle_vec_minmaxclamp(prod.ctypes.data_as(FP), b.ctypes.data_as(FP), mn.ctypes.data_as(FP), mx.ctypes.data_as(FP), cl2.ctypes.data_as(FP), ctypes.c_int(a.size))
     assert np.array_equal(canon(gpu_op(engine, 17, a, b)), canon(cl2))
+
+
+@pytest.mark.parametrize("form", [0, 1, 2])
+def test_divergent_value_atomics_behave_like_a_serial_execution(engine, form):
+    """jh_selftest_atomics: per-lane-value returning atomics on one address inside a loop that lanes skip and leave at
+    different trips (the pattern LLVM's atomic optimizer miscompiled in its DPP strategy), plain (0), through
+    wave_bump (1) and the LDS forms (2): every range handed out tiles [0, counter) exactly / the words equal the serial result."""
+    engine.hip.jh_selftest_atomics.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
+    engine.hip.jh_selftest_atomics.restype = ctypes.c_int
+    for seed, waves in ((1, 1), (2, 4), (3, 37), (4, 1024), (5, 4096)):
+        assert engine.hip.jh_selftest_atomics(engine.ctx, form, seed, waves) == 0, (form, seed, waves)
+    assert engine.hip.jh_selftest_atomics(engine.ctx, 3, 1, 1) < 0
+    assert engine.hip.jh_selftest_atomics(engine.ctx, 0, 1, 0) < 0

@@ -323,248 +323,414 @@ JD void load_segraw_clamped(const float* __restrict__ segments, uint32_t segment
 }
 
 // ------------------------------------------------------------------------------------------------
-// fill_path_ms / fill_path_ms_evenodd (fine.wgsl:148-711): multisampled coverage, 8 or 16 samples per pixel.
-// The WGSL is written for a 64-invocation workgroup with workgroup-memory atomics -- exactly one wave64 with
-// LDS atomics here, so this is a direct restatement: count pass (lane = segment), wave prefix sum, load-balanced
-// pixel pass (lane = pixel touched by a segment; binary search over the prefix sums) that bumps SWAR-packed
-// winding deltas, then the x/y prefix and the per-sample resolve.  All integer; every atomic is a commutative
-// add/xor, so the words do not depend on the order.  WGSL rules: shift amounts are taken modulo 32,
-// out-of-range workgroup indices drop the write, float->int conversions saturate (dmath.h).
+// Multisampled coverage, 8 or 16 samples per pixel (fine_msaa8 / fine_msaa16; the arithmetic is fine.wgsl:148-711's, the sample
+// masks are the LUT of renderer/mask.go:43-105 that the caller binds).
+//
+// What the reference computes per FILL: every segment walks the pixels it touches (a conservative DDA: count = columns + rows
+// spanned - 1); each TOUCHED PIXEL takes a half-plane sample mask from the LUT (slope row, offset column), trimmed at the
+// segment's two ends, and adds +-1 to the winding counter of every sample the mask covers; a segment that crosses the top of
+// a pixel leaves a +-1 for all pixels to its right (an x-prefix afterwards), one that touches the tile's left edge a +-1 for all
+// rows below (a y-prefix).  A pixel's coverage is the number of its samples whose counter differs from zero (non-zero rule) or is
+// odd (even-odd).  Everything is integer: every decomposition of the sums gives the same words.
+//
+// MI355X design (round 6; rounds 2-5 ran a restatement of the WGSL's workgroup program, which is gone).  The WGSL starts from
+// scratch for every FILL -- 5 segments and ~30 touched pixels on the headline scene, 13 fills per tile -- so each fill pays a
+// count pass on 5 lanes, a prefix sum, a binary search over it in workgroup memory per touched pixel, the DDA set-up with its
+// division per touched pixel, a dependent LUT fetch, the atomics, and three barriers: a chain of ~15 dependent round trips on a
+// wave that is a tenth full.  Here the touched pixels are produced per BATCH of consecutive segments of the tile's segment
+// stream (its slices are contiguous: a batch spans ~8 fills), on full waves, ahead of the command stream:
+//   set-up   lane = segment : DDA constants (the division once per SEGMENT), number of touched pixels, the left-edge term;
+//            a wave prefix sum cuts the batch at MS_CAP touched pixels
+//   pixels   lane = touched pixel, 64 per pass: its segment = running maximum (DPP) over marks the segments leave at their first
+//            pixel; the pixel, its trimmed sample mask (the LUT fetches of all passes are in flight together) and its flags are
+//            packed into ONE word (8 samples; two for 16) in a list in segment order -- rule-agnostic: the two rules differ in one
+//            flag, both are kept
+//   per FILL the entries of its segments are a contiguous range of that list: lanes take them 64 at a time and add them to the
+//            tile's sample words with LDS atomics (commutative), the segments' left-edge terms likewise; the x-prefix runs in
+//            registers (SWAR inside the lane's word, DPP across the four lanes of a pixel row), the y-prefix on the four uniform
+//            words; the lane resolves its own four pixels.
+// A fill therefore costs: clear, one list read, the atomics, one read-back -- no search, no division, no global access.
+// WGSL rules kept: shift amounts modulo 32, saturating float -> int conversions, pixels outside the tile drop their writes
+// (their index is formed with the WGSL's own u32 arithmetic first), segments behind the buffer read as zeros -- and a zero
+// segment touches the tile corner: it does count.
 // ------------------------------------------------------------------------------------------------
-struct MsLds {
-    // rolling window over the tile's segment stream (its slices are contiguous, in command order): 64 segments' end
-    // points, so that a fill of a few segments does not start with a global round trip of its own
-    alignas(16) float sh_seg[64][4];
-    alignas(16) uint32_t sh_samples[1024];  // (16-byte aligned: the 16-sample variant moves four words per pixel at a time)
-    alignas(16) uint32_t sh_count[64];
-    alignas(16) uint32_t sh_winding[64];
-    uint32_t sh_winding_y[4], sh_winding_y_prefix[4];
-    uint32_t seg_win_base, seg_win_valid;
+#define MS_CAP 256u  // touched pixels per batch (a sane segment has at most 31; one with more is walked directly, see ms_direct)
+template <int SAMPLES> struct MsEnt { typedef uint32_t type; };     // mask 8 | trim 5 | pixel 8 | flags 6 = 27 bits
+template <> struct MsEnt<16> { typedef unsigned long long type; };  // mask 16 | trim 5 | pixel 8 | flags 6 = 35 bits
+#define MS_F_DOWN 1u      // the segment runs downwards as given (sign of its winding contribution)
+#define MS_F_BUMP_NZ 2u   // the whole pixel takes the contribution too (left-edge crossing): non-zero rule
+#define MS_F_BUMP_EO 4u   // ... even-odd rule (differs at the tile's left edge only)
+#define MS_F_CARRY 8u     // crosses the pixel's top: +-1 for the pixels to the right
+#define MS_F_HEAD 16u     // the segment's first touched pixel: the mask is trimmed above the start point unless the pixel is bumped
+#define MS_F_LIVE 32u     // the pixel lies inside the tile
+#define MS_S_DOWN 1u
+#define MS_S_RIGHT 2u     // x does not decrease along the (downward) segment
+#define MS_S_TOP_ON_EDGE 4u   // the upper end point has x == 0
+#define MS_S_BOT_OFF_EDGE 8u  // the lower end point has x != 0
+struct MsSeg {  // what a touched pixel needs of its segment (written by lane = segment, read by lane = touched pixel): 32 bytes
+    float a, b;          // z = floor(a * k + b): columns crossed after k steps of the DDA
+    int32_t x0i;         // column of the first pixel
+    float top_y, bot_y;  // y of the upper / lower end point
+    float lut_row;       // LUT row of the slope, times the row length
+    uint32_t bits;       // MS_S_* | touched pixels << 8
+    uint32_t first;      // index of the first touched pixel in the batch's list
+};
+template <int SAMPLES> struct MsLds {
+    union {
+        MsSeg seg[64];    // while a batch is built
+        float4 pre[64];   // between builds: the next window's end points, in flight (global_load_lds)
+    };
+    alignas(16) uint32_t samples[SAMPLES == 8 ? 512 : 1024];  // [pixel][word]: SWAR winding counters, four samples per word (non-zero); [pixel]: parity bits (even-odd)
+    typename MsEnt<SAMPLES>::type ent[MS_CAP];                // the batch's touched pixels, in segment order
+    uint32_t carry_x[64];  // non-zero: [pixel / 4] a byte per pixel; even-odd: [row] a bit per pixel
+    alignas(16) uint32_t carry_y[4];  // non-zero: a byte per row; even-odd: word 0, a bit per row
+    uint32_t mark[64];
 };
 JD uint32_t shl32(uint32_t v, uint32_t s) { return v << (s & 31u); }
 JD uint32_t shr32(uint32_t v, uint32_t s) { return v >> (s & 31u); }
 JD uint32_t ms_span(float a, float b) { return to_u32(fmax_(ceil_(fmax_(a, b)) - floor_(fmin_(a, b)), 1.0f)); }
 
+// lane = segment (or every lane the same segment: ms_direct): fine.wgsl:180-203 / :237-262.  Returns the number of touched pixels;
+// `edge` = the left-edge term: row | 16 if it counts upwards | 32 if there is one.
 template <int SAMPLES>
-JD void fill_path_ms(MsLds& T, uint32_t lane, uint32_t size_and_rule, uint32_t seg_data, int32_t backdrop, const float* __restrict__ segments,
-                     uint32_t segments_n, const uint32_t* __restrict__ mask_lut, uint32_t mask_lut_n, float (&area)[4]) {
-    const bool even_odd = (size_and_rule & 1u) != 0u;  // uniform
-    const uint32_t n_segs = size_and_rule >> 1;
-    const uint32_t MASK_WIDTH = SAMPLES == 8 ? 32u : 64u, MASK_HEIGHT = MASK_WIDTH;
-    const uint32_t WORDS = even_odd ? 1u : (SAMPLES == 8 ? 2u : 4u);
-    const uint32_t SH_SAMPLES_SIZE = SAMPLES == 8 ? 512u : 1024u;
+JD uint32_t ms_setup(float x0, float y0, float x1, float y1, MsSeg& K, uint32_t& edge) {
+    const float LUT_W = SAMPLES == 8 ? 32.0f : 64.0f, HALF_H = SAMPLES == 8 ? 16.0f : 32.0f;
+    uint32_t touched = 0u;
+    if (!(y0 == y1 && y0 == floor_(y0))) touched = ms_span(x0, x1) + ms_span(y0, y1) - 1u;  // (a horizontal line on the pixel grid touches nothing)
+    float edge_y = 16.0f;
+    if (x0 == 0.0f) edge_y = y0;
+    else if (x1 == 0.0f) edge_y = y1;
+    const uint32_t edge_row = to_u32(ceil_(edge_y));
+    edge = edge_row < 16u ? (edge_row | (x1 <= x0 ? 16u : 0u) | 32u) : 0u;
+    const bool down = y1 >= y0;
+    const float tx = down ? x0 : x1, ty = down ? y0 : y1, bx = down ? x1 : x0, by = down ? y1 : y0;  // top / bottom end
+    const float dx = abs_(bx - tx), dy = by - ty;
+    const float inv = 1.0f / (dx + dy);
+    float a = dx * inv;
+    const bool right = bx >= tx;
+    const float sgn = right ? 1.0f : -1.0f;
+    const float xt = floor_(tx * sgn);
+    const float frac = tx * sgn - xt;
+    const float row0 = floor_(ty);
+    const float b = fmin_((dy * frac + dx * ((row0 + 1.0f) - ty)) * inv, 0.99999994f);
+    const uint32_t cols = ms_span(tx, bx) - 1u;
+    const uint32_t steps = cols + ms_span(ty, by);
+    const float err = floor_(a * ((float)steps - 1.0f) + b) - (float)cols;
+    if (err != 0.0f) a -= 2e-7f * sign_(err);
+    K.a = a; K.b = b;
+    K.x0i = to_i32(xt * sgn + 0.5f * (sgn - 1.0f));
+    K.top_y = ty; K.bot_y = by;
+    K.lut_row = floor_(fmin_(a * HALF_H, HALF_H - 1.0f)) * LUT_W;
+    K.bits = (down ? MS_S_DOWN : 0u) | (right ? MS_S_RIGHT : 0u) | (tx == 0.0f ? MS_S_TOP_ON_EDGE : 0u) | (bx != 0.0f ? MS_S_BOT_OFF_EDGE : 0u);
+    return touched;
+}
+// lane = touched pixel k of a segment with `touched` of them (fine.wgsl:264-340): everything of its entry but the LUT mask --
+// pixel, flags, the trim of the head -- plus the LUT index and the bits the tail trim keeps.
+template <int SAMPLES>
+JD uint32_t ms_pixel(const MsSeg& K, uint32_t k, uint32_t touched, uint32_t& lut_ix, uint32_t& keep) {
     const uint32_t FULL = SAMPLES == 8 ? 0xffu : 0xffffu;
-    const uint32_t th_ix = lane, lx = lane & 3u, ly = lane >> 2;
-    const uint32_t init = even_odd ? 0u : 0x80808080u;
-    if (even_odd) {
-        if (th_ix < 16u) {
-            if (th_ix == 0u) T.sh_winding_y[0] = 0u;
-            T.sh_winding[th_ix] = 0u;
-        }
+    const float LUT_W = SAMPLES == 8 ? 32.0f : 64.0f;
+    const bool right = (K.bits & MS_S_RIGHT) != 0u;
+    const float sgn = right ? 1.0f : -1.0f;
+    const float zf = K.a * (float)k + K.b;
+    const float z = floor_(zf);
+    const int32_t x = K.x0i + to_i32(sgn * z);
+    const float row0 = floor_(K.top_y);
+    const int32_t y = (int32_t)((uint32_t)to_i32(row0) + k - (uint32_t)to_i32(z));
+    const float z_before = floor_(K.a * (float)(k - 1u) + K.b);
+    bool top, bump_nz, bump_eo;
+    if (k == 0u) {
+        top = row0 == K.top_y;
+        bump_eo = (K.bits & MS_S_TOP_ON_EDGE) != 0u;
+        bump_nz = bump_eo && row0 != K.top_y;
     } else {
-        if (th_ix < 4u) T.sh_winding_y[th_ix] = init;
-        T.sh_winding[th_ix] = init;
+        top = z == z_before;
+        bump_nz = bump_eo = right && !top;
     }
-    for (uint32_t i = 0u; i < 4u * WORDS; i++) T.sh_samples[th_ix * 4u * WORDS + i] = init;
-    wave_sync();
-    auto load_seg = [&](uint32_t so, float& p0x, float& p0y, float& p1x, float& p1y) {  // (so inside the window)
-        const uint32_t w = so - T.seg_win_base;
-        p0x = T.sh_seg[w][0]; p0y = T.sh_seg[w][1]; p1x = T.sh_seg[w][2]; p1y = T.sh_seg[w][3];
-    };
-    const uint32_t n_batch = (n_segs + 63u) / 64u;
-    for (uint32_t batch = 0u; batch < n_batch; batch++) {
-        const uint32_t slice_size = umin_(n_segs - batch * 64u, 64u);
-        {   // make the window cover [first, first + slice_size)
-            const uint32_t first = seg_data + batch * 64u;
-            const bool inside = T.seg_win_valid != 0u && first >= T.seg_win_base && first - T.seg_win_base + slice_size <= 64u;  // uniform
-            if (!inside) {
-                wave_sync();  // (everybody has read the flags above)
-                const uint32_t so = first + th_ix;
-                float2 a = make_float2(0.0f, 0.0f), b = a;  // segments behind the buffer read as zeros (robust access)
-                if (so < segments_n) {
-                    const float2* sp = (const float2*)(segments + (size_t)so * 6);
-                    a = sp[0]; b = sp[1];
-                }
-                T.sh_seg[th_ix][0] = a.x; T.sh_seg[th_ix][1] = a.y; T.sh_seg[th_ix][2] = b.x; T.sh_seg[th_ix][3] = b.y;
-                if (th_ix == 0u) { T.seg_win_base = first; T.seg_win_valid = 1u; }
-                wave_sync();
-            }
-        }
-        uint32_t count = 0u;
-        if (th_ix < slice_size) {  // fine.wgsl:176-203 / :532-555
-            float x0, y0, x1, y1;
-            load_seg(seg_data + batch * 64u + th_ix, x0, y0, x1, y1);
-            float y_edge_f = 16.0f;
-            const int32_t delta = (x1 <= x0) ? 1 : -1;
-            if (x0 == 0.0f) y_edge_f = y0;
-            else if (x1 == 0.0f) y_edge_f = y1;
-            if (!(y0 == y1 && y0 == floor_(y0))) count = ms_span(x0, x1) + ms_span(y0, y1) - 1u;
-            const uint32_t y_edge = to_u32(ceil_(y_edge_f));
-            if (y_edge < 16u) {
-                if (even_odd) atomicXor(&T.sh_winding_y[0], shl32(1u, y_edge));
-                else atomicAdd(&T.sh_winding_y[y_edge >> 2], shl32((uint32_t)delta, (y_edge & 3u) << 3));
-            }
-        }
-        const uint32_t incl = wave_incl_scan_u32(count);  // :205-215 (Hillis-Steele in the WGSL)
-        T.sh_count[th_ix] = incl;
-        wave_sync();
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(slice_size - 1u));
-        for (uint32_t i = th_ix; i < total; i += 64u) {  // :217-383 / :566-675
-            uint32_t lo = 0u, hi = slice_size;
-            while (hi > lo + 1u) {
-                uint32_t mid = (lo + hi) >> 1;
-                if (i >= T.sh_count[mid - 1u]) lo = mid; else hi = mid;
-            }
-            const uint32_t el_ix = lo;
-            const bool last_pixel = i + 1u == T.sh_count[el_ix];
-            const uint32_t sub_ix = i - (el_ix > 0u ? T.sh_count[el_ix - 1u] : 0u);
-            float in0x, in0y, in1x, in1y;
-            load_seg(seg_data + batch * 64u + el_ix, in0x, in0y, in1x, in1y);
-            const bool is_down = in1y >= in0y;
-            const float xy0x = is_down ? in0x : in1x, xy0y = is_down ? in0y : in1y;
-            const float xy1x = is_down ? in1x : in0x, xy1y = is_down ? in1y : in0y;
-            const float dx = abs_(xy1x - xy0x);
-            const float dy = xy1y - xy0y;
-            const float idxdy = 1.0f / (dx + dy);
-            float a = dx * idxdy;
-            const bool is_positive_slope = xy1x >= xy0x;
-            const float x_sign = is_positive_slope ? 1.0f : -1.0f;
-            const float xt0 = floor_(xy0x * x_sign);
-            const float c = xy0x * x_sign - xt0;
-            const float y0i = floor_(xy0y);
-            const float ytop = y0i + 1.0f;
-            const float b = fmin_((dy * c + dx * (ytop - xy0y)) * idxdy, 0.99999994f);
-            const uint32_t count_x = ms_span(xy0x, xy1x) - 1u;
-            const uint32_t cnt = count_x + ms_span(xy0y, xy1y);
-            const float robust_err = floor_(a * ((float)cnt - 1.0f) + b) - (float)count_x;
-            if (robust_err != 0.0f) a -= 2e-7f * sign_(robust_err);
-            const int32_t x0i = to_i32(xt0 * x_sign + 0.5f * (x_sign - 1.0f));
-            const float zf = a * (float)sub_ix + b;
-            const float z = floor_(zf);
-            const int32_t x = x0i + to_i32(x_sign * z);
-            const int32_t y = (int32_t)((uint32_t)to_i32(y0i) + sub_ix - (uint32_t)to_i32(z));
-            bool is_delta, is_bump = false;
-            const float zp = floor_(a * (float)(sub_ix - 1u) + b);
-            if (sub_ix == 0u) {
-                is_delta = y0i == xy0y;
-                is_bump = even_odd ? (xy0x == 0.0f) : (xy0x == 0.0f && y0i != xy0y);
-            } else {
-                is_delta = z == zp;
-                is_bump = is_positive_slope && !is_delta;
-            }
-            const uint32_t pix_ix = (uint32_t)y * 16u + (uint32_t)x;
-            if ((uint32_t)x < 15u && (uint32_t)y < 16u && is_delta) {
-                if (even_odd) {
-                    atomicXor(&T.sh_winding[y], shl32(2u, (uint32_t)x));
-                } else {
-                    const uint32_t delta_pix = pix_ix + 1u;
-                    atomicAdd(&T.sh_winding[delta_pix >> 2], shl32(is_down ? 1u : 0xffffffffu, (delta_pix & 3u) << 3));
-                }
-            }
-            const uint32_t mask_block = (is_positive_slope ? 1u : 0u) * (MASK_WIDTH * MASK_HEIGHT / 2u);
-            const float half_height = (float)(MASK_HEIGHT / 2u);
-            const float mask_row = floor_(fmin_(a * half_height, half_height - 1.0f)) * (float)MASK_WIDTH;
-            const float mask_col = floor_((zf - z) * (float)MASK_WIDTH);
-            const uint32_t mask_ix = mask_block + to_u32(mask_row + mask_col);
-            uint32_t mask;
-            if (SAMPLES == 8) {
-                const uint32_t wi = mask_ix / 4u;
-                mask = shr32(wi < mask_lut_n ? mask_lut[wi] : 0u, (mask_ix % 4u) * 8u) & 0xffu;
-            } else {
-                const uint32_t wi = mask_ix / 2u;
-                mask = shr32(wi < mask_lut_n ? mask_lut[wi] : 0u, (mask_ix % 2u) * 16u) & 0xffffu;
-            }
-            const float sf = (float)SAMPLES;
-            if (sub_ix == 0u && !is_bump) mask &= shl32(FULL, to_u32(round_(sf * (xy0y - (float)y))));
-            if (last_pixel && xy1x != 0.0f) mask &= ~shl32(FULL, to_u32(round_(sf * (xy1y - (float)y))));
-            if (even_odd) {
-                if (is_bump) mask ^= FULL;
-                if (pix_ix < SH_SAMPLES_SIZE) atomicXor(&T.sh_samples[pix_ix], mask);
-            } else {
-                const uint32_t bump_delta = is_down ? 0x1010101u : (uint32_t)-0x1010101;
-#pragma unroll
-                for (uint32_t half = 0u; half < (SAMPLES == 8 ? 1u : 2u); half++) {
-                    const uint32_t m8 = (mask >> (8u * half)) & 0xffu;
-                    const uint32_t ma = m8 ^ (m8 << 7);
-                    const uint32_t mb = ma ^ (ma << 14);
-                    const uint32_t e0 = mb & 0x1010101u, e1 = (mb >> 4) & 0x1010101u;
-                    uint32_t s0 = is_down ? (uint32_t)(-(int32_t)e0) : e0, s1 = is_down ? (uint32_t)(-(int32_t)e1) : e1;
-                    if (is_bump) { s0 += bump_delta; s1 += bump_delta; }
-                    const uint32_t w0 = pix_ix * WORDS + 2u * half;
-                    if (w0 < SH_SAMPLES_SIZE) atomicAdd(&T.sh_samples[w0], s0);
-                    if (w0 + 1u < SH_SAMPLES_SIZE) atomicAdd(&T.sh_samples[w0 + 1u], s1);
-                }
-            }
-        }
-        wave_sync();
+    const uint32_t pix = (uint32_t)y * 16u + (uint32_t)x;
+    const bool carry = (uint32_t)x < 15u && (uint32_t)y < 16u && top;
+    lut_ix = (right ? (SAMPLES == 8 ? 512u : 2048u) : 0u) + to_u32(K.lut_row + floor_((zf - z) * LUT_W));
+    const float sf = (float)SAMPLES, yf = (float)y;
+    uint32_t trim = 0u;  // head: the samples from `trim` on stay (a shift by >= SAMPLES clears the mask; the WGSL's shift is modulo 32)
+    if (k == 0u) trim = umin_(to_u32(round_(sf * (K.top_y - yf))) & 31u, (uint32_t)SAMPLES);
+    keep = FULL;
+    if (k + 1u == touched && (K.bits & MS_S_BOT_OFF_EDGE) != 0u) keep = FULL & ~shl32(FULL, to_u32(round_(sf * (K.bot_y - yf))));
+    if (pix >= 256u) return 0u;  // outside the tile: every write of this pixel is dropped
+    const uint32_t flags = ((K.bits & MS_S_DOWN) != 0u ? MS_F_DOWN : 0u) | (bump_nz ? MS_F_BUMP_NZ : 0u) | (bump_eo ? MS_F_BUMP_EO : 0u) | (carry ? MS_F_CARRY : 0u) |
+                           (k == 0u ? MS_F_HEAD : 0u) | MS_F_LIVE;
+    return trim | (pix << 5) | (flags << 13);  // (the mask goes below: << SAMPLES)
+}
+template <int SAMPLES>
+JD uint32_t ms_lut(const uint32_t* __restrict__ lut, uint32_t lut_n, uint32_t ix) {
+    if (SAMPLES == 8) {
+        const uint32_t w = ix / 4u;
+        return shr32(w < lut_n ? lut[w] : 0u, (ix % 4u) * 8u) & 0xffu;
     }
-    // resolve (:386-501 / :677-710)
+    const uint32_t w = ix / 2u;
+    return shr32(w < lut_n ? lut[w] : 0u, (ix % 2u) * 16u) & 0xffffu;
+}
+// One entry into the tile's accumulators (fine.wgsl:341-383 / :640-675).
+template <int SAMPLES>
+JD void ms_apply(MsLds<SAMPLES>& T, typename MsEnt<SAMPLES>::type e, bool even_odd) {
+    const uint32_t FULL = SAMPLES == 8 ? 0xffu : 0xffffu;
+    const uint32_t meta = (uint32_t)(e >> SAMPLES);
+    const uint32_t flags = meta >> 13;
+    if ((flags & MS_F_LIVE) == 0u) return;
+    uint32_t mask = (uint32_t)e & FULL;
+    const uint32_t pix = (meta >> 5) & 0xffu;
+    const bool bump = (flags & (even_odd ? MS_F_BUMP_EO : MS_F_BUMP_NZ)) != 0u;
+    if ((flags & MS_F_HEAD) != 0u && !bump) mask &= FULL << (meta & 31u);
     if (even_odd) {
-        uint32_t scan_x = T.sh_winding[ly];
-        scan_x ^= scan_x << 1; scan_x ^= scan_x << 2; scan_x ^= scan_x << 4; scan_x ^= scan_x << 8;
-        uint32_t scan_y = T.sh_winding_y[0];
-        scan_y ^= scan_y << 1; scan_y ^= scan_y << 2; scan_y ^= scan_y << 4; scan_y ^= scan_y << 8;
-        const uint32_t row_parity = (scan_y >> ly) ^ (uint32_t)backdrop;
-#pragma unroll
-        for (uint32_t i = 0u; i < 4u; i++) {
-            const uint32_t pix_ix = th_ix * 4u + i;
-            const uint32_t samples = T.sh_samples[pix_ix];
-            const uint32_t pix_parity = row_parity ^ (scan_x >> (pix_ix % 16u));
-            const uint32_t pix_mask = (uint32_t)(-(int32_t)(pix_parity & 1u));
-            area[i] = (float)__builtin_popcount((samples ^ pix_mask) & FULL) * (SAMPLES == 8 ? 0.125f : 0.0625f);
-        }
-        wave_sync();  // the arrays are reused by the next fill
+        if (bump) mask ^= FULL;
+        atomicXor(&T.samples[pix], mask);
+        if ((flags & MS_F_CARRY) != 0u) atomicXor(&T.carry_x[pix >> 4], 2u << (pix & 15u));
         return;
     }
-    const uint32_t major = th_ix;
-    uint32_t packed_w = T.sh_winding[major];
-    packed_w += (packed_w - 0x808080u) << 8;
-    packed_w += (packed_w - 0x8080u) << 16;
-    uint32_t packed_y = T.sh_winding_y[ly >> 2];
-    packed_y += (packed_y - 0x808080u) << 8;
-    packed_y += (packed_y - 0x8080u) << 16;
-    uint32_t wind_y = (packed_y >> ((ly & 3u) << 3)) - 0x80u;
-    wave_sync();  // every lane has read sh_winding / sh_winding_y before they are overwritten
-    if ((ly & 3u) == 3u && lx == 0u) T.sh_winding_y_prefix[ly >> 2] = wind_y;
-    T.sh_winding[major] = ((packed_w >> 24) - 0x80u) * 0x1010101u;
-    wave_sync();
-    for (uint32_t i = (major & ~3u); i < major; i++) packed_w += T.sh_winding[i];
-    for (uint32_t i = 0u; i < (ly >> 2); i++) wind_y += T.sh_winding_y_prefix[i];
+    const bool down = (flags & MS_F_DOWN) != 0u;
+    const uint32_t whole = down ? 0x1010101u : (uint32_t)-0x1010101;
 #pragma unroll
-    for (uint32_t i = 0u; i < 4u; i++) {
-        const uint32_t pix_ix = th_ix * 4u + i;
-        const uint32_t expected_zero = (((packed_w >> (i * 8u)) + wind_y) & 0xffu) - (uint32_t)backdrop;
-        if (expected_zero >= 256u) {
-            area[i] = 1.0f;
-        } else if (SAMPLES == 8) {
-            const uint32_t samples0 = T.sh_samples[pix_ix * 2u], samples1 = T.sh_samples[pix_ix * 2u + 1u];
-            const uint32_t xored0 = (expected_zero * 0x1010101u) ^ samples0;
-            const uint32_t xored0_2 = xored0 | (xored0 * 2u);
-            const uint32_t xored1 = (expected_zero * 0x1010101u) ^ samples1;
-            const uint32_t xored1_2 = xored1 | (xored1 >> 1);
-            const uint32_t xored2 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
-            const uint32_t xored4 = xored2 | (xored2 * 4u);
-            const uint32_t xored8 = xored4 | (xored4 * 16u);
-            area[i] = (float)__builtin_popcount(xored8 & 0xC0C0C0C0u) * 0.125f;
-        } else {
-            const uint32_t e = expected_zero * 0x1010101u;
-            const uint32_t xored0 = e ^ T.sh_samples[pix_ix * 4u], xored1 = e ^ T.sh_samples[pix_ix * 4u + 1u];
-            const uint32_t xored2 = e ^ T.sh_samples[pix_ix * 4u + 2u], xored3 = e ^ T.sh_samples[pix_ix * 4u + 3u];
-            const uint32_t xored0_2 = xored0 | (xored0 * 2u), xored1_2 = xored1 | (xored1 >> 1);
-            const uint32_t xored01 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
-            const uint32_t xored01_4 = xored01 | (xored01 * 4u);
-            const uint32_t xored2_2 = xored2 | (xored2 * 2u), xored3_2 = xored3 | (xored3 >> 1);
-            const uint32_t xored23 = (xored2_2 & 0xAAAAAAAAu) | (xored3_2 & 0x55555555u);
-            const uint32_t xored23_4 = xored23 | (xored23 >> 2);
-            const uint32_t xored4 = (xored01_4 & 0xCCCCCCCCu) | (xored23_4 & 0x33333333u);
-            const uint32_t xored8 = xored4 | (xored4 * 16u);
-            area[i] = (float)__builtin_popcount(xored8 & 0xF0F0F0F0u) * 0.0625f;
+    for (uint32_t h = 0u; h < (SAMPLES == 8 ? 1u : 2u); h++) {
+        // eight mask bits -> eight bytes of 0 / 1 in two words (samples 0 2 4 6 | 1 3 5 7 ... in the WGSL's own interleaving)
+        const uint32_t m8 = (mask >> (8u * h)) & 0xffu;
+        const uint32_t ma = m8 ^ (m8 << 7);
+        const uint32_t mb = ma ^ (ma << 14);
+        const uint32_t e0 = mb & 0x1010101u, e1 = (mb >> 4) & 0x1010101u;
+        uint32_t s0 = down ? (uint32_t)(-(int32_t)e0) : e0, s1 = down ? (uint32_t)(-(int32_t)e1) : e1;
+        if (bump) { s0 += whole; s1 += whole; }
+        uint32_t* w = &T.samples[pix * (SAMPLES == 8 ? 2u : 4u) + 2u * h];
+        atomicAdd(w, s0);
+        atomicAdd(w + 1, s1);
+    }
+    if ((flags & MS_F_CARRY) != 0u) {
+        const uint32_t to = pix + 1u;
+        atomicAdd(&T.carry_x[to >> 2], (down ? 1u : 0xffffffffu) << ((to & 3u) << 3));
+    }
+}
+// The batch state that lives in registers: uniform values + two per-lane words (lane = segment of the batch).
+struct MsState {
+    uint32_t base, hi;      // the batch covers the segments [base, hi) of the tile's stream
+    uint32_t next;          // the window in flight to T.pre starts here (~0: none)
+    uint32_t total;         // touched pixels in the list
+    bool direct;            // the batch is ONE segment with more than MS_CAP touched pixels: walked at the fill, no list
+    uint32_t first;         // per lane: list index of my segment's first touched pixel (lanes behind the batch: total)
+    uint32_t edge;          // per lane: my segment's left-edge term (ms_setup)
+};
+template <int SAMPLES>
+JD void ms_build(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t so, const float* __restrict__ segments, uint32_t segments_n,
+                 const uint32_t* __restrict__ lut, uint32_t lut_n) {
+    typedef typename MsEnt<SAMPLES>::type Ent;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): whatever window was in flight has landed in T.pre (it aliases T.seg)
+    wave_sync();
+    float x0, y0, x1, y1;
+    if (B.next == so) {
+        const float4 t = lds_ld_f4(lds_addr(&T.pre[lane]));
+        x0 = t.x; y0 = t.y; x1 = t.z; y1 = t.w;
+    } else {
+        const float2* sp = (const float2*)(segments + (size_t)umin_(so + lane, umax_(segments_n, 1u) - 1u) * 6);
+        const float2 p = sp[0], q = sp[1];
+        x0 = p.x; y0 = p.y; x1 = q.x; y1 = q.y;
+    }
+    if (!(so + lane < segments_n && so + lane >= so)) { x0 = 0.0f; y0 = 0.0f; x1 = 0.0f; y1 = 0.0f; }  // robust access: zeros
+    MsSeg K;
+    uint32_t edge;
+    const uint32_t touched = ms_setup<SAMPLES>(x0, y0, x1, y1, K, edge);
+    const uint32_t capped = umin_(touched, MS_CAP + 1u);
+    const uint32_t incl = wave_incl_scan_u32(capped);
+    const uint64_t fit = __builtin_amdgcn_ballot_w64(incl <= MS_CAP);  // a prefix of the lanes (incl is monotone)
+    const uint32_t n = (uint32_t)__builtin_popcountll(fit);
+    B.base = so;
+    B.edge = edge;
+    B.direct = n == 0u;
+    B.hi = so + (n == 0u ? 1u : n);
+    B.total = n == 0u ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(n - 1u));
+    const uint32_t first = incl - capped;
+    B.first = lane < n ? first : B.total;
+    wave_sync();
+    if (lane < n) { K.bits |= touched << 8; K.first = first; T.seg[lane] = K; }
+    const bool starts = lane < n && touched != 0u;
+    // The touched pixels, 64 per pass; all passes' LUT fetches are issued before the first is consumed.
+    constexpr uint32_t PASSES = MS_CAP / 64u;
+    uint32_t part[PASSES], keep[PASSES], word[PASSES];
+#pragma unroll
+    for (uint32_t p = 0u; p < PASSES; p++) {
+        part[p] = 0u; keep[p] = 0u; word[p] = 0u;
+        if (p * 64u < B.total) {  // uniform
+            T.mark[lane] = 0u;
+            wave_sync();
+            if (starts && first - p * 64u < 64u) T.mark[first - p * 64u] = lane + 1u;
+            wave_sync();
+            // the segment the pass's first pixel belongs to when it does not start there
+            const uint64_t earlier = __builtin_amdgcn_ballot_w64(starts && first < p * 64u);
+            const uint32_t carry = earlier != 0ull ? 64u - (uint32_t)__builtin_clzll(earlier) : 0u;
+            const uint32_t owner = umax_(wave_incl_max_u32(T.mark[lane]), carry);
+            const uint32_t e = p * 64u + lane;
+            if (e < B.total) {
+                const MsSeg S = T.seg[(owner - 1u) & 63u];
+                uint32_t ix;
+                part[p] = ms_pixel<SAMPLES>(S, e - S.first, S.bits >> 8, ix, keep[p]);
+                if (SAMPLES == 8) { const uint32_t w = ix / 4u; word[p] = shr32(w < lut_n ? lut[w] : 0u, (ix % 4u) * 8u); }
+                else { const uint32_t w = ix / 2u; word[p] = shr32(w < lut_n ? lut[w] : 0u, (ix % 2u) * 16u); }
+            }
+            wave_sync();  // (the next pass rewrites the marks)
         }
     }
-    wave_sync();  // the arrays are reused by the next fill
+#pragma unroll
+    for (uint32_t p = 0u; p < PASSES; p++) {
+        if (p * 64u < B.total) {  // uniform
+            const uint32_t e = p * 64u + lane;
+            if (e < B.total) T.ent[e] = (Ent)(word[p] & keep[p]) | ((Ent)part[p] << SAMPLES);
+        }
+    }
+    wave_sync();
+    // request the next window: 16 bytes per lane straight into T.pre (index clamped: robust access); T.seg is dead from here on
+    B.next = B.hi;
+    {
+        const float* gp = segments + (size_t)umin_(B.next + lane, umax_(segments_n, 1u) - 1u) * 6;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (JK_LDS void*)&T.pre[0], 16, 0, 0);
+    }
+}
+// One FILL (fine.wgsl:148-501 / :503-711): leaves the coverage of the lane's four pixels in area[].
+template <int SAMPLES>
+JD void ms_fill(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t size_and_rule, uint32_t seg_data, int32_t backdrop, const float* __restrict__ segments,
+                uint32_t segments_n, const uint32_t* __restrict__ lut, uint32_t lut_n, float (&area)[4]) {
+    const bool even_odd = (size_and_rule & 1u) != 0u;  // uniform
+    const uint32_t FULL = SAMPLES == 8 ? 0xffu : 0xffffu;
+    constexpr uint32_t WORDS = SAMPLES == 8 ? 2u : 4u;
+    const uint32_t ly = lane >> 2, lx = lane & 3u;
+    {   // clear the accumulators: counters at zero = 0x80 per byte (non-zero), parities 0 (even-odd)
+        const uint32_t z = even_odd ? 0u : 0x80808080u;
+        const uint4 z4 = make_uint4(z, z, z, z);
+        uint4* s = (uint4*)&T.samples[0];
+        if (even_odd) s[lane] = z4;
+        else {
+#pragma unroll
+            for (uint32_t i = 0u; i < WORDS; i++) s[lane * WORDS + i] = z4;
+        }
+        T.carry_x[lane] = z;
+        if (lane < 4u) T.carry_y[lane] = z;
+    }
+    wave_sync();
+    uint32_t sa = seg_data, remaining = size_and_rule >> 1;
+    while (remaining != 0u) {  // uniform
+        if (sa - B.base >= B.hi - B.base) ms_build<SAMPLES>(T, B, lane, sa, segments, segments_n, lut, lut_n);
+        const uint32_t take = umin_(remaining, B.hi - sa);
+        const uint32_t r0 = sa - B.base;  // the batch's segments [r0, r0 + take)
+        if (lane - r0 < take && (B.edge & 32u) != 0u) {  // the left-edge terms of my segment
+            const uint32_t row = B.edge & 15u;
+            if (even_odd) atomicXor(&T.carry_y[0], 1u << row);
+            else atomicAdd(&T.carry_y[row >> 2], ((B.edge & 16u) != 0u ? 1u : 0xffffffffu) << ((row & 3u) << 3));
+        }
+        if (B.direct) {
+            // A segment with more touched pixels than the list holds (coordinates far outside the tile: never what path_tiling
+            // writes) is walked here, every lane with the segment's constants in its own registers.
+            float x0 = 0.0f, y0 = 0.0f, x1 = 0.0f, y1 = 0.0f;
+            if (sa < segments_n) {
+                const float2* sp = (const float2*)(segments + (size_t)sa * 6);
+                const float2 p = sp[0], q = sp[1];
+                x0 = p.x; y0 = p.y; x1 = q.x; y1 = q.y;
+            }
+            MsSeg K;
+            uint32_t edge_unused;
+            const uint32_t touched = ms_setup<SAMPLES>(x0, y0, x1, y1, K, edge_unused);
+            for (uint32_t k0 = 0u; k0 < touched; k0 += 64u) {  // uniform
+                const uint32_t k = k0 + lane;
+                if (k < touched && k >= k0) {
+                    uint32_t ix, keep;
+                    const uint32_t part = ms_pixel<SAMPLES>(K, k, touched, ix, keep);
+                    ms_apply<SAMPLES>(T, (typename MsEnt<SAMPLES>::type)(ms_lut<SAMPLES>(lut, lut_n, ix) & keep) | ((typename MsEnt<SAMPLES>::type)part << SAMPLES), even_odd);
+                }
+                if (touched - k0 <= 64u) break;  // (k0 + 64 may wrap)
+            }
+        } else {
+            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)B.first, (int)(r0 & 63u));
+            const uint32_t e1 = r0 + take >= 64u ? B.total : (uint32_t)__builtin_amdgcn_readlane((int)B.first, (int)((r0 + take) & 63u));
+            for (uint32_t eb = e0; eb < e1; eb += 64u)  // uniform
+                if (eb + lane < e1) ms_apply<SAMPLES>(T, T.ent[eb + lane], even_odd);
+        }
+        sa += take;
+        remaining -= take;
+    }
+    wave_sync();
+    // resolve: the lane's own four pixels (fine.wgsl:386-501 / :677-710)
+    if (even_odd) {
+        uint32_t px = T.carry_x[ly];
+        px ^= px << 1; px ^= px << 2; px ^= px << 4; px ^= px << 8;
+        uint32_t py = T.carry_y[0];
+        py ^= py << 1; py ^= py << 2; py ^= py << 4; py ^= py << 8;
+        const uint32_t row_parity = (py >> ly) ^ (uint32_t)backdrop;
+        const uint4 s = ((const uint4*)&T.samples[0])[lane];
+        const uint32_t sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (uint32_t i = 0u; i < 4u; i++) {
+            const uint32_t parity = row_parity ^ (px >> (lx * 4u + i));
+            const uint32_t flip = (uint32_t)(-(int32_t)(parity & 1u));
+            area[i] = (float)__builtin_popcount((sv[i] ^ flip) & FULL) * (SAMPLES == 8 ? 0.125f : 0.0625f);
+        }
+        wave_sync();  // (the accumulators are cleared by the next fill)
+        return;
+    }
+    // x: inclusive sum of the carries of my four pixels inside the word, then the totals of the lanes to my left in my row
+    uint32_t wx = T.carry_x[lane];
+    wx += (wx - 0x808080u) << 8;
+    wx += (wx - 0x8080u) << 16;
+    {
+        const uint32_t tot = ((wx >> 24) - 0x80u) * 0x1010101u;
+        const uint32_t t1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tot, JK_DPP_ROW_SHR(1), 0xf, 0xf, false);
+        const uint32_t t2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tot, JK_DPP_ROW_SHR(2), 0xf, 0xf, false);
+        const uint32_t t3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tot, JK_DPP_ROW_SHR(3), 0xf, 0xf, false);
+        wx += (lx >= 1u ? t1 : 0u) + (lx >= 2u ? t2 : 0u) + (lx >= 3u ? t3 : 0u);
+    }
+    // y: the same on the four uniform words; a row's value = its byte of its word's running sum + the totals of the words above
+    uint32_t wy;
+    {
+        const uint4 yv = *(const uint4*)&T.carry_y[0];
+        uint32_t p[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) { p[i] += (p[i] - 0x808080u) << 8; p[i] += (p[i] - 0x8080u) << 16; }
+        const uint32_t g = ly >> 2;
+        const uint32_t mine = g == 0u ? p[0] : (g == 1u ? p[1] : (g == 2u ? p[2] : p[3]));
+        wy = (mine >> ((ly & 3u) << 3)) - 0x80u;
+        if (g >= 1u) wy += (p[0] >> 24) - 0x80u;
+        if (g >= 2u) wy += (p[1] >> 24) - 0x80u;
+        if (g >= 3u) wy += (p[2] >> 24) - 0x80u;
+    }
+    uint32_t sw[4 * WORDS];
+    {
+        const uint4* s = (const uint4*)&T.samples[0];
+#pragma unroll
+        for (uint32_t i = 0u; i < WORDS; i++) { const uint4 v = s[lane * WORDS + i]; sw[4 * i] = v.x; sw[4 * i + 1] = v.y; sw[4 * i + 2] = v.z; sw[4 * i + 3] = v.w; }
+    }
+#pragma unroll
+    for (uint32_t i = 0u; i < 4u; i++) {
+        // the winding number every sample of the pixel starts from; a sample is covered when its counter differs from "zero"
+        const uint32_t zero = (((wx >> (i * 8u)) + wy) & 0xffu) - (uint32_t)backdrop;
+        if (zero >= 256u) {
+            area[i] = 1.0f;
+        } else if (SAMPLES == 8) {
+            const uint32_t d0 = (zero * 0x1010101u) ^ sw[i * 2u], d1 = (zero * 0x1010101u) ^ sw[i * 2u + 1u];
+            const uint32_t d0_2 = d0 | (d0 * 2u), d1_2 = d1 | (d1 >> 1);
+            const uint32_t d2 = (d0_2 & 0xAAAAAAAAu) | (d1_2 & 0x55555555u);
+            const uint32_t d4 = d2 | (d2 * 4u);
+            const uint32_t d8 = d4 | (d4 * 16u);
+            area[i] = (float)__builtin_popcount(d8 & 0xC0C0C0C0u) * 0.125f;
+        } else {
+            const uint32_t z4 = zero * 0x1010101u;
+            const uint32_t d0 = z4 ^ sw[i * 4u], d1 = z4 ^ sw[i * 4u + 1u], d2 = z4 ^ sw[i * 4u + 2u], d3 = z4 ^ sw[i * 4u + 3u];
+            const uint32_t d0_2 = d0 | (d0 * 2u), d1_2 = d1 | (d1 >> 1);
+            const uint32_t d01 = (d0_2 & 0xAAAAAAAAu) | (d1_2 & 0x55555555u);
+            const uint32_t d01_4 = d01 | (d01 * 4u);
+            const uint32_t d2_2 = d2 | (d2 * 2u), d3_2 = d3 | (d3 >> 1);
+            const uint32_t d23 = (d2_2 & 0xAAAAAAAAu) | (d3_2 & 0x55555555u);
+            const uint32_t d23_4 = d23 | (d23 >> 2);
+            const uint32_t d4 = (d01_4 & 0xCCCCCCCCu) | (d23_4 & 0x33333333u);
+            const uint32_t d8 = d4 | (d4 * 16u);
+            area[i] = (float)__builtin_popcount(d8 & 0xF0F0F0F0u) * 0.0625f;
+        }
+    }
+    wave_sync();  // (the accumulators are cleared by the next fill)
 }
 
-template <int AA> struct FineLdsSel { typedef MsLds type; };
+template <int AA> struct FineLdsSel { typedef MsLds<AA> type; };
 template <> struct FineLdsSel<0> { typedef FillLds type; };
 // The first JL_BLEND_STACK_SPLIT levels of the clip / blend stack (fine.wgsl:938-973 keeps them in registers; deeper
 // levels go to blend_spill), one float4 per pixel, lane-contiguous (conflict-free 16-byte accesses), addressed by the
@@ -584,8 +750,13 @@ template <> struct FineStackSel<false> { struct type { float4 lvl[1][1][1]; }; }
 // Tile-waves per workgroup: two where LDS is small (the CU runs at most 16 workgroups, so single-wave workgroups would cap
 // the occupancy at 4 waves per SIMD); one for the clip instantiations, whose 22 KB per wave then pack 7 to a CU instead of 6.
 #define FINE_WG_WAVES(CLIPS) ((CLIPS) ? 1 : FINE_WAVES)
+#ifndef FINE_LEAN_MS_WAVES_PER_EU
+#define FINE_LEAN_MS_WAVES_PER_EU 5  // (96 VGPRs: the batch build keeps four passes' entries in registers)
+#endif
+#define FINE_WAVES_PER_EU(AA, CLIPS, PAINTS) \
+    ((CLIPS) ? ((AA) != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : ((PAINTS) ? 4 : ((AA) != 0 ? FINE_LEAN_MS_WAVES_PER_EU : FINE_LEAN_WAVES_PER_EU)))
 template <int AA, bool CLIPS, bool PAINTS>
-__global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_waves_per_eu(CLIPS ? (AA != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU), CLIPS ? (AA != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : (PAINTS ? 4 : FINE_LEAN_WAVES_PER_EU)))) void k_fine_area(const JlConfig* __restrict__ cfg, FineCfg fc, const float* __restrict__ segments, uint32_t segments_n,
+__global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_waves_per_eu(FINE_WAVES_PER_EU(AA, CLIPS, PAINTS), FINE_WAVES_PER_EU(AA, CLIPS, PAINTS)))) void k_fine_area(const JlConfig* __restrict__ cfg, FineCfg fc, const float* __restrict__ segments, uint32_t segments_n,
                                                   const uint32_t* __restrict__ ptcl, uint32_t ptcl_n, const uint32_t* __restrict__ info,
                                                   uint32_t info_n, Buf<V4> blend_spill, uint16_t* __restrict__ output, uint32_t out_w,
                                                   uint32_t out_h, const uint16_t* __restrict__ gradients, uint32_t grad_h, FineImages images,
@@ -637,10 +808,8 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
     // no per-word address arithmetic, and no memory latency between short commands (a scalar load per command had
     // ~1 us of it: fatal for streams of hundreds of one-word clip commands).
     uint32_t pc = uni(tile_ix * JL_PTCL_INITIAL_ALLOC);  // absolute word index of the next command
-    if constexpr (AA != 0) {
-        if (lane == 0u) F.seg_win_valid = 0u;  // fill_path_ms: no segment window yet
-    }
-    wave_sync();
+    MsState msb;  // (AA != 0) the batch of touched pixels: nothing yet
+    msb.base = 0u; msb.hi = 0u; msb.next = 0xffffffffu; msb.total = 0u; msb.direct = false; msb.first = 0u; msb.edge = 0u;
     auto I = [&](uint32_t i) -> uint32_t { return i < info_n ? info[i] : 0u; };
     const uint32_t blend_offset = pc < ptcl_n ? ptcl[pc] : 0u;
     pc += 1u;
@@ -1129,7 +1298,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         }
       } else {
         (void)n_segs; (void)even_odd;
-        fill_path_ms<AA>(F, lane, size_and_rule, seg_data, backdrop, segments, segments_n, mask_lut, mask_lut_n, area);
+        ms_fill<AA>(F, msb, lane, size_and_rule, seg_data, backdrop, segments, segments_n, mask_lut, mask_lut_n, area);
       }
     };
     auto ensure_window = [&]() {
@@ -1598,7 +1767,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         atomicAdd(&t[5], 1ull);
     }
 #endif
-    if constexpr (AA == 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no window may still be in flight to this wave's LDS when it ends
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no window may still be in flight to this wave's LDS when it ends
     // fine.wgsl:1092-1102: un-premultiply, store RGBA16F (four adjacent pixels = 32 bytes per lane; 4 lanes = one 128-B row)
     const uint32_t cx0 = tile_x * 16u + lx * 4u;
     const uint32_t cy = tile_y * 16u + ly;

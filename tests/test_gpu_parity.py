@@ -83,11 +83,14 @@ def test_large_shapes(engine, aa):
     assert r["bump"]["tile"] > 90000
 
 
-def test_dense_polygon_and_long_lines(engine):
+@pytest.mark.parametrize("aa", [jello_amd.Aa.Area, jello_amd.Aa.Msaa8, jello_amd.Aa.Msaa16])
+def test_dense_polygon_and_long_lines(engine, aa):
     """40 k radial zigzag edges of one path (more than 1024 crossings in a single tile: the wave-per-tile ranking of
-    path_count in several LDS passes) and edge-to-edge strokes (lines handed to a whole wave in k_pc_emit)."""
+    path_count in several LDS passes) and edge-to-edge strokes (lines handed to a whole wave in k_pc_emit).  With the
+    multisampled modes: fills of hundreds of segments per tile, i.e. fills that span many batches of touched pixels (ms_build)."""
     s, p = scenes.scene_dense_polygon()
     p.bump = BumpSizes(lines=1 << 17, seg_counts=1 << 20, segments=1 << 20, ptcl=1 << 22)
+    p.aa = aa
     r = compare(engine, s, p)
     assert r["bump"]["seg_counts"] > 90000
     assert r["max_tile_segments"] > 1024

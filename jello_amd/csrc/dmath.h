@@ -41,16 +41,33 @@ JD float sqrt_(float x) { return sqrtf(x); }
 JD float fract_(float x) { return x - floorf(x); }
 JD float mix_(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 
+// WGSL's saturating conversions (NaN -> 0).  On the device ONE instruction each: v_cvt_u32_f32 / v_cvt_i32_f32 truncate, clamp out-of-range
+// magnitudes to 0 / 0xffffffff resp. to +-2^31 (min_int for the negative side) and turn NaN into 0 (CDNA ISA, "V_CVT_U32_F32"); written as
+// assembly because the C++ cast is undefined out of range, so the compiler is free to assume the range; tests/test_gpu_math.py holds
+// both to the table of edge cases.  (Round 6: five instructions each as compare + select chains before; line_setup of path_count /
+// path_tiling and the multisampled fine kernel convert per line / per touched pixel.)
 JD uint32_t to_u32(float f) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(JD_NO_ASM_CVT)
+    uint32_t r;
+    asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+#else
     if (!(f > 0.0f)) return 0u;
     if (f >= 4294967296.0f) return 0xffffffffu;
     return (uint32_t)f;
+#endif
 }
 JD int32_t to_i32(float f) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(JD_NO_ASM_CVT)
+    int32_t r;
+    asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+#else
     if (f != f) return 0;
     if (f >= 2147483648.0f) return 2147483647;
     if (f <= -2147483648.0f) return (int32_t)0x80000000;
     return (int32_t)f;
+#endif
 }
 
 // ---- binary64 kernels ----

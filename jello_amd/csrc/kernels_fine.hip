@@ -354,7 +354,17 @@ JD void load_segraw_clamped(const float* __restrict__ segments, uint32_t segment
 // (their index is formed with the WGSL's own u32 arithmetic first), segments behind the buffer read as zeros -- and a zero
 // segment touches the tile corner: it does count.
 // ------------------------------------------------------------------------------------------------
+// FINE_MS_SKIP (timing-only variant builds, results WRONG): bit 0 no entries are applied at the fills, bit 1 no resolve arithmetic,
+// bit 2 no touched-pixel passes in the batch build, bit 3 no clearing of the accumulators
+#ifndef FINE_MS_SKIP
+#define FINE_MS_SKIP 0
+#endif
+#if FINE_MS_SKIP != 0 && !defined(JH_VARIANT_BUILD)
+#error "FINE_MS_SKIP changes results: build it as a variant library"
+#endif
+#ifndef MS_CAP
 #define MS_CAP 256u  // touched pixels per batch (a sane segment has at most 31; one with more is walked directly, see ms_direct)
+#endif
 template <int SAMPLES> struct MsEnt { typedef uint32_t type; };     // mask 8 | trim 5 | pixel 8 | flags 6 = 27 bits
 template <> struct MsEnt<16> { typedef unsigned long long type; };  // mask 16 | trim 5 | pixel 8 | flags 6 = 35 bits
 #define MS_F_DOWN 1u      // the segment runs downwards as given (sign of its winding contribution)
@@ -372,8 +382,8 @@ struct MsSeg {  // what a touched pixel needs of its segment (written by lane = 
     int32_t x0i;         // column of the first pixel
     float top_y, bot_y;  // y of the upper / lower end point
     float lut_row;       // LUT row of the slope, times the row length
-    uint32_t bits;       // MS_S_* | touched pixels << 8
-    uint32_t first;      // index of the first touched pixel in the batch's list
+    uint32_t bits;       // MS_S_* | trim of the first pixel's mask << 4 | touched pixels << 9
+    uint32_t first;      // index of the first touched pixel in the batch's list | the bits the last pixel's mask keeps << 16
 };
 template <int SAMPLES> struct MsLds {
     union {
@@ -421,7 +431,19 @@ JD uint32_t ms_setup(float x0, float y0, float x1, float y1, MsSeg& K, uint32_t&
     K.x0i = to_i32(xt * sgn + 0.5f * (sgn - 1.0f));
     K.top_y = ty; K.bot_y = by;
     K.lut_row = floor_(fmin_(a * HALF_H, HALF_H - 1.0f)) * LUT_W;
-    K.bits = (down ? MS_S_DOWN : 0u) | (right ? MS_S_RIGHT : 0u) | (tx == 0.0f ? MS_S_TOP_ON_EDGE : 0u) | (bx != 0.0f ? MS_S_BOT_OFF_EDGE : 0u);
+    // The sample masks of the first and the last touched pixel are trimmed at the end points (fine.wgsl:356-365): both depend on the
+    // segment alone -- the pixel rows come out of the expressions ms_pixel evaluates at k = 0 and k = touched - 1 -- so they are
+    // worked out here, once per segment, not by every touched pixel.
+    const uint32_t FULL = SAMPLES == 8 ? 0xffu : 0xffffu;
+    const float sf = (float)SAMPLES;
+    const uint32_t r0 = (uint32_t)to_i32(row0);
+    const int32_t y_head = (int32_t)(r0 - (uint32_t)to_i32(floor_(a * 0.0f + b)));
+    const uint32_t trim = umin_(to_u32(round_(sf * (ty - (float)y_head))) & 31u, (uint32_t)SAMPLES);  // (a shift by >= SAMPLES clears the mask; the WGSL's shift is modulo 32)
+    const uint32_t kl = touched - 1u;
+    const int32_t y_tail = (int32_t)(r0 + kl - (uint32_t)to_i32(floor_(a * (float)kl + b)));
+    const uint32_t keep = bx != 0.0f ? (FULL & ~shl32(FULL, to_u32(round_(sf * (by - (float)y_tail))))) : FULL;
+    K.bits = (down ? MS_S_DOWN : 0u) | (right ? MS_S_RIGHT : 0u) | (tx == 0.0f ? MS_S_TOP_ON_EDGE : 0u) | (bx != 0.0f ? MS_S_BOT_OFF_EDGE : 0u) | (trim << 4);
+    K.first = keep << 16;
     return touched;
 }
 // lane = touched pixel k of a segment with `touched` of them (fine.wgsl:264-340): everything of its entry but the LUT mask --
@@ -450,11 +472,8 @@ JD uint32_t ms_pixel(const MsSeg& K, uint32_t k, uint32_t touched, uint32_t& lut
     const uint32_t pix = (uint32_t)y * 16u + (uint32_t)x;
     const bool carry = (uint32_t)x < 15u && (uint32_t)y < 16u && top;
     lut_ix = (right ? (SAMPLES == 8 ? 512u : 2048u) : 0u) + to_u32(K.lut_row + floor_((zf - z) * LUT_W));
-    const float sf = (float)SAMPLES, yf = (float)y;
-    uint32_t trim = 0u;  // head: the samples from `trim` on stay (a shift by >= SAMPLES clears the mask; the WGSL's shift is modulo 32)
-    if (k == 0u) trim = umin_(to_u32(round_(sf * (K.top_y - yf))) & 31u, (uint32_t)SAMPLES);
-    keep = FULL;
-    if (k + 1u == touched && (K.bits & MS_S_BOT_OFF_EDGE) != 0u) keep = FULL & ~shl32(FULL, to_u32(round_(sf * (K.bot_y - yf))));
+    const uint32_t trim = k == 0u ? (K.bits >> 4) & 31u : 0u;  // head: the samples from `trim` on stay
+    keep = k + 1u == touched ? K.first >> 16 : FULL;          // tail
     if (pix >= 256u) return 0u;  // outside the tile: every write of this pixel is dropped
     const uint32_t flags = ((K.bits & MS_S_DOWN) != 0u ? MS_F_DOWN : 0u) | (bump_nz ? MS_F_BUMP_NZ : 0u) | (bump_eo ? MS_F_BUMP_EO : 0u) | (carry ? MS_F_CARRY : 0u) |
                            (k == 0u ? MS_F_HEAD : 0u) | MS_F_LIVE;
@@ -519,6 +538,7 @@ template <int SAMPLES>
 JD void ms_build(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t so, const float* __restrict__ segments, uint32_t segments_n,
                  const uint32_t* __restrict__ lut, uint32_t lut_n) {
     typedef typename MsEnt<SAMPLES>::type Ent;
+    const uint32_t FULL = SAMPLES == 8 ? 0xffu : 0xffffu;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): whatever window was in flight has landed in T.pre (it aliases T.seg)
     wave_sync();
     float x0, y0, x1, y1;
@@ -546,15 +566,15 @@ JD void ms_build(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t so, cons
     const uint32_t first = incl - capped;
     B.first = lane < n ? first : B.total;
     wave_sync();
-    if (lane < n) { K.bits |= touched << 8; K.first = first; T.seg[lane] = K; }
+    if (lane < n) { K.bits |= touched << 9; K.first |= first; T.seg[lane] = K; }
     const bool starts = lane < n && touched != 0u;
     // The touched pixels, 64 per pass; all passes' LUT fetches are issued before the first is consumed.
     constexpr uint32_t PASSES = MS_CAP / 64u;
-    uint32_t part[PASSES], keep[PASSES], word[PASSES];
+    uint32_t word[PASSES];
 #pragma unroll
     for (uint32_t p = 0u; p < PASSES; p++) {
-        part[p] = 0u; keep[p] = 0u; word[p] = 0u;
-        if (p * 64u < B.total) {  // uniform
+        word[p] = 0u;
+        if (p * 64u < B.total && !(FINE_MS_SKIP & 4)) {  // uniform
             T.mark[lane] = 0u;
             wave_sync();
             if (starts && first - p * 64u < 64u) T.mark[first - p * 64u] = lane + 1u;
@@ -566,8 +586,9 @@ JD void ms_build(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t so, cons
             const uint32_t e = p * 64u + lane;
             if (e < B.total) {
                 const MsSeg S = T.seg[(owner - 1u) & 63u];
-                uint32_t ix;
-                part[p] = ms_pixel<SAMPLES>(S, e - S.first, S.bits >> 8, ix, keep[p]);
+                uint32_t ix, keep;
+                const uint32_t part = ms_pixel<SAMPLES>(S, e - (S.first & 0xffffu), S.bits >> 9, ix, keep);
+                T.ent[e] = (Ent)keep | ((Ent)part << SAMPLES);  // (the LUT mask is ANDed in below, once it has arrived)
                 if (SAMPLES == 8) { const uint32_t w = ix / 4u; word[p] = shr32(w < lut_n ? lut[w] : 0u, (ix % 4u) * 8u); }
                 else { const uint32_t w = ix / 2u; word[p] = shr32(w < lut_n ? lut[w] : 0u, (ix % 2u) * 16u); }
             }
@@ -578,7 +599,7 @@ JD void ms_build(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t so, cons
     for (uint32_t p = 0u; p < PASSES; p++) {
         if (p * 64u < B.total) {  // uniform
             const uint32_t e = p * 64u + lane;
-            if (e < B.total) T.ent[e] = (Ent)(word[p] & keep[p]) | ((Ent)part[p] << SAMPLES);
+            if (e < B.total) atomicAnd(&T.ent[e], (Ent)(word[p] & FULL) | ~(Ent)FULL);
         }
     }
     wave_sync();
@@ -597,7 +618,7 @@ JD void ms_fill(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t size_and_
     const uint32_t FULL = SAMPLES == 8 ? 0xffu : 0xffffu;
     constexpr uint32_t WORDS = SAMPLES == 8 ? 2u : 4u;
     const uint32_t ly = lane >> 2, lx = lane & 3u;
-    {   // clear the accumulators: counters at zero = 0x80 per byte (non-zero), parities 0 (even-odd)
+    if (!(FINE_MS_SKIP & 8)) {   // clear the accumulators: counters at zero = 0x80 per byte (non-zero), parities 0 (even-odd)
         const uint32_t z = even_odd ? 0u : 0x80808080u;
         const uint4 z4 = make_uint4(z, z, z, z);
         uint4* s = (uint4*)&T.samples[0];
@@ -644,7 +665,7 @@ JD void ms_fill(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t size_and_
         } else {
             const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)B.first, (int)(r0 & 63u));
             const uint32_t e1 = r0 + take >= 64u ? B.total : (uint32_t)__builtin_amdgcn_readlane((int)B.first, (int)((r0 + take) & 63u));
-            for (uint32_t eb = e0; eb < e1; eb += 64u)  // uniform
+            for (uint32_t eb = e0; eb < e1 && !(FINE_MS_SKIP & 1); eb += 64u)  // uniform
                 if (eb + lane < e1) ms_apply<SAMPLES>(T, T.ent[eb + lane], even_odd);
         }
         sa += take;
@@ -684,6 +705,9 @@ JD void ms_fill(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t size_and_
     uint32_t wy;
     {
         const uint4 yv = *(const uint4*)&T.carry_y[0];
+        if (uni((yv.x ^ 0x80808080u) | (yv.y ^ 0x80808080u) | (yv.z ^ 0x80808080u) | (yv.w ^ 0x80808080u)) == 0u) {
+            wy = 0u;  // (uniform, and the usual case: no segment of the fill touches the tile's left edge)
+        } else {
         uint32_t p[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) { p[i] += (p[i] - 0x808080u) << 8; p[i] += (p[i] - 0x8080u) << 16; }
@@ -693,6 +717,7 @@ JD void ms_fill(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t size_and_
         if (g >= 1u) wy += (p[0] >> 24) - 0x80u;
         if (g >= 2u) wy += (p[1] >> 24) - 0x80u;
         if (g >= 3u) wy += (p[2] >> 24) - 0x80u;
+        }
     }
     uint32_t sw[4 * WORDS];
     {
@@ -704,7 +729,9 @@ JD void ms_fill(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t size_and_
     for (uint32_t i = 0u; i < 4u; i++) {
         // the winding number every sample of the pixel starts from; a sample is covered when its counter differs from "zero"
         const uint32_t zero = (((wx >> (i * 8u)) + wy) & 0xffu) - (uint32_t)backdrop;
-        if (zero >= 256u) {
+        if (FINE_MS_SKIP & 2) {
+            area[i] = u2f((sw[i * WORDS] & 0x7fffffu) | 0x3f000000u);
+        } else if (zero >= 256u) {
             area[i] = 1.0f;
         } else if (SAMPLES == 8) {
             const uint32_t d0 = (zero * 0x1010101u) ^ sw[i * 2u], d1 = (zero * 0x1010101u) ^ sw[i * 2u + 1u];
@@ -751,7 +778,7 @@ template <> struct FineStackSel<false> { struct type { float4 lvl[1][1][1]; }; }
 // the occupancy at 4 waves per SIMD); one for the clip instantiations, whose 22 KB per wave then pack 7 to a CU instead of 6.
 #define FINE_WG_WAVES(CLIPS) ((CLIPS) ? 1 : FINE_WAVES)
 #ifndef FINE_LEAN_MS_WAVES_PER_EU
-#define FINE_LEAN_MS_WAVES_PER_EU 5  // (96 VGPRs: the batch build keeps four passes' entries in registers)
+#define FINE_LEAN_MS_WAVES_PER_EU 6  // (C3 msaa8: 580 / 522 / 490 us at 4 / 5 / 6 waves per SIMD)
 #endif
 #define FINE_WAVES_PER_EU(AA, CLIPS, PAINTS) \
     ((CLIPS) ? ((AA) != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : ((PAINTS) ? 4 : ((AA) != 0 ? FINE_LEAN_MS_WAVES_PER_EU : FINE_LEAN_WAVES_PER_EU)))

@@ -77,6 +77,21 @@ def test_ieee_div_sqrt_round_and_no_fma(engine):
     sat = np.array([-1.0, 0.0, 0.9, 1.0, 4.2949673e9, 5e9, np.nan, -np.inf, np.inf, 2.5], dtype=np.float32)
     assert list(gpu_op(engine, 9, sat).view(np.uint32)) == [0, 0, 0, 1, 0xffffffff, 0xffffffff, 0, 0, 0xffffffff, 2]
     assert list(gpu_op(engine, 10, sat).view(np.int32)) == [-1, 0, 0, 1, 2147483647, 2147483647, 0, -2147483648, 2147483647, 2]
+    # (round 6: the conversions are single hardware instructions now -- every edge of their range against the definition)
+    edge = np.array([-2147483648.0, -2147483904.0, -2147483520.0, 2147483520.0, 2147483648.0, 4294967040.0, 4294967296.0, -3e9, -0.9, -1e-40, 1e-40,
+                     -0.0, 16777217.0, -16777216.0, 3.9999998, -3.9999998, 1e38, -1e38], dtype=np.float32)
+
+    def ref_u(f):
+        return 0 if not f > 0 else (0xffffffff if f >= 4294967296.0 else int(f))
+
+    def ref_i(f):
+        return 0 if f != f else (2147483647 if f >= 2147483648.0 else (-2147483648 if f <= -2147483648.0 else int(f)))
+    assert list(gpu_op(engine, 9, edge).view(np.uint32)) == [ref_u(float(f)) for f in edge]
+    assert list(gpu_op(engine, 10, edge).view(np.int32)) == [ref_i(float(f)) for f in edge]
+    rng2 = np.random.default_rng(12)
+    wide = (rng2.standard_normal(1 << 18) * 10 ** rng2.uniform(-3, 11, 1 << 18)).astype(np.float32)
+    assert np.array_equal(gpu_op(engine, 9, wide).view(np.uint32), np.array([ref_u(float(f)) for f in wide], dtype=np.uint64).astype(np.uint32))
+    assert np.array_equal(gpu_op(engine, 10, wide).view(np.int32), np.array([ref_i(float(f)) for f in wide], dtype=np.int64).astype(np.int32))
 
 
 def test_f16_store_conversion(engine):

@@ -363,26 +363,25 @@ JD void load_segraw_clamped(const float* __restrict__ segments, uint32_t segment
 #error "FINE_MS_SKIP changes results: build it as a variant library"
 #endif
 #ifndef MS_CAP
-#define MS_CAP 256u  // touched pixels per batch (a sane segment has at most 31; one with more is walked directly, see ms_direct)
+#define MS_CAP 256u  // touched pixels per batch (a sane segment has at most 31; one with more is walked at the fill: MsState::direct)
 #endif
-template <int SAMPLES> struct MsEnt { typedef uint32_t type; };     // mask 8 | trim 5 | pixel 8 | flags 6 = 27 bits
-template <> struct MsEnt<16> { typedef unsigned long long type; };  // mask 16 | trim 5 | pixel 8 | flags 6 = 35 bits
+// An entry of the list, ONE word: sample mask (8 or 16 bits) | pixel << SAMPLES | flags << (SAMPLES + 8): 21 / 29 bits
 #define MS_F_DOWN 1u      // the segment runs downwards as given (sign of its winding contribution)
 #define MS_F_BUMP_NZ 2u   // the whole pixel takes the contribution too (left-edge crossing): non-zero rule
 #define MS_F_BUMP_EO 4u   // ... even-odd rule (differs at the tile's left edge only)
 #define MS_F_CARRY 8u     // crosses the pixel's top: +-1 for the pixels to the right
-#define MS_F_HEAD 16u     // the segment's first touched pixel: the mask is trimmed above the start point unless the pixel is bumped
-#define MS_F_LIVE 32u     // the pixel lies inside the tile
+#define MS_F_LIVE 16u     // the pixel lies inside the tile
 #define MS_S_DOWN 1u
 #define MS_S_RIGHT 2u     // x does not decrease along the (downward) segment
 #define MS_S_TOP_ON_EDGE 4u   // the upper end point has x == 0
 #define MS_S_BOT_OFF_EDGE 8u  // the lower end point has x != 0
+#define MS_S_BY_RULE 16u      // the first pixel's mask depends on the fill rule (see ms_setup): such a segment is walked at the fill
 struct MsSeg {  // what a touched pixel needs of its segment (written by lane = segment, read by lane = touched pixel): 32 bytes
     float a, b;          // z = floor(a * k + b): columns crossed after k steps of the DDA
     int32_t x0i;         // column of the first pixel
     float top_y, bot_y;  // y of the upper / lower end point
     float lut_row;       // LUT row of the slope, times the row length
-    uint32_t bits;       // MS_S_* | trim of the first pixel's mask << 4 | touched pixels << 9
+    uint32_t bits;       // MS_S_* | trim of the first pixel's mask << 5 | touched pixels << 10
     uint32_t first;      // index of the first touched pixel in the batch's list | the bits the last pixel's mask keeps << 16
 };
 template <int SAMPLES> struct MsLds {
@@ -391,7 +390,7 @@ template <int SAMPLES> struct MsLds {
         float4 pre[64];   // between builds: the next window's end points, in flight (global_load_lds)
     };
     alignas(16) uint32_t samples[SAMPLES == 8 ? 512 : 1024];  // [pixel][word]: SWAR winding counters, four samples per word (non-zero); [pixel]: parity bits (even-odd)
-    typename MsEnt<SAMPLES>::type ent[MS_CAP];                // the batch's touched pixels, in segment order
+    uint32_t ent[MS_CAP];                                     // the batch's touched pixels, in segment order
     uint32_t carry_x[64];  // non-zero: [pixel / 4] a byte per pixel; even-odd: [row] a bit per pixel
     alignas(16) uint32_t carry_y[4];  // non-zero: a byte per row; even-odd: word 0, a bit per row
     uint32_t mark[64];
@@ -442,14 +441,21 @@ JD uint32_t ms_setup(float x0, float y0, float x1, float y1, MsSeg& K, uint32_t&
     const uint32_t kl = touched - 1u;
     const int32_t y_tail = (int32_t)(r0 + kl - (uint32_t)to_i32(floor_(a * (float)kl + b)));
     const uint32_t keep = bx != 0.0f ? (FULL & ~shl32(FULL, to_u32(round_(sf * (by - (float)y_tail))))) : FULL;
-    K.bits = (down ? MS_S_DOWN : 0u) | (right ? MS_S_RIGHT : 0u) | (tx == 0.0f ? MS_S_TOP_ON_EDGE : 0u) | (bx != 0.0f ? MS_S_BOT_OFF_EDGE : 0u) | (trim << 4);
+    // The head trim applies unless the first pixel is "bumped", and at the tile's left edge the two rules bump differently: non-zero
+    // only when the start point is not on a pixel row (fine.wgsl:306-310), even-odd always (:598).  They then differ exactly when
+    // the start point lies on the edge AND on a row -- where the trim is 0 samples, a no-op, for every finite segment (the first
+    // pixel's row IS the start point's).  A segment for which it is not (infinite coordinates) cannot go into a rule-agnostic
+    // list: MS_S_BY_RULE sends it through the walk at the fill (ms_fill's direct route), which knows the rule.
+    const bool by_rule = tx == 0.0f && row0 == ty && trim != 0u;
+    K.bits = (down ? MS_S_DOWN : 0u) | (right ? MS_S_RIGHT : 0u) | (tx == 0.0f ? MS_S_TOP_ON_EDGE : 0u) | (bx != 0.0f ? MS_S_BOT_OFF_EDGE : 0u) | (by_rule ? MS_S_BY_RULE : 0u) | (trim << 5);
     K.first = keep << 16;
     return touched;
 }
-// lane = touched pixel k of a segment with `touched` of them (fine.wgsl:264-340): everything of its entry but the LUT mask --
-// pixel, flags, the trim of the head -- plus the LUT index and the bits the tail trim keeps.
+// lane = touched pixel k of a segment with `touched` of them (fine.wgsl:264-340): pixel | flags << 8 of its entry (0: outside the
+// tile), the LUT index of its sample mask, the bits the trims at the segment's two ends leave of it -- `keep` with the head trim of
+// the non-zero rule; `keep_eo` with the even-odd rule's (the same except for MS_S_BY_RULE segments).
 template <int SAMPLES>
-JD uint32_t ms_pixel(const MsSeg& K, uint32_t k, uint32_t touched, uint32_t& lut_ix, uint32_t& keep) {
+JD uint32_t ms_pixel(const MsSeg& K, uint32_t k, uint32_t touched, uint32_t& lut_ix, uint32_t& keep, uint32_t& keep_eo) {
     const uint32_t FULL = SAMPLES == 8 ? 0xffu : 0xffffu;
     const float LUT_W = SAMPLES == 8 ? 32.0f : 64.0f;
     const bool right = (K.bits & MS_S_RIGHT) != 0u;
@@ -472,12 +478,13 @@ JD uint32_t ms_pixel(const MsSeg& K, uint32_t k, uint32_t touched, uint32_t& lut
     const uint32_t pix = (uint32_t)y * 16u + (uint32_t)x;
     const bool carry = (uint32_t)x < 15u && (uint32_t)y < 16u && top;
     lut_ix = (right ? (SAMPLES == 8 ? 512u : 2048u) : 0u) + to_u32(K.lut_row + floor_((zf - z) * LUT_W));
-    const uint32_t trim = k == 0u ? (K.bits >> 4) & 31u : 0u;  // head: the samples from `trim` on stay
-    keep = k + 1u == touched ? K.first >> 16 : FULL;          // tail
+    const uint32_t tail = k + 1u == touched ? K.first >> 16 : FULL;
+    const uint32_t head = k == 0u ? FULL & (FULL << ((K.bits >> 5) & 31u)) : FULL;
+    keep = bump_nz ? tail : tail & head;
+    keep_eo = bump_eo ? tail : tail & head;
     if (pix >= 256u) return 0u;  // outside the tile: every write of this pixel is dropped
-    const uint32_t flags = ((K.bits & MS_S_DOWN) != 0u ? MS_F_DOWN : 0u) | (bump_nz ? MS_F_BUMP_NZ : 0u) | (bump_eo ? MS_F_BUMP_EO : 0u) | (carry ? MS_F_CARRY : 0u) |
-                           (k == 0u ? MS_F_HEAD : 0u) | MS_F_LIVE;
-    return trim | (pix << 5) | (flags << 13);  // (the mask goes below: << SAMPLES)
+    const uint32_t flags = ((K.bits & MS_S_DOWN) != 0u ? MS_F_DOWN : 0u) | (bump_nz ? MS_F_BUMP_NZ : 0u) | (bump_eo ? MS_F_BUMP_EO : 0u) | (carry ? MS_F_CARRY : 0u) | MS_F_LIVE;
+    return pix | (flags << 8);
 }
 template <int SAMPLES>
 JD uint32_t ms_lut(const uint32_t* __restrict__ lut, uint32_t lut_n, uint32_t ix) {
@@ -490,15 +497,13 @@ JD uint32_t ms_lut(const uint32_t* __restrict__ lut, uint32_t lut_n, uint32_t ix
 }
 // One entry into the tile's accumulators (fine.wgsl:341-383 / :640-675).
 template <int SAMPLES>
-JD void ms_apply(MsLds<SAMPLES>& T, typename MsEnt<SAMPLES>::type e, bool even_odd) {
+JD void ms_apply(MsLds<SAMPLES>& T, uint32_t e, bool even_odd) {
     const uint32_t FULL = SAMPLES == 8 ? 0xffu : 0xffffu;
-    const uint32_t meta = (uint32_t)(e >> SAMPLES);
-    const uint32_t flags = meta >> 13;
+    const uint32_t flags = e >> (SAMPLES + 8);
     if ((flags & MS_F_LIVE) == 0u) return;
-    uint32_t mask = (uint32_t)e & FULL;
-    const uint32_t pix = (meta >> 5) & 0xffu;
+    uint32_t mask = e & FULL;
+    const uint32_t pix = (e >> SAMPLES) & 0xffu;
     const bool bump = (flags & (even_odd ? MS_F_BUMP_EO : MS_F_BUMP_NZ)) != 0u;
-    if ((flags & MS_F_HEAD) != 0u && !bump) mask &= FULL << (meta & 31u);
     if (even_odd) {
         if (bump) mask ^= FULL;
         atomicXor(&T.samples[pix], mask);
@@ -533,11 +538,11 @@ struct MsState {
     bool direct;            // the batch is ONE segment with more than MS_CAP touched pixels: walked at the fill, no list
     uint32_t first;         // per lane: list index of my segment's first touched pixel (lanes behind the batch: total)
     uint32_t edge;          // per lane: my segment's left-edge term (ms_setup)
+    uint32_t clean;         // the sample words hold the cleared state of: 0 the non-zero rule, 1 even-odd, 2 neither
 };
 template <int SAMPLES>
 JD void ms_build(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t so, const float* __restrict__ segments, uint32_t segments_n,
                  const uint32_t* __restrict__ lut, uint32_t lut_n) {
-    typedef typename MsEnt<SAMPLES>::type Ent;
     const uint32_t FULL = SAMPLES == 8 ? 0xffu : 0xffffu;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): whatever window was in flight has landed in T.pre (it aliases T.seg)
     wave_sync();
@@ -554,7 +559,7 @@ JD void ms_build(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t so, cons
     MsSeg K;
     uint32_t edge;
     const uint32_t touched = ms_setup<SAMPLES>(x0, y0, x1, y1, K, edge);
-    const uint32_t capped = umin_(touched, MS_CAP + 1u);
+    const uint32_t capped = (K.bits & MS_S_BY_RULE) != 0u ? MS_CAP + 1u : umin_(touched, MS_CAP + 1u);  // (what does not fit the list ends the batch)
     const uint32_t incl = wave_incl_scan_u32(capped);
     const uint64_t fit = __builtin_amdgcn_ballot_w64(incl <= MS_CAP);  // a prefix of the lanes (incl is monotone)
     const uint32_t n = (uint32_t)__builtin_popcountll(fit);
@@ -566,7 +571,7 @@ JD void ms_build(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t so, cons
     const uint32_t first = incl - capped;
     B.first = lane < n ? first : B.total;
     wave_sync();
-    if (lane < n) { K.bits |= touched << 9; K.first |= first; T.seg[lane] = K; }
+    if (lane < n) { K.bits |= touched << 10; K.first |= first; T.seg[lane] = K; }
     const bool starts = lane < n && touched != 0u;
     // The touched pixels, 64 per pass; all passes' LUT fetches are issued before the first is consumed.
     constexpr uint32_t PASSES = MS_CAP / 64u;
@@ -586,9 +591,9 @@ JD void ms_build(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t so, cons
             const uint32_t e = p * 64u + lane;
             if (e < B.total) {
                 const MsSeg S = T.seg[(owner - 1u) & 63u];
-                uint32_t ix, keep;
-                const uint32_t part = ms_pixel<SAMPLES>(S, e - (S.first & 0xffffu), S.bits >> 9, ix, keep);
-                T.ent[e] = (Ent)keep | ((Ent)part << SAMPLES);  // (the LUT mask is ANDed in below, once it has arrived)
+                uint32_t ix, keep, keep_eo;
+                const uint32_t part = ms_pixel<SAMPLES>(S, e - (S.first & 0xffffu), S.bits >> 10, ix, keep, keep_eo);
+                T.ent[e] = keep | (part << SAMPLES);  // (the LUT mask is ANDed in below, once it has arrived)
                 if (SAMPLES == 8) { const uint32_t w = ix / 4u; word[p] = shr32(w < lut_n ? lut[w] : 0u, (ix % 4u) * 8u); }
                 else { const uint32_t w = ix / 2u; word[p] = shr32(w < lut_n ? lut[w] : 0u, (ix % 2u) * 16u); }
             }
@@ -599,7 +604,7 @@ JD void ms_build(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t so, cons
     for (uint32_t p = 0u; p < PASSES; p++) {
         if (p * 64u < B.total) {  // uniform
             const uint32_t e = p * 64u + lane;
-            if (e < B.total) atomicAnd(&T.ent[e], (Ent)(word[p] & FULL) | ~(Ent)FULL);
+            if (e < B.total) atomicAnd(&T.ent[e], (word[p] & FULL) | ~FULL);
         }
     }
     wave_sync();
@@ -618,19 +623,26 @@ JD void ms_fill(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t size_and_
     const uint32_t FULL = SAMPLES == 8 ? 0xffu : 0xffffu;
     constexpr uint32_t WORDS = SAMPLES == 8 ? 2u : 4u;
     const uint32_t ly = lane >> 2, lx = lane & 3u;
-    if (!(FINE_MS_SKIP & 8)) {   // clear the accumulators: counters at zero = 0x80 per byte (non-zero), parities 0 (even-odd)
-        const uint32_t z = even_odd ? 0u : 0x80808080u;
-        const uint4 z4 = make_uint4(z, z, z, z);
+    // The accumulators start from zero: 0x80 per counter byte (non-zero), parity 0 (even-odd).  The sample words -- 2 to 16 KB-writes
+    // per fill if cleared wholesale, and a fill touches ~25 of the 256 pixels -- are left clean by the fill before (its own touched
+    // pixels reset after the read-back, below) unless that fill had another rule or took more than one piece of a list.  16 samples
+    // only (C3: 604.6 -> 591 us); with 8 the wholesale clear is two stores and the reset pass costs more than it saves (445 -> 462 us).
+    const uint32_t cleared = even_odd ? 0u : 0x80808080u;
+    {
+        const uint4 z4 = make_uint4(cleared, cleared, cleared, cleared);
         uint4* s = (uint4*)&T.samples[0];
-        if (even_odd) s[lane] = z4;
-        else {
+        if (B.clean != (even_odd ? 1u : 0u) && !(FINE_MS_SKIP & 8)) {  // uniform
+            if (even_odd) s[lane] = z4;
+            else {
 #pragma unroll
-            for (uint32_t i = 0u; i < WORDS; i++) s[lane * WORDS + i] = z4;
+                for (uint32_t i = 0u; i < WORDS; i++) s[lane * WORDS + i] = z4;
+            }
         }
-        T.carry_x[lane] = z;
-        if (lane < 4u) T.carry_y[lane] = z;
+        T.carry_x[lane] = cleared;
+        if (lane < 4u) T.carry_y[lane] = cleared;
     }
     wave_sync();
+    uint32_t pieces = 0u, piece_e0 = 0u, piece_e1 = 0u;  // list pieces this fill has taken; the last one's range
     uint32_t sa = seg_data, remaining = size_and_rule >> 1;
     while (remaining != 0u) {  // uniform
         if (sa - B.base >= B.hi - B.base) ms_build<SAMPLES>(T, B, lane, sa, segments, segments_n, lut, lut_n);
@@ -642,8 +654,9 @@ JD void ms_fill(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t size_and_
             else atomicAdd(&T.carry_y[row >> 2], ((B.edge & 16u) != 0u ? 1u : 0xffffffffu) << ((row & 3u) << 3));
         }
         if (B.direct) {
-            // A segment with more touched pixels than the list holds (coordinates far outside the tile: never what path_tiling
-            // writes) is walked here, every lane with the segment's constants in its own registers.
+            // A segment with more touched pixels than the list holds, or one whose first mask depends on the rule (coordinates far
+            // outside the tile / infinite: never what path_tiling writes) is walked here, every lane with the segment's constants in
+            // its own registers.
             float x0 = 0.0f, y0 = 0.0f, x1 = 0.0f, y1 = 0.0f;
             if (sa < segments_n) {
                 const float2* sp = (const float2*)(segments + (size_t)sa * 6);
@@ -656,9 +669,9 @@ JD void ms_fill(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t size_and_
             for (uint32_t k0 = 0u; k0 < touched; k0 += 64u) {  // uniform
                 const uint32_t k = k0 + lane;
                 if (k < touched && k >= k0) {
-                    uint32_t ix, keep;
-                    const uint32_t part = ms_pixel<SAMPLES>(K, k, touched, ix, keep);
-                    ms_apply<SAMPLES>(T, (typename MsEnt<SAMPLES>::type)(ms_lut<SAMPLES>(lut, lut_n, ix) & keep) | ((typename MsEnt<SAMPLES>::type)part << SAMPLES), even_odd);
+                    uint32_t ix, keep, keep_eo;
+                    const uint32_t part = ms_pixel<SAMPLES>(K, k, touched, ix, keep, keep_eo);
+                    ms_apply<SAMPLES>(T, (ms_lut<SAMPLES>(lut, lut_n, ix) & (even_odd ? keep_eo : keep)) | (part << SAMPLES), even_odd);
                 }
                 if (touched - k0 <= 64u) break;  // (k0 + 64 may wrap)
             }
@@ -667,7 +680,9 @@ JD void ms_fill(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t size_and_
             const uint32_t e1 = r0 + take >= 64u ? B.total : (uint32_t)__builtin_amdgcn_readlane((int)B.first, (int)((r0 + take) & 63u));
             for (uint32_t eb = e0; eb < e1 && !(FINE_MS_SKIP & 1); eb += 64u)  // uniform
                 if (eb + lane < e1) ms_apply<SAMPLES>(T, T.ent[eb + lane], even_odd);
+            piece_e0 = e0; piece_e1 = e1;
         }
+        pieces += B.direct ? 2u : 1u;
         sa += take;
         remaining -= take;
     }
@@ -687,7 +702,18 @@ JD void ms_fill(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t size_and_
             const uint32_t flip = (uint32_t)(-(int32_t)(parity & 1u));
             area[i] = (float)__builtin_popcount((sv[i] ^ flip) & FULL) * (SAMPLES == 8 ? 0.125f : 0.0625f);
         }
-        wave_sync();  // (the accumulators are cleared by the next fill)
+        wave_sync();
+        B.clean = 2u;
+        if (SAMPLES == 16 && pieces <= 1u) {  // uniform: the pixels this fill touched are all in one range of the list that is still there
+            for (uint32_t eb = piece_e0; eb < piece_e1; eb += 64u) {
+                if (eb + lane < piece_e1) {
+                    const uint32_t e = T.ent[eb + lane];
+                    if (((e >> (SAMPLES + 8)) & MS_F_LIVE) != 0u) T.samples[(e >> SAMPLES) & 0xffu] = 0u;
+                }
+            }
+            B.clean = 1u;
+            wave_sync();
+        }
         return;
     }
     // x: inclusive sum of the carries of my four pixels inside the word, then the totals of the lanes to my left in my row
@@ -754,7 +780,22 @@ JD void ms_fill(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t size_and_
             area[i] = (float)__builtin_popcount(d8 & 0xF0F0F0F0u) * 0.0625f;
         }
     }
-    wave_sync();  // (the accumulators are cleared by the next fill)
+    wave_sync();
+    B.clean = 2u;
+    if (SAMPLES == 16 && pieces <= 1u) {  // uniform: as above
+        for (uint32_t eb = piece_e0; eb < piece_e1; eb += 64u) {
+            if (eb + lane < piece_e1) {
+                const uint32_t e = T.ent[eb + lane];
+                if (((e >> (SAMPLES + 8)) & MS_F_LIVE) != 0u) {
+                    const uint32_t pix = (e >> SAMPLES) & 0xffu;
+                    if (SAMPLES == 8) *(uint2*)&T.samples[pix * 2u] = make_uint2(0x80808080u, 0x80808080u);
+                    else *(uint4*)&T.samples[pix * 4u] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+                }
+            }
+        }
+        B.clean = 0u;
+        wave_sync();
+    }
 }
 
 template <int AA> struct FineLdsSel { typedef MsLds<AA> type; };
@@ -781,7 +822,7 @@ template <> struct FineStackSel<false> { struct type { float4 lvl[1][1][1]; }; }
 #define FINE_LEAN_MS_WAVES_PER_EU 6  // (C3 msaa8: 580 / 522 / 490 us at 4 / 5 / 6 waves per SIMD)
 #endif
 #define FINE_WAVES_PER_EU(AA, CLIPS, PAINTS) \
-    ((CLIPS) ? ((AA) != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : ((PAINTS) ? 4 : ((AA) != 0 ? FINE_LEAN_MS_WAVES_PER_EU : FINE_LEAN_WAVES_PER_EU)))
+    ((CLIPS) ? ((AA) != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : ((PAINTS) ? 4 : ((AA) == 16 ? 5 : ((AA) != 0 ? FINE_LEAN_MS_WAVES_PER_EU : FINE_LEAN_WAVES_PER_EU))))  /* (16 samples: 7.7 KB of LDS per tile-wave allow 5 per SIMD anyway) */
 template <int AA, bool CLIPS, bool PAINTS>
 __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_waves_per_eu(FINE_WAVES_PER_EU(AA, CLIPS, PAINTS), FINE_WAVES_PER_EU(AA, CLIPS, PAINTS)))) void k_fine_area(const JlConfig* __restrict__ cfg, FineCfg fc, const float* __restrict__ segments, uint32_t segments_n,
                                                   const uint32_t* __restrict__ ptcl, uint32_t ptcl_n, const uint32_t* __restrict__ info,
@@ -836,7 +877,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
     // ~1 us of it: fatal for streams of hundreds of one-word clip commands).
     uint32_t pc = uni(tile_ix * JL_PTCL_INITIAL_ALLOC);  // absolute word index of the next command
     MsState msb;  // (AA != 0) the batch of touched pixels: nothing yet
-    msb.base = 0u; msb.hi = 0u; msb.next = 0xffffffffu; msb.total = 0u; msb.direct = false; msb.first = 0u; msb.edge = 0u;
+    msb.base = 0u; msb.hi = 0u; msb.next = 0xffffffffu; msb.total = 0u; msb.direct = false; msb.first = 0u; msb.edge = 0u; msb.clean = 2u;
     auto I = [&](uint32_t i) -> uint32_t { return i < info_n ? info[i] : 0u; };
     const uint32_t blend_offset = pc < ptcl_n ? ptcl[pc] : 0u;
     pc += 1u;

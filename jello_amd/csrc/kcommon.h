@@ -39,6 +39,7 @@ static inline Buf<T> mkbuf(void* p, uint64_t bytes) {
 
 // ---- wave64 primitives ----
 JD uint32_t lane_id() { return threadIdx.x & 63u; }
+JD uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }  // a value that is the same in every lane, as a scalar
 // Inclusive wave64 prefix operations on the DPP path (row_shr 1,2,4,8 inside each 16-lane row, then
 // row_bcast:15 / row_bcast:31 across rows): six VALU instructions, no LDS crossbar round trips
 // (__shfl_up compiles to ds_bpermute_b32, ~100 cycles each and six of them dependent).

@@ -144,6 +144,11 @@ JD void alloc_cmd(Cmd& c, uint32_t size) {  // coarse.wgsl:70-88
 #ifndef COARSE_MAX_SPLIT
 #define COARSE_MAX_SPLIT 16u
 #endif
+// The one-walk route of scenes with clip layers walks a tile's elements with the LANES of a wave (round 6, see the walk below);
+// 0: one lane per tile, as the scenes without clips and rounds 1-5.
+#ifndef COARSE_PAR_WALK
+#define COARSE_PAR_WALK 1
+#endif
 
 // Element record, word 0 (see stage2 in k_coarse)
 #define CM_CLIP 1u             // BEGIN_CLIP or END_CLIP (draw tag bit 0)
@@ -219,7 +224,12 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
     // (backdrop, segment count) of the (draw, tile) pairs of the current window of elements.  The command walk reads Tiles
     // from here ONLY: a global load inside its loop makes every trip wait for the PTCL stores of the trip before
     // (vmcnt counts loads and stores in one order) -- 1 us per trip in the write pass.
-    __shared__ uint2 sh_tile_cache[COARSE_TILE_CACHE];
+    constexpr bool PAR = MODE == 2 && CLIPS && COARSE_PAR_WALK != 0;  // lanes = the elements of ONE tile (see the walk)
+    __shared__ uint2 sh_tile_cache[PAR ? 1u : COARSE_TILE_CACHE];
+    // PAR: the walk state of the workgroup's tiles (write position and limit, chunk words, segments, clip state: Walk / Cmd below) and,
+    // per wave, two lists of the elements that include the tile it works on / the one it prepares
+    __shared__ uint32_t sh_st[8][PAR ? JL_N_TILE : 1u];
+    __shared__ uint8_t sh_list[JL_WG / 64][2][PAR ? JL_N_TILE : 1u];
     __shared__ uint32_t sh_pool[JL_WG / 64][2];  // MODE 2: the waves' shares of the chunk arena (alloc_cmd)
     if (MODE == 2 && threadIdx.x < JL_WG / 64) { sh_pool[threadIdx.x][0] = 0u; sh_pool[threadIdx.x][1] = 0u; }  // (barriers follow before any walk)
 
@@ -322,6 +332,12 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         w.slice_ix = 7u; w.bitmap = 0u; w.nz = 0u; w.el_next = 0xffffffffu;
         w.q0 = make_uint4(0u, 0u, 0u, 0u); w.q2 = w.q0;
         w.tile.backdrop = 0; w.tile.segment_count_or_ix = 0u;
+    }
+    if constexpr (PAR) {  // (tile t of the workgroup's part = thread t; barriers follow before the first walk)
+        if (W[0].has_tile) {
+            sh_st[0][lid] = W[0].c.cmd_offset; sh_st[1][lid] = W[0].c.cmd_limit; sh_st[2][lid] = 0u; sh_st[3][lid] = 0u;
+            sh_st[4][lid] = 0u; sh_st[5][lid] = 0u; sh_st[6][lid] = 0u; sh_st[7][lid] = 0u;
+        }
     }
     uint32_t partition_ix = 0u, rd_ix = 0u, wr_ix = 0u, part_start_ix = 0u, ready_ix = 0u;
 
@@ -456,8 +472,8 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         uint32_t win_e0 = 0u, win_p0 = 0u;
         bool did_stage2 = false;
         for (;;) {
-        uint32_t win_e1 = win_e0;  // largest e1 with sh_tile_count[e1 - 1] - win_p0 <= COARSE_TILE_CACHE (uniform)
-        for (uint32_t step = 256u; step > 0u; step >>= 1)
+        uint32_t win_e1 = PAR ? JL_N_TILE : win_e0;  // largest e1 with sh_tile_count[e1 - 1] - win_p0 <= COARSE_TILE_CACHE (uniform); PAR: no cache, the whole batch
+        for (uint32_t step = 256u; step > 0u && !PAR; step >>= 1)
             if (win_e1 + step <= JL_N_TILE && sh_tile_count[win_e1 + step - 1u] - win_p0 <= COARSE_TILE_CACHE) win_e1 += step;
         const uint32_t win_p1 = sh_tile_count[win_e1 - 1u];
         // (draw, tile) include test, coarse.wgsl:318-341.  The Tile loads are issued four at a time per thread instead
@@ -497,7 +513,7 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                 const uint32_t ix = base + u * JL_N_TILE + lid;
                 const uint32_t el_ix = p_el[u];
                 const JlTile tile = p_t[u];
-                sh_tile_cache[ix - win_p0] = make_uint2((uint32_t)tile.backdrop, tile.segment_count_or_ix);
+                if (!PAR) sh_tile_cache[ix - win_p0] = make_uint2((uint32_t)tile.backdrop, tile.segment_count_or_ix);
                 const uint32_t meta = sh_r0[el_ix].x;
                 const bool is_clip = (meta & CM_CLIP) != 0u, is_blend = (meta & CM_BLEND) != 0u;
                 const bool even_odd = (meta & CM_EVENODD_INCLUDE) != 0u;
@@ -511,6 +527,207 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
         }
         if (has_next && !did_stage2) { stage2(); did_stage2 = true; }
         __syncthreads();
+        if constexpr (PAR) {
+            // ---- The walk, lanes = the ELEMENTS of one tile (round 6) ------------------------------------------------------------------
+            // With one lane per tile a wave issues ~130 instructions per (tile, element) trip for 64 tiles at best, one walking wave
+            // per workgroup, and a C4 tile sees 640 elements: 0.51 ms of one instruction after the other on a quarter of the SIMDs.
+            // Here every wave of the workgroup takes tiles of its own (tile = wave, wave + 4, ...), and the elements of the batch that
+            // include the tile -- the set bits of its bitmaps, compacted -- are its lanes.  What the sequential walk carries from
+            // element to element becomes wave arithmetic:
+            //   * write positions: prefix sums of the command sizes; a chunk boundary is the first command that does not fit
+            //     (ballot + count-trailing-zeros), the commands behind it are re-based, and so on (a boundary per ~50 commands);
+            //   * segment indices: a prefix sum;
+            //   * the clip state machine (coarse.wgsl:398-441).  A BEGIN_CLIP whose tile is empty starts a stretch that emits nothing
+            //     up to its END_CLIP.  The stretches nest properly, so the elements that emit nothing are the UNION of the
+            //     (begin, end] intervals of ALL empty BEGIN_CLIPs, reached or not: an element is skipped iff more empty BEGIN_CLIPs
+            //     than their END_CLIPs lie in front of it (two mbcnt), plus the stretch the tile entered the chunk in.  An END_CLIP
+            //     finds its BEGIN_CLIP as the clip kernels do: per nesting level one ballot of the level's BEGINs, masked to the lanes
+            //     below, count-leading-zeros.  Blend depth and its maximum are a prefix sum and a wave maximum.
+            // The Tile of a (tile, element) pair is read from memory again (the include test has just had it: L2), requested for the
+            // wave's NEXT tile before the current one is worked on; no Tile cache, no windows.  Commands are stored with their exact
+            // sizes: the lanes of one store instruction must not overlap (the one-lane walk pads to 16 bytes and lets the next command
+            // overwrite the padding).
+            const uint32_t wv = lid >> 6, lane = lid & 63u;
+            const uint64_t below = (1ull << lane) - 1ull, above = ~below & ~(1ull << lane);
+            auto mbcnt64 = [&](uint64_t m) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+            // the elements of tile t in buffer `buf` of the wave's lists; returns their number and requests the first 64 Tiles
+            auto prepare = [&](uint32_t t, uint32_t buf, uint32_t& e_out, JlTile& tl) -> uint32_t {
+                e_out = 0u; tl.backdrop = 0; tl.segment_count_or_ix = 0u;
+                if (t >= part_tiles) return 0u;  // uniform
+                const uint32_t ty = part_y0 + t / JL_N_TILE_X, tx = t % JL_N_TILE_X, xy = ty * JL_N_TILE_X + tx;
+                uint32_t n = 0u;
+#pragma unroll
+                for (uint32_t c = 0u; c < 4u; c++) {
+                    const uint64_t m = (uint64_t)uni(sh_bitmaps[2u * c][xy]) | ((uint64_t)uni(sh_bitmaps[2u * c + 1u][xy]) << 32);
+                    if (m != 0ull) {  // uniform
+                        if ((m >> lane) & 1ull) sh_list[wv][buf][(n + mbcnt64(m)) & 255u] = (uint8_t)(64u * c + lane);
+                        n += (uint32_t)__builtin_popcountll(m);
+                    }
+                }
+                wave_sync();
+                if (lane < n) {
+                    e_out = sh_list[wv][buf][lane];
+                    const uint4 q0 = sh_r0[e_out];
+                    tl = tiles.rd(q0.z + q0.w * ty + tx);
+                }
+                return n;
+            };
+            uint32_t nx_e; JlTile nx_tile;
+            uint32_t nx_n = prepare(wv, 0u, nx_e, nx_tile);
+            uint32_t buf = 0u;
+            for (uint32_t t = wv; t < part_tiles; t += JL_WG / 64u, buf ^= 1u) {  // uniform per wave
+                const uint32_t n = nx_n, e_first = nx_e;
+                const JlTile tile_first = nx_tile;
+                nx_n = prepare(t + JL_WG / 64u, buf ^ 1u, nx_e, nx_tile);
+                if (n == 0u) continue;  // uniform: nothing of this batch includes the tile
+                const uint32_t ty = part_y0 + t / JL_N_TILE_X, tx = t % JL_N_TILE_X;
+                const uint32_t slot = bin_ix * JL_N_TILE + ty * JL_N_TILE_X + tx;
+                uint32_t off = uni(sh_st[0][t]), lim = uni(sh_st[1][t]), chunkw = uni(sh_st[2][t]), segused = uni(sh_st[3][t]);
+                uint32_t czd = uni(sh_st[4][t]), depth = uni(sh_st[5][t]), rbd = uni(sh_st[6][t]), maxbd = uni(sh_st[7][t]);
+                const uint32_t dyn_start = cfg->width_in_tiles * cfg->height_in_tiles * JL_PTCL_INITIAL_ALLOC;
+                for (uint32_t k0 = 0u; k0 < n; k0 += 64u) {  // uniform
+                    const bool live = k0 + lane < n;
+                    uint32_t e = e_first;
+                    JlTile tile = tile_first;
+                    if (k0 != 0u) {  // (more than 64 elements of one batch on one tile: rare)
+                        e = live ? sh_list[wv][buf][k0 + lane] : 0u;
+                        tile.backdrop = 0; tile.segment_count_or_ix = 0u;
+                        if (live) { const uint4 t0 = sh_r0[e]; tile = tiles.rd(t0.z + t0.w * ty + tx); }
+                    }
+                    const uint4 q0 = sh_r0[e], q2 = sh_r2[e];
+                    const uint32_t meta = live ? q0.x : 0u;
+                    const uint32_t n_segs = live ? tile.segment_count_or_ix : 0u;
+                    const uint32_t is_begin = (meta / CM_BEGIN) & 1u, is_end = (meta / CM_END) & 1u, has_path = (meta / CM_PATH) & 1u;
+                    const uint32_t has_segs = umin_(n_segs, 1u);
+                    const uint32_t zero_tile = live ? 1u - umin_(n_segs | (uint32_t)tile.backdrop, 1u) : 0u;
+                    // nesting depth in front of the element
+                    const uint32_t dlt = is_begin - is_end;
+                    const uint32_t d_incl = wave_incl_scan_u32(dlt);
+                    const uint32_t D = depth + d_incl - dlt;
+                    const uint64_t begins = __builtin_amdgcn_ballot_w64(is_begin != 0u);
+                    const uint64_t zb = __builtin_amdgcn_ballot_w64((is_begin & zero_tile) != 0u);
+                    // partners inside the chunk, level by level
+                    uint32_t has_partner = 0u, partner_empty = 0u, matched = 0u;
+                    for (uint64_t todo = begins; todo != 0ull;) {  // uniform: one trip per nesting level with a BEGIN_CLIP in the chunk
+                        const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)__builtin_ctzll(todo));
+                        const bool bl_me = is_begin != 0u && D == L, el_me = is_end != 0u && D == L + 1u;
+                        const uint64_t bl = __builtin_amdgcn_ballot_w64(bl_me), el = __builtin_amdgcn_ballot_w64(el_me);
+                        if (el_me) {
+                            const uint64_t c = bl & below;
+                            if (c != 0ull) { has_partner = 1u; partner_empty = (uint32_t)(zb >> (63u - (uint32_t)__builtin_clzll(c))) & 1u; }
+                        }
+                        if (bl_me) {
+                            const uint64_t ea = el & above, ba = bl & above;
+                            matched = (ea != 0ull && (ba == 0ull || __builtin_ctzll(ea) < __builtin_ctzll(ba))) ? 1u : 0u;
+                        }
+                        todo &= ~bl;
+                    }
+                    const uint64_t ze = __builtin_amdgcn_ballot_w64((is_end & partner_empty) != 0u);
+                    uint32_t skipped = mbcnt64(zb) > mbcnt64(ze) ? 1u : 0u;  // (the intervals nest: the counts below a lane never cross)
+                    uint32_t czd_out;
+                    bool entered_persists = false;
+                    if (czd != 0u) {  // uniform: the tile entered the chunk inside a skipped stretch; it ends at the END_CLIP of that depth
+                        const uint64_t fin = __builtin_amdgcn_ballot_w64(is_end != 0u && has_partner == 0u && D == czd);
+                        const uint32_t endl = fin != 0ull ? (uint32_t)__builtin_ctzll(fin) : 64u;
+                        if (lane <= endl) skipped = 1u;
+                        entered_persists = fin == 0ull;
+                    }
+                    if (entered_persists) {
+                        czd_out = czd;
+                    } else {  // the outermost empty BEGIN_CLIP still open behind the chunk
+                        const uint64_t open_z = __builtin_amdgcn_ballot_w64((is_begin & zero_tile) != 0u && matched == 0u);
+                        czd_out = open_z != 0ull ? (uint32_t)__builtin_amdgcn_readlane((int)D, (int)__builtin_ctzll(open_z)) + 1u : 0u;
+                    }
+                    const uint32_t active = 1u - skipped;
+                    // blend depth
+                    const uint32_t opened = is_begin & active & (1u - zero_tile), closes = is_end & active;
+                    const uint32_t rd = opened - closes;
+                    const uint32_t r_incl = wave_incl_scan_u32(rd);
+                    const uint32_t peak = rbd + r_incl - rd + opened;
+                    maxbd = umax_(maxbd, (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max_u32(peak), 63));
+                    rbd += (uint32_t)__builtin_amdgcn_readlane((int)r_incl, 63);
+                    depth += (uint32_t)__builtin_amdgcn_readlane((int)d_incl, 63);
+                    czd = czd_out;
+                    // commands: sizes, segment index, positions
+                    const uint32_t emit_path = active & has_path;
+                    const uint32_t emit_brush = active & (1u - (is_begin & zero_tile));
+                    const uint32_t s1 = emit_path * (1u + 3u * has_segs);
+                    const uint32_t s2 = emit_brush * ((meta >> CM_NBRUSH_SHIFT) & 7u);
+                    const uint32_t segs_here = emit_path * n_segs;
+                    const uint32_t sg_incl = wave_incl_scan_u32(segs_here);
+                    const uint32_t seg_ix = segused + sg_incl - segs_here;  // (tile-relative: the relocation adds the tile's base)
+                    segused += (uint32_t)__builtin_amdgcn_readlane((int)sg_incl, 63);
+                    const uint32_t sz_incl = wave_incl_scan_u32(s1 + s2);
+                    uint32_t o1 = off + sz_incl - (s1 + s2), o2 = o1 + s1;  // as if everything fitted the current chunk
+                    uint32_t fl = 0u, fslot = 0u;  // commands in front of (fl, fslot) are placed
+                    for (uint32_t guard = 0u; guard < 130u; guard++) {  // uniform; one trip per chunk boundary
+                        const bool at1 = lane > fl || (lane == fl && fslot == 0u), at2 = lane >= fl;
+                        const uint64_t m1 = __builtin_amdgcn_ballot_w64(s1 != 0u && at1 && o1 + s1 >= lim);
+                        const uint64_t m2 = __builtin_amdgcn_ballot_w64(s2 != 0u && at2 && o2 + s2 >= lim);
+                        if ((m1 | m2) == 0ull) break;
+                        const uint32_t l1 = m1 != 0ull ? (uint32_t)__builtin_ctzll(m1) : 64u, l2 = m2 != 0ull ? (uint32_t)__builtin_ctzll(m2) : 64u;
+                        const uint32_t bl = l1 <= l2 ? l1 : l2, bslot = l1 <= l2 ? 0u : 1u;
+                        const uint32_t bo = (uint32_t)__builtin_amdgcn_readlane((int)(bslot == 0u ? o1 : o2), (int)bl);
+                        // a chunk from the wave's share of the arena (alloc_cmd<2>, one chunk at a time)
+                        uint32_t pn = uni(sh_pool[wv][0]), pe = uni(sh_pool[wv][1]);
+                        if (pe - pn < JL_PTCL_INCREMENT) {
+                            const uint32_t grab = COARSE_POOL_CHUNKS * JL_PTCL_INCREMENT;
+                            uint32_t base = 0u;
+                            if (lane == 0u) base = atomicAdd(R.arena_ctr, grab);
+                            base = uni(base);
+                            // (the chunks of the share that are not handed out now have no owner yet and may never get one)
+                            if (lane >= 1u && lane < COARSE_POOL_CHUNKS && dyn_start + base + lane * JL_PTCL_INCREMENT + JL_PTCL_INCREMENT <= ptcl.n)
+                                R.owner[base / JL_PTCL_INCREMENT + lane] = make_uint2(0xffffffffu, 0u);
+                            pn = base; pe = base + grab;
+                        }
+                        wave_sync();
+                        if (lane == 0u) { sh_pool[wv][0] = pn + JL_PTCL_INCREMENT; sh_pool[wv][1] = pe; }
+                        wave_sync();
+                        uint32_t new_cmd = dyn_start + pn;
+                        if (new_cmd + JL_PTCL_INCREMENT > ptcl.n || new_cmd + JL_PTCL_INCREMENT < new_cmd) {
+                            new_cmd = 0u;  // (an arena that overflows: k_coarse_bases raises the flag)
+                        } else {
+                            if (lane == 0u) R.owner[pn / JL_PTCL_INCREMENT] = make_uint2(slot, chunkw / JL_PTCL_INCREMENT);
+                            if (lane < 4u) ((ulonglong2*)(R.masks + (size_t)(new_cmd >> 6) * 2u))[lane] = make_ulonglong2(0ull, 0ull);  // nothing marked yet
+                        }
+                        if (lane == 0u) {
+                            ptcl.wr(bo, JL_CMD_JUMP);
+                            ptcl.wr(bo + 1u, new_cmd);  // (provisional: the relocation writes the canonical address over it)
+                            if (bo + 1u < ptcl.n) atomicOr(R.masks + (size_t)((bo + 1u) >> 6) * 2u + 1u, 1ull << ((bo + 1u) & 63u));
+                        }
+                        if (lane > bl || (lane == bl && bslot == 0u)) o1 = o1 - bo + new_cmd;
+                        if (lane >= bl) o2 = o2 - bo + new_cmd;
+                        lim = new_cmd + (JL_PTCL_INCREMENT - JL_PTCL_HEADROOM);
+                        chunkw += JL_PTCL_INCREMENT;
+                        fl = bl; fslot = bslot;
+                    }
+                    off = (uint32_t)__builtin_amdgcn_readlane((int)(o2 + s2), 63);
+                    // stores, exact sizes
+                    if (s1 == 4u) {
+                        const uint32_t at = o1 + 2u;
+                        if (at < ptcl.n) {  // seg_ix is tile-relative: marked, the relocation adds the tile's base and writes the Tile
+                            atomicOr(R.masks + (size_t)(at >> 6) * 2u, 1ull << (at & 63u));
+                            R.aux[at >> 2] = q0.z + q0.w * ty + tx;
+                        }
+                        ptcl_wr4(ptcl, o1, JL_CMD_FILL, (n_segs << 1) | ((meta / CM_EVENODD_FILL) & 1u), seg_ix, (uint32_t)tile.backdrop);
+                    } else if (s1 == 1u) {
+                        ptcl.wr(o1, JL_CMD_SOLID);
+                    }
+                    if (s2 >= 4u) {
+                        ptcl_wr4(ptcl, o2, q0.y, q2.x, q2.y, q2.z);
+                        if (s2 == 5u) ptcl.wr(o2 + 4u, q2.w);
+                    } else if (s2 != 0u) {
+                        ptcl.wr(o2, q0.y);
+                        if (s2 >= 2u) ptcl.wr(o2 + 1u, q2.x);
+                        if (s2 >= 3u) ptcl.wr(o2 + 2u, q2.y);
+                    }
+                }
+                if (lane == 0u) {
+                    sh_st[0][t] = off; sh_st[1][t] = lim; sh_st[2][t] = chunkw; sh_st[3][t] = segused;
+                    sh_st[4][t] = czd; sh_st[5][t] = depth; sh_st[6][t] = rbd; sh_st[7][t] = maxbd;
+                }
+            }
+        } else {
         // Write the per-tile command lists (coarse.wgsl:344-444).  The reads of a tile's NEXT element (bitmap -> record ->
         // cached Tile) are issued before the commands of the current one are written.
         auto next_el = [&](Walk& w) -> uint32_t {  // next set bit of the tile's bitmaps, ~0u at the end
@@ -642,12 +859,20 @@ __global__ __launch_bounds__(JL_WG) void k_coarse(const JlConfig* __restrict__ c
                 c.cmd_offset += s2;
             }
         }
-        if (win_p1 >= total_tile_count) break;
+        }  // (!PAR)
+        if (PAR || win_p1 >= total_tile_count) break;
         __syncthreads();  // the next window's include test overwrites the Tile cache
         win_e0 = win_e1; win_p0 = win_p1;
         }
         if (!has_next) break;
         __syncthreads();
+    }
+    if constexpr (PAR) {  // (thread = tile again)
+        __syncthreads();
+        if (W[0].has_tile) {
+            W[0].c.cmd_offset = sh_st[0][lid]; W[0].c.chunk_words = sh_st[2][lid]; W[0].c.seg_used = sh_st[3][lid];
+            W[0].max_blend_depth = sh_st[7][lid];
+        }
     }
     MonoidK<3> my_tot;
     my_tot.v[0] = 0u; my_tot.v[1] = 0u; my_tot.v[2] = 0u;

@@ -185,7 +185,6 @@ struct FineCfg {  // ConfigUniform fields of the host shadow, by value (valid = 
     uint32_t valid, width_in_tiles;
     float base_color[4];
 };
-JD uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // LDS byte addresses as integers (stage 4 of fill_path walks addresses)
 #define JK_LDS __attribute__((address_space(3)))
 JD uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(JK_LDS const void*)p; }

@@ -149,6 +149,11 @@ JD void alloc_cmd(Cmd& c, uint32_t size) {  // coarse.wgsl:70-88
 #ifndef COARSE_PAR_WALK
 #define COARSE_PAR_WALK 1
 #endif
+// ... and splits the bins for this many workgroups per CU: every wave of a workgroup walks, so more workgroups are more walkers
+// (C4 k_coarse<2>: 554 / 328 / 245 us with 1 / 2 / 4; nested C4 1061 / 616 / 423; the LDS of one allows four)
+#ifndef COARSE_PAR_WG_PER_CU
+#define COARSE_PAR_WG_PER_CU 4u
+#endif
 
 // Element record, word 0 (see stage2 in k_coarse)
 #define CM_CLIP 1u             // BEGIN_CLIP or END_CLIP (draw tag bit 0)
@@ -1103,7 +1108,8 @@ int jh_launch_coarse(const JhLaunch& L) {
     JlBump* bump = (JlBump*)L.b[7].ptr;
     auto ptcl = mkbuf<uint32_t>(L.b[8].ptr, L.b[8].size);
     // workgroups per bin: enough to give every CU COARSE_WG_PER_CU workgroups (the LDS of one allows four per CU)
-    const uint32_t want = COARSE_WG_PER_CU * (uint32_t)(L.num_cus > 0 ? L.num_cus : 256);
+    const bool clips_early = !(L.cfg_host && L.cfg_host->layout.n_clip == 0u);
+    const uint32_t want = (clips_early && COARSE_RELOCATE && COARSE_PAR_WALK ? COARSE_PAR_WG_PER_CU : COARSE_WG_PER_CU) * (uint32_t)(L.num_cus > 0 ? L.num_cus : 256);
     uint32_t split = 1u;
     while (split < COARSE_MAX_SPLIT && L.gx * L.gy * split < want) split *= 2u;
     const uint32_t n_wg = L.gx * L.gy * split;

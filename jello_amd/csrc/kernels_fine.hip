@@ -269,6 +269,10 @@ JD V4 over(V4 bg, V4 fg, float area) {
 // own `area += a * dy`), finalisation, composite, store -- and none of what moves it between lanes (pair -> segment mapping,
 // row sort, entries, marks, owner scan, row walk).  What stage 1 and the classification cost is in it: without them the
 // number of pairs and crossing pixels is not known.
+// 7 (round 6, timing only) stage 4 TRANSPOSED: a lane = (fill slot, pixel row) of the batch -- four slots of equal shares of the batch's
+// segments stand in for its fills, the real row masks give the trip counts -- walks its row's entries of its slot with all sixteen
+// pixels in registers (four 16-byte reads and eight packed adds per entry), the areas go back through the entry planes, and a FILL
+// reads its four with one 16-byte load: what VERDICT r05 asked to be measured instead of estimated.
 #ifndef FINE_SKIP
 #define FINE_SKIP 0
 #endif
@@ -1126,6 +1130,43 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             }
         }
         wave_sync();
+#if FINE_SKIP == 7
+        {
+            const uint32_t f = lane >> 4, r = lane & 15u;
+            const uint32_t per = (e_rel + 3u) / 4u;
+            const uint32_t s_lo = umin_(f * per, e_rel), s_hi = umin_(s_lo + per, e_rel);
+            const uint32_t firstv = lane < e_rel ? first : n_pairs;
+            const uint32_t p_lo = __shfl(firstv, (int)(s_lo & 63u), 64), p_hi = s_hi < 64u ? __shfl(firstv, (int)(s_hi & 63u), 64) : n_pairs;
+            const uint64_t rm = F.rowmask[r];
+            auto below = [](uint32_t P) -> uint64_t { return (1ull << (P & 63u)) - 1ull; };
+            const uint32_t before = (uint32_t)__builtin_popcountll(rm & below(p_lo));
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(rm & below(p_hi)) - before;
+            uint32_t addr = lds_addr(&F.ent[0][0]) + (__shfl(excl16, (int)r, 64) + before) * 16u;
+            jk_v2f a[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) a[q] = {lyf, lyf};
+            for (uint32_t trip = 0u; __builtin_amdgcn_ballot_w64(trip < cnt) != 0ull; trip++) {
+                if (trip < cnt) {
+#pragma unroll
+                    for (uint32_t q = 0u; q < 4u; q++) {
+                        const float4 v = lds_ld_f4(addr + q * (FB_PLANE * 16u));
+                        a[2 * q] += jk_v2f{v.x, v.y}; a[2 * q + 1] += jk_v2f{v.z, v.w};
+                    }
+                    addr += 16u;
+                }
+            }
+            {   // one y_edge term per lane stands in for the slot's edge segments
+                const float2 ed = F.edge[s_lo & 63u];
+                const float ye = ed.y * clamp_((float)r - ed.x + 1.0f, 0.0f, 1.0f);
+#pragma unroll
+                for (int q = 0; q < 8; q++) a[q] += jk_v2f{ye, ye};
+            }
+            wave_sync();
+#pragma unroll
+            for (uint32_t q = 0u; q < 4u; q++) F.ent[q][lane] = make_float4(a[2 * q].x, a[2 * q].y, a[2 * q + 1].x, a[2 * q + 1].y);
+            wave_sync();
+        }
+#endif
       } else {
         (void)so;
       }
@@ -1289,7 +1330,13 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                 area[0] = a01.x; area[1] = a01.y; area[2] = a23.x; area[3] = a23.y;
             }
 #endif
-            for (; FINE_SKIP != 2 && FINE_SKIP != 4 && FINE_SKIP != 6;) {  // uniform
+#if FINE_SKIP == 7
+            {
+                const float4 v = lds_ld_f4(lds_addr(&F.ent[lx][((r0 & 3u) * 16u + ly) & 63u]));
+                area[0] += v.x; area[1] += v.y; area[2] += v.z; area[3] += v.w;
+            }
+#endif
+            for (; FINE_SKIP != 2 && FINE_SKIP != 4 && FINE_SKIP != 6 && FINE_SKIP != 7;) {  // uniform
                 const uint32_t e_sl = em != 0ull ? (uint32_t)__builtin_ctzll(em) : 0u;
                 const uint32_t seg_end = em != 0ull ? e_sl + 1u : r0 + take;  // the run covers window segments < seg_end
                 done = (uint32_t)__builtin_popcountll(my_rowmask & below(first_of(seg_end)));

@@ -1199,7 +1199,7 @@ int jh_debug_clip_hint_overflows(jh_ctx* ctx, uint32_t* count, int reset) {
     }
     return JH_OK;
 }
-#ifdef FINE_TIMING
+#if defined(FINE_TIMING) || defined(FINE_EB_STATS)
 extern "C" int jh_debug_fine_timing(jh_ctx* ctx, unsigned long long* out6, int reset) {
     if (!ctx || !ctx->hint_overflow) return JH_ERR_INVALID;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

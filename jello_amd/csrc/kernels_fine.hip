@@ -36,6 +36,13 @@ using namespace jd;
 
 namespace {
 
+#ifndef FINE_PLAIN_INLINE
+#define FINE_PLAIN_INLINE 1
+#endif
+#ifndef FINE_BLEND_UNIFORM_DISPATCH
+#define FINE_BLEND_UNIFORM_DISPATCH 1
+#endif
+
 struct V4 {
     float x, y, z, w;
 };
@@ -143,6 +150,13 @@ JD V4 blend_compose(V3 cb, V3 cs, float ab, float as_, uint32_t mode) {  // blen
 // formula is the rare case.
 __device__ __attribute__((noinline)) V4 blend_mix_compose(V4 backdrop, V4 src, uint32_t mode) {  // blend.wgsl:288-310
     const float EPSILON = 1e-15f;
+#if FINE_BLEND_UNIFORM_DISPATCH
+    // `mode` is a PTCL word: the same in every lane.  As a function argument it arrives in a vector register, and the two switches
+    // below became trees of v_cmp / s_and_saveexec / s_cbranch_execz -- ~25 vector + scalar instructions per call in front of the
+    // arithmetic (round 6: nested C4 spends 55 % of its fine kernel in here, 85 calls x 4 pixels per tile).  As a scalar the switches
+    // are compare-and-branch on the scalar pipe.
+    mode = (uint32_t)__builtin_amdgcn_readfirstlane((int)mode);
+#endif
     if ((mode & 0x7fffu) == 0u) {
         float k = 1.0f - src.w;
         return v4(backdrop.x * k + src.x, backdrop.y * k + src.y, backdrop.z * k + src.z, backdrop.w * k + src.w);
@@ -250,6 +264,9 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #define FB_PLANE 65
 #ifndef FINE_FINAL_ASM
 #define FINE_FINAL_ASM 1  // (C3 fine 351.3 -> 347.0 us on the same box)
+#endif
+#ifndef FINE_COLOR_BPERM
+#define FINE_COLOR_BPERM 0
 #endif
 #ifndef FINE_LAYER_FILL
 #define FINE_LAYER_FILL 1
@@ -1439,7 +1456,14 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             // (as an arm of the general decoder below the pair carried that decoder's flag variables, state copies and branch chain).
             for (uint32_t hot = 0; hot < (1u << 24) && tag == JL_CMD_FILL && W(4) == JL_CMD_COLOR; hot++) {  // uniform
                 do_fill(W(1), W(2), (int32_t)W(3));
+#if FINE_COLOR_BPERM
+                // (the colour through the LDS crossbar into vector registers instead of four v_readlane with a scalar lane select, 8 cycles
+                // of the vector pipe each: the kernel is bound by vector issue, the LDS pipe is a third busy)
+                auto WB = [&](uint32_t k) -> float { return u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)((woff + k) << 2), (int)wcur)); };
+                const V4 fgc = v4(WB(5), WB(6), WB(7), WB(8));
+#else
                 const V4 fgc = v4(u2f(W(5)), u2f(W(6)), u2f(W(7)), u2f(W(8)));
+#endif
                 pc += 9u;
                 materialize();
 #pragma unroll
@@ -1704,7 +1728,17 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                         bg = blend_spill.rd(spill_base + pix_spill(k));
                     }
                     V4 src = v4(rgba[k].x * area[k] * alpha, rgba[k].y * area[k] * alpha, rgba[k].z * area[k] * alpha, rgba[k].w * area[k] * alpha);
-                    rgba[k] = blend_mix_compose(bg, src, blend);
+#if defined(FINE_DIFF_BLEND) && defined(JH_VARIANT_BUILD)  // (differential build: every full END_CLIP blends plain src-over)
+                    rgba[k] = blend_mix_compose(bg, src, 0u);
+#else
+                    // (plain / clip layers -- two of three in a nest of clips -- here, not behind the call: eight operations; blend.wgsl:289-291)
+                    if (FINE_PLAIN_INLINE && (blend & 0x7fffu) == 0u) {  // uniform
+                        const float kk = 1.0f - src.w;
+                        rgba[k] = v4(bg.x * kk + src.x, bg.y * kk + src.y, bg.z * kk + src.z, bg.w * kk + src.w);
+                    } else {
+                        rgba[k] = blend_mix_compose(bg, src, blend);
+                    }
+#endif
                 }
                 pushed_depth = level;
             }
@@ -1734,6 +1768,11 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                 int32_t x = to_i32(round_(extend_mode(my_d, ext) * 511.0f));
                 rgba[k] = over(rgba[k], load_grad(x, index), area[k]);
             }
+#if defined(FINE_DIFF_GRAD) && defined(JH_VARIANT_BUILD)  // (differential build: a radial gradient composites like a transparent colour)
+        } else if (PAINTS && tag == JL_CMD_RAD_GRAD) {
+            have_fg = true;
+            pc += 3u;
+#endif
         } else if (PAINTS && tag == JL_CMD_RAD_GRAD) {
             materialize();
             pc += 3u;

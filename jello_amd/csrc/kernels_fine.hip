@@ -36,9 +36,6 @@ using namespace jd;
 
 namespace {
 
-#ifndef FINE_PLAIN_INLINE
-#define FINE_PLAIN_INLINE 1
-#endif
 #ifndef FINE_BLEND_UNIFORM_DISPATCH
 #define FINE_BLEND_UNIFORM_DISPATCH 1
 #endif
@@ -1731,13 +1728,9 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
 #if defined(FINE_DIFF_BLEND) && defined(JH_VARIANT_BUILD)  // (differential build: every full END_CLIP blends plain src-over)
                     rgba[k] = blend_mix_compose(bg, src, 0u);
 #else
-                    // (plain / clip layers -- two of three in a nest of clips -- here, not behind the call: eight operations; blend.wgsl:289-291)
-                    if (FINE_PLAIN_INLINE && (blend & 0x7fffu) == 0u) {  // uniform
-                        const float kk = 1.0f - src.w;
-                        rgba[k] = v4(bg.x * kk + src.x, bg.y * kk + src.y, bg.z * kk + src.z, bg.w * kk + src.w);
-                    } else {
-                        rgba[k] = blend_mix_compose(bg, src, blend);
-                    }
+                    // (the plain / clip case inlined here instead of behind the call -- two of three full blends of a nest of clips -- measured
+                    // SLOWER, 2928 -> 3095 us on nested C4: the instantiation has no register to spare, ten more spills)
+                    rgba[k] = blend_mix_compose(bg, src, blend);
 #endif
                 }
                 pushed_depth = level;

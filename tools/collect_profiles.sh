@@ -38,13 +38,13 @@ echo "other scenes done"
 for S in c1 c2; do timeout -k 10 300 python3 bench.py --scene $S --no-cpu-baseline > "$O/${S}_bench.json" 2>/dev/null; done
 bash tools/pmc_flatten.sh > "$O/pmc_flatten_tile_kernels.txt" 2>&1 && echo "pmc flatten / tile kernels done"
 bash tools/flatten_split.sh > "$O/flatten_split.txt" 2>&1 && echo "flatten split done"
-# round 5: k_flatten_lines split, frames in flight, and -- if the round-4 library was built next to the product one
-# (jello_amd/libjello_hip_r04.so: `git archive 4c55da8 jello_amd/csrc include | tar -x -C /tmp/r04src && make -C /tmp/r04src/jello_amd/csrc`,
+# round 5: k_flatten_lines split, frames in flight, and -- if the round-5 library was built next to the product one
+# (jello_amd/libjello_hip_r05.so: `git archive 5df0f7a jello_amd/csrc include | tar -x -C /tmp/r05src && make -C /tmp/r05src/jello_amd/csrc`,
 # copied in) -- the same-box A/B of every kernel against it
 bash tools/lines_split.sh > "$O/lines_split.txt" 2>&1 && echo "lines split done"
 for S in c3 c4 c4n; do timeout -k 10 250 python3 tools/frames_in_flight.py --scene $S --max-in-flight 3 > "$O/frames_in_flight_$S.json" 2>/dev/null; done
 echo "frames in flight done"
-if [ -s jello_amd/libjello_hip_r04.so ]; then
-  ( bash tools/ab_kernels.sh "k_" r04 product; AB_ARGS="--scene c4" bash tools/ab_kernels.sh "k_" r04 product; AB_ARGS="--scene c4n" bash tools/ab_kernels.sh "k_fine|k_coarse|k_clip" r04 product ) > "$O/ab_r04_vs_r05.txt" 2>&1
-  echo "A/B against round 4 done"
+if [ -s jello_amd/libjello_hip_r05.so ]; then
+  ( bash tools/ab_kernels.sh "k_" r05 product; AB_ARGS="--scene c4" bash tools/ab_kernels.sh "k_" r05 product; AB_ARGS="--scene c4n" bash tools/ab_kernels.sh "k_fine|k_coarse|k_clip" r05 product; AB_ARGS="--aa msaa8" bash tools/ab_kernels.sh "k_fine" r05 product; AB_ARGS="--aa msaa16" bash tools/ab_kernels.sh "k_fine" r05 product ) > "$O/ab_r05_vs_r06.txt" 2>&1
+  echo "A/B against round 5 done"
 fi

@@ -276,12 +276,7 @@ def run_rank(args, world):
     # 4.15 x at 8 GPUs at this render time, whatever the renderer does), so with `--gather-dst all` the headline is the gather whose
     # destination rotates when it ran, else the gather-free loop; gather-to-rank-0 stays under `modes` with its ceiling.  An explicit
     # `--gather-dst 0` / `rotate` is reported as asked.
-    if not gather:
-        head_mode = None
-    elif args.gather_dst == "all":
-        head_mode = "rotate" if "rotate" in good_modes else None
-    else:
-        head_mode = good_modes[0]
+    head_mode = sharding.headline_mode(args.gather_dst, good_modes) if gather else None
     gather = head_mode is not None
     blocks = blocks_by_mode[head_mode] if gather else blocks_plain
     elapsed_plain = blocks_plain[len(blocks_plain) // 2]

@@ -189,3 +189,14 @@ def launch_ranks(script, script_args, n, env=None, timeout=None):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         e.pop(k, None)
     return subprocess.run(cmd, env=e, timeout=timeout).returncode
+
+
+def headline_mode(gather_dst, good_modes):
+    """Which gather mode a multi-GPU bench line reports as `value`: with `--gather-dst all` the gather whose destination rotates when
+    it ran (a gather to ONE rank is capped by that rank's inbound links -- gather_model -- whatever the renderer does), else none (the
+    gather-free loop); an explicit `--gather-dst 0` / `rotate` is reported as asked.  None = the gather-free loop."""
+    if not good_modes:
+        return None
+    if gather_dst == "all":
+        return "rotate" if "rotate" in good_modes else None
+    return good_modes[0]

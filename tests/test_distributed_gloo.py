@@ -269,3 +269,15 @@ def test_a_failing_gather_mode_is_reported_and_the_others_survive(built):
         assert list(blocks) == ["rotate"] and blocks["rotate"] == [2.0, 3.0]
         assert list(errors) == ["0"]
     assert "simulated RCCL failure" in res[1][1]["0"] and res[0][1]["0"] == "failed on another rank"
+
+
+def test_headline_mode_of_a_multi_gpu_line():
+    """bench.py's `value` for N > 1: the rotating gather when it ran, else the gather-free loop; gather-to-rank-0 only when asked for."""
+    from jello_amd import sharding
+    assert sharding.headline_mode("all", ["0", "rotate"]) == "rotate"
+    assert sharding.headline_mode("all", ["0"]) is None          # (the rotating gather died: the line falls back to no gather)
+    assert sharding.headline_mode("all", []) is None
+    assert sharding.headline_mode("0", ["0"]) == "0"
+    assert sharding.headline_mode("rotate", ["rotate"]) == "rotate"
+    m8 = sharding.gather_model(8, 0.81, 4096 * 4096 * 8, "0")
+    assert m8["ceiling_speedup"] < 6.0 < sharding.gather_model(8, 0.81, 4096 * 4096 * 8, "rotate")["ceiling_speedup"]

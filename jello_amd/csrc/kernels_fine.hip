@@ -246,7 +246,7 @@ JD V4 over(V4 bg, V4 fg, float area) {
 // ------------------------------------------------------------------------------------------------
 #define FB_SPEC 128u
 #ifndef FINE_LEAN_WAVES_PER_EU
-#define FINE_LEAN_WAVES_PER_EU 6
+#define FINE_LEAN_WAVES_PER_EU 7  // (72 registers; 6 208 bytes of LDS per tile-wave allow 26 per CU)
 #endif
 #ifndef FINE_CLIP_WAVES_PER_EU
 #define FINE_CLIP_WAVES_PER_EU 4  // 128 VGPRs (5 spilled in the clip + paint instantiation); LDS (4 KiB of stack + 6.6 KiB per tile-wave) allows 15 waves per CU.
@@ -313,7 +313,8 @@ JD V4 over(V4 bg, V4 fg, float area) {
 // Everything a batch leaves behind for stage 4 lives in LDS, not in registers: the command loop then carries no per-lane
 // batch state around its back edge (as registers the nine values cost ~30 moves per command: the compiler keeps a second
 // copy of every loop-carried value that a nested loop redefines).
-struct FillLds {
+template <bool LEAN> struct FillLdsT;
+template <> struct FillLdsT<false> {
     alignas(16) float4 pre[64];    // the NEXT window's segments (p0x p0y p1x p1y), written by global_load_lds (no registers)
     alignas(16) float4 ent[4][FB_PLANE]; // the batch's (segment,row) pairs SORTED BY ROW (segment order inside a row): [pixel quad]
                                    // [position] = the pair's a*dy for the quad's 4 pixels of its row.  One plane per quad: lane = pair
@@ -329,6 +330,25 @@ struct FillLds {
         uint8_t specmark[FB_SPEC];   // stage 3: crossing pixel k of the pass is the first one of pair specmark[k] - 1 (0: of none)
     };
 };
+// The instantiations without clip layers keep the walk state of the lanes in registers (lanest / first unused) and mark pairs with
+// bytes: 6 208 bytes per tile-wave instead of 6 656.  That is the difference between 24 and 26 tile-waves per CU, and on this part
+// the 25th and 26th are worth 6 % of the kernel (round 6, a what-if sweep over the LDS size at 72 registers: 341 us at 6 464 bytes
+// and above, 321 at 6 208 and below -- profiles/r06_fine_lds_sweep.txt); the kernel fits 72 registers (seven waves per SIMD) once the
+// walk's fixed temporaries sit at v64-v71 instead of v72-v79.
+template <> struct FillLdsT<true> {
+    alignas(16) float4 pre[64];
+    alignas(16) float4 ent[4][FB_PLANE];
+    float pre_ye[64];
+    float2 edge[64];
+    uint64_t rowmask[16];
+    uint32_t lanest[1];  // (not used)
+    uint8_t first[4];    // (not used)
+    union {
+        uint8_t pairflag[64];
+        uint8_t specmark[FB_SPEC];
+    };
+};
+typedef FillLdsT<false> FillLds;
 // The load is unconditional (index clamped) so that it can stay in flight as a prefetch; out-of-range segments are
 // zeroed when the registers are consumed (robust-access rule) -- a predicated load would be waited for at once.
 JD void load_segraw_clamped(const float* __restrict__ segments, uint32_t segments_n, uint32_t so, float& p0x, float& p0y, float& p1x,
@@ -815,8 +835,8 @@ JD void ms_fill(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t size_and_
     }
 }
 
-template <int AA> struct FineLdsSel { typedef MsLds<AA> type; };
-template <> struct FineLdsSel<0> { typedef FillLds type; };
+template <int AA, bool CLIPS> struct FineLdsSel { typedef MsLds<AA> type; };
+template <bool CLIPS> struct FineLdsSel<0, CLIPS> { typedef FillLdsT<!CLIPS> type; };
 // The first JL_BLEND_STACK_SPLIT levels of the clip / blend stack (fine.wgsl:938-973 keeps them in registers; deeper
 // levels go to blend_spill), one float4 per pixel, lane-contiguous (conflict-free 16-byte accesses), addressed by the
 // (uniform) level: levels 0 and 1 in wave-private LDS (8 KiB), levels 2 and 3 in a per-tile slice of a global scratch
@@ -854,7 +874,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
     // FINE_WAVES independent waves (= tiles, side by side in x) per workgroup: the CU runs at most 16 workgroups, so
     // single-wave workgroups would cap the occupancy at 4 waves per SIMD.  The waves never synchronise with each other.
     constexpr uint32_t WV = FINE_WG_WAVES(CLIPS);
-    __shared__ typename FineLdsSel<AA>::type F_all[WV];
+    __shared__ typename FineLdsSel<AA, CLIPS>::type F_all[WV];
     __shared__ typename FineStackSel<CLIPS>::type S_all[WV];
     const uint32_t wave_in_wg = threadIdx.x >> 6;
     auto& F = F_all[wave_in_wg];
@@ -1368,28 +1388,28 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                         "1:\n"
                         "v_cmpx_lt_u32_e32 vcc, %[cur], %[hi]\n"
                         "s_cbranch_execz 3f\n"
-                        "ds_read_b128 v[72:75], " FINE_WALK_RD "\n"
+                        "ds_read_b128 v[64:67], " FINE_WALK_RD "\n"
                         "v_add_u32_e32 %[t], 16, %[cur]\n"
                         "v_cmp_lt_u32_e32 vcc, %[t], %[hi]\n"
                         "s_mov_b64 %[s1], exec\n"
                         "s_and_b64 exec, exec, vcc\n"
-                        "ds_read_b128 v[76:79], " FINE_WALK_RD " offset:16\n"
+                        "ds_read_b128 v[68:71], " FINE_WALK_RD " offset:16\n"
                         "s_mov_b64 exec, %[s1]\n"
                         "v_add_u32_e32 %[cur], 32, %[cur]\n"
                         "s_waitcnt lgkmcnt(1)\n"
-                        "v_pk_add_f32 %[a01], %[a01], v[72:73]\n"
-                        "v_pk_add_f32 %[a23], %[a23], v[74:75]\n"
+                        "v_pk_add_f32 %[a01], %[a01], v[64:65]\n"
+                        "v_pk_add_f32 %[a23], %[a23], v[66:67]\n"
                         "s_and_b64 exec, exec, vcc\n"
                         "s_waitcnt lgkmcnt(0)\n"
-                        "v_pk_add_f32 %[a01], %[a01], v[76:77]\n"
-                        "v_pk_add_f32 %[a23], %[a23], v[78:79]\n"
+                        "v_pk_add_f32 %[a01], %[a01], v[68:69]\n"
+                        "v_pk_add_f32 %[a23], %[a23], v[70:71]\n"
                         "s_mov_b64 exec, %[s1]\n"
                         "s_branch 1b\n"
                         "3:\n"
                         "s_mov_b64 exec, %[sv]\n"
                         : [cur] "+v"(cur), [a01] "+v"(a01), [a23] "+v"(a23), [sv] "=&s"(sv), [s1] "=&s"(s1), [t] "=&v"(t)
                         : [hi] "v"(hi) FINE_WALK_RD_OPERAND
-                        : "vcc", "memory", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79");
+                        : "vcc", "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");
                     area[0] = a01.x; area[1] = a01.y; area[2] = a23.x; area[3] = a23.y;
                 }
                 cur = hi;

@@ -204,10 +204,12 @@ typedef float jk_v2f __attribute__((ext_vector_type(2)));
 #if defined(__HIP_DEVICE_COMPILE__)
 JD float4 lds_ld_f4(uint32_t a) { const jk_v4f v = *(const JK_LDS jk_v4f*)a; return make_float4(v.x, v.y, v.z, v.w); }
 JD void lds_st_u16(uint32_t a, uint16_t v) { *(JK_LDS uint16_t*)a = v; }
+JD void lds_st_u8(uint32_t a, uint8_t v) { *(JK_LDS uint8_t*)a = v; }
 JD float lds_ld_f32(uint32_t a) { return *(const JK_LDS float*)a; }
 #else  // (the host pass only parses the kernels)
 JD float4 lds_ld_f4(uint32_t) { return make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
 JD void lds_st_u16(uint32_t, uint16_t) {}
+JD void lds_st_u8(uint32_t, uint8_t) {}
 JD float lds_ld_f32(uint32_t) { return 0.0f; }
 #endif
 
@@ -314,22 +316,26 @@ JD V4 over(V4 bg, V4 fg, float area) {
 // batch state around its back edge (as registers the nine values cost ~30 moves per command: the compiler keeps a second
 // copy of every loop-carried value that a nested loop redefines).
 template <bool LEAN> struct FillLdsT;
-template <> struct FillLdsT<false> {
+template <> struct FillLdsT<false> {  // the clip instantiations: the lanes' walk state in LDS (they have no registers to spare)
     alignas(16) float4 pre[64];    // the NEXT window's segments (p0x p0y p1x p1y), written by global_load_lds (no registers)
-    alignas(16) float4 ent[4][FB_PLANE]; // the batch's (segment,row) pairs SORTED BY ROW (segment order inside a row): [pixel quad]
-                                   // [position] = the pair's a*dy for the quad's 4 pixels of its row.  One plane per quad: lane = pair
-                                   // writes and lane = pixel quad reads both touch consecutive 16-byte slots (the plane stride is
-                                   // 65 slots, so the four quads of one position lie in different banks)
+    alignas(16) float4 ent[4][63]; // the batch's (segment,row) pairs SORTED BY ROW (segment order inside a row): [pixel quad]
+                                   // [position] = the pair's a*dy for the quad's 4 pixels of its row (a batch has at most 63 pairs).
+                                   // One plane per quad: lane = pair writes and lane = pixel quad reads touch consecutive 16-byte slots
     float pre_ye[64];              // ... and their y_edge
-    float2 edge[64];               // window segments: y_edge, sign(dx)  (read by stage 4 at a uniform index: a broadcast)
+    float edge_y[64];              // window segments: y_edge ...
+    int8_t edge_s[64];             // ... and sign(dx)  (read by stage 4 at a uniform index: a broadcast)
     uint64_t rowmask[16];          // per pixel row: bit j = pair j of the batch lies in this row
-    uint32_t lanest[64];           // lane = pixel quad: LDS address of my row's first entry (my quad of it) | entries consumed << 16
-    uint8_t first[64];             // first pair of window segment s (segments behind the batch: the number of pairs)
+    uint32_t lanest[64];           // lane = pixel quad: LDS address of my row's first entry (my quad of it) | entries consumed << 16;
+                                   // lane = window segment: | first pair of the segment << 24 (segments behind the batch: the number of pairs)
     union {
-        uint32_t pairflag[64];       // batch set-up: pair -> (window segment + 1) at the first pair of each segment, else 0
-        uint8_t specmark[FB_SPEC];   // stage 3: crossing pixel k of the pass is the first one of pair specmark[k] - 1 (0: of none)
+        uint8_t pairflag[64];        // batch set-up: pair -> (window segment + 1) at the first pair of each segment, else 0
+        uint8_t specmark[64];        // stage 3: crossing pixel k of the pass is the first one of pair specmark[k] - 1 (0: of none)
     };
+    // 6 080 bytes + the 4 KiB of blend-stack level 0 = 10 176 per tile-wave: SIXTEEN per CU (the four waves per SIMD the registers allow);
+    // at 10 752 (float2 edges, word marks, a byte array of first pairs, 65-slot planes, 128 marks) it was fifteen, and the sixteenth
+    // is worth 6 % on nested C4 and 3 % on C4 (round 6, a what-if sweep: 2 938 us at 10 320 bytes and above, 2 759 at 9 936).
 };
+
 // The instantiations without clip layers keep the walk state of the lanes in registers (lanest / first unused) and mark pairs with
 // bytes: 6 208 bytes per tile-wave instead of 6 656.  That is the difference between 24 and 26 tile-waves per CU, and on this part
 // the 25th and 26th are worth 6 % of the kernel (round 6, a what-if sweep over the LDS size at 72 registers: 341 us at 6 464 bytes
@@ -964,7 +970,8 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         }
         cur_base = so;
         const float dlx = c_p1x - c_p0x, dly = c_p1y - c_p0y;
-        F.edge[lane] = make_float2(c_ye, sign_(dlx));
+        if constexpr (CLIPS) { F.edge_y[lane] = c_ye; F.edge_s[lane] = (int8_t)(dlx > 0.0f ? 1 : (dlx < 0.0f ? -1 : 0)); }
+        else F.edge[lane] = make_float2(c_ye, sign_(dlx));
         // stage 1: conservative superset of the rows with dy != 0.  Coordinates are tile relative (|v| <= 16
         // for what path_tiling writes): with |v| <= 64 every rounding error of the WGSL's row arithmetic is
         // < 1e-4, so widening by 1e-3 is safe; anything else takes all 16 rows.
@@ -981,7 +988,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         const uint32_t e_rel = (uint32_t)__builtin_popcountll(fit);       // > 0: one segment has at most 16 pairs
         n_pairs = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(e_rel - 1u));
         const uint32_t first = incl - my_cnt;
-        if constexpr (CLIPS) F.first[lane] = (uint8_t)(lane < e_rel ? first : n_pairs); else s4_first = lane < e_rel ? first : n_pairs;
+        if constexpr (!CLIPS) s4_first = lane < e_rel ? first : n_pairs;  // (CLIPS: packed into F.lanest below)
         // y_edge >= 16 (path_tiling's "no edge" value is 1e9) clamps to 0 for every row of the tile
         edge_mask = __builtin_amdgcn_ballot_w64(c_ye < 16.0f) & fit;
         const uint32_t meta = first | ((uint32_t)ra << 8) | (sane ? (1u << 16) : 0u);
@@ -1079,7 +1086,7 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         const uint32_t excl16 = inc16 - c16;
         const uint32_t pos = (__shfl(excl16, (int)row, 64) + rank) & 63u;
         if constexpr (CLIPS) {
-            F.lanest[lane] = ent_lds + __shfl(excl16, (int)ly, 64) * 16u;  // nothing consumed yet
+            F.lanest[lane] = (ent_lds + __shfl(excl16, (int)ly, 64) * 16u) | ((lane < e_rel ? first : n_pairs) << 24);  // nothing consumed yet
         } else {
             s4_row_addr = ent_lds + __shfl(excl16, (int)ly, 64) * 16u;
             s4_done = 0u;  // nothing consumed yet
@@ -1127,16 +1134,17 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
         // segments).  Crossing pixel k of the batch belongs to the last pair whose first crossing pixel (spos) is <= k:
         // the pairs mark their starts in a byte array, a running maximum over the lanes turns the marks into owners.
         const uint32_t packed = ((uint32_t)n0r & 15u) | (pos << 4) | (spos << 10);
-        for (uint32_t pass = 0u; pass < nspec; pass += FB_SPEC) {
+        constexpr uint32_t SPEC = (uint32_t)sizeof(F.specmark);  // crossing pixels per pass: 128 (64 in the clip instantiations)
+        for (uint32_t pass = 0u; pass < nspec; pass += SPEC) {
             wave_sync();  // (the entries above / the previous pass's mark reads are done)
-            ((uint16_t*)F.specmark)[lane] = 0u;
+            if constexpr (SPEC == 128u) ((uint16_t*)F.specmark)[lane] = 0u; else F.specmark[lane] = 0u;
             wave_sync();
-            if (nrest != 0u && spos - pass < FB_SPEC) F.specmark[spos - pass] = (uint8_t)(lane + 1u);
+            if (nrest != 0u && spos - pass < SPEC) F.specmark[spos - pass] = (uint8_t)(lane + 1u);
             wave_sync();
             // the pair the first position of the pass belongs to when it does not start there
             const uint64_t before = __builtin_amdgcn_ballot_w64(nrest != 0u && spos < pass);
             uint32_t carry = before != 0ull ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
-            const uint32_t n_here = umin_(nspec - pass, FB_SPEC);
+            const uint32_t n_here = umin_(nspec - pass, SPEC);
             for (uint32_t k0 = 0u; k0 < n_here; k0 += 64u) {
                 const uint32_t own = umax_(wave_incl_max_u32(F.specmark[k0 + lane]), carry);
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)own, 63);
@@ -1183,14 +1191,15 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                 if (trip < cnt) {
 #pragma unroll
                     for (uint32_t q = 0u; q < 4u; q++) {
-                        const float4 v = lds_ld_f4(addr + q * (FB_PLANE * 16u));
+                        const float4 v = lds_ld_f4(addr + q * (uint32_t)sizeof(F.ent[0]));
                         a[2 * q] += jk_v2f{v.x, v.y}; a[2 * q + 1] += jk_v2f{v.z, v.w};
                     }
                     addr += 16u;
                 }
             }
             {   // one y_edge term per lane stands in for the slot's edge segments
-                const float2 ed = F.edge[s_lo & 63u];
+                float2 ed;
+                if constexpr (CLIPS) ed = make_float2(F.edge_y[s_lo & 63u], 1.0f); else ed = F.edge[s_lo & 63u];
                 const float ye = ed.y * clamp_((float)r - ed.x + 1.0f, 0.0f, 1.0f);
 #pragma unroll
                 for (int q = 0; q < 8; q++) a[q] += jk_v2f{ye, ye};
@@ -1345,9 +1354,9 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
             if constexpr (CLIPS) {  // (the clip instantiations have no registers to spare: the state stays in LDS)
                 my_rowmask = F.rowmask[ly];
                 const uint32_t st = F.lanest[lane];
-                my_first = F.first[lane];
+                my_first = st >> 24;
                 row_addr = st & 0xffffu;
-                done = st >> 16;
+                done = (st >> 16) & 0xffu;
             } else {
                 my_rowmask = s4_rowmask; my_first = s4_first; row_addr = s4_row_addr; done = s4_done;
             }
@@ -1415,13 +1424,14 @@ __global__ __launch_bounds__(64 * FINE_WG_WAVES(CLIPS)) __attribute__((amdgpu_wa
                 cur = hi;
                 if (em == 0ull) break;
                 {
-                    const float2 ed = F.edge[e_sl];
+                    float2 ed;
+                    if constexpr (CLIPS) ed = make_float2(F.edge_y[e_sl], (float)F.edge_s[e_sl]); else ed = F.edge[e_sl];
                     const float y_edge = ed.y * clamp_(lyf - ed.x + 1.0f, 0.0f, 1.0f);
                     area[0] += y_edge; area[1] += y_edge; area[2] += y_edge; area[3] += y_edge;
                 }
                 em &= em - 1ull;
             }
-            if constexpr (CLIPS) lds_st_u16(lds_addr(&F.lanest[lane]) + 2u, (uint16_t)done); else s4_done = done;
+            if constexpr (CLIPS) lds_st_u8(lds_addr(&F.lanest[lane]) + 2u, (uint8_t)done); else s4_done = done;
 #ifdef FINE_TIMING
             tm_walk += __builtin_readcyclecounter() - tb1;
 #endif

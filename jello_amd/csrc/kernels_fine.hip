@@ -405,8 +405,11 @@ JD void load_segraw_clamped(const float* __restrict__ segments, uint32_t segment
 #if FINE_MS_SKIP != 0 && !defined(JH_VARIANT_BUILD)
 #error "FINE_MS_SKIP changes results: build it as a variant library"
 #endif
+// Touched pixels per batch (a sane segment has at most 31; one with more is walked at the fill: MsState::direct).  192 with 8
+// samples: 4 944 bytes of LDS per tile-wave then -- LDS is handed out in blocks of 1 280 bytes on this part (two what-if sweeps found
+// the steps, profiles/r06_fine_lds_sweep.txt / r06_fine_clip_lds.txt), so 5 120 is the line between 25 and 32 tile-waves per CU.
 #ifndef MS_CAP
-#define MS_CAP 256u  // touched pixels per batch (a sane segment has at most 31; one with more is walked at the fill: MsState::direct)
+#define MS_CAP(SAMPLES) ((SAMPLES) == 8 ? 192u : 256u)
 #endif
 // An entry of the list, ONE word: sample mask (8 or 16 bits) | pixel << SAMPLES | flags << (SAMPLES + 8): 21 / 29 bits
 #define MS_F_DOWN 1u      // the segment runs downwards as given (sign of its winding contribution)
@@ -419,10 +422,10 @@ JD void load_segraw_clamped(const float* __restrict__ segments, uint32_t segment
 #define MS_S_TOP_ON_EDGE 4u   // the upper end point has x == 0
 #define MS_S_BOT_OFF_EDGE 8u  // the lower end point has x != 0
 #define MS_S_BY_RULE 16u      // the first pixel's mask depends on the fill rule (see ms_setup): such a segment is walked at the fill
-struct MsSeg {  // what a touched pixel needs of its segment (written by lane = segment, read by lane = touched pixel): 32 bytes
+struct MsSeg {  // what a touched pixel needs of its segment (written by lane = segment, read by lane = touched pixel): 28 bytes
     float a, b;          // z = floor(a * k + b): columns crossed after k steps of the DDA
     int32_t x0i;         // column of the first pixel
-    float top_y, bot_y;  // y of the upper / lower end point
+    float top_y;         // y of the upper end point
     float lut_row;       // LUT row of the slope, times the row length
     uint32_t bits;       // MS_S_* | trim of the first pixel's mask << 5 | touched pixels << 10
     uint32_t first;      // index of the first touched pixel in the batch's list | the bits the last pixel's mask keeps << 16
@@ -433,10 +436,10 @@ template <int SAMPLES> struct MsLds {
         float4 pre[64];   // between builds: the next window's end points, in flight (global_load_lds)
     };
     alignas(16) uint32_t samples[SAMPLES == 8 ? 512 : 1024];  // [pixel][word]: SWAR winding counters, four samples per word (non-zero); [pixel]: parity bits (even-odd)
-    uint32_t ent[MS_CAP];                                     // the batch's touched pixels, in segment order
+    uint32_t ent[MS_CAP(SAMPLES)];                                  // the batch's touched pixels, in segment order
     uint32_t carry_x[64];  // non-zero: [pixel / 4] a byte per pixel; even-odd: [row] a bit per pixel
     alignas(16) uint32_t carry_y[4];  // non-zero: a byte per row; even-odd: word 0, a bit per row
-    uint32_t mark[64];
+    uint8_t mark[64];
 };
 JD uint32_t shl32(uint32_t v, uint32_t s) { return v << (s & 31u); }
 JD uint32_t shr32(uint32_t v, uint32_t s) { return v >> (s & 31u); }
@@ -471,7 +474,7 @@ JD uint32_t ms_setup(float x0, float y0, float x1, float y1, MsSeg& K, uint32_t&
     if (err != 0.0f) a -= 2e-7f * sign_(err);
     K.a = a; K.b = b;
     K.x0i = to_i32(xt * sgn + 0.5f * (sgn - 1.0f));
-    K.top_y = ty; K.bot_y = by;
+    K.top_y = ty;
     K.lut_row = floor_(fmin_(a * HALF_H, HALF_H - 1.0f)) * LUT_W;
     // The sample masks of the first and the last touched pixel are trimmed at the end points (fine.wgsl:356-365): both depend on the
     // segment alone -- the pixel rows come out of the expressions ms_pixel evaluates at k = 0 and k = touched - 1 -- so they are
@@ -602,9 +605,9 @@ JD void ms_build(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t so, cons
     MsSeg K;
     uint32_t edge;
     const uint32_t touched = ms_setup<SAMPLES>(x0, y0, x1, y1, K, edge);
-    const uint32_t capped = (K.bits & MS_S_BY_RULE) != 0u ? MS_CAP + 1u : umin_(touched, MS_CAP + 1u);  // (what does not fit the list ends the batch)
+    const uint32_t capped = (K.bits & MS_S_BY_RULE) != 0u ? MS_CAP(SAMPLES) + 1u : umin_(touched, MS_CAP(SAMPLES) + 1u);  // (what does not fit the list ends the batch)
     const uint32_t incl = wave_incl_scan_u32(capped);
-    const uint64_t fit = __builtin_amdgcn_ballot_w64(incl <= MS_CAP);  // a prefix of the lanes (incl is monotone)
+    const uint64_t fit = __builtin_amdgcn_ballot_w64(incl <= MS_CAP(SAMPLES));  // a prefix of the lanes (incl is monotone)
     const uint32_t n = (uint32_t)__builtin_popcountll(fit);
     B.base = so;
     B.edge = edge;
@@ -617,7 +620,7 @@ JD void ms_build(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t so, cons
     if (lane < n) { K.bits |= touched << 10; K.first |= first; T.seg[lane] = K; }
     const bool starts = lane < n && touched != 0u;
     // The touched pixels, 64 per pass; all passes' LUT fetches are issued before the first is consumed.
-    constexpr uint32_t PASSES = MS_CAP / 64u;
+    constexpr uint32_t PASSES = MS_CAP(SAMPLES) / 64u;
     uint32_t word[PASSES];
 #pragma unroll
     for (uint32_t p = 0u; p < PASSES; p++) {
@@ -862,7 +865,7 @@ template <> struct FineStackSel<false> { struct type { float4 lvl[1][1][1]; }; }
 // the occupancy at 4 waves per SIMD); one for the clip instantiations, whose 22 KB per wave then pack 7 to a CU instead of 6.
 #define FINE_WG_WAVES(CLIPS) ((CLIPS) ? 1 : FINE_WAVES)
 #ifndef FINE_LEAN_MS_WAVES_PER_EU
-#define FINE_LEAN_MS_WAVES_PER_EU 6  // (C3 msaa8: 580 / 522 / 490 us at 4 / 5 / 6 waves per SIMD)
+#define FINE_LEAN_MS_WAVES_PER_EU 7  // (C3 msaa8: 580 / 522 / 490 us at 4 / 5 / 6 waves per SIMD; 7 -- 72 registers, four spilled -- once the LDS allows 28 tile-waves: 440 -> 429)
 #endif
 #define FINE_WAVES_PER_EU(AA, CLIPS, PAINTS) \
     ((CLIPS) ? ((AA) != 0 ? FINE_CLIP_MS_WAVES_PER_EU : FINE_CLIP_WAVES_PER_EU) : ((PAINTS) ? 4 : ((AA) == 16 ? 5 : ((AA) != 0 ? FINE_LEAN_MS_WAVES_PER_EU : FINE_LEAN_WAVES_PER_EU))))  /* (16 samples: 7.7 KB of LDS per tile-wave allow 5 per SIMD anyway) */

@@ -4,11 +4,12 @@
 // un-premultiplied RGBA16F.
 //
 // MI355X design (round 3): one wave64 per tile (64 lanes x 4 horizontally adjacent pixels, exactly the WGSL's (4,16)
-// workgroup), ONE tile-wave per workgroup (the CU takes 24 of them: 6 per SIMD for the lean instantiation; two or four waves
-// per workgroup measured 4 % / 6 % slower).  The PTCL stream and the segment records are the same for all 64 lanes, so each
+// workgroup), ONE tile-wave per workgroup (the CU takes 25 of them for the lean instantiation -- LDS comes in blocks of 1 280 bytes:
+// five per tile-wave, FillLdsT below --; two or four waves per workgroup measured 4 % / 6 % slower).  The PTCL stream and the segment records are the same for all 64 lanes, so each
 // datum is fetched ONCE per tile with wide coalesced loads (the algorithmic-bytes model of the roofline) and shared on-chip:
 //   * PTCL: a REGISTER window -- lane k of a VGPR holds word k of the stream (one 256-byte load per 64 words, the next
-//     window requested one ahead, re-based with ds_bpermute); a command's words are read off the lanes with v_readlane;
+//     window requested one ahead, re-based with ds_bpermute); a command's words are read off the lanes with v_readlane
+//     (control words) or taken through the LDS crossbar (the colour of a FILL + COLOR pair);
 //   * segments: coarse allocates a tile's segment slices back to back; they are evaluated in batches of up to 63
 //     (segment,row) pairs by the wave-level pipeline described above fill_path below; the next batch's segment window is
 //     requested straight into LDS (global_load_lds) while the current batch is evaluated, and EVERYTHING a batch leaves
@@ -17,7 +18,7 @@
 // Clip / blend stack: level 0 in wave-private LDS, levels 1-3 in a per-tile slice of a global scratch array, deeper levels in
 // blend_spill exactly like the WGSL; layers are lazy (see pushed_depth).  Instantiations: coverage mode (area / msaa8 /
 // msaa16) x with/without the clip stack x with/without gradient+image code; the launcher picks by ConfigUniform.n_clip
-// and by whether any ramp/image is bound.  Lean area variant: 80 VGPRs, no scratch, 6.6 KB of LDS per tile-wave.
+// and by whether any ramp/image is bound.  Lean area variant: 72 VGPRs, no scratch, 6.1 KB of LDS per tile-wave.
 // Command loop: loops per PATTERN in front of a general decoder.  FILL followed by COLOR (the pair a plain scene consists of) runs in a
 // loop of its own, and so do the empty layers of clip scenes (BEGIN_CLIP ... [SOLID] END_CLIP closed by the shortcut): one definition of the
 // sixteen colour registers around one back edge each.  As arms of one decoder loop with many exits they carried its flag variables, state

@@ -314,3 +314,15 @@ func (e *Engine) TrimScratch() {
 func (e *Engine) SetBand(row0, row1 uint32) {
 	e.check(C.jh_set_band(e.ctx, C.uint32_t(row0), C.uint32_t(row1)), "set_band")
 }
+
+// SelfTest runs the library's toolchain checks on the device: the allocation patterns the kernels rely on (jh_selftest_atomics,
+// forms 0 plain per-lane atomic / 1 hand-aggregated / 2 wave-private LDS) against a serial execution.  A deployment that rebuilds
+// libjello_hip.so with another ROCm can call it once after New; it returns an error naming the form that disagrees.
+func (e *Engine) SelfTest() error {
+	for form := 0; form < 3; form++ {
+		if rc := C.jh_selftest_atomics(e.ctx, C.int(form), C.uint32_t(1+form), 1024); rc != 0 {
+			return fmt.Errorf("hip_engine: jh_selftest_atomics form %d: %d", form, int(rc))
+		}
+	}
+	return nil
+}

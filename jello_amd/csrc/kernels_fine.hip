@@ -409,7 +409,9 @@ JD void load_segraw_clamped(const float* __restrict__ segments, uint32_t segment
 // Touched pixels per batch (a sane segment has at most 31; one with more is walked at the fill: MsState::direct).  192 with 8
 // samples: 4 944 bytes of LDS per tile-wave then -- LDS is handed out in blocks of 1 280 bytes on this part (two what-if sweeps found
 // the steps, profiles/r06_fine_lds_sweep.txt / r06_fine_clip_lds.txt), so 5 120 is the line between 25 and 32 tile-waves per CU.
-#ifndef MS_CAP
+#ifdef MS_CAP_OVERRIDE  // (soak builds: a multiple of 64)
+#define MS_CAP(SAMPLES) MS_CAP_OVERRIDE
+#else
 #define MS_CAP(SAMPLES) ((SAMPLES) == 8 ? 192u : 256u)
 #endif
 // An entry of the list, ONE word: sample mask (8 or 16 bits) | pixel << SAMPLES | flags << (SAMPLES + 8): 21 / 29 bits
@@ -606,7 +608,12 @@ JD void ms_build(MsLds<SAMPLES>& T, MsState& B, uint32_t lane, uint32_t so, cons
     MsSeg K;
     uint32_t edge;
     const uint32_t touched = ms_setup<SAMPLES>(x0, y0, x1, y1, K, edge);
-    const uint32_t capped = (K.bits & MS_S_BY_RULE) != 0u ? MS_CAP(SAMPLES) + 1u : umin_(touched, MS_CAP(SAMPLES) + 1u);  // (what does not fit the list ends the batch)
+#ifdef MS_FORCE_DIRECT_ABOVE  // (soak builds, tools/soak_round6_shapes.sh: segments with more touched pixels than this take the walk at the fill, which no sane scene reaches otherwise)
+    const bool force_direct = touched > MS_FORCE_DIRECT_ABOVE;
+#else
+    const bool force_direct = false;
+#endif
+    const uint32_t capped = ((K.bits & MS_S_BY_RULE) != 0u || force_direct) ? MS_CAP(SAMPLES) + 1u : umin_(touched, MS_CAP(SAMPLES) + 1u);  // (what does not fit the list ends the batch)
     const uint32_t incl = wave_incl_scan_u32(capped);
     const uint64_t fit = __builtin_amdgcn_ballot_w64(incl <= MS_CAP(SAMPLES));  // a prefix of the lanes (incl is monotone)
     const uint32_t n = (uint32_t)__builtin_popcountll(fit);

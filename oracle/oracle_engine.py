@@ -60,11 +60,15 @@ class OracleEngine:
             self.bufs[bid] = b
         return b
 
-    def run(self, recording, stop_after=None):
-        from jello_amd.engine import CMD
+    def run(self, recording, stop_after=None, only=None):
+        """only = a stage name: nothing but the dispatches of that stage, on the buffers an earlier run() left (tests that change a
+        buffer between two stages)."""
+        from jello_amd.engine import CMD, STAGE_NAMES as _NAMES
         pending_clear = set()
         for c in recording.commands():
             k = c["kind"]
+            if only is not None and not (k in (CMD.DISPATCH, CMD.DISPATCH_INDIRECT) and _NAMES[c["shader"]] == only):
+                continue
             if k in (CMD.UPLOAD, CMD.UPLOAD_UNIFORM):
                 self.bufs[c["buf_id"]] = np.frombuffer(c["data"], dtype=np.uint8).copy()
             elif k == CMD.UPLOAD_IMAGE:

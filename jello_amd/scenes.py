@@ -366,3 +366,79 @@ def scene_fuzz(seed, size=256, n=40, extreme=False):
         open_layers -= 1
     p = RenderParams(size, size, base_color=(r.uniform(), r.uniform(), r.uniform(), 1.0))
     return s, p
+
+
+def scene_clip_torture(kind, size=256, seed=SEED + 31):
+    """Clip-layer patterns that stress coarse's per-tile state machine (kernels_coarse.hip, the walk with lanes = elements) and
+    fine's lazy layers far beyond what the C4 recipes produce -- small targets, so that the oracle finishes in seconds:
+      deep       one nest of 120 layers around the centre, every fifth one with a mix mode, content at several depths
+      siblings   1500 sibling layers over the same tiles, alternately covering them, missing them (empty: everything inside is
+                 skipped) and cutting through them, each with two fills inside -- hundreds of elements per tile and batch
+      comb       layers that open in one batch of 256 draw objects and close several batches later: 40 long-lived layers
+                 interleaved with 1200 fills, some of the layers empty on half of the target
+      mixed      random interleavings of pushes, pops and fills, up to 60 layers open at once"""
+    r = SplitMix64(seed + {"deep": 0, "siblings": 1, "comb": 2, "mixed": 3}[kind])
+    s = Scene()
+    col = lambda: Brush.solid((r.uniform(), r.uniform(), r.uniform(), r.uniform(0.3, 1.0)))
+
+    def blob(cx, cy, rad):
+        p = Path().move_to(cx + r.uniform(-rad, rad), cy + r.uniform(-rad, rad))
+        for _ in range(3):
+            p.line_to(cx + r.uniform(-rad, rad), cy + r.uniform(-rad, rad))
+        return p.close()
+    c = size * 0.5
+    if kind == "deep":
+        depth = 120
+        for d in range(depth):
+            rad = size * 0.48 - d * (size * 0.4 / depth)
+            mix = Mix((d // 5) % 16) if d % 5 == 0 else Mix.Clip
+            s.push_layer(mix, Compose.SrcOver, 0.9 if d % 5 == 0 else 1.0, None, Path.circle(c + r.uniform(-2, 2), c + r.uniform(-2, 2), rad))
+            if d % 7 == 0:
+                s.fill(Fill.NonZero, None, col(), None, blob(c, c, size * 0.3))
+        s.fill(Fill.EvenOdd, None, col(), None, blob(c, c, size * 0.2))
+        for _ in range(depth):
+            s.pop_layer()
+    elif kind == "siblings":
+        for i in range(1500):
+            k = i % 3
+            if k == 0:
+                clip = Path.rect(-10, -10, size + 10, size + 10)                      # covers every tile
+            elif k == 1:
+                clip = Path.circle(r.uniform(0, size), r.uniform(0, size), 6.0)       # misses almost every tile
+            else:
+                clip = blob(r.uniform(0, size), r.uniform(0, size), size * 0.4)       # cuts through
+            s.push_layer(Mix(i % 16) if i % 4 == 0 else Mix.Clip, Compose.SrcOver, 0.8, None, clip)
+            s.fill(Fill.NonZero, None, col(), None, blob(r.uniform(0, size), r.uniform(0, size), 30.0))
+            s.fill(Fill.NonZero, None, col(), None, blob(r.uniform(0, size), r.uniform(0, size), 12.0))
+            s.pop_layer()
+    elif kind == "comb":
+        open_ = 0
+        for i in range(1200):
+            if i % 30 == 0 and open_ < 40:
+                half = Path.rect(0, 0, size * (0.5 if (i // 30) % 2 else 1.0), size)
+                s.push_layer(Mix((i // 30) % 16), Compose.SrcOver, 0.7, None, half)
+                open_ += 1
+            s.fill(Fill.NonZero, None, col(), None, blob(r.uniform(0, size), r.uniform(0, size), 25.0))
+            if i % 97 == 96 and open_ > 0:
+                s.pop_layer()
+                open_ -= 1
+        for _ in range(open_):
+            s.pop_layer()
+    else:
+        open_ = 0
+        for i in range(2500):
+            u = r.uniform()
+            if u < 0.25 and open_ < 60:
+                rad = 10.0 ** r.uniform(0.3, math.log10(size * 0.7))
+                s.push_layer(Mix(int(r.uniform(0, 16))) if r.uniform() < 0.3 else Mix.Clip, Compose.SrcOver, r.uniform(0.5, 1.0), None,
+                             Path.circle(r.uniform(0, size), r.uniform(0, size), rad))
+                open_ += 1
+            elif u < 0.5:
+                if open_ > 0:
+                    s.pop_layer()
+                    open_ -= 1
+            else:
+                s.fill(Fill.NonZero if r.uniform() < 0.8 else Fill.EvenOdd, None, col(), None, blob(r.uniform(0, size), r.uniform(0, size), 10.0 ** r.uniform(0.5, 2.0)))
+        for _ in range(open_):
+            s.pop_layer()
+    return s, RenderParams(size, size, base_color=(0.1, 0.1, 0.1, 1.0))

@@ -333,3 +333,17 @@ def test_poisoned_scratch_and_growing_scenes(engine):
     s, p = scenes.scene_c4(1500, 512)
     compare(engine, s, p)
     compare(engine, *small)
+
+
+@pytest.mark.parametrize("aa", [jello_amd.Aa.Area, jello_amd.Aa.Msaa8])
+@pytest.mark.parametrize("kind", ["deep", "siblings", "comb", "mixed"])
+def test_clip_torture(engine, kind, aa):
+    """Clip-layer patterns far beyond the C4 recipes (scenes.scene_clip_torture): a nest 120 deep, 1500 sibling layers over the same tiles
+    (covering, missing and cutting them), layers that stay open across many batches of 256 draw objects, random interleavings with up to
+    60 open layers -- the per-tile state machine of coarse (lanes = the elements of a tile: skipped stretches, partners per nesting level,
+    chunk boundaries inside a wave step, more than 64 elements of one batch on one tile) and fine's lazy layers / blend spill."""
+    s, p = scenes.scene_clip_torture(kind)
+    p.bump = BumpSizes(ptcl=1 << 24, blend_spill=1 << 23)
+    p.aa = aa
+    r = compare(engine, s, p)
+    assert r["bump"]["failed"] == 0

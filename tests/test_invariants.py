@@ -293,3 +293,37 @@ def test_coverage_matches_supersampling(built, rule, aa):
     else:
         assert err.max() <= (0.25 if aa == "msaa8" else 0.18)   # 8 / 16 samples against 64; measured 0.20 / 0.14
         assert err.mean() < 0.004
+
+
+@pytest.mark.parametrize("kind", ["deep", "siblings", "comb", "mixed"])
+def test_clip_torture_streams_are_well_formed(built, kind):
+    """scenes.scene_clip_torture on the oracle (the checker of test_gpu_parity.test_clip_torture): every tile's command stream parses to
+    its END without leaving its chunks (the host's own PTCL walker), BEGIN_CLIP and END_CLIP balance in every tile, no stage failed,
+    the image is finite."""
+    s, p = scenes.scene_clip_torture(kind)
+    p.bump = BumpSizes(ptcl=1 << 24, blend_spill=1 << 23)
+    rec, o = run(s, p)
+    bump = o.get(rec, "bumpBuf", np.uint32)
+    assert int(bump[0]) == 0
+    ptcl = o.get(rec, "ptclBuf", np.uint32)
+    cfg = rec.config
+    L = jello_amd.load_host()
+    st = (ctypes.c_uint64 * 8)()
+    assert L.jl_ptcl_stats(ptcl.ctypes.data, ptcl.size, cfg["width_in_tiles"], cfg["height_in_tiles"], st) == 0
+    # walk every tile's stream: tags 10 / 11 balance, nesting never negative
+    sizes = {1: 4, 3: 1, 5: 5, 6: 3, 7: 3, 8: 3, 9: 2, 10: 1, 11: 3}
+    for t in range(cfg["width_in_tiles"] * cfg["height_in_tiles"]):
+        pc, depth = t * 64 + 1, 0
+        for _ in range(1 << 20):
+            tag = int(ptcl[pc])
+            if tag == 0:
+                break
+            if tag == 12:
+                pc = int(ptcl[pc + 1])
+                continue
+            depth += 1 if tag == 10 else (-1 if tag == 11 else 0)
+            assert depth >= 0 and tag in sizes, (t, pc, tag)
+            pc += sizes[tag]
+        assert depth == 0, (t, depth)
+    img = f16img(o, rec)
+    assert np.isfinite(img).all()

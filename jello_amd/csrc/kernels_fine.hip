@@ -252,14 +252,14 @@ JD V4 over(V4 bg, V4 fg, float area) {
 #define FINE_LEAN_WAVES_PER_EU 7  // (72 registers; 6 208 bytes of LDS per tile-wave allow 26 per CU)
 #endif
 #ifndef FINE_CLIP_WAVES_PER_EU
-#define FINE_CLIP_WAVES_PER_EU 4  // 128 VGPRs (5 spilled in the clip + paint instantiation); LDS (4 KiB of stack + 6.6 KiB per tile-wave) allows 15 waves per CU.
+#define FINE_CLIP_WAVES_PER_EU 4  // 128 VGPRs (6 spilled in the clip + paint instantiation); LDS (4 KiB of stack + 5.9 KiB per tile-wave = eight blocks of 1 280 bytes) allows 16 waves per CU.
                                   // (3, ~140 VGPRs without spills: C4 fine 1.24 instead of 1.19 ms, nested 3.35 instead of 3.15, once the command loops were split)
 #endif
 #ifndef FINE_CLIP_MS_WAVES_PER_EU
 #define FINE_CLIP_MS_WAVES_PER_EU 3
 #endif
 #ifndef FINE_WAVES
-#define FINE_WAVES 1  // tile-waves per workgroup (round 3, C3: 0.405 ms with 1, 0.421 with 2, 0.428 with 4: the CU takes 24 one-wave workgroups)
+#define FINE_WAVES 1  // tile-waves per workgroup (round 3, C3: 0.405 ms with 1, 0.421 with 2, 0.428 with 4)
 #endif
 #define FB_PLANE 65
 #ifndef FINE_FINAL_ASM
@@ -870,7 +870,7 @@ template <> struct FineStackSel<false> { struct type { float4 lvl[1][1][1]; }; }
 // Pixel ownership = the WGSL's: lane = ly*4 + lx (workgroup (4,16)), pixel i = 0..3 at column 4*lx + i.
 // AA = 0: analytic area coverage (fine_area); 8 / 16: fine_msaa8 / fine_msaa16.
 // Tile-waves per workgroup: two where LDS is small (the CU runs at most 16 workgroups, so single-wave workgroups would cap
-// the occupancy at 4 waves per SIMD); one for the clip instantiations, whose 22 KB per wave then pack 7 to a CU instead of 6.
+// the occupancy at 4 waves per SIMD); one for the clip instantiations (a history note of round 2: their LDS is 10 KB per wave now).
 #define FINE_WG_WAVES(CLIPS) ((CLIPS) ? 1 : FINE_WAVES)
 #ifndef FINE_LEAN_MS_WAVES_PER_EU
 #define FINE_LEAN_MS_WAVES_PER_EU 7  // (C3 msaa8: 580 / 522 / 490 us at 4 / 5 / 6 waves per SIMD; 7 -- 72 registers, four spilled -- once the LDS allows 28 tile-waves: 440 -> 429)
